@@ -1,0 +1,214 @@
+"""Pins the CPU oracle (oracle/) against the reference's own golden vectors.
+
+Every assertion here restates an assertion (or a literal) of the reference's test-suite;
+citations are relative to /root/reference. If these fail the oracle is not trustworthy and
+no GPU parity claim means anything.
+"""
+import numpy as np
+import pytest
+
+from oracle import clipper_ref as ref
+
+
+def _affinity_case(golden):
+    g = golden["affinity_test"]
+    return np.array(g["model"]), np.array(g["data"]), np.array(g["Mtrue"])
+
+
+def test_all_to_all_order():
+    # affinity_test.cpp:61-72
+    A = ref.create_all_to_all(4, 3)
+    assert A.shape == (12, 2)
+    for i in range(4):
+        for j in range(3):
+            assert tuple(A[i * 3 + j]) == (i, j)
+
+
+def test_k2ij_row_major_upper_order():
+    # utils.cpp:87-97: k=0 -> (0,1), 1 -> (0,2) ...; enumerates every i<j exactly once
+    for n in (2, 3, 7, 12, 101):
+        want = [(i, j) for i in range(n) for j in range(i + 1, n)]
+        got = [ref.k2ij(k, n) for k in range(n * (n - 1) // 2)]
+        assert got == want
+
+
+def test_affinity_euclidean_matches_reference_Mtrue(golden):
+    model, data, Mtrue = _affinity_case(golden)
+    c = ref.RefClipper()
+    c.score_pairwise_consistency_euclidean(model, data)  # empty A -> all-to-all (clipper.cpp:24)
+    A = c.get_initial_associations()
+    assert np.array_equal(A, ref.create_all_to_all(4, 3))  # affinity_test.cpp:61-72
+    M, Cm = c.get_affinity_matrix(), c.get_constraint_matrix()
+    assert M.shape == (12, 12)                              # :79-80
+    assert np.array_equal(np.diag(M), np.ones(12))          # :83
+    assert np.array_equal(M, M.T) and np.array_equal(Cm, Cm.T)  # :86-87
+    assert np.array_equal(M, Cm)                            # :91
+    assert np.array_equal(M, Mtrue)                         # :93-107, EXACT equality
+
+
+@pytest.mark.parametrize("dense_temp", [0, 1])
+@pytest.mark.parametrize("parallelize", [False, True])
+def test_affinity_routes_agree(golden, dense_temp, parallelize):
+    model, data, Mtrue = _affinity_case(golden)
+    c = ref.RefClipper()
+    c.parallelize = parallelize
+    c.score_pairwise_consistency_euclidean(model, data, dense_temp=dense_temp)
+    assert np.array_equal(c.get_affinity_matrix(), Mtrue)
+
+
+def test_numpy_mirror_matches_reference_Mtrue(golden):
+    model, data, Mtrue = _affinity_case(golden)
+    Mup, m = ref.numpy_affinity_euclidean(model, data, ref.create_all_to_all(4, 3))
+    assert np.array_equal(Mup + Mup.T + np.eye(m), Mtrue)
+
+
+def _u0s(n, count=40):
+    rng = np.random.default_rng(2024)
+    return [np.ones(n) / np.sqrt(n)] + [rng.random(n) for _ in range(count)]
+
+
+def test_solve_known_answer(golden):
+    # clipper_test.cpp:54-66: scorePairwiseConsistency + solve(), 3 selected associations
+    # with A(i,0)==A(i,1). The reference draws u0 at random (utils.cpp:22-29) and the answer
+    # depends on u0, so here it is checked for a fixed uniform u0 and counted over 40 seeded
+    # random ones (the 3-clique must be what most of them reach).
+    model, data, _ = _affinity_case(golden)
+    c = ref.RefClipper()
+    c.score_pairwise_consistency_euclidean(model, data)
+    hits = 0
+    for idx, u0 in enumerate(_u0s(12)):
+        s = c.solve(u0)
+        Ain = c.get_selected_associations()
+        ok = (Ain.shape[0] == 3) and bool(np.all(Ain[:, 0] == Ain[:, 1]))
+        if idx == 0:
+            assert ok, "uniform u0 must give the reference's 3 inliers"
+            assert sorted(s.nodes.tolist()) == golden["affinity_test"]["expected_inlier_nodes"]
+            assert abs(s.score - 3.0) < 1e-6
+        hits += ok
+    assert hits >= 30
+
+
+def test_solve_cxx_oracle_equals_numpy_mirror(golden):
+    model, data, _ = _affinity_case(golden)
+    A = ref.create_all_to_all(4, 3)
+    c = ref.RefClipper()
+    c.score_pairwise_consistency_euclidean(model, data)
+    Mup, _ = ref.numpy_affinity_euclidean(model, data, A)
+    Cup = (Mup != 0).astype(float)
+    for u0 in _u0s(12, 10):
+        s1 = c.solve(u0)
+        s2 = ref.numpy_solve(Mup, Cup, u0)
+        assert s1.nodes.tolist() == s2.nodes.tolist()
+        assert s1.ifinal == s2.ifinal and s1.n_trials == s2.n_trials
+        assert abs(s1.score - s2.score) <= 1e-12 * max(1.0, abs(s2.score))
+        assert np.allclose(s1.u, s2.u, rtol=0, atol=1e-12)
+
+
+def test_get_set_matrix_round_trip(golden):
+    # clipper_test.cpp:115-133: get*Matrix (identity added) -> setMatrixData (strict upper
+    # kept) reproduces the problem; solving the round-tripped problem gives the same answer.
+    model, data, Mtrue = _affinity_case(golden)
+    c = ref.RefClipper()
+    c.score_pairwise_consistency_euclidean(model, data)
+    M, Cm = c.get_affinity_matrix(), c.get_constraint_matrix()
+    c2 = ref.RefClipper()
+    c2.set_matrix_data(M, Cm)
+    assert np.array_equal(c2.get_affinity_matrix(), Mtrue)
+    assert np.array_equal(c2.get_constraint_matrix(), Mtrue)
+    u0 = np.ones(12) / np.sqrt(12)
+    s1, s2 = c.solve(u0), c2.solve(u0)
+    assert s1.nodes.tolist() == s2.nodes.tolist() and s1.score == s2.score
+
+
+def test_set_matrix_ignores_lower_triangle_and_diagonal():
+    # clipper.cpp:151-157: triangularView<Upper>, diagonal zeroed
+    rng = np.random.default_rng(1)
+    M = rng.random((6, 6))
+    Cm = (rng.random((6, 6)) > 0.3).astype(float)
+    c = ref.RefClipper()
+    c.set_matrix_data(M, Cm)
+    Mu = np.triu(M, 1)
+    assert np.array_equal(c.get_affinity_matrix(), Mu + Mu.T + np.eye(6))
+    Cu = np.triu(Cm, 1)
+    assert np.array_equal(c.get_constraint_matrix(), Cu + Cu.T + np.eye(6))
+
+
+def test_dsd_matrix_solve_runs_and_mirrors_numpy(golden):
+    # sdp_test.cpp:38-56: setMatrixData(M, C=(M>0)); solve() — the reference asserts nothing,
+    # so this fixture only cross-checks the two restatements on a weighted (non-binary) M.
+    M = np.array(golden["dsd_test_20x20"]["M"])
+    Cm = (M > 0).astype(float)
+    c = ref.RefClipper()
+    c.set_matrix_data(M, Cm)
+    u0 = np.ones(20) / np.sqrt(20)
+    s1 = c.solve(u0)
+    s2 = ref.numpy_solve(np.triu(M, 1), np.triu(Cm, 1), u0)
+    assert s1.nodes.tolist() == s2.nodes.tolist()
+    assert abs(s1.score - s2.score) < 1e-10
+    assert len(s1.nodes) >= 2
+
+
+def test_pointnormal_planecloud_ground_truth(golden):
+    # ex3_planecloud.m:79-98: all-to-all, PointNormalDistance{sign=deg2rad(1.5), epsn=1},
+    # selected associations == Agt = [1 4; 2 3; 3 2] (1-based) for a good u0.
+    g = golden["planecloud"]
+    D1, D2 = np.array(g["D1"]), np.array(g["D2"])
+    inv = g["invariant"]
+    c = ref.RefClipper()
+    c.score_pairwise_consistency_pointnormal(D1, D2, (), **inv)
+    A = c.get_initial_associations()
+    Mnp = ref.numpy_affinity_pointnormal(D1, D2, A, **inv)
+    M = c.get_affinity_matrix()
+    assert np.allclose(np.triu(M, 1), Mnp, rtol=1e-13, atol=0)
+    assert np.array_equal(np.triu(M, 1) != 0, Mnp != 0)
+    assert int((Mnp != 0).sum()) == 40  # SURVEY.md 8c [scratch]: 40 upper non-zeros
+    want = sorted(map(tuple, g["Agt_zero_based"]))
+    found = 0
+    for u0 in _u0s(16, 20):
+        c.solve(u0)
+        got = sorted(map(tuple, c.get_selected_associations().tolist()))
+        found += (got == want)
+    assert found >= 1
+
+
+def test_pointnormal_acos_nan_gives_zero():
+    # pointnormal_distance.cpp:21-22,28: acos(>1) = NaN -> comparison false -> 0
+    import ctypes as C
+    L = ref.lib()
+    a = np.array([0, 0, 0, 1.0, 0.5, 0.0])      # |n|>1 so n.n > 1
+    b = np.array([1, 0, 0, 1.0, 0.5, 0.0])
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    assert L.clipper_ref_score_pointnormal(dp(a), dp(b), dp(a), dp(b), 0.5, 0.5, 0.1, 0.35) == 0.0
+
+
+def test_k_largest_semantics():
+    # utils.cpp:33-55: descending by (value, index); ties keep the earlier-inserted larger
+    # index ordering of std::pair comparison; k<1 -> {}
+    x = np.array([0.3, 0.9, 0.9, 0.1, 0.5])
+    assert ref.k_largest(x, 0).tolist() == []
+    assert ref.k_largest(x, 1).tolist() == [1]       # strict '<' keeps the first 0.9
+    assert ref.k_largest(x, 2).tolist() == [2, 1]    # (0.9,2) > (0.9,1) in pair order
+    assert ref.k_largest(x, 3).tolist() == [2, 1, 4]
+    assert ref.k_largest(x, 99).tolist() == ref.numpy_k_largest(x, 99).tolist()
+    rng = np.random.default_rng(7)
+    for _ in range(20):
+        v = rng.integers(0, 5, size=30).astype(float)  # many ties
+        for k in (1, 3, 10, 30):
+            assert ref.k_largest(v, k).tolist() == ref.numpy_k_largest(v, k).tolist()
+
+
+def test_mindist_and_epsilon_branches():
+    # euclidean_distance.cpp:23-30
+    import ctypes as C
+    L = ref.lib()
+    dp = lambda x: np.asarray(x, float).ctypes.data_as(C.POINTER(C.c_double))
+    z, e1 = np.zeros(3), np.array([1.0, 0, 0])
+    s = L.clipper_ref_score_euclidean(dp(z), dp(e1), dp(z), dp(e1), 3, 0.01, 0.06, 0.0)
+    assert s == 1.0
+    s = L.clipper_ref_score_euclidean(dp(z), dp(e1), dp(z), dp(e1), 3, 0.01, 0.06, 2.0)
+    assert s == 0.0  # l1 < mindist
+    e2 = np.array([1.05, 0, 0])
+    s = L.clipper_ref_score_euclidean(dp(z), dp(e1), dp(z), dp(e2), 3, 0.01, 0.06, 0.0)
+    assert abs(s - np.exp(-0.5 * 0.05**2 / 0.01**2)) < 1e-15
+    e3 = np.array([1.07, 0, 0])
+    assert L.clipper_ref_score_euclidean(dp(z), dp(e1), dp(z), dp(e3), 3, 0.01, 0.06, 0.0) == 0.0
