@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — CLIPPER dense-cluster hot path on MI355X: affinity build + solve().
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic registration problem:
+  affinity build (scorePairwiseConsistency, EuclideanDistance) + solve() (findDenseClique)
+on BASELINE.json's headline configuration: m = 10 000 putative associations, 95 % outliers,
+synthetic 3-D points (SURVEY.md 8d recipe, clipper_amd/synth.py). The inputs (D1, D2, A,
+u0) are staged into HBM before the timed region; every step re-runs the affinity kernel and
+the full solver. With N > 1 the SAME problem is column-sharded over the N GPUs (one process
+per GPU, per-pass RCCL all-gather of the (M_off x, C_off x) slices): strong scaling.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement), extended with
+  "roofline"     achieved HBM GB/s of the dominant kernel (the fused mat-vec k_gemv), from
+                 HIP events recorded on the solver stream around every launch in the timed
+                 region; algorithmic bytes per launch = s*m*W (s = 4, fp32 storage)
+  "cpu_baseline" the oracle (oracle/libclipper_ref.so, a port of the reference) timed on
+                 this box's host cores on the same problem (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--m", type=int, default=10000, help="putative associations")
+    ap.add_argument("--rho", type=float, default=None, help="outlier ratio (default 0.95; 0.90 at m<=1000)")
+    ap.add_argument("--storage", choices=["f32", "f64"], default="f32",
+                    help="element type of the dense M in HBM (vectors/accumulators are always f64)")
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(problem, args):
+    """Oracle (port of the reference) on the host cores: OpenMP affinity loop on all cores,
+    single-threaded sparse self-adjoint solver — the reference's own threading model."""
+    from clipper_amd import synth
+    from oracle import clipper_ref as ref
+
+    r = ref.RefClipper()
+    t0 = time.perf_counter()
+    r.score_pairwise_consistency_euclidean(problem.D1, problem.D2, problem.A,
+                                           **synth.EUCLID_BENCH_PARAMS)
+    t1 = time.perf_counter()
+    s = r.solve(problem.u0)
+    t2 = time.perf_counter()
+    return {
+        "value": round((t2 - t0) * 1e3, 3), "unit": "ms", "cores": ref.omp_threads(),
+        "kind": "port",
+        "sample": (f"1 full step at m={args.m}: affinity {1e3 * (t1 - t0):.1f} ms on "
+                   f"{ref.omp_threads()} OpenMP threads + solve {1e3 * (t2 - t1):.1f} ms on 1 thread "
+                   f"({s.n_passes} reference-counted passes, nnz={r.nnz})"),
+        "affinity_ms": round((t1 - t0) * 1e3, 3), "solve_ms": round((t2 - t1) * 1e3, 3),
+        "nproc": os.cpu_count(),
+    }, s
+
+
+def main():
+    args = parse()
+    N = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != N:
+        if world == 1 and N > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        N = world
+    rho = args.rho if args.rho is not None else (0.90 if args.m <= 1000 else 0.95)
+
+    # the product library first (binds the ROCm runtime in /opt/rocm), then torch for the
+    # contract's barrier / synchronize / max-over-ranks plumbing
+    from clipper_amd import _abi as abi
+    from clipper_amd import synth
+
+    abi.load_library()
+    import torch
+    import torch.distributed as dist
+
+    if N > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=N)
+
+    def barrier_sync():
+        if N > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    storage = abi.STORE_F32 if args.storage == "f32" else abi.STORE_F64
+    problem = synth.make_euclidean_problem(args.m, rho, seed=args.seed)  # identical on every rank
+    if N > 1:
+        g = abi.HipClipper(device=local_rank, storage=storage, rank=rank, world=N)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(g.unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, src=0)
+        g.comm_init(bytes(uid.numpy().tobytes()))
+    else:
+        g = abi.HipClipper(device=local_rank, storage=storage)
+
+    inv = synth.EUCLID_BENCH_PARAMS
+    # inputs resident in HBM before the timed region
+    g.stage_inputs(problem.D1, problem.D2, problem.A)
+    g.affinity_euclidean_staged(**inv)
+    g.stage_u0(problem.u0)
+
+    def step():
+        g.affinity_euclidean_staged(**inv)
+        return g.solve_staged()
+
+    for _ in range(args.warmup):
+        step()
+
+    g.set_profiling(True)
+    aff_ms, solve_ms, gemv_us, gemv_n = [], [], [], []
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ta = time.perf_counter()
+        g.affinity_euclidean_staged(**inv)
+        tb = time.perf_counter()
+        sol = g.solve_staged()
+        tc = time.perf_counter()
+        aff_ms.append((tb - ta) * 1e3)
+        solve_ms.append((tc - tb) * 1e3)
+        tm = g.timings()
+        gemv_us.append(tm.gemv_avg_us * tm.gemv_launches)
+        gemv_n.append(tm.gemv_launches)
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    g.set_profiling(False)
+
+    if N > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tm = g.timings()
+    ms_per_step = elapsed * 1e3 / args.steps
+    gemv_avg_us = sum(gemv_us) / max(1, sum(gemv_n))
+    gemv_bytes = tm.gemv_bytes  # s * m * W_local: algorithmic bytes of ONE launch on THIS rank
+    achieved = gemv_bytes / (gemv_avg_us * 1e-6) / 1e9 if gemv_avg_us > 0 else 0.0
+
+    # PCIe-inclusive variant (host buffers handed to the drop-in entry points), for DESIGN.md
+    th0 = time.perf_counter()
+    g.score_pairwise_consistency_euclidean(problem.D1, problem.D2, problem.A, **inv)
+    sol_h = g.solve(problem.u0)
+    host_ms = (time.perf_counter() - th0) * 1e3
+    if N > 1:
+        dist.barrier(device_ids=[local_rank])
+
+    out = None
+    if rank == 0:
+        name, cus, hbm = g.device_info()
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "gemv_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"m{args.m}_{args.storage}_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "affinity+solve ms and GEMV HBM GB/s, n=10k assoc, 95% outliers, 1/8 GPU",
+            "value": round(ms_per_step, 4),
+            "unit": "ms",
+            "n_gpus": N,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64" if args.storage == "f64" else "f64 (M stored f32)",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"synthetic 3-D registration, m={args.m} putative associations, "
+                             f"{int(round(rho * 100))}% outliers, EuclideanDistance"
+                             f"{{sigma=0.015,epsilon=0.05}}, clipper::Params defaults, "
+                             f"explicit u0 (seed {args.seed}+1)"),
+                "m": args.m, "rho": rho, "storage": args.storage,
+                "parallelism": "single GPU" if N == 1 else f"column-sharded M over {N} GPUs, RCCL all-gather per pass",
+                "device": name, "cus": cus,
+            },
+            "affinity_ms": round(sum(aff_ms) / len(aff_ms), 4),
+            "solve_ms": round(sum(solve_ms) / len(solve_ms), 4),
+            "affinity_kernel_ms": round(tm.affinity_kernel_ms, 4),
+            "gemv_passes_per_solve": int(sol.n_passes),
+            "gemv_avg_us": round(gemv_avg_us, 3),
+            "gemv_min_us": round(tm.gemv_min_us, 3),
+            "ms_per_step_host_buffers": round(host_ms, 4),
+            "solution": {"score": sol.score, "nodes": int(len(sol.nodes)), "ifinal": int(sol.ifinal)},
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "kernel": "k_gemv", "bytes_per_launch": gemv_bytes,
+            },
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            cb, sref = cpu_baseline(problem, args)
+            out["cpu_baseline"] = cb
+            out["parity"] = {
+                "set_identical": sref.nodes.tolist() == sol.nodes.tolist(),
+                "rel_dscore": abs(sref.score - sol.score) / abs(sref.score),
+            }
+        print(json.dumps(out), flush=True)
+    if N > 1:
+        dist.destroy_process_group()
+    g.close()
+
+
+if __name__ == "__main__":
+    main()

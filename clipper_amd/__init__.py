@@ -1,0 +1,9 @@
+"""clipper_amd — MI355X-native implementation of CLIPPER's dense-cluster hot path
+(affinity build + projected-gradient solver). See DESIGN.md.
+
+  clipper_amd/csrc/        hand-written gfx950 HIP kernels + the C ABI (include/clipper_hip.h)
+  clipper_amd/csrc/host/   C++ facade `clipper::CLIPPER` + pybind11 module `clipperpy`
+  clipper_amd/_abi.py      ctypes view of the C ABI (tests, bench)
+  clipper_amd/synth.py     seeded synthetic registration problems (measurement recipe)
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,372 @@
+"""ctypes binding of the C ABI in include/clipper_hip.h (clipper_amd/lib/libclipper_hip.so).
+
+This is the thinnest possible Python view of the drop-in boundary: every method is one
+C call. The user-facing Python surface of the reference (`clipperpy`, py_clipper.cpp) is
+provided by the pybind11 module built from clipper_amd/csrc/host/; this module is what the
+parity tests and bench.py drive so that they exercise exactly the exported symbols.
+
+There is no fallback: if the shared library is missing or no HIP device is usable, the
+constructors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libclipper_hip.so")
+
+STORE_F32, STORE_F64 = 0, 1
+ROUNDING_NONZERO, ROUNDING_DSD, ROUNDING_DSD_HEU = 0, 1, 2
+
+# every symbol include/clipper_hip.h declares (checked by tests/test_abi_exports.py)
+EXPORTED_SYMBOLS = [
+    "clipper_hip_device_count", "clipper_hip_create", "clipper_hip_create_group",
+    "clipper_hip_create_rank", "clipper_hip_comm_unique_id", "clipper_hip_comm_init",
+    "clipper_hip_destroy", "clipper_hip_last_error", "clipper_hip_affinity_euclidean",
+    "clipper_hip_affinity_pointnormal", "clipper_hip_num_associations",
+    "clipper_hip_get_associations", "clipper_hip_set_matrix", "clipper_hip_set_sparse",
+    "clipper_hip_get_matrix", "clipper_hip_solve", "clipper_hip_get_nodes",
+    "clipper_hip_get_selected_associations", "clipper_hip_matvec", "clipper_hip_set_profiling",
+    "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
+    "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
+    "clipper_hip_affinity_pointnormal_staged", "clipper_hip_stage_u0",
+    "clipper_hip_solve_staged",
+]
+
+
+class Params(C.Structure):
+    """clipper_params_t == clipper::Params (reference include/clipper/clipper.h:27-60)."""
+
+    _fields_ = [
+        ("tol_u", C.c_double), ("tol_F", C.c_double), ("tol_Fop", C.c_double),
+        ("maxiniters", C.c_int32), ("maxoliters", C.c_int32), ("beta", C.c_double),
+        ("maxlsiters", C.c_int32), ("eps", C.c_double), ("affinityeps", C.c_double),
+        ("rescale_u0", C.c_int32), ("rounding", C.c_int32),
+    ]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.tol_u, self.tol_F, self.tol_Fop = 1e-8, 1e-9, 1e-10
+        self.maxiniters, self.maxoliters = 200, 1000
+        self.beta, self.maxlsiters = 0.25, 99
+        self.eps, self.affinityeps = 1e-9, 1e-4
+        self.rescale_u0, self.rounding = 1, ROUNDING_DSD_HEU
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [
+        ("score", C.c_double), ("seconds", C.c_double), ("d", C.c_double),
+        ("ifinal", C.c_int32), ("num_nodes", C.c_int32),
+        ("n_passes", C.c_int64), ("n_trials", C.c_int64),
+    ]
+
+
+class Timings(C.Structure):
+    _fields_ = [
+        ("affinity_kernel_ms", C.c_double), ("affinity_total_ms", C.c_double),
+        ("solve_total_ms", C.c_double), ("gemv_avg_us", C.c_double),
+        ("gemv_min_us", C.c_double), ("gemv_launches", C.c_int64), ("gemv_bytes", C.c_double),
+    ]
+
+
+@dataclass
+class Solution:
+    """clipper::Solution (clipper.h:65-73) plus the counters this build reports."""
+
+    t: float = 0.0
+    ifinal: int = 0
+    nodes: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    u0: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    u: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    score: float = 0.0
+    d: float = 0.0
+    n_passes: int = 0
+    n_trials: int = 0
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the product library and declare the prototypes. Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(path)
+    dp, ip, i64, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int64, C.c_void_p
+    L.clipper_hip_device_count.restype = C.c_int
+    L.clipper_hip_create.argtypes = [C.c_int, C.c_int]
+    L.clipper_hip_create.restype = vp
+    L.clipper_hip_create_group.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int]
+    L.clipper_hip_create_group.restype = vp
+    L.clipper_hip_create_rank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.clipper_hip_create_rank.restype = vp
+    L.clipper_hip_comm_unique_id.argtypes = [vp]
+    L.clipper_hip_comm_init.argtypes = [vp, vp]
+    L.clipper_hip_destroy.argtypes = [vp]
+    L.clipper_hip_destroy.restype = None
+    L.clipper_hip_last_error.restype = C.c_char_p
+    L.clipper_hip_affinity_euclidean.argtypes = [
+        vp, dp, C.c_int, i64, dp, i64, ip, i64, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.clipper_hip_affinity_pointnormal.argtypes = [
+        vp, dp, C.c_int, i64, dp, i64, ip, i64, C.c_double, C.c_double, C.c_double, C.c_double,
+        C.c_double]
+    L.clipper_hip_stage_inputs.argtypes = [vp, dp, C.c_int, i64, dp, i64, ip, i64]
+    L.clipper_hip_affinity_euclidean_staged.argtypes = [vp] + [C.c_double] * 4
+    L.clipper_hip_affinity_pointnormal_staged.argtypes = [vp] + [C.c_double] * 5
+    L.clipper_hip_stage_u0.argtypes = [vp, dp]
+    L.clipper_hip_solve_staged.argtypes = [vp, C.POINTER(Params), dp, C.POINTER(SolveInfo)]
+    L.clipper_hip_num_associations.argtypes = [vp]
+    L.clipper_hip_num_associations.restype = i64
+    L.clipper_hip_get_associations.argtypes = [vp, ip]
+    L.clipper_hip_set_matrix.argtypes = [vp, dp, dp, i64]
+    L.clipper_hip_set_sparse.argtypes = [vp, i64, C.POINTER(i64), ip, dp, C.POINTER(i64), ip, dp]
+    L.clipper_hip_get_matrix.argtypes = [vp, dp, dp]
+    L.clipper_hip_solve.argtypes = [vp, dp, C.POINTER(Params), dp, C.POINTER(SolveInfo)]
+    L.clipper_hip_get_nodes.argtypes = [vp, ip, C.c_int32]
+    L.clipper_hip_get_selected_associations.argtypes = [vp, ip, C.c_int32]
+    L.clipper_hip_matvec.argtypes = [vp, dp, dp, dp]
+    L.clipper_hip_set_profiling.argtypes = [vp, C.c_int]
+    L.clipper_hip_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.clipper_hip_bench_matvec.argtypes = [vp, C.c_int, dp]
+    L.clipper_hip_device_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(i64)]
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _i64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _f64_colmajor(D):
+    return np.asfortranarray(np.asarray(D, dtype=np.float64))
+
+
+def _assoc_colmajor(A):
+    A = np.asarray(A)
+    if A.size == 0:
+        return None, 0
+    A = np.asfortranarray(A.astype(np.int32, copy=False))
+    if A.ndim != 2 or A.shape[1] != 2:
+        raise ValueError("A must be m x 2")
+    return A, A.shape[0]
+
+
+class HipClipper:
+    """One problem instance on the GPU(s); method names follow clipperpy.CLIPPER."""
+
+    def __init__(self, params: Params | None = None, device: int = 0, storage: int = STORE_F32,
+                 group: list[int] | None = None, rank: int | None = None, world: int = 1):
+        self.L = load_library()
+        self.params = params or Params()
+        if group is not None:
+            arr = (C.c_int * len(group))(*group)
+            h = self.L.clipper_hip_create_group(arr, len(group), storage)
+        elif rank is not None:
+            h = self.L.clipper_hip_create_rank(device, storage, rank, world)
+        else:
+            h = self.L.clipper_hip_create(device, storage)
+        if not h:
+            raise RuntimeError("clipper_hip_create failed: " + self.last_error())
+        self.h = C.c_void_p(h)
+        self.storage = storage
+        self.soln = Solution()
+
+    def last_error(self) -> str:
+        return self.L.clipper_hip_last_error().decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.clipper_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RuntimeError(f"clipper_hip error {rc}: {self.last_error()}")
+        return rc
+
+    # ---- communicator (multi-process shards) ----------------------------------------------
+    def unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._check(self.L.clipper_hip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid: bytes):
+        buf = C.create_string_buffer(uid, 128)
+        self._check(self.L.clipper_hip_comm_init(self.h, buf))
+
+    # ---- affinity --------------------------------------------------------------------------
+    def score_pairwise_consistency_euclidean(self, D1, D2, A=(), sigma=0.01, epsilon=0.06,
+                                             mindist=0.0):
+        D1, D2 = _f64_colmajor(D1), _f64_colmajor(D2)
+        if D1.shape[0] != D2.shape[0]:
+            raise ValueError("D1 and D2 must have the same number of rows")
+        Ac, m = _assoc_colmajor(A)
+        self._check(self.L.clipper_hip_affinity_euclidean(
+            self.h, _dp(D1), D1.shape[0], D1.shape[1], _dp(D2), D2.shape[1],
+            _ip(Ac) if Ac is not None else None, m, sigma, epsilon, mindist,
+            self.params.affinityeps))
+
+    def score_pairwise_consistency_pointnormal(self, D1, D2, A=(), sigp=0.5, epsp=0.5, sign=0.10,
+                                               epsn=0.35):
+        D1, D2 = _f64_colmajor(D1), _f64_colmajor(D2)
+        Ac, m = _assoc_colmajor(A)
+        self._check(self.L.clipper_hip_affinity_pointnormal(
+            self.h, _dp(D1), D1.shape[0], D1.shape[1], _dp(D2), D2.shape[1],
+            _ip(Ac) if Ac is not None else None, m, sigp, epsp, sign, epsn,
+            self.params.affinityeps))
+
+    # split forms: inputs resident in HBM, device work callable (and timeable) on its own
+    def stage_inputs(self, D1, D2, A=()):
+        D1, D2 = _f64_colmajor(D1), _f64_colmajor(D2)
+        if D1.shape[0] != D2.shape[0]:
+            raise ValueError("D1 and D2 must have the same number of rows")
+        Ac, m = _assoc_colmajor(A)
+        self._check(self.L.clipper_hip_stage_inputs(
+            self.h, _dp(D1), D1.shape[0], D1.shape[1], _dp(D2), D2.shape[1],
+            _ip(Ac) if Ac is not None else None, m))
+
+    def affinity_euclidean_staged(self, sigma=0.01, epsilon=0.06, mindist=0.0):
+        self._check(self.L.clipper_hip_affinity_euclidean_staged(
+            self.h, sigma, epsilon, mindist, self.params.affinityeps))
+
+    def affinity_pointnormal_staged(self, sigp=0.5, epsp=0.5, sign=0.10, epsn=0.35):
+        self._check(self.L.clipper_hip_affinity_pointnormal_staged(
+            self.h, sigp, epsp, sign, epsn, self.params.affinityeps))
+
+    def stage_u0(self, u0):
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        if u0.shape != (self.m,):
+            raise ValueError(f"u0 must have shape ({self.m},)")
+        self._u0 = u0
+        self._check(self.L.clipper_hip_stage_u0(self.h, _dp(u0)))
+
+    def solve_staged(self):
+        n = self.m
+        u = np.zeros(n)
+        info = SolveInfo()
+        self._check(self.L.clipper_hip_solve_staged(self.h, C.byref(self.params), _dp(u),
+                                                    C.byref(info)))
+        nodes = np.zeros(max(info.num_nodes, 1), dtype=np.int32)
+        k = self._check(self.L.clipper_hip_get_nodes(self.h, _ip(nodes), nodes.size))
+        self.soln = Solution(t=info.seconds, ifinal=info.ifinal, nodes=nodes[:k].copy(),
+                             u0=getattr(self, "_u0", np.zeros(0)), u=u, score=info.score,
+                             d=info.d, n_passes=info.n_passes, n_trials=info.n_trials)
+        return self.soln
+
+    @property
+    def m(self) -> int:
+        return int(self.L.clipper_hip_num_associations(self.h))
+
+    def get_initial_associations(self):
+        A = np.zeros((self.m, 2), dtype=np.int32, order="F")
+        self._check(self.L.clipper_hip_get_associations(self.h, _ip(A)))
+        return np.ascontiguousarray(A)
+
+    # ---- matrices --------------------------------------------------------------------------
+    def set_matrix_data(self, M, Cm):
+        M, Cm = _f64_colmajor(M), _f64_colmajor(Cm)
+        if M.shape != Cm.shape or M.shape[0] != M.shape[1]:
+            raise ValueError("M and C must be square and of equal size")
+        self._check(self.L.clipper_hip_set_matrix(self.h, _dp(M), _dp(Cm), M.shape[0]))
+
+    def set_sparse_matrix_data(self, m, Mcolptr, Mrow, Mval, Ccolptr, Crow, Cval):
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        Mcp, Mr, Mv = a(Mcolptr, np.int64), a(Mrow, np.int32), a(Mval, np.float64)
+        Ccp, Cr, Cv = a(Ccolptr, np.int64), a(Crow, np.int32), a(Cval, np.float64)
+        self._check(self.L.clipper_hip_set_sparse(self.h, m, _i64p(Mcp), _ip(Mr), _dp(Mv),
+                                                  _i64p(Ccp), _ip(Cr), _dp(Cv)))
+
+    def get_affinity_matrix(self):
+        m = self.m
+        M = np.zeros((m, m), order="F")
+        self._check(self.L.clipper_hip_get_matrix(self.h, _dp(M), None))
+        return M
+
+    def get_constraint_matrix(self):
+        m = self.m
+        Cm = np.zeros((m, m), order="F")
+        self._check(self.L.clipper_hip_get_matrix(self.h, None, _dp(Cm)))
+        return Cm
+
+    def matvec(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        yM, yC = np.zeros_like(x), np.zeros_like(x)
+        self._check(self.L.clipper_hip_matvec(self.h, _dp(x), _dp(yM), _dp(yC)))
+        return yM, yC
+
+    # ---- solver ----------------------------------------------------------------------------
+    def solve(self, u0):
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        n = self.m
+        if u0.shape != (n,):
+            raise ValueError(f"u0 must have shape ({n},)")
+        u = np.zeros(n)
+        info = SolveInfo()
+        self._check(self.L.clipper_hip_solve(self.h, _dp(u0), C.byref(self.params), _dp(u),
+                                             C.byref(info)))
+        nodes = np.zeros(max(info.num_nodes, 1), dtype=np.int32)
+        k = self._check(self.L.clipper_hip_get_nodes(self.h, _ip(nodes), nodes.size))
+        self.soln = Solution(t=info.seconds, ifinal=info.ifinal, nodes=nodes[:k].copy(), u0=u0,
+                             u=u, score=info.score, d=info.d, n_passes=info.n_passes,
+                             n_trials=info.n_trials)
+        return self.soln
+
+    def get_solution(self):
+        return self.soln
+
+    def get_selected_associations(self):
+        k = len(self.soln.nodes)
+        buf = np.zeros(2 * max(k, 1), dtype=np.int32)
+        kk = self._check(self.L.clipper_hip_get_selected_associations(self.h, _ip(buf), max(k, 1)))
+        if kk == 0:
+            return np.zeros((0, 2), dtype=np.int32)
+        return np.stack([buf[:kk], buf[kk:2 * kk]], axis=1)
+
+    # ---- measurement ------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._check(self.L.clipper_hip_set_profiling(self.h, int(on)))
+
+    def timings(self) -> Timings:
+        t = Timings()
+        self._check(self.L.clipper_hip_get_timings(self.h, C.byref(t)))
+        return t
+
+    def bench_matvec(self, reps: int = 20) -> float:
+        us = C.c_double()
+        self._check(self.L.clipper_hip_bench_matvec(self.h, reps, C.byref(us)))
+        return us.value
+
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        cus, hbm = C.c_int(), C.c_int64()
+        self._check(self.L.clipper_hip_device_info(self.h, name, C.byref(cus), C.byref(hbm)))
+        return name.value.decode(), cus.value, hbm.value
+
+
+def device_count() -> int:
+    return int(load_library().clipper_hip_device_count())

@@ -1,0 +1,1189 @@
+// clipper_hip.hip — host side of the C ABI declared in include/clipper_hip.h.
+//
+// Owns device memory, streams and the solve loop; all arithmetic runs in the kernels of
+// kernels.hip.h. There is no CPU fallback anywhere in this file: if HIP is unusable the
+// entry points return an error.
+//
+// Solve loop (CLIPPER::solve -> findDenseClique, /root/reference/src/clipper.cpp:172-323):
+// the whole state machine — line search, convergence tests, penalty homotopy — lives in
+// device memory (SolverState) and is advanced by k_vec. The host only enqueues
+// [k_gemv, k_reduce, (exchange), k_vec] iterations in batches and polls the `done` flag
+// of the previous batch while the next one is already queued, so the GPU never waits for
+// the host; kernels launched after convergence return immediately.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <queue>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/clipper_hip.h"
+#include "kernels.hip.h"
+
+using namespace clipper_hip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(e_ == hipErrorOutOfMemory ? CLIPPER_HIP_E_NOMEM : CLIPPER_HIP_E_HIP, \
+                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+                  __LINE__);                                                          \
+  } while (0)
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// mat-vec kernel geometry (tuned on MI355X)
+constexpr int GEMV_NW = 4;      // waves per workgroup
+constexpr int GEMV_UNR_F32 = 8; // rows in flight per wave, fp32 storage (8 x 16 B per lane)
+constexpr int GEMV_UNR_F64 = 4; // fp64 storage (4 x 32 B per lane)
+constexpr int MAX_EVENT_PAIRS = 4096;
+
+// ---- RCCL, bound at run time so the single-GPU path never loads librccl -----------------
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.lib) return 0;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* n : names) {
+    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(CLIPPER_HIP_E_COMM, "cannot load librccl: %s", dlerror());
+  auto sym = [&](const char* s) { return dlsym(lib, s); };
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
+  g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(sym("ncclAllGather"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+  g_rccl.GetErrorString =
+      reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+    return fail(CLIPPER_HIP_E_COMM, "librccl is missing required symbols");
+  g_rccl.lib = lib;
+  return 0;
+}
+
+// ---- one column slice of M on one device ------------------------------------------------
+struct Shard {
+  int device = 0;
+  int slot = 0;  // global shard index: owns columns [slot*W, slot*W + W)
+  hipStream_t stream = nullptr;
+  void* S = nullptr;   // m x W, element = float | double
+  void* Cs = nullptr;  // explicit constraint matrix, same shape (only when C != pattern(M))
+  double* part = nullptr;  // [ntiles][2][W]
+  double *u0 = nullptr, *u = nullptr, *g = nullptr, *x = nullptr, *gnew = nullptr;
+  double* ab = nullptr;  // [P][2][W]
+  SolverState* st = nullptr;
+  // affinity inputs (staged once, reused while the sizes fit)
+  double *P1 = nullptr, *P2 = nullptr;  // gathered point tables [d][pstride]
+  int32_t* Adev = nullptr;              // [2][m]
+  double *dD1 = nullptr, *dD2 = nullptr;  // raw D1, D2 as uploaded
+  size_t capP = 0, capA = 0, capD1 = 0, capD2 = 0;
+  hipEvent_t ev_reduced = nullptr, ev_copied = nullptr;
+  size_t bytes_S = 0;
+};
+
+}  // namespace
+
+struct clipper_hip_ctx {
+  int storage = CLIPPER_HIP_STORE_F32;
+  int world = 1;        // total shards P
+  bool multiproc = false;
+  std::vector<Shard> sh;  // local shards
+  ncclComm_t comm = nullptr;
+
+  int64_t m = 0;  // associations / matrix dimension
+  int64_t W = 0;  // shard pitch
+  int64_t alloc_m = 0, alloc_W = 0;
+  bool has_matrix = false;
+  bool explicitC = false;
+  int staged_d = 0;          // dimension of the staged point tables (0 = nothing staged)
+  int64_t staged_pstride = 0;
+  bool u0_staged = false;
+  int ntiles = 1, rows_per_tile = 0, nstrips = 0;
+  int cus = 256;
+
+  std::vector<int32_t> A;  // column-major m x 2 (host copy)
+  std::vector<int32_t> nodes;
+
+  SolverState* host_state = nullptr;  // pinned, 2 slots
+  hipEvent_t ev_poll[2] = {nullptr, nullptr};
+
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created lazily
+  int ev_used = 0;
+  clipper_hip_timings_t tm{};
+
+  size_t esize() const { return storage == CLIPPER_HIP_STORE_F64 ? 8 : 4; }
+};
+
+namespace {
+
+using Ctx = clipper_hip_ctx;
+
+int free_shard_buffers(Shard& s) {
+  hipSetDevice(s.device);
+  auto fr = [](auto*& p) {
+    if (p) hipFree(p);
+    p = nullptr;
+  };
+  fr(s.S);
+  fr(s.Cs);
+  fr(s.part);
+  fr(s.u0);
+  fr(s.u);
+  fr(s.g);
+  fr(s.x);
+  fr(s.gnew);
+  fr(s.ab);
+  fr(s.st);
+  fr(s.P1);
+  fr(s.P2);
+  fr(s.Adev);
+  fr(s.dD1);
+  fr(s.dD2);
+  s.capP = s.capA = s.capD1 = s.capD2 = 0;
+  s.bytes_S = 0;
+  return 0;
+}
+
+void plan_tiles(Ctx* h) {
+  const int unr = (h->storage == CLIPPER_HIP_STORE_F64) ? GEMV_UNR_F64 : GEMV_UNR_F32;
+  const int64_t chunk = static_cast<int64_t>(GEMV_NW) * unr;
+  h->nstrips = static_cast<int>(ceil_div(h->W, 256));
+  // aim at ~8 workgroups of 4 waves per CU so the whole chip streams (>> 256 workgroups)
+  const int64_t target = static_cast<int64_t>(h->cus) * 8;
+  int64_t nt = std::max<int64_t>(1, ceil_div(target, h->nstrips));
+  nt = std::min<int64_t>(nt, std::max<int64_t>(1, ceil_div(h->m, chunk)));
+  int64_t rpt = round_up(ceil_div(h->m, nt), chunk);
+  h->rows_per_tile = static_cast<int>(rpt);
+  h->ntiles = static_cast<int>(ceil_div(h->m, rpt));
+}
+
+// (re)allocate everything for an m x m problem
+int ensure_problem(Ctx* h, int64_t m) {
+  if (m <= 0) return fail(CLIPPER_HIP_E_INVALID, "m must be positive");
+  const int64_t P = h->world;
+  const int64_t W = round_up(ceil_div(m, P), 64);
+  h->m = m;
+  h->W = W;
+  plan_tiles(h);
+  if (h->alloc_m == m && h->alloc_W == W) return 0;
+  for (auto& s : h->sh) {
+    free_shard_buffers(s);
+    HIPCHK(hipSetDevice(s.device));
+    const size_t bytesS = static_cast<size_t>(m) * static_cast<size_t>(W) * h->esize();
+    HIPCHK(hipMalloc(&s.S, bytesS));
+    s.bytes_S = bytesS;
+    const size_t nvec = static_cast<size_t>(P * W) * sizeof(double);
+    HIPCHK(hipMalloc(&s.u0, nvec));
+    HIPCHK(hipMalloc(&s.u, nvec));
+    HIPCHK(hipMalloc(&s.g, nvec));
+    HIPCHK(hipMalloc(&s.x, nvec));
+    HIPCHK(hipMalloc(&s.gnew, nvec));
+    HIPCHK(hipMalloc(&s.ab, 2 * nvec));
+    HIPCHK(hipMemsetAsync(s.ab, 0, 2 * nvec, s.stream));
+    // the tile plan depends only on (m, W, storage): size for the worst case of both
+    const int64_t max_tiles = std::max<int64_t>(h->ntiles, 1);
+    HIPCHK(hipMalloc(&s.part, static_cast<size_t>(max_tiles) * 2 * W * sizeof(double)));
+    HIPCHK(hipMalloc(&s.st, sizeof(SolverState)));
+    HIPCHK(hipMemsetAsync(s.st, 0, sizeof(SolverState), s.stream));
+  }
+  h->alloc_m = m;
+  h->alloc_W = W;
+  h->has_matrix = false;
+  h->explicitC = false;
+  h->u0_staged = false;
+  h->staged_d = 0;
+  return 0;
+}
+
+template <typename T, bool HASC>
+void launch_gemv_t(Ctx* h, Shard& s, const double* x, const SolverState* st) {
+  constexpr int UNR = (sizeof(T) == 8) ? GEMV_UNR_F64 : GEMV_UNR_F32;
+  dim3 grid(h->nstrips, h->ntiles), block(GEMV_NW * 64);
+  hipLaunchKernelGGL((k_gemv<T, HASC, GEMV_NW, UNR>), grid, block, 0, s.stream,
+                     static_cast<const T*>(s.S), static_cast<const T*>(s.Cs), h->W, h->m,
+                     h->rows_per_tile, x, s.part, st);
+}
+
+void launch_gemv(Ctx* h, Shard& s, const double* x, const SolverState* st) {
+  if (h->storage == CLIPPER_HIP_STORE_F64) {
+    if (h->explicitC) launch_gemv_t<double, true>(h, s, x, st);
+    else launch_gemv_t<double, false>(h, s, x, st);
+  } else {
+    if (h->explicitC) launch_gemv_t<float, true>(h, s, x, st);
+    else launch_gemv_t<float, false>(h, s, x, st);
+  }
+}
+
+void launch_reduce(Ctx* h, Shard& s, const SolverState* st) {
+  dim3 grid(static_cast<unsigned>(ceil_div(h->W, 256))), block(256);
+  hipLaunchKernelGGL(k_reduce, grid, block, 0, s.stream, s.part, h->ntiles, h->W,
+                     s.ab + static_cast<int64_t>(s.slot) * 2 * h->W, st);
+}
+
+// exchange of the per-shard [a|b] blocks so that every shard holds the full gathered pair
+int exchange(Ctx* h) {
+  if (h->world == 1) return 0;
+  const size_t blk = static_cast<size_t>(2 * h->W) * sizeof(double);
+  if (h->multiproc) {
+    if (!h->comm) return fail(CLIPPER_HIP_E_COMM, "clipper_hip_comm_init was not called");
+    Shard& s = h->sh[0];
+    ncclResult_t r = g_rccl.AllGather(s.ab + static_cast<int64_t>(s.slot) * 2 * h->W, s.ab,
+                                      static_cast<size_t>(2 * h->W), ncclDouble, h->comm,
+                                      s.stream);
+    if (r != ncclSuccess)
+      return fail(CLIPPER_HIP_E_COMM, "ncclAllGather: %s",
+                  g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+    return 0;
+  }
+  // in-process group: device-to-device copies, ordered with events
+  for (auto& p : h->sh) {
+    HIPCHK(hipSetDevice(p.device));
+    HIPCHK(hipEventRecord(p.ev_reduced, p.stream));
+  }
+  for (auto& q : h->sh) {
+    HIPCHK(hipSetDevice(q.device));
+    for (auto& p : h->sh) {
+      if (p.slot == q.slot) continue;
+      HIPCHK(hipStreamWaitEvent(q.stream, p.ev_reduced, 0));
+      const int64_t off = static_cast<int64_t>(p.slot) * 2 * h->W;
+      if (p.device == q.device) {
+        HIPCHK(hipMemcpyAsync(q.ab + off, p.ab + off, blk, hipMemcpyDeviceToDevice, q.stream));
+      } else {
+        HIPCHK(hipMemcpyPeerAsync(q.ab + off, q.device, p.ab + off, p.device, blk, q.stream));
+      }
+    }
+    HIPCHK(hipEventRecord(q.ev_copied, q.stream));
+  }
+  // a producer may not overwrite its block (next k_reduce) before every consumer copied it
+  for (auto& p : h->sh) {
+    HIPCHK(hipSetDevice(p.device));
+    for (auto& q : h->sh) {
+      if (p.slot == q.slot) continue;
+      HIPCHK(hipStreamWaitEvent(p.stream, q.ev_copied, 0));
+    }
+  }
+  return 0;
+}
+
+// one pass over M on vector `x` of every shard: afterwards every shard's `ab` is complete
+int enqueue_pass(Ctx* h, bool use_state) {
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    const SolverState* st = use_state ? s.st : nullptr;
+    const bool prof = h->profiling && (&s == &h->sh[0]) && h->ev_used < MAX_EVENT_PAIRS;
+    if (prof) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
+    launch_gemv(h, s, s.x, st);
+    if (prof) {
+      HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used + 1], s.stream));
+      ++h->ev_used;
+    }
+    launch_reduce(h, s, st);
+  }
+  return exchange(h);
+}
+
+int enqueue_vec(Ctx* h, const SolverParams& prm) {
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    VecArgs a;
+    a.st = s.st;
+    a.prm = prm;
+    a.m = h->m;
+    a.W = h->W;
+    a.u0 = s.u0;
+    a.u = s.u;
+    a.g = s.g;
+    a.x = s.x;
+    a.gnew = s.gnew;
+    a.ab = s.ab;
+    hipLaunchKernelGGL(k_vec, dim3(1), dim3(1024), 0, s.stream, a);
+  }
+  return 0;
+}
+
+int sync_all(Ctx* h) {
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// utils::findIndicesOfkLargest (utils.cpp:33-55): min-heap of (value,index), strict '<'
+// replacement, output descending. k is clamped to n (the reference pops an empty queue).
+std::vector<int32_t> indices_of_k_largest(const std::vector<double>& x, int k) {
+  using T = std::pair<double, int>;
+  if (k < 1) return {};
+  if (static_cast<size_t>(k) > x.size()) k = static_cast<int>(x.size());
+  std::priority_queue<T, std::vector<T>, std::greater<T>> q;
+  for (size_t i = 0; i < x.size(); ++i) {
+    if (q.size() < static_cast<size_t>(k)) {
+      q.push({x[i], static_cast<int>(i)});
+    } else if (q.top().first < x[i]) {
+      q.pop();
+      q.push({x[i], static_cast<int>(i)});
+    }
+  }
+  std::vector<int32_t> out(static_cast<size_t>(k));
+  for (int i = 0; i < k; ++i) {
+    out[static_cast<size_t>(k - i - 1)] = q.top().second;
+    q.pop();
+  }
+  return out;
+}
+
+Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_slot,
+              bool multiproc) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fail(CLIPPER_HIP_E_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+    return nullptr;
+  }
+  if (storage != CLIPPER_HIP_STORE_F32 && storage != CLIPPER_HIP_STORE_F64) {
+    fail(CLIPPER_HIP_E_INVALID, "storage must be CLIPPER_HIP_STORE_F32 or _F64");
+    return nullptr;
+  }
+  Ctx* h = new Ctx();
+  h->storage = storage;
+  h->world = world;
+  h->multiproc = multiproc;
+  h->sh.resize(static_cast<size_t>(nlocal));
+  for (int p = 0; p < nlocal; ++p) {
+    Shard& s = h->sh[static_cast<size_t>(p)];
+    s.device = devices[p];
+    s.slot = first_slot + p;
+    if (s.device < 0 || s.device >= ndev) {
+      fail(CLIPPER_HIP_E_INVALID, "device %d out of range (%d visible)", s.device, ndev);
+      delete h;
+      return nullptr;
+    }
+    if (hipSetDevice(s.device) != hipSuccess ||
+        hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s.ev_reduced, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming) != hipSuccess) {
+      fail(CLIPPER_HIP_E_HIP, "cannot create stream/events on device %d", s.device);
+      delete h;
+      return nullptr;
+    }
+  }
+  // peer access between distinct devices of an in-process group
+  for (auto& a : h->sh)
+    for (auto& b : h->sh)
+      if (a.device != b.device) {
+        hipSetDevice(a.device);
+        int can = 0;
+        hipDeviceCanAccessPeer(&can, a.device, b.device);
+        if (can) {
+          hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+          (void)hipGetLastError();
+        }
+      }
+  hipSetDevice(h->sh[0].device);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, h->sh[0].device) == hipSuccess)
+    h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->host_state), 2 * sizeof(SolverState),
+                    hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_poll[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_poll[1], hipEventDisableTiming) != hipSuccess) {
+    fail(CLIPPER_HIP_E_HIP, "cannot allocate pinned solver state");
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+// uploads D (d x n, column-major) and gathers the per-association point table on device
+template <typename T>
+int ensure_cap(T*& p, size_t& cap, size_t bytes) {
+  if (bytes <= cap && p) return 0;
+  if (p) hipFree(p);
+  p = nullptr;
+  cap = 0;
+  HIPCHK(hipMalloc(&p, bytes));
+  cap = bytes;
+  return 0;
+}
+
+int upload_points(Ctx* h, Shard& s, const double* D1, const double* D2, int d, int64_t n1,
+                  int64_t n2, int64_t pstride) {
+  const size_t b1 = static_cast<size_t>(d) * n1 * sizeof(double);
+  const size_t b2 = static_cast<size_t>(d) * n2 * sizeof(double);
+  const size_t bp = static_cast<size_t>(d) * pstride * sizeof(double);
+  const size_t ba = static_cast<size_t>(2 * h->m) * sizeof(int32_t);
+  int rc;
+  if ((rc = ensure_cap(s.dD1, s.capD1, b1))) return rc;
+  if ((rc = ensure_cap(s.dD2, s.capD2, b2))) return rc;
+  size_t capP2 = s.capP;
+  if ((rc = ensure_cap(s.P1, s.capP, bp))) return rc;
+  if ((rc = ensure_cap(s.P2, capP2, bp))) return rc;
+  if ((rc = ensure_cap(s.Adev, s.capA, ba))) return rc;
+  HIPCHK(hipMemcpyAsync(s.dD1, D1, b1, hipMemcpyHostToDevice, s.stream));
+  HIPCHK(hipMemcpyAsync(s.dD2, D2, b2, hipMemcpyHostToDevice, s.stream));
+  HIPCHK(hipMemcpyAsync(s.Adev, h->A.data(), ba, hipMemcpyHostToDevice, s.stream));
+  dim3 grid(static_cast<unsigned>(ceil_div(pstride, 256))), block(256);
+  hipLaunchKernelGGL(k_gather_points, grid, block, 0, s.stream, s.dD1, d, s.Adev, h->m, pstride,
+                     s.P1);
+  hipLaunchKernelGGL(k_gather_points, grid, block, 0, s.stream, s.dD2, d, s.Adev + h->m, h->m,
+                     pstride, s.P2);
+  HIPCHK(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+// common front part of both affinity entry points: A handling + allocation + point tables
+int stage_inputs(Ctx* h, const double* D1, int d, int64_t n1, const double* D2, int64_t n2,
+                 const int32_t* A, int64_t m_in) {
+  if (!h || !D1 || !D2 || d < 1 || n1 < 1 || n2 < 1)
+    return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  int64_t m = m_in;
+  if (A == nullptr || m_in == 0) {  // clipper.cpp:24 -> utils::createAllToAll (utils.h:61-71)
+    m = n1 * n2;
+    h->A.assign(static_cast<size_t>(2 * m), 0);
+    for (int64_t i = 0; i < n1; ++i)
+      for (int64_t j = 0; j < n2; ++j) {
+        h->A[static_cast<size_t>(j + i * n2)] = static_cast<int32_t>(i);
+        h->A[static_cast<size_t>(m + j + i * n2)] = static_cast<int32_t>(j);
+      }
+  } else {
+    h->A.assign(A, A + 2 * m);
+  }
+  for (int64_t r = 0; r < m; ++r) {
+    const int32_t a0 = h->A[static_cast<size_t>(r)], a1 = h->A[static_cast<size_t>(m + r)];
+    if (a0 < 0 || a0 >= n1 || a1 < 0 || a1 >= n2)
+      return fail(CLIPPER_HIP_E_INVALID, "association %lld = (%d,%d) out of range",
+                  static_cast<long long>(r), a0, a1);
+  }
+  h->nodes.clear();
+  int rc = ensure_problem(h, m);
+  if (rc) return rc;
+  const int64_t pstride = round_up(m, 64);
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    rc = upload_points(h, s, D1, D2, d, n1, n2, pstride);
+    if (rc) return rc;
+  }
+  h->staged_d = d;
+  h->staged_pstride = pstride;
+  return 0;
+}
+
+template <typename Launch>
+int run_affinity(Ctx* h, Launch launch) {
+  // explicit constraint storage is not needed on this path: C == pattern(M)
+  for (auto& s : h->sh) {
+    if (s.Cs) {
+      hipSetDevice(s.device);
+      hipFree(s.Cs);
+      s.Cs = nullptr;
+    }
+  }
+  h->explicitC = false;
+  hipEvent_t e0, e1;
+  Shard& s0 = h->sh[0];
+  HIPCHK(hipSetDevice(s0.device));
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, s0.stream));
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    launch(s);
+  }
+  HIPCHK(hipSetDevice(s0.device));
+  HIPCHK(hipEventRecord(e1, s0.stream));
+  int rc = sync_all(h);
+  if (rc) return rc;
+  float ms = 0.f;
+  HIPCHK(hipSetDevice(s0.device));
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  h->tm.affinity_kernel_ms = ms;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  h->has_matrix = true;
+  return 0;
+}
+
+constexpr int AFF_ROWS_PER_BLK = 32;
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+const char* clipper_hip_last_error(void) { return g_err.c_str(); }
+
+int clipper_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+clipper_hip_t* clipper_hip_create(int device, int storage) {
+  return make_ctx(&device, 1, storage, 1, 0, false);
+}
+
+clipper_hip_t* clipper_hip_create_group(const int* devices, int nshards, int storage) {
+  if (!devices || nshards < 1) {
+    fail(CLIPPER_HIP_E_INVALID, "invalid shard list");
+    return nullptr;
+  }
+  return make_ctx(devices, nshards, storage, nshards, 0, false);
+}
+
+clipper_hip_t* clipper_hip_create_rank(int device, int storage, int rank, int world) {
+  if (world < 1 || rank < 0 || rank >= world) {
+    fail(CLIPPER_HIP_E_INVALID, "rank %d / world %d invalid", rank, world);
+    return nullptr;
+  }
+  return make_ctx(&device, 1, storage, world, rank, world > 1);
+}
+
+int clipper_hip_comm_unique_id(void* id128) {
+  if (!id128) return fail(CLIPPER_HIP_E_INVALID, "null id buffer");
+  int rc = load_rccl();
+  if (rc) return rc;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(CLIPPER_HIP_E_COMM, "ncclGetUniqueId failed (%d)", (int)r);
+  std::memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+int clipper_hip_comm_init(clipper_hip_t* h, const void* id128) {
+  if (!h || !id128) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (!h->multiproc) return 0;  // nothing to exchange
+  int rc = load_rccl();
+  if (rc) return rc;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  HIPCHK(hipSetDevice(h->sh[0].device));
+  ncclResult_t r = g_rccl.CommInitRank(&h->comm, h->world, id, h->sh[0].slot);
+  if (r != ncclSuccess)
+    return fail(CLIPPER_HIP_E_COMM, "ncclCommInitRank: %s",
+                g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+  return 0;
+}
+
+void clipper_hip_destroy(clipper_hip_t* h) {
+  if (!h) return;
+  for (auto& s : h->sh) {
+    hipSetDevice(s.device);
+    if (s.stream) hipStreamSynchronize(s.stream);
+  }
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  for (auto& s : h->sh) {
+    free_shard_buffers(s);
+    if (s.ev_reduced) hipEventDestroy(s.ev_reduced);
+    if (s.ev_copied) hipEventDestroy(s.ev_copied);
+    if (s.stream) hipStreamDestroy(s.stream);
+  }
+  if (!h->sh.empty()) hipSetDevice(h->sh[0].device);
+  for (hipEvent_t e : h->ev_pairs) hipEventDestroy(e);
+  if (h->ev_poll[0]) hipEventDestroy(h->ev_poll[0]);
+  if (h->ev_poll[1]) hipEventDestroy(h->ev_poll[1]);
+  if (h->host_state) hipHostFree(h->host_state);
+  delete h;
+}
+
+// ---- affinity --------------------------------------------------------------------------
+
+int clipper_hip_stage_inputs(clipper_hip_t* h, const double* D1, int d, int64_t n1,
+                             const double* D2, int64_t n2, const int32_t* A, int64_t m) {
+  return stage_inputs(h, D1, d, n1, D2, n2, A, m);
+}
+
+int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double epsilon,
+                                          double mindist, double affinityeps) {
+  if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (h->staged_d < 1) return fail(CLIPPER_HIP_E_STATE, "clipper_hip_stage_inputs not called");
+  const EuclidParams prm{sigma, epsilon, mindist, affinityeps};
+  const int64_t mm = h->m, W = h->W, pstride = h->staged_pstride;
+  const int d = h->staged_d;
+  return run_affinity(h, [&](Shard& s) {
+    dim3 grid(static_cast<unsigned>(ceil_div(W, 1024)),
+              static_cast<unsigned>(ceil_div(mm, AFF_ROWS_PER_BLK))),
+        block(256);
+    const int64_t c0 = static_cast<int64_t>(s.slot) * W;
+    const int32_t* A0 = s.Adev;
+    const int32_t* A1 = s.Adev + mm;
+#define LAUNCH_EUCLID(T, D)                                                                 \
+  hipLaunchKernelGGL((k_affinity_euclid<T, D>), grid, block, 0, s.stream,                   \
+                     static_cast<T*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, d, s.P1, s.P2, pstride, \
+                     A0, A1, prm)
+    if (h->storage == CLIPPER_HIP_STORE_F64) {
+      if (d == 3) LAUNCH_EUCLID(double, 3);
+      else if (d == 2) LAUNCH_EUCLID(double, 2);
+      else LAUNCH_EUCLID(double, 0);
+    } else {
+      if (d == 3) LAUNCH_EUCLID(float, 3);
+      else if (d == 2) LAUNCH_EUCLID(float, 2);
+      else LAUNCH_EUCLID(float, 0);
+    }
+#undef LAUNCH_EUCLID
+  });
+}
+
+int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, double epsp,
+                                            double sign, double epsn, double affinityeps) {
+  if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (h->staged_d != 6)
+    return fail(CLIPPER_HIP_E_STATE, "PointNormalDistance needs staged inputs with d == 6");
+  const PointNormalParams prm{sigp, epsp, sign, epsn, affinityeps};
+  const int64_t mm = h->m, W = h->W, pstride = h->staged_pstride;
+  return run_affinity(h, [&](Shard& s) {
+    dim3 grid(static_cast<unsigned>(ceil_div(W, 1024)),
+              static_cast<unsigned>(ceil_div(mm, AFF_ROWS_PER_BLK))),
+        block(256);
+    const int64_t c0 = static_cast<int64_t>(s.slot) * W;
+    if (h->storage == CLIPPER_HIP_STORE_F64)
+      hipLaunchKernelGGL((k_affinity_pointnormal<double>), grid, block, 0, s.stream,
+                         static_cast<double*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2,
+                         pstride, s.Adev, s.Adev + mm, prm);
+    else
+      hipLaunchKernelGGL((k_affinity_pointnormal<float>), grid, block, 0, s.stream,
+                         static_cast<float*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2,
+                         pstride, s.Adev, s.Adev + mm, prm);
+  });
+}
+
+int clipper_hip_affinity_euclidean(clipper_hip_t* h, const double* D1, int d, int64_t n1,
+                                   const double* D2, int64_t n2, const int32_t* A, int64_t m,
+                                   double sigma, double epsilon, double mindist,
+                                   double affinityeps) {
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  int rc = stage_inputs(h, D1, d, n1, D2, n2, A, m);
+  if (rc) return rc;
+  rc = clipper_hip_affinity_euclidean_staged(h, sigma, epsilon, mindist, affinityeps);
+  if (rc) return rc;
+  h->tm.affinity_total_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0)
+          .count();
+  return 0;
+}
+
+int clipper_hip_affinity_pointnormal(clipper_hip_t* h, const double* D1, int d, int64_t n1,
+                                     const double* D2, int64_t n2, const int32_t* A, int64_t m,
+                                     double sigp, double epsp, double sign, double epsn,
+                                     double affinityeps) {
+  if (d != 6) return fail(CLIPPER_HIP_E_INVALID, "PointNormalDistance needs d == 6");
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  int rc = stage_inputs(h, D1, d, n1, D2, n2, A, m);
+  if (rc) return rc;
+  rc = clipper_hip_affinity_pointnormal_staged(h, sigp, epsp, sign, epsn, affinityeps);
+  if (rc) return rc;
+  h->tm.affinity_total_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0)
+          .count();
+  return 0;
+}
+
+int64_t clipper_hip_num_associations(const clipper_hip_t* h) { return h ? h->m : 0; }
+
+int clipper_hip_get_associations(const clipper_hip_t* h, int32_t* A_out) {
+  if (!h || !A_out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (h->A.size() != static_cast<size_t>(2 * h->m))
+    return fail(CLIPPER_HIP_E_STATE, "no association list is held");
+  std::memcpy(A_out, h->A.data(), h->A.size() * sizeof(int32_t));
+  return 0;
+}
+
+// ---- matrix set / get ------------------------------------------------------------------
+
+int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, int64_t m) {
+  if (!h || !M || !C || m < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (h->A.size() != static_cast<size_t>(2 * m)) h->A.clear();
+  h->nodes.clear();
+  int rc = ensure_problem(h, m);
+  if (rc) return rc;
+  const size_t bytes = static_cast<size_t>(m) * m * sizeof(double);
+  const int64_t W = h->W;
+  // pass 1: fill S and detect whether C is anything other than pattern(M)
+  std::vector<double*> dM(h->sh.size(), nullptr), dC(h->sh.size(), nullptr);
+  std::vector<int*> dflag(h->sh.size(), nullptr);
+  int mismatch = 0;
+  for (size_t k = 0; k < h->sh.size(); ++k) {
+    Shard& s = h->sh[k];
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMalloc(&dM[k], bytes));
+    HIPCHK(hipMalloc(&dC[k], bytes));
+    HIPCHK(hipMalloc(&dflag[k], sizeof(int)));
+    HIPCHK(hipMemsetAsync(dflag[k], 0, sizeof(int), s.stream));
+    HIPCHK(hipMemcpyAsync(dM[k], M, bytes, hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipMemcpyAsync(dC[k], C, bytes, hipMemcpyHostToDevice, s.stream));
+    if (s.Cs) {
+      hipFree(s.Cs);
+      s.Cs = nullptr;
+    }
+    dim3 grid(static_cast<unsigned>(ceil_div(W, 256)), static_cast<unsigned>(m)), block(256);
+    const int64_t c0 = static_cast<int64_t>(s.slot) * W;
+    if (h->storage == CLIPPER_HIP_STORE_F64)
+      hipLaunchKernelGGL((k_from_dense_upper<double>), grid, block, 0, s.stream,
+                         static_cast<double*>(s.S), W, m, c0, dM[k], dC[k],
+                         static_cast<double*>(nullptr), dflag[k]);
+    else
+      hipLaunchKernelGGL((k_from_dense_upper<float>), grid, block, 0, s.stream,
+                         static_cast<float*>(s.S), W, m, c0, dM[k], dC[k],
+                         static_cast<float*>(nullptr), dflag[k]);
+    int f = 0;
+    HIPCHK(hipMemcpyAsync(&f, dflag[k], sizeof(int), hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    mismatch |= f;
+  }
+  // NOTE: in multi-process mode every rank sees the whole (M, C), so `mismatch` agrees.
+  // The full upper triangle must be inspected, not only owned columns: do it on the host
+  // cheaply when sharded (owned columns cover all (lo,hi) pairs with hi or lo owned only).
+  if (h->world > 1 && !mismatch) {
+    for (int64_t hi = 1; hi < m && !mismatch; ++hi)
+      for (int64_t lo = 0; lo < hi; ++lo) {
+        const double mv = M[lo + hi * m], cv = C[lo + hi * m];
+        if (cv != ((mv != 0.0) ? 1.0 : 0.0)) {
+          mismatch = 1;
+          break;
+        }
+      }
+  }
+  h->explicitC = (mismatch != 0);
+  if (h->explicitC) {
+    for (size_t k = 0; k < h->sh.size(); ++k) {
+      Shard& s = h->sh[k];
+      HIPCHK(hipSetDevice(s.device));
+      HIPCHK(hipMalloc(&s.Cs, s.bytes_S));
+      dim3 grid(static_cast<unsigned>(ceil_div(W, 256)), static_cast<unsigned>(m)), block(256);
+      const int64_t c0 = static_cast<int64_t>(s.slot) * W;
+      if (h->storage == CLIPPER_HIP_STORE_F64)
+        hipLaunchKernelGGL((k_from_dense_upper<double>), grid, block, 0, s.stream,
+                           static_cast<double*>(s.S), W, m, c0, dM[k], dC[k],
+                           static_cast<double*>(s.Cs), static_cast<int*>(nullptr));
+      else
+        hipLaunchKernelGGL((k_from_dense_upper<float>), grid, block, 0, s.stream,
+                           static_cast<float*>(s.S), W, m, c0, dM[k], dC[k],
+                           static_cast<float*>(s.Cs), static_cast<int*>(nullptr));
+    }
+  }
+  rc = sync_all(h);
+  for (size_t k = 0; k < h->sh.size(); ++k) {
+    hipSetDevice(h->sh[k].device);
+    hipFree(dM[k]);
+    hipFree(dC[k]);
+    hipFree(dflag[k]);
+  }
+  if (rc) return rc;
+  h->has_matrix = true;
+  return 0;
+}
+
+int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
+                           const int32_t* Mrow, const double* Mval, const int64_t* Ccolptr,
+                           const int32_t* Crow, const double* Cval) {
+  if (!h || !Mcolptr || !Ccolptr || m < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  const int64_t nnzM = Mcolptr[m], nnzC = Ccolptr[m];
+  if ((nnzM > 0 && (!Mrow || !Mval)) || (nnzC > 0 && (!Crow || !Cval)))
+    return fail(CLIPPER_HIP_E_INVALID, "null CSC arrays");
+  if (h->A.size() != static_cast<size_t>(2 * m)) h->A.clear();
+  h->nodes.clear();
+  int rc = ensure_problem(h, m);
+  if (rc) return rc;
+  // C == pattern(M)?  (same structure, every stored C equal to 1, every stored M non-zero)
+  bool pattern = (nnzM == nnzC) && std::equal(Mcolptr, Mcolptr + m + 1, Ccolptr) &&
+                 std::equal(Mrow, Mrow + nnzM, Crow);
+  for (int64_t p = 0; pattern && p < nnzM; ++p) pattern = (Cval[p] == 1.0) && (Mval[p] != 0.0);
+  h->explicitC = !pattern;
+  const int64_t W = h->W;
+  auto scatter = [&](Shard& s, void* dst, const int64_t* cp, const int32_t* ri, const double* va,
+                     int64_t nnz) -> int {
+    int64_t* dcp = nullptr;
+    int32_t* dri = nullptr;
+    double* dva = nullptr;
+    HIPCHK(hipMalloc(&dcp, static_cast<size_t>(m + 1) * sizeof(int64_t)));
+    HIPCHK(hipMalloc(&dri, std::max<size_t>(1, static_cast<size_t>(nnz)) * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&dva, std::max<size_t>(1, static_cast<size_t>(nnz)) * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(dcp, cp, static_cast<size_t>(m + 1) * sizeof(int64_t),
+                          hipMemcpyHostToDevice, s.stream));
+    if (nnz > 0) {
+      HIPCHK(hipMemcpyAsync(dri, ri, static_cast<size_t>(nnz) * sizeof(int32_t),
+                            hipMemcpyHostToDevice, s.stream));
+      HIPCHK(hipMemcpyAsync(dva, va, static_cast<size_t>(nnz) * sizeof(double),
+                            hipMemcpyHostToDevice, s.stream));
+    }
+    HIPCHK(hipMemsetAsync(dst, 0, s.bytes_S, s.stream));
+    const int64_t c0 = static_cast<int64_t>(s.slot) * W;
+    dim3 grid(static_cast<unsigned>(m)), block(256);
+    if (h->storage == CLIPPER_HIP_STORE_F64)
+      hipLaunchKernelGGL((k_from_csc<double>), grid, block, 0, s.stream,
+                         static_cast<double*>(dst), W, m, c0, W, dcp, dri, dva);
+    else
+      hipLaunchKernelGGL((k_from_csc<float>), grid, block, 0, s.stream, static_cast<float*>(dst),
+                         W, m, c0, W, dcp, dri, dva);
+    HIPCHK(hipStreamSynchronize(s.stream));
+    hipFree(dcp);
+    hipFree(dri);
+    hipFree(dva);
+    return 0;
+  };
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    if (s.Cs) {
+      hipFree(s.Cs);
+      s.Cs = nullptr;
+    }
+    rc = scatter(s, s.S, Mcolptr, Mrow, Mval, nnzM);
+    if (rc) return rc;
+    if (h->explicitC) {
+      HIPCHK(hipMalloc(&s.Cs, s.bytes_S));
+      rc = scatter(s, s.Cs, Ccolptr, Crow, Cval, nnzC);
+      if (rc) return rc;
+    }
+  }
+  h->has_matrix = true;
+  return 0;
+}
+
+int clipper_hip_get_matrix(clipper_hip_t* h, double* M_out, double* C_out) {
+  if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
+  if (h->multiproc)
+    return fail(CLIPPER_HIP_E_STATE, "get_matrix is not available on a multi-process shard");
+  const int64_t m = h->m, W = h->W;
+  const bool f64 = (h->storage == CLIPPER_HIP_STORE_F64);
+  std::vector<unsigned char> buf;
+  auto fetch = [&](Shard& s, const void* src, double* out, bool as_pattern) -> int {
+    buf.resize(s.bytes_S);
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMemcpy(buf.data(), src, s.bytes_S, hipMemcpyDeviceToHost));
+    const int64_t c0 = static_cast<int64_t>(s.slot) * W;
+    for (int64_t c = 0; c < W; ++c) {
+      const int64_t g = c0 + c;
+      if (g >= m) break;
+      for (int64_t j = 0; j < m; ++j) {
+        const double v = f64 ? reinterpret_cast<const double*>(buf.data())[j * W + c]
+                             : static_cast<double>(
+                                   reinterpret_cast<const float*>(buf.data())[j * W + c]);
+        double o = as_pattern ? ((v != 0.0) ? 1.0 : 0.0) : v;
+        if (j == g) o += 1.0;  // clipper.cpp:133-134, 142-143: identity added
+        out[j + g * m] = o;
+      }
+    }
+    return 0;
+  };
+  for (auto& s : h->sh) {
+    int rc;
+    if (M_out && (rc = fetch(s, s.S, M_out, false))) return rc;
+    if (C_out) {
+      rc = h->explicitC ? fetch(s, s.Cs, C_out, false) : fetch(s, s.S, C_out, true);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+// ---- solver ------------------------------------------------------------------------------
+
+int clipper_hip_stage_u0(clipper_hip_t* h, const double* u0) {
+  if (!h || !u0) return fail(CLIPPER_HIP_E_INVALID, "u0 is required");
+  if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
+  const size_t vbytes = static_cast<size_t>(h->m) * sizeof(double);
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMemcpyAsync(s.u0, u0, vbytes, hipMemcpyHostToDevice, s.stream));
+  }
+  int rc = sync_all(h);
+  if (rc) return rc;
+  h->u0_staged = true;
+  return 0;
+}
+
+int clipper_hip_solve(clipper_hip_t* h, const double* u0, const clipper_params_t* P,
+                      double* u_out, clipper_solve_info_t* info) {
+  if (!h || !u0 || !P) return fail(CLIPPER_HIP_E_INVALID, "u0 and params are required");
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  int rc = clipper_hip_stage_u0(h, u0);
+  if (rc) return rc;
+  rc = clipper_hip_solve_staged(h, P, u_out, info);
+  if (rc) return rc;
+  const double secs =
+      std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+  h->tm.solve_total_ms = secs * 1e3;
+  if (info) info->seconds = secs;
+  return 0;
+}
+
+int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double* u_out,
+                             clipper_solve_info_t* info) {
+  if (!h || !P) return fail(CLIPPER_HIP_E_INVALID, "params are required");
+  if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
+  if (!h->u0_staged) return fail(CLIPPER_HIP_E_STATE, "clipper_hip_stage_u0 not called");
+  if (P->rounding == CLIPPER_ROUNDING_DSD)
+    return fail(CLIPPER_HIP_E_SCOPE,
+                "Rounding::DSD (exact densest sub-graph, dsd.cpp) is outside the hot-path scope");
+  if (P->rounding != CLIPPER_ROUNDING_NONZERO && P->rounding != CLIPPER_ROUNDING_DSD_HEU)
+    return fail(CLIPPER_HIP_E_INVALID, "unknown rounding mode %d", P->rounding);
+  if (P->maxlsiters < 1) return fail(CLIPPER_HIP_E_INVALID, "maxlsiters must be >= 1");
+
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  const int64_t m = h->m;
+  const size_t vbytes = static_cast<size_t>(m) * sizeof(double);
+
+  if (h->profiling && h->ev_pairs.empty()) {
+    HIPCHK(hipSetDevice(h->sh[0].device));
+    h->ev_pairs.resize(2 * MAX_EVENT_PAIRS);
+    for (auto& e : h->ev_pairs) HIPCHK(hipEventCreate(&e));
+  }
+  h->ev_used = 0;
+
+  SolverParams prm;
+  prm.tol_u = P->tol_u;
+  prm.tol_F = P->tol_F;
+  prm.beta = P->beta;
+  prm.eps = P->eps;
+  prm.maxiniters = P->maxiniters;
+  prm.maxoliters = P->maxoliters;
+  prm.maxlsiters = P->maxlsiters;
+
+  SolverState init;
+  std::memset(&init, 0, sizeof(init));
+  init.alpha = 1.0;
+  init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMemcpyAsync(s.x, s.u0, vbytes, hipMemcpyDeviceToDevice, s.stream));
+    HIPCHK(hipMemcpyAsync(s.st, &init, sizeof(init), hipMemcpyHostToDevice, s.stream));
+  }
+  int rc = 0;
+  if (!P->rescale_u0) {
+    if ((rc = enqueue_vec(h, prm))) return rc;  // PH_NORMALIZE consumes no pass
+  }
+
+  // Batched, pipelined enqueue: batch n+1 is queued before the host looks at the state
+  // snapshot taken after batch n.
+  Shard& s0 = h->sh[0];
+  int batch = 8;
+  int slot = 0;
+  bool have_prev = false;
+  bool done = false;
+  while (!done) {
+    for (int it = 0; it < batch; ++it) {
+      if ((rc = enqueue_pass(h, true))) return rc;
+      if ((rc = enqueue_vec(h, prm))) return rc;
+    }
+    HIPCHK(hipSetDevice(s0.device));
+    HIPCHK(hipMemcpyAsync(&h->host_state[slot], s0.st, sizeof(SolverState),
+                          hipMemcpyDeviceToHost, s0.stream));
+    HIPCHK(hipEventRecord(h->ev_poll[slot], s0.stream));
+    if (have_prev) {
+      HIPCHK(hipEventSynchronize(h->ev_poll[slot ^ 1]));
+      if (h->host_state[slot ^ 1].done) done = true;
+    }
+    have_prev = true;
+    slot ^= 1;
+    if (batch < 32) batch *= 2;
+    if (done) break;
+    // with a single batch in flight and nothing queued behind it, peek without waiting
+    if (hipEventQuery(h->ev_poll[slot ^ 1]) == hipSuccess) {
+      if (h->host_state[slot ^ 1].done) done = true;
+    } else {
+      (void)hipGetLastError();  // hipErrorNotReady is not a failure
+    }
+  }
+  if ((rc = sync_all(h))) return rc;
+
+  SolverState fin;
+  HIPCHK(hipSetDevice(s0.device));
+  HIPCHK(hipMemcpy(&fin, s0.st, sizeof(fin), hipMemcpyDeviceToHost));
+  std::vector<double> u(static_cast<size_t>(m));
+  HIPCHK(hipMemcpy(u.data(), s0.u, vbytes, hipMemcpyDeviceToHost));
+
+  // rounding — clipper.cpp:287-310 with utils.cpp:33-68, on the host
+  std::vector<int32_t> nodes;
+  if (P->rounding == CLIPPER_ROUNDING_NONZERO) {
+    for (int64_t i = 0; i < m; ++i)
+      if (u[static_cast<size_t>(i)] > 0.0) nodes.push_back(static_cast<int32_t>(i));
+  } else {
+    const int omega = static_cast<int>(std::round(fin.F));  // :305
+    nodes = indices_of_k_largest(u, omega);                 // :308
+  }
+  h->nodes = nodes;
+  if (u_out) std::memcpy(u_out, u.data(), vbytes);
+
+  const double secs =
+      std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+  h->tm.solve_total_ms = secs * 1e3;
+  if (info) {
+    info->score = fin.F;
+    info->seconds = secs;
+    info->d = fin.d;
+    info->ifinal = fin.ifinal;
+    info->num_nodes = static_cast<int32_t>(nodes.size());
+    info->n_passes = fin.n_passes;
+    info->n_trials = fin.n_trials;
+  }
+
+  // mat-vec timings from the event pairs
+  h->tm.gemv_avg_us = h->tm.gemv_min_us = 0.0;
+  h->tm.gemv_launches = 0;
+  h->tm.gemv_bytes =
+      static_cast<double>(h->esize()) * static_cast<double>(m) * static_cast<double>(h->W) *
+      (h->explicitC ? 2.0 : 1.0);
+  if (h->profiling && h->ev_used > 0) {
+    // only launches that did real work count: the first n_passes of them
+    const int64_t nreal = std::min<int64_t>(h->ev_used, fin.n_passes);
+    double sum = 0.0, mn = 1e30;
+    for (int64_t k = 0; k < nreal; ++k) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, h->ev_pairs[2 * k], h->ev_pairs[2 * k + 1]));
+      sum += ms;
+      mn = std::min<double>(mn, ms);
+    }
+    if (nreal > 0) {
+      h->tm.gemv_avg_us = sum / static_cast<double>(nreal) * 1e3;
+      h->tm.gemv_min_us = mn * 1e3;
+      h->tm.gemv_launches = nreal;
+    }
+  }
+  return 0;
+}
+
+int clipper_hip_get_nodes(const clipper_hip_t* h, int32_t* out, int32_t capacity) {
+  if (!h || !out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  const int32_t k = static_cast<int32_t>(h->nodes.size());
+  if (capacity < k) return fail(CLIPPER_HIP_E_INVALID, "capacity %d < %d nodes", capacity, k);
+  if (k) std::memcpy(out, h->nodes.data(), static_cast<size_t>(k) * sizeof(int32_t));
+  return k;
+}
+
+// utils::selectInlierAssociations — utils.cpp:101-108
+int clipper_hip_get_selected_associations(const clipper_hip_t* h, int32_t* A_out,
+                                          int32_t capacity) {
+  if (!h || !A_out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  const int32_t k = static_cast<int32_t>(h->nodes.size());
+  if (capacity < k) return fail(CLIPPER_HIP_E_INVALID, "capacity %d < %d nodes", capacity, k);
+  if (k == 0) return 0;
+  if (h->A.size() != static_cast<size_t>(2 * h->m))
+    return fail(CLIPPER_HIP_E_STATE, "no association list is held");
+  for (int32_t r = 0; r < k; ++r) {
+    const size_t n = static_cast<size_t>(h->nodes[static_cast<size_t>(r)]);
+    A_out[r] = h->A[n];
+    A_out[k + r] = h->A[static_cast<size_t>(h->m) + n];
+  }
+  return k;
+}
+
+int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC) {
+  if (!h || !x) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
+  const int64_t m = h->m, W = h->W;
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMemcpyAsync(s.x, x, static_cast<size_t>(m) * sizeof(double),
+                          hipMemcpyHostToDevice, s.stream));
+  }
+  const bool prof = h->profiling;
+  h->profiling = false;
+  int rc = enqueue_pass(h, false);
+  h->profiling = prof;
+  if (rc) return rc;
+  if ((rc = sync_all(h))) return rc;
+  std::vector<double> ab(static_cast<size_t>(h->world) * 2 * W);
+  Shard& s0 = h->sh[0];
+  HIPCHK(hipSetDevice(s0.device));
+  HIPCHK(hipMemcpy(ab.data(), s0.ab, ab.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < m; ++i) {
+    const int64_t p = i / W, off = i - p * W;
+    if (yM) yM[i] = ab[static_cast<size_t>(p * 2 * W + off)];
+    if (yC) yC[i] = ab[static_cast<size_t>(p * 2 * W + W + off)];
+  }
+  return 0;
+}
+
+// ---- measurement ---------------------------------------------------------------------------
+
+int clipper_hip_set_profiling(clipper_hip_t* h, int on) {
+  if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  h->profiling = (on != 0);
+  return 0;
+}
+
+int clipper_hip_get_timings(const clipper_hip_t* h, clipper_hip_timings_t* out) {
+  if (!h || !out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  *out = h->tm;
+  return 0;
+}
+
+int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
+  if (!h || reps < 1 || !avg_us) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
+  Shard& s = h->sh[0];
+  HIPCHK(hipSetDevice(s.device));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) launch_gemv(h, s, s.x, nullptr);
+  HIPCHK(hipEventRecord(e0, s.stream));
+  for (int r = 0; r < reps; ++r) launch_gemv(h, s, s.x, nullptr);
+  HIPCHK(hipEventRecord(e1, s.stream));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *avg_us = static_cast<double>(ms) * 1e3 / reps;
+  h->tm.gemv_bytes = static_cast<double>(h->esize()) * static_cast<double>(h->m) *
+                     static_cast<double>(h->W) * (h->explicitC ? 2.0 : 1.0);
+  return 0;
+}
+
+int clipper_hip_device_info(const clipper_hip_t* h, char* name64, int* cus, int64_t* hbm_bytes) {
+  if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, h->sh[0].device));
+  if (name64) {
+    std::snprintf(name64, 64, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (cus) *cus = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,725 @@
+// kernels.hip.h — hand-written CDNA4 (gfx950, wave64) kernels of the CLIPPER hot path.
+//
+// Compiled with -ffp-contract=off: every fp64 expression rounds exactly as written and
+// fused multiply-adds appear only where fma() is spelled out — the same convention as the
+// CPU oracle, so that threshold decisions (c < epsilon, scr > affinityeps, deltaF < -eps)
+// are taken on bit-identical operands wherever the operation order can be shared.
+//
+// Data layout (see include/clipper_hip.h): a shard owns global columns [c0, c0+W) of the
+// symmetric matrix M_off and stores S[j][c] = M(j, c0+c), j = 0..m-1, row pitch ld = W
+// (multiple of 64 elements, zero padded). Because M is symmetric, column c of S is row
+// (c0+c) of M, so   (M_off x)[c0+c] = sum_j S[j][c] * x[j]:
+// every lane owns output columns, walks down the rows with a wave-uniform x[j] (scalar
+// load), and never needs a cross-lane reduction; a wave's 64 lanes read 64 x 16 B =
+// 1 KiB of one row per load instruction — fully coalesced HBM streaming.
+//
+// Reference sites (relative to /root/reference):
+//   k_affinity_*  : src/clipper.cpp:31-56 + src/invariants/euclidean_distance.cpp:13-31,
+//                   src/invariants/pointnormal_distance.cpp:13-35
+//   k_gemv        : every `M_.selfadjointView<Upper>() * v` / `C_...* v` in
+//                   src/clipper.cpp:194,202,205,219,240-241,268,271 (one fused pass gives both)
+//   k_vec         : the O(m) algebra and control flow of findDenseClique,
+//                   src/clipper.cpp:193-209 (init), :219-220 (gradient), :226-262 (step,
+//                   projection, line search), :268-280 (penalty update)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clipper_hip {
+
+// ------------------------------------------------------------------------------------------
+// solver state that lives in device memory for the whole solve (the host only polls `done`)
+// ------------------------------------------------------------------------------------------
+
+enum Phase : int32_t {
+  PH_NORMALIZE = 0,  // no rescale: u = u0/||u0||, no pass consumed       (clipper.cpp:196-198)
+  PH_RESCALE = 1,    // pass was on x = u0: u = M_off u0 + u0, normalise  (clipper.cpp:193-198)
+  PH_INIT = 2,       // pass was on x = u: initial d, first gradient      (clipper.cpp:200-220)
+  PH_TRIAL = 3       // pass was on x = unew: line-search bookkeeping     (clipper.cpp:234-262)
+};
+
+struct SolverState {
+  double d;       // penalty
+  double F;       // objective at u
+  double alpha;   // current step size
+  double s;       // sum(u)
+  double sx;      // sum(x) of the pending trial vector
+  int32_t phase;
+  int32_t i, j, k;  // outer / inner / line-search counters (clipper.cpp:217)
+  int32_t done;
+  int32_t ifinal;
+  int64_t n_passes;
+  int64_t n_trials;
+};
+
+struct SolverParams {
+  double tol_u, tol_F, beta, eps;
+  int32_t maxiniters, maxoliters, maxlsiters;
+};
+
+struct VecArgs {
+  SolverState* st;
+  SolverParams prm;
+  int64_t m;   // problem size
+  int64_t W;   // shard pitch: element i lives in block p = i / W of `ab`
+  const double* u0;
+  double* u;
+  double* g;     // gradF at u
+  double* x;     // vector the next / last pass runs on (unew)
+  double* gnew;  // gradF at x
+  const double* ab;  // [P][2][W]: a = M_off x, b = C_off x, gathered from all shards
+};
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask, 64);
+  hi = __shfl_xor(hi, mask, 64);
+  return __hiloint2double(hi, lo);
+}
+
+// Deterministic block reduction of N doubles over a 1024-thread block (16 waves):
+// xor-butterfly inside each wave, then every thread sums the 16 wave partials in index
+// order, so all threads hold the identical result and the summation tree is fixed.
+template <int N>
+__device__ __forceinline__ void block_reduce_1024(double (&v)[N], double* lds /* [16*N] */) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] += shfl_xor_f64(v[q], off);
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // previous users of `lds` are done
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) lds[wave * N + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    double acc = lds[q];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) acc += lds[w * N + q];
+    v[q] = acc;
+  }
+}
+
+__device__ __forceinline__ void ab_at(const double* ab, int64_t W, int64_t i, double& a,
+                                      double& b) {
+  const int64_t p = i / W;
+  const int64_t off = i - p * W;
+  const double* blk = ab + p * 2 * W;
+  a = blk[off];
+  b = blk[W + off];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_vec — all O(m) vector algebra and every branch decision of findDenseClique, on device.
+// One 1024-thread workgroup; thread t owns elements t, t+1024, ... in every sweep, so the
+// sweeps need no synchronisation between them apart from the reductions.
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(1024) void k_vec(VecArgs A) {
+  SolverState* st = A.st;
+  if (st->done) return;
+
+  __shared__ double red[16 * 2];
+  const int tid = threadIdx.x;
+  const int64_t m = A.m;
+  const SolverParams P = A.prm;
+
+  const int phase = st->phase;
+  double d = st->d, F = st->F, alpha = st->alpha, s = st->s;
+  int i_ = st->i, j_ = st->j, k_ = st->k;
+  int64_t n_passes = st->n_passes, n_trials = st->n_trials;
+  if (phase != PH_NORMALIZE) ++n_passes;
+
+  if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
+    // clipper.cpp:193-198 — u = M_off*u0 + u0 (or u0), then u /= u.norm()
+    double z[1] = {0.0};
+    for (int64_t i = tid; i < m; i += 1024) {
+      double ui = A.u0[i];
+      if (phase == PH_RESCALE) {
+        double a, b;
+        ab_at(A.ab, A.W, i, a, b);
+        ui = a + ui;
+      }
+      A.u[i] = ui;
+      z[0] += ui * ui;
+    }
+    block_reduce_1024<1>(z, red);
+    const double nrm = sqrt(z[0]);
+    for (int64_t i = tid; i < m; i += 1024) {
+      const double ui = A.u[i] / nrm;
+      A.u[i] = ui;
+      A.x[i] = ui;
+    }
+    if (tid == 0) {
+      st->phase = PH_INIT;
+      st->n_passes = n_passes;
+    }
+    return;
+  }
+
+  bool begin_outer = false, end_inner = false, finished = false;
+
+  if (phase == PH_INIT) {
+    // clipper.cpp:200-209 — initial d from the pass on u
+    double sv[1] = {0.0};
+    for (int64_t i = tid; i < m; i += 1024) sv[0] += A.u[i];
+    block_reduce_1024<1>(sv, red);
+    s = sv[0];
+    double ca[2] = {0.0, 0.0};  // count, sum of ratios
+    for (int64_t i = tid; i < m; i += 1024) {
+      double a, b;
+      ab_at(A.ab, A.W, i, a, b);
+      const double ui = A.u[i];
+      const double cbu = s - b - ui;  // :202
+      if (cbu > P.eps && ui > P.eps) {  // :203
+        ca[0] += 1.0;
+        ca[1] += (a + ui) / cbu;  // :205-208
+      }
+    }
+    block_reduce_1024<2>(ca, red);
+    d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
+    i_ = 0;
+    begin_outer = true;
+  } else {  // PH_TRIAL — clipper.cpp:238-262 for the trial vector x = unew
+    ++n_trials;
+    const double sx = st->sx;
+    double r[2] = {0.0, 0.0};  // Fnew, ||x-u||^2
+    for (int64_t i = tid; i < m; i += 1024) {
+      double a, b;
+      ab_at(A.ab, A.W, i, a, b);
+      const double xi = A.x[i];
+      const double gn = (1 + d) * xi - d * sx + a + b * d;  // :238-241
+      A.gnew[i] = gn;
+      r[0] += xi * gn;  // :242
+      const double t = xi - A.u[i];
+      r[1] += t * t;  // :253
+    }
+    block_reduce_1024<2>(r, red);
+    const double Fnew = r[0];
+    const double deltaF = Fnew - F;  // :244
+    bool accept = true;
+    if (deltaF < -P.eps) {  // :246-248
+      alpha = alpha * P.beta;
+      ++k_;
+      if (k_ < P.maxlsiters) accept = false;  // :234 loop bound; last trial is kept
+    }
+    if (accept) {
+      const double deltau = sqrt(r[1]);
+      F = Fnew;  // :256-258
+      for (int64_t i = tid; i < m; i += 1024) {
+        A.u[i] = A.x[i];
+        A.g[i] = A.gnew[i];
+      }
+      s = sx;
+      ++j_;
+      if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
+        end_inner = true;
+      } else {
+        alpha = 1.0;  // :227
+        k_ = 0;
+      }
+    }
+  }
+
+  // Transitions that need no pass over M: penalty update (:268-280) and the gradient at the
+  // start of the next outer iteration (:219-220) reuse (a, b) of the accepted vector.
+  while (true) {
+    if (end_inner) {
+      double ca[2] = {0.0, 0.0};
+      for (int64_t i = tid; i < m; i += 1024) {
+        double a, b;
+        ab_at(A.ab, A.W, i, a, b);
+        const double ui = A.u[i];
+        const double cbu = s - b - ui;  // :268
+        if (cbu > P.eps && ui > P.eps) {  // :269
+          ca[0] += 1.0;
+          ca[1] += fabs((a + ui) / cbu);  // :271-274
+        }
+      }
+      block_reduce_1024<2>(ca, red);
+      end_inner = false;
+      if (ca[0] > 0.0) {
+        d += ca[1] / ca[0];  // :276
+        ++i_;                // :218 loop increment
+        begin_outer = true;
+      } else {
+        finished = true;  // :278-280 break
+        break;
+      }
+    }
+    if (begin_outer) {
+      begin_outer = false;
+      if (i_ >= P.maxoliters) {  // :218 loop bound
+        finished = true;
+        break;
+      }
+      double f[1] = {0.0};
+      for (int64_t i = tid; i < m; i += 1024) {
+        double a, b;
+        ab_at(A.ab, A.W, i, a, b);
+        const double ui = A.u[i];
+        const double gi = (1 + d) * ui - d * s + a + b * d;  // :219
+        A.g[i] = gi;
+        f[0] += ui * gi;  // :220
+      }
+      block_reduce_1024<1>(f, red);
+      F = f[0];
+      j_ = 0;
+      if (P.maxiniters <= 0) {
+        end_inner = true;
+        continue;
+      }
+      alpha = 1.0;
+      k_ = 0;
+    }
+    break;
+  }
+
+  double sx_new = 0.0;
+  if (!finished) {
+    // :235-237 — gradient step, projection onto the positive orthant, normalisation
+    double z[1] = {0.0};
+    for (int64_t i = tid; i < m; i += 1024) {
+      double t = A.u[i] + alpha * A.g[i];
+      t = (t > 0.0) ? t : 0.0;
+      A.x[i] = t;
+      z[0] += t * t;
+    }
+    block_reduce_1024<1>(z, red);
+    double sxv[1] = {0.0};
+    if (z[0] > 0.0) {  // Eigen's normalize(): only when squaredNorm() > 0
+      const double nrm = sqrt(z[0]);
+      for (int64_t i = tid; i < m; i += 1024) {
+        const double xi = A.x[i] / nrm;
+        A.x[i] = xi;
+        sxv[0] += xi;
+      }
+    }
+    block_reduce_1024<1>(sxv, red);
+    sx_new = sxv[0];
+  }
+
+  if (tid == 0) {
+    st->d = d;
+    st->F = F;
+    st->alpha = alpha;
+    st->s = s;
+    st->sx = sx_new;
+    st->phase = PH_TRIAL;
+    st->i = i_;
+    st->j = j_;
+    st->k = k_;
+    st->n_passes = n_passes;
+    st->n_trials = n_trials;
+    if (finished) {
+      st->ifinal = i_;
+      st->done = 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gemv — the fused symmetric mat-vec pair  a = M_off x,  b = C_off x  in ONE pass over M.
+//
+// grid = (strips of 256 columns, row tiles). A workgroup of NW waves shares one column
+// strip; wave w takes rows r0 + w*UNR + k*NW*UNR ... of its tile, UNR rows per iteration
+// so UNR independent 16-byte loads per lane are in flight. x[row] is wave-uniform: the
+// compiler turns it into scalar loads. Per-wave partials are combined through LDS in wave
+// order and written to part[tile][2][ld]; k_reduce adds the tiles in tile order. Nothing
+// is atomic: the result is bit-reproducible from run to run and from rank to rank.
+//
+// HBM-bound: s*m*W bytes per launch (s = sizeof(T)); per element one cvt, one fma, one
+// compare/select, one add — far below the fp64 vector rate, MFMA has nothing to offer a
+// rank-1 product.
+// ------------------------------------------------------------------------------------------
+
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+  using type = float4;
+};
+template <>
+struct Vec4<double> {
+  using type = double4;
+};
+
+template <typename T>
+__device__ __forceinline__ typename Vec4<T>::type load4(const T* p) {
+  return *reinterpret_cast<const typename Vec4<T>::type*>(p);
+}
+
+template <typename T, bool HASC, int NW, int UNR>
+__global__ __launch_bounds__(NW * 64) void k_gemv(const T* __restrict__ S,
+                                                   const T* __restrict__ Cs, int64_t ld,
+                                                   int64_t m, int rows_per_tile,
+                                                   const double* __restrict__ x,
+                                                   double* __restrict__ part,
+                                                   const SolverState* __restrict__ st) {
+  if (st != nullptr && st->done) return;
+
+  __shared__ double lds[NW * 2 * 256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t col = static_cast<int64_t>(blockIdx.x) * 256 + lane * 4;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_tile;
+  const int64_t r1 = (r0 + rows_per_tile < m) ? r0 + rows_per_tile : m;
+
+  double aa[4] = {0.0, 0.0, 0.0, 0.0};
+  double bb[4] = {0.0, 0.0, 0.0, 0.0};
+
+  if (col < ld) {
+    const T* p = S + col;
+    const T* pc = HASC ? Cs + col : nullptr;
+    int64_t r = r0 + static_cast<int64_t>(wave) * UNR;
+    for (; r + UNR <= r1; r += static_cast<int64_t>(NW) * UNR) {
+      typename Vec4<T>::type v[UNR];
+      typename Vec4<T>::type c[UNR];
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) {
+        v[q] = load4(p + (r + q) * ld);
+        if (HASC) c[q] = load4(pc + (r + q) * ld);
+      }
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) {
+        const double xr = x[r + q];
+        const double m0 = static_cast<double>(v[q].x), m1 = static_cast<double>(v[q].y),
+                     m2 = static_cast<double>(v[q].z), m3 = static_cast<double>(v[q].w);
+        aa[0] = fma(m0, xr, aa[0]);
+        aa[1] = fma(m1, xr, aa[1]);
+        aa[2] = fma(m2, xr, aa[2]);
+        aa[3] = fma(m3, xr, aa[3]);
+        if (HASC) {
+          bb[0] = fma(static_cast<double>(c[q].x), xr, bb[0]);
+          bb[1] = fma(static_cast<double>(c[q].y), xr, bb[1]);
+          bb[2] = fma(static_cast<double>(c[q].z), xr, bb[2]);
+          bb[3] = fma(static_cast<double>(c[q].w), xr, bb[3]);
+        } else {
+          bb[0] += (v[q].x != T(0)) ? xr : 0.0;
+          bb[1] += (v[q].y != T(0)) ? xr : 0.0;
+          bb[2] += (v[q].z != T(0)) ? xr : 0.0;
+          bb[3] += (v[q].w != T(0)) ? xr : 0.0;
+        }
+      }
+    }
+    // tail rows of this wave's last chunk
+    for (int q = 0; q < UNR; ++q) {
+      const int64_t rr = r + q;
+      if (rr < r1) {
+        const typename Vec4<T>::type v = load4(p + rr * ld);
+        const double xr = x[rr];
+        const double mm[4] = {static_cast<double>(v.x), static_cast<double>(v.y),
+                              static_cast<double>(v.z), static_cast<double>(v.w)};
+        double cc[4];
+        if (HASC) {
+          const typename Vec4<T>::type c = load4(pc + rr * ld);
+          cc[0] = static_cast<double>(c.x);
+          cc[1] = static_cast<double>(c.y);
+          cc[2] = static_cast<double>(c.z);
+          cc[3] = static_cast<double>(c.w);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          aa[e] = fma(mm[e], xr, aa[e]);
+          if (HASC) {
+            bb[e] = fma(cc[e], xr, bb[e]);
+          } else {
+            bb[e] += (mm[e] != 0.0) ? xr : 0.0;
+          }
+        }
+      }
+    }
+  }
+
+  // cross-wave combine in wave order (fixed summation tree)
+  double* mine = lds + wave * 512 + lane * 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mine[e] = aa[e];
+    mine[256 + e] = bb[e];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 512; t += NW * 64) {
+    double acc = lds[t];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) acc += lds[w * 512 + t];
+    const int which = t >> 8;  // 0 = a, 1 = b
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
+    if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * 2 + which) * ld + c] = acc;
+  }
+}
+
+// k_reduce — adds the row-tile partials in tile order and writes this shard's block of the
+// gathered vector pair: ab_block = [a (W) | b (W)].
+__global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ part, int ntiles,
+                                                 int64_t ld, double* __restrict__ ab_block,
+                                                 const SolverState* __restrict__ st) {
+  if (st != nullptr && st->done) return;
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= ld) return;
+  double a = 0.0, b = 0.0;
+  for (int t = 0; t < ntiles; ++t) {
+    a += part[(static_cast<int64_t>(t) * 2 + 0) * ld + c];
+    b += part[(static_cast<int64_t>(t) * 2 + 1) * ld + c];
+  }
+  ab_block[c] = a;
+  ab_block[ld + c] = b;
+}
+
+// ------------------------------------------------------------------------------------------
+// affinity fill
+// ------------------------------------------------------------------------------------------
+
+// P[k * pstride + i] = D[k + d * idx[i]] : per-association point table, structure of arrays,
+// so that column data loads in the fill kernels are contiguous across lanes.
+__global__ __launch_bounds__(256) void k_gather_points(const double* __restrict__ D, int d,
+                                                        const int32_t* __restrict__ idx,
+                                                        int64_t m, int64_t pstride,
+                                                        double* __restrict__ P) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= pstride) return;
+  const int64_t src = (i < m) ? idx[i] : 0;
+  for (int k = 0; k < d; ++k) P[k * pstride + i] = (i < m) ? D[k + d * src] : 0.0;
+}
+
+template <typename T>
+__device__ __forceinline__ T store_score(double scr, double affinityeps) {
+  // clipper.cpp:53-55 — keep the score only when it exceeds affinityeps.
+  if (!(scr > affinityeps)) return T(0);
+  T v = static_cast<T>(scr);
+  // an fp32 underflow must not erase an entry from the pattern (C == pattern(M))
+  if (v == T(0)) v = static_cast<T>(1.17549435e-38);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, T a, T b, T c, T d);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4<double>(double* p, double a, double b, double c,
+                                               double d) {
+  *reinterpret_cast<double4*>(p) = make_double4(a, b, c, d);
+}
+
+struct EuclidParams {
+  double sigma, epsilon, mindist, affinityeps;
+};
+
+// One thread = 4 adjacent columns of S, looping down `rows_per_blk` rows; the 4 columns'
+// points and association indices stay in registers for the whole loop, the row's point is
+// wave-uniform (scalar loads). Each lane stores 4 consecutive elements, a wave 256: whole
+// 1 KiB (fp32) row segments per store instruction.
+// D > 0: compile-time dimension (2 or 3); D == 0: run-time dimension `d` (slow path).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_affinity_euclid(
+    T* __restrict__ S, int64_t ld, int64_t m, int64_t c0, int rows_per_blk, int d,
+    const double* __restrict__ P1, const double* __restrict__ P2, int64_t pstride,
+    const int32_t* __restrict__ A0, const int32_t* __restrict__ A1, EuclidParams prm) {
+  const int64_t c = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  if (c >= ld) return;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_blk;
+  const int64_t r1 = (r0 + rows_per_blk < m) ? r0 + rows_per_blk : m;
+  constexpr int DD = (D > 0) ? D : 1;
+
+  int64_t gi[4];
+  bool valid[4];
+  int32_t a0c[4], a1c[4];
+  double p1c[4][DD], p2c[4][DD];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t g = c0 + c + q;
+    valid[q] = g < m;
+    gi[q] = valid[q] ? g : (m - 1);
+    a0c[q] = A0[gi[q]];
+    a1c[q] = A1[gi[q]];
+    if (D > 0) {
+#pragma unroll
+      for (int k = 0; k < DD; ++k) {
+        p1c[q][k] = P1[k * pstride + gi[q]];
+        p2c[q][k] = P2[k * pstride + gi[q]];
+      }
+    }
+  }
+
+  for (int64_t r = r0; r < r1; ++r) {
+    const int32_t a0r = A0[r], a1r = A1[r];
+    double p1r[DD], p2r[DD];
+    if (D > 0) {
+#pragma unroll
+      for (int k = 0; k < DD; ++k) {
+        p1r[k] = P1[k * pstride + r];
+        p2r[k] = P2[k * pstride + r];
+      }
+    }
+    T out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double s1 = 0.0, s2 = 0.0;  // euclidean_distance.cpp:18-19, sequential fma chain
+      if (D > 0) {
+#pragma unroll
+        for (int k = 0; k < DD; ++k) {
+          const double t1 = p1r[k] - p1c[q][k];
+          const double t2 = p2r[k] - p2c[q][k];
+          s1 = fma(t1, t1, s1);
+          s2 = fma(t2, t2, s2);
+        }
+      } else {
+        for (int k = 0; k < d; ++k) {
+          const double t1 = P1[k * pstride + r] - P1[k * pstride + gi[q]];
+          const double t2 = P2[k * pstride + r] - P2[k * pstride + gi[q]];
+          s1 = fma(t1, t1, s1);
+          s2 = fma(t2, t2, s2);
+        }
+      }
+      const double l1 = sqrt(s1), l2 = sqrt(s2);
+      // clipper.cpp:35-38 distinctness; the diagonal (r == column) fails it by construction
+      bool ok = valid[q] && (a0r != a0c[q]) && (a1r != a1c[q]);
+      // euclidean_distance.cpp:23-25
+      if (prm.mindist > 0 && (l1 < prm.mindist || l2 < prm.mindist)) ok = false;
+      const double cc = fabs(l1 - l2);  // :28
+      double scr = 0.0;
+      if (ok && cc < prm.epsilon) scr = exp(-0.5 * cc * cc / (prm.sigma * prm.sigma));  // :30
+      out[q] = store_score<T>(scr, prm.affinityeps);
+    }
+    store4<T>(S + r * ld + c, out[0], out[1], out[2], out[3]);
+  }
+}
+
+struct PointNormalParams {
+  double sigp, epsp, sign, epsn, affinityeps;
+};
+
+// PointNormalDistance: datum = [x y z nx ny nz] (pointnormal_distance.cpp:13-35).
+template <typename T>
+__global__ __launch_bounds__(256) void k_affinity_pointnormal(
+    T* __restrict__ S, int64_t ld, int64_t m, int64_t c0, int rows_per_blk,
+    const double* __restrict__ P1, const double* __restrict__ P2, int64_t pstride,
+    const int32_t* __restrict__ A0, const int32_t* __restrict__ A1, PointNormalParams prm) {
+  const int64_t c = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  if (c >= ld) return;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_blk;
+  const int64_t r1 = (r0 + rows_per_blk < m) ? r0 + rows_per_blk : m;
+
+  bool valid[4];
+  int32_t a0c[4], a1c[4];
+  double p1c[4][6], p2c[4][6];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t g = c0 + c + q;
+    valid[q] = g < m;
+    const int64_t gi = valid[q] ? g : (m - 1);
+    a0c[q] = A0[gi];
+    a1c[q] = A1[gi];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      p1c[q][k] = P1[k * pstride + gi];
+      p2c[q][k] = P2[k * pstride + gi];
+    }
+  }
+
+  for (int64_t r = r0; r < r1; ++r) {
+    const int32_t a0r = A0[r], a1r = A1[r];
+    double p1r[6], p2r[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      p1r[k] = P1[k * pstride + r];
+      p2r[k] = P2[k * pstride + r];
+    }
+    T out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double t1 = p1r[k] - p1c[q][k];
+        const double t2 = p2r[k] - p2c[q][k];
+        s1 = fma(t1, t1, s1);
+        s2 = fma(t2, t2, s2);
+      }
+      const double l1 = sqrt(s1), l2 = sqrt(s2);  // :17-18
+      const double dot1 = fma(p1r[5], p1c[q][5], fma(p1r[4], p1c[q][4], p1r[3] * p1c[q][3]));
+      const double dot2 = fma(p2r[5], p2c[q][5], fma(p2r[4], p2c[q][4], p2r[3] * p2c[q][3]));
+      const bool ok = valid[q] && (a0r != a0c[q]) && (a1r != a1c[q]);
+      double scr = 0.0;
+      if (ok) {
+        const double alpha1 = acos(dot1);  // :21 (NaN when |dot| > 1, as in the reference)
+        const double alpha2 = acos(dot2);  // :22
+        const double dp = fabs(l1 - l2);          // :25
+        const double dn = fabs(alpha1 - alpha2);  // :26
+        if (dp < prm.epsp && dn < prm.epsn) {     // :28
+          const double sp = exp(-0.5 * dp * dp / (prm.sigp * prm.sigp));  // :29
+          const double sn = exp(-0.5 * dn * dn / (prm.sign * prm.sign));  // :30
+          scr = sp * sn;                                                  // :31
+        }
+      }
+      out[q] = store_score<T>(scr, prm.affinityeps);
+    }
+    store4<T>(S + r * ld + c, out[0], out[1], out[2], out[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// matrix upload (setMatrixData / setSparseMatrixData) — clipper.cpp:149-166
+// ------------------------------------------------------------------------------------------
+
+// S[j][c] = Mdense(min(j,g), max(j,g)) for g = c0+c != j, 0 on the diagonal / padding.
+// Mdense is column-major m x m fp64 in device memory (only its strict upper triangle is
+// read). `mismatch` is raised when Cdense's upper triangle differs from pattern(Mdense).
+template <typename T>
+__global__ __launch_bounds__(256) void k_from_dense_upper(T* __restrict__ S, int64_t ld,
+                                                           int64_t m, int64_t c0,
+                                                           const double* __restrict__ Md,
+                                                           const double* __restrict__ Cd,
+                                                           T* __restrict__ Cs,
+                                                           int* __restrict__ mismatch) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t j = blockIdx.y;
+  if (c >= ld) return;
+  const int64_t g = c0 + c;
+  double mv = 0.0, cv = 0.0;
+  if (g < m && g != j) {
+    const int64_t lo = (j < g) ? j : g, hi = (j < g) ? g : j;
+    mv = Md[lo + hi * m];
+    cv = Cd[lo + hi * m];
+    if (mismatch != nullptr) {
+      const double want = (mv != 0.0) ? 1.0 : 0.0;
+      if (cv != want) *mismatch = 1;
+    }
+  }
+  T sv = static_cast<T>(mv);
+  if (mv != 0.0 && sv == T(0)) sv = (mv > 0) ? static_cast<T>(1.17549435e-38)
+                                             : static_cast<T>(-1.17549435e-38);
+  S[j * ld + c] = sv;
+  if (Cs != nullptr) Cs[j * ld + c] = static_cast<T>(cv);
+}
+
+// scatter of strictly-upper CSC entries (both mirror images) into a zeroed slice
+template <typename T>
+__global__ __launch_bounds__(256) void k_from_csc(T* __restrict__ S, int64_t ld, int64_t m,
+                                                   int64_t c0, int64_t W,
+                                                   const int64_t* __restrict__ colptr,
+                                                   const int32_t* __restrict__ row,
+                                                   const double* __restrict__ val) {
+  const int64_t j = blockIdx.x;  // CSC column
+  for (int64_t p = colptr[j] + threadIdx.x; p < colptr[j + 1]; p += 256) {
+    const int64_t i = row[p];
+    if (i == j) continue;  // the solver treats the diagonal as implicit identity
+    const T v = static_cast<T>(val[p]);
+    // element (i,j): lives at S[i][j-c0] if j is an owned column, and at S[j][i-c0] if i is
+    if (j >= c0 && j < c0 + W) S[i * ld + (j - c0)] = v;
+    if (i >= c0 && i < c0 + W) S[j * ld + (i - c0)] = v;
+  }
+}
+
+}  // namespace clipper_hip

@@ -1,0 +1,184 @@
+/*
+ * clipper_hip.h — C ABI of the MI355X (gfx950) implementation of CLIPPER's dense-cluster
+ * hot path. This is the drop-in boundary: plain pointers, sizes and PODs only, no C++
+ * or framework types. The reference has no FFI of its own for this path (it is one C++
+ * shared library, CMakeLists.txt:93); each entry point below names the reference member
+ * function (file:line relative to /root/reference) whose work it takes over, and
+ * clipper_amd/csrc/host/ holds the `clipper::CLIPPER` facade + `clipperpy` module that a
+ * maintainer binds to it.
+ *
+ * Conventions
+ *   - Matrices are column-major fp64 (Eigen default). A is column-major m x 2 int32.
+ *   - Every function returns 0 on success, <0 on failure (CLIPPER_HIP_E_*); the message
+ *     is available from clipper_hip_last_error() (thread-local). Nothing throws.
+ *   - Calls are synchronous from the caller's view; one context = one problem instance,
+ *     not thread-safe per context (same as clipper::CLIPPER), independent across contexts.
+ *   - There is NO CPU fallback: without a usable HIP device every call fails loudly.
+ *
+ * Storage of the affinity matrix on device
+ *   M_off (strict off-diagonal, symmetric, both triangles) is kept dense in HBM as
+ *   column slices: a context that owns global columns [c0, c0+W) stores S[j][c] =
+ *   M(j, c0+c) for all m rows j, row pitch W (multiple of 64 elements, zero padded).
+ *   Element type is fp32 (CLIPPER_HIP_STORE_F32: 4*m^2 bytes, what BASELINE.json's
+ *   "~360 GB fp32 M at m=300k" implies) or fp64 (CLIPPER_HIP_STORE_F64). All vectors,
+ *   accumulators and scalars of the solver are fp64 in either mode.
+ *   On the scorePairwiseConsistency path C == pattern(M) (clipper.cpp:63-64) and is not
+ *   stored: the mat-vec kernel derives C_off*x from the same pass over M. setMatrixData
+ *   with any other C stores a second dense matrix.
+ */
+#ifndef CLIPPER_HIP_H
+#define CLIPPER_HIP_H
+
+#include "clipper_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct clipper_hip_ctx clipper_hip_t;
+
+enum { CLIPPER_HIP_STORE_F32 = 0, CLIPPER_HIP_STORE_F64 = 1 };
+
+enum {
+  CLIPPER_HIP_OK = 0,
+  CLIPPER_HIP_E_INVALID = -1,  /* bad argument                       */
+  CLIPPER_HIP_E_NOMEM = -2,    /* device or host allocation failed   */
+  CLIPPER_HIP_E_HIP = -3,      /* HIP runtime error                  */
+  CLIPPER_HIP_E_NODEVICE = -4, /* no gfx950 device visible           */
+  CLIPPER_HIP_E_STATE = -5,    /* call out of order (no matrix yet)  */
+  CLIPPER_HIP_E_COMM = -6,     /* RCCL error / communicator missing  */
+  CLIPPER_HIP_E_SCOPE = -7     /* Rounding::DSD — outside this path  */
+};
+
+/* Timings of the most recent calls, from HIP events on the context's own stream. */
+typedef struct clipper_hip_timings_t {
+  double affinity_kernel_ms; /* affinity fill kernel(s) only                           */
+  double affinity_total_ms;  /* H2D of D1,D2,A + gather + fill, host wall clock         */
+  double solve_total_ms;     /* host wall clock of clipper_hip_solve                    */
+  double gemv_avg_us;        /* mean duration of the mat-vec kernel over the last solve
+                                (only when profiling is on; else 0)                     */
+  double gemv_min_us;
+  int64_t gemv_launches;     /* number of mat-vec launches that were timed              */
+  double gemv_bytes;         /* algorithmic bytes one launch moves: s*m*W_local         */
+} clipper_hip_timings_t;
+
+/* ---- life cycle --------------------------------------------------------------------- */
+
+int clipper_hip_device_count(void);
+
+/* One device holds the whole matrix. Replaces the construction of CLIPPER's members
+ * M_, C_ (clipper.h:155-156). `storage` is CLIPPER_HIP_STORE_F32 / _F64. */
+clipper_hip_t* clipper_hip_create(int device, int storage);
+
+/* In-process column sharding: `nshards` slices driven by one host thread; devices[p] may
+ * repeat (several logical shards on one GPU — used to test the sharded protocol on a
+ * 1-GPU box). Slices exchange their (M_off*x, C_off*x) pieces by device-to-device copies. */
+clipper_hip_t* clipper_hip_create_group(const int* devices, int nshards, int storage);
+
+/* Multi-process column sharding, one process per GPU: this context is shard `rank` of
+ * `world`. The per-pass exchange is an RCCL all-gather over xGMI; call
+ * clipper_hip_comm_init before the first solve. */
+clipper_hip_t* clipper_hip_create_rank(int device, int storage, int rank, int world);
+/* ncclGetUniqueId into a 128-byte buffer (rank 0), to be broadcast by the launcher. */
+int clipper_hip_comm_unique_id(void* id128);
+/* ncclCommInitRank on this context's device with the broadcast id. */
+int clipper_hip_comm_init(clipper_hip_t* h, const void* id128);
+
+void clipper_hip_destroy(clipper_hip_t* h);
+const char* clipper_hip_last_error(void);
+
+/* ---- affinity build ----------------------------------------------------------------- */
+
+/* CLIPPER::scorePairwiseConsistency (clipper.cpp:21-65) with the built-in
+ * EuclideanDistance invariant (euclidean_distance.cpp:13-31, Params .h:22-27).
+ * D1: d x n1, D2: d x n2 column-major fp64 host buffers; A: column-major m x 2 int32
+ * host buffer, or NULL / m == 0 for the all-to-all hypothesis (utils.h:61-71).
+ * Host buffers are only read during the call. */
+int clipper_hip_affinity_euclidean(clipper_hip_t* h, const double* D1, int d, int64_t n1,
+                                   const double* D2, int64_t n2, const int32_t* A, int64_t m,
+                                   double sigma, double epsilon, double mindist,
+                                   double affinityeps);
+
+/* Same with PointNormalDistance (pointnormal_distance.cpp:13-35, Params .h:25-31); d == 6. */
+int clipper_hip_affinity_pointnormal(clipper_hip_t* h, const double* D1, int d, int64_t n1,
+                                     const double* D2, int64_t n2, const int32_t* A, int64_t m,
+                                     double sigp, double epsp, double sign, double epsn,
+                                     double affinityeps);
+
+/* The same work split at the PCIe boundary, so a caller (and bench.py) can keep the inputs
+ * resident in HBM and time the device work alone:
+ *   clipper_hip_stage_inputs   = clipper.cpp:24-25 (A or all-to-all) + H2D of D1, D2, A +
+ *                                gather of the per-association point tables
+ *   clipper_hip_affinity_*_staged = the pair loop clipper.cpp:31-56 + :61-64 on device.
+ * clipper_hip_affinity_euclidean(...) == stage_inputs(...) then ..._euclidean_staged(...). */
+int clipper_hip_stage_inputs(clipper_hip_t* h, const double* D1, int d, int64_t n1,
+                             const double* D2, int64_t n2, const int32_t* A, int64_t m);
+int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double epsilon,
+                                          double mindist, double affinityeps);
+int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, double epsp,
+                                            double sign, double epsn, double affinityeps);
+
+/* rows of A_ (= dimension of M_); CLIPPER::getInitialAssociations (clipper.cpp:117-120) */
+int64_t clipper_hip_num_associations(const clipper_hip_t* h);
+int clipper_hip_get_associations(const clipper_hip_t* h, int32_t* A_out /* col-major m x 2 */);
+
+/* ---- matrix get / set ---------------------------------------------------------------- */
+
+/* CLIPPER::setMatrixData (clipper.cpp:149-158): dense column-major m x m host matrices;
+ * only the strict upper triangle is used. Keeps the current association list if its
+ * length is m (so getSelectedAssociations keeps working), else clears it. */
+int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, int64_t m);
+
+/* CLIPPER::setSparseMatrixData (clipper.cpp:162-166): strictly-upper CSC, int64 column
+ * pointers, int32 row indices. */
+int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
+                           const int32_t* Mrow, const double* Mval, const int64_t* Ccolptr,
+                           const int32_t* Crow, const double* Cval);
+
+/* CLIPPER::getAffinityMatrix / getConstraintMatrix (clipper.cpp:131-145): dense symmetric
+ * fp64 with the identity added. Either pointer may be NULL. Moves 8*m^2 bytes per matrix
+ * over PCIe: for tests and interoperability, not for the hot loop. */
+int clipper_hip_get_matrix(clipper_hip_t* h, double* M_out, double* C_out);
+
+/* ---- solver -------------------------------------------------------------------------- */
+
+/* CLIPPER::solve -> findDenseClique (clipper.cpp:69-78, 172-323). u0: m doubles (host),
+ * required (the facade supplies utils::randvec when the caller gives none). u_out (m
+ * doubles) may be NULL. Rounding NONZERO and DSD_HEU are done on the host with the
+ * reference's exact tie-breaking (utils.cpp:33-68); DSD returns CLIPPER_HIP_E_SCOPE. */
+int clipper_hip_solve(clipper_hip_t* h, const double* u0, const clipper_params_t* params,
+                      double* u_out, clipper_solve_info_t* info);
+
+/* Split form: clipper_hip_stage_u0 copies u0 to HBM; clipper_hip_solve_staged runs
+ * findDenseClique on it (device loop + D2H of u + host rounding).
+ * clipper_hip_solve(u0, ...) == stage_u0(u0) then solve_staged(...). */
+int clipper_hip_stage_u0(clipper_hip_t* h, const double* u0);
+int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* params, double* u_out,
+                             clipper_solve_info_t* info);
+
+/* Solution::nodes (clipper.h:69); returns the count or <0. */
+int clipper_hip_get_nodes(const clipper_hip_t* h, int32_t* nodes_out, int32_t capacity);
+/* CLIPPER::getSelectedAssociations (clipper.cpp:124-127): column-major k x 2. */
+int clipper_hip_get_selected_associations(const clipper_hip_t* h, int32_t* A_out,
+                                          int32_t capacity);
+
+/* One pass of the mat-vec kernel: yM = M_off*x, yC = C_off*x (the products at
+ * clipper.cpp:194,202,205,219,240-241,268,271). x, yM, yC: m doubles on the host. */
+int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+
+/* When on, every mat-vec launch of a solve is bracketed by HIP events on the stream it
+ * runs on; clipper_hip_get_timings then reports their mean / min duration. */
+int clipper_hip_set_profiling(clipper_hip_t* h, int on);
+int clipper_hip_get_timings(const clipper_hip_t* h, clipper_hip_timings_t* out);
+/* Launches the mat-vec kernel `reps` times back to back on resident data and returns the
+ * mean kernel time in microseconds (events on the launch stream). */
+int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us);
+/* Device name, CU count, HBM bytes (for bench.py's report). */
+int clipper_hip_device_info(const clipper_hip_t* h, char* name64, int* cus, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPPER_HIP_H */
