@@ -85,14 +85,18 @@ def main():
         N = world
     rho = args.rho if args.rho is not None else (0.90 if args.m <= 1000 else 0.95)
 
-    # the product library first (binds the ROCm runtime in /opt/rocm), then torch for the
-    # contract's barrier / synchronize / max-over-ranks plumbing
+    # torch first: it must bind its own bundled ROCm runtime (importing it after another
+    # libamdhip64 is already loaded leaves torch.cuda without devices — measured on the GPU
+    # box); the product library then shares that runtime. torch is only plumbing here:
+    # barrier / synchronize / max-over-ranks and the broadcast of the RCCL unique id.
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.init()
     from clipper_amd import _abi as abi
     from clipper_amd import synth
 
     abi.load_library()
-    import torch
-    import torch.distributed as dist
 
     if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

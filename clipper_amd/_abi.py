@@ -323,9 +323,9 @@ class HipClipper:
     def solve(self, u0):
         u0 = np.ascontiguousarray(u0, dtype=np.float64)
         n = self.m
-        if u0.shape != (n,):
+        if n > 0 and u0.shape != (n,):
             raise ValueError(f"u0 must have shape ({n},)")
-        u = np.zeros(n)
+        u = np.zeros(max(n, 1))[:n]
         info = SolveInfo()
         self._check(self.L.clipper_hip_solve(self.h, _dp(u0), C.byref(self.params), _dp(u),
                                              C.byref(info)))

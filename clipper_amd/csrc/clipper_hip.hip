@@ -544,6 +544,16 @@ int run_affinity(Ctx* h, Launch launch) {
 
 constexpr int AFF_ROWS_PER_BLK = 32;
 
+// ALGORITHMIC bytes one mat-vec launch of shard 0 must move: s * m * (valid owned columns)
+// (= s*m^2 on one GPU; the zero padding up to the 64-column pitch is not counted), doubled
+// when an explicit constraint matrix is read as well.
+double algorithmic_gemv_bytes(const Ctx* h) {
+  const int64_t c0 = static_cast<int64_t>(h->sh[0].slot) * h->W;
+  const int64_t valid = std::max<int64_t>(0, std::min<int64_t>(h->W, h->m - c0));
+  return static_cast<double>(h->esize()) * static_cast<double>(h->m) *
+         static_cast<double>(valid) * (h->explicitC ? 2.0 : 1.0);
+}
+
 }  // namespace
 
 // ============================================================================================
@@ -1063,9 +1073,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   // mat-vec timings from the event pairs
   h->tm.gemv_avg_us = h->tm.gemv_min_us = 0.0;
   h->tm.gemv_launches = 0;
-  h->tm.gemv_bytes =
-      static_cast<double>(h->esize()) * static_cast<double>(m) * static_cast<double>(h->W) *
-      (h->explicitC ? 2.0 : 1.0);
+  h->tm.gemv_bytes = algorithmic_gemv_bytes(h);
   if (h->profiling && h->ev_used > 0) {
     // only launches that did real work count: the first n_passes of them
     const int64_t nreal = std::min<int64_t>(h->ev_used, fin.n_passes);
@@ -1169,8 +1177,7 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   *avg_us = static_cast<double>(ms) * 1e3 / reps;
-  h->tm.gemv_bytes = static_cast<double>(h->esize()) * static_cast<double>(h->m) *
-                     static_cast<double>(h->W) * (h->explicitC ? 2.0 : 1.0);
+  h->tm.gemv_bytes = algorithmic_gemv_bytes(h);
   return 0;
 }
 

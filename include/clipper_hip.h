@@ -59,7 +59,7 @@ typedef struct clipper_hip_timings_t {
                                 (only when profiling is on; else 0)                     */
   double gemv_min_us;
   int64_t gemv_launches;     /* number of mat-vec launches that were timed              */
-  double gemv_bytes;         /* algorithmic bytes one launch moves: s*m*W_local         */
+  double gemv_bytes;         /* algorithmic bytes of one launch: s*m*(owned columns)    */
 } clipper_hip_timings_t;
 
 /* ---- life cycle --------------------------------------------------------------------- */
