@@ -59,10 +59,13 @@ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // mat-vec kernel geometry (tuned on MI355X)
-constexpr int GEMV_NW = 4;      // waves per workgroup
+constexpr int GEMV_NW = 8;      // waves per workgroup
 constexpr int GEMV_UNR_F32 = 8; // rows in flight per wave, fp32 storage (8 x 16 B per lane)
 constexpr int GEMV_UNR_F64 = 4; // fp64 storage (4 x 32 B per lane)
+constexpr int GEMV_WG_PER_CU = 2;
+constexpr int SOLVE_BATCH = 16;  // solver iterations queued between two looks at the done flag
 constexpr int MAX_EVENT_PAIRS = 4096;
+constexpr int PROFILE_EVERY = 4;  // time every 4th mat-vec launch (events perturb the stream)
 
 // ---- RCCL, bound at run time so the single-GPU path never loads librccl -----------------
 struct Rccl {
@@ -106,8 +109,10 @@ struct Shard {
   void* S = nullptr;   // m x W, element = float | double
   void* Cs = nullptr;  // explicit constraint matrix, same shape (only when C != pattern(M))
   double* part = nullptr;  // [ntiles][2][W]
-  double *u0 = nullptr, *u = nullptr, *g = nullptr, *x = nullptr, *gnew = nullptr;
-  double* ab = nullptr;  // [P][2][W]
+  double* u0 = nullptr;
+  double *U[2] = {nullptr, nullptr}, *G[2] = {nullptr, nullptr}, *T[2] = {nullptr, nullptr};
+  double* ab = nullptr;    // [P][2][W]
+  double* scal = nullptr;  // [nwg][NSCAL] partial scalars of k_tail
   SolverState* st = nullptr;
   // affinity inputs (staged once, reused while the sizes fit)
   double *P1 = nullptr, *P2 = nullptr;  // gathered point tables [d][pstride]
@@ -146,7 +151,9 @@ struct clipper_hip_ctx {
 
   bool profiling = false;
   std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created lazily
+  std::vector<int64_t> ev_launch_index;  // which mat-vec launch of the solve each pair timed
   int ev_used = 0;
+  int64_t launch_counter = 0;
   clipper_hip_timings_t tm{};
 
   size_t esize() const { return storage == CLIPPER_HIP_STORE_F64 ? 8 : 4; }
@@ -166,11 +173,13 @@ int free_shard_buffers(Shard& s) {
   fr(s.Cs);
   fr(s.part);
   fr(s.u0);
-  fr(s.u);
-  fr(s.g);
-  fr(s.x);
-  fr(s.gnew);
+  for (int k = 0; k < 2; ++k) {
+    fr(s.U[k]);
+    fr(s.G[k]);
+    fr(s.T[k]);
+  }
   fr(s.ab);
+  fr(s.scal);
   fr(s.st);
   fr(s.P1);
   fr(s.P2);
@@ -186,8 +195,10 @@ void plan_tiles(Ctx* h) {
   const int unr = (h->storage == CLIPPER_HIP_STORE_F64) ? GEMV_UNR_F64 : GEMV_UNR_F32;
   const int64_t chunk = static_cast<int64_t>(GEMV_NW) * unr;
   h->nstrips = static_cast<int>(ceil_div(h->W, 256));
-  // aim at ~8 workgroups of 4 waves per CU so the whole chip streams (>> 256 workgroups)
-  const int64_t target = static_cast<int64_t>(h->cus) * 8;
+  // two 8-wave workgroups per CU (16 waves x 8 rows x 16 B = 2 KiB per lane-row in flight per
+  // CU... measured with tools/gemv_tune.hip: at m = 10k this geometry sits at the box's pure
+  // streaming-read ceiling while needing only ~13 row tiles, i.e. few partials for k_reduce)
+  const int64_t target = static_cast<int64_t>(h->cus) * GEMV_WG_PER_CU;
   int64_t nt = std::max<int64_t>(1, ceil_div(target, h->nstrips));
   nt = std::min<int64_t>(nt, std::max<int64_t>(1, ceil_div(h->m, chunk)));
   int64_t rpt = round_up(ceil_div(h->m, nt), chunk);
@@ -212,10 +223,14 @@ int ensure_problem(Ctx* h, int64_t m) {
     s.bytes_S = bytesS;
     const size_t nvec = static_cast<size_t>(P * W) * sizeof(double);
     HIPCHK(hipMalloc(&s.u0, nvec));
-    HIPCHK(hipMalloc(&s.u, nvec));
-    HIPCHK(hipMalloc(&s.g, nvec));
-    HIPCHK(hipMalloc(&s.x, nvec));
-    HIPCHK(hipMalloc(&s.gnew, nvec));
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipMalloc(&s.U[k], nvec));
+      HIPCHK(hipMalloc(&s.G[k], nvec));
+      HIPCHK(hipMalloc(&s.T[k], nvec));
+      HIPCHK(hipMemsetAsync(s.T[k], 0, nvec, s.stream));
+    }
+    HIPCHK(hipMalloc(&s.scal, static_cast<size_t>(ceil_div(m, TAIL_THREADS)) * NSCAL *
+                                  sizeof(double)));
     HIPCHK(hipMalloc(&s.ab, 2 * nvec));
     HIPCHK(hipMemsetAsync(s.ab, 0, 2 * nvec, s.stream));
     // the tile plan depends only on (m, W, storage): size for the worst case of both
@@ -234,26 +249,27 @@ int ensure_problem(Ctx* h, int64_t m) {
 }
 
 template <typename T, bool HASC>
-void launch_gemv_t(Ctx* h, Shard& s, const double* x, const SolverState* st) {
+void launch_gemv_t(Ctx* h, Shard& s, const double* x0, const double* x1, const SolverState* st) {
   constexpr int UNR = (sizeof(T) == 8) ? GEMV_UNR_F64 : GEMV_UNR_F32;
   dim3 grid(h->nstrips, h->ntiles), block(GEMV_NW * 64);
   hipLaunchKernelGGL((k_gemv<T, HASC, GEMV_NW, UNR>), grid, block, 0, s.stream,
                      static_cast<const T*>(s.S), static_cast<const T*>(s.Cs), h->W, h->m,
-                     h->rows_per_tile, x, s.part, st);
+                     h->rows_per_tile, x0, x1, s.part, st);
 }
 
-void launch_gemv(Ctx* h, Shard& s, const double* x, const SolverState* st) {
+// x = T[st->sel] when `st` is given (solver), else x0
+void launch_gemv(Ctx* h, Shard& s, const double* x0, const double* x1, const SolverState* st) {
   if (h->storage == CLIPPER_HIP_STORE_F64) {
-    if (h->explicitC) launch_gemv_t<double, true>(h, s, x, st);
-    else launch_gemv_t<double, false>(h, s, x, st);
+    if (h->explicitC) launch_gemv_t<double, true>(h, s, x0, x1, st);
+    else launch_gemv_t<double, false>(h, s, x0, x1, st);
   } else {
-    if (h->explicitC) launch_gemv_t<float, true>(h, s, x, st);
-    else launch_gemv_t<float, false>(h, s, x, st);
+    if (h->explicitC) launch_gemv_t<float, true>(h, s, x0, x1, st);
+    else launch_gemv_t<float, false>(h, s, x0, x1, st);
   }
 }
 
 void launch_reduce(Ctx* h, Shard& s, const SolverState* st) {
-  dim3 grid(static_cast<unsigned>(ceil_div(h->W, 256))), block(256);
+  dim3 grid(static_cast<unsigned>(ceil_div(2 * h->W, 256))), block(256);
   hipLaunchKernelGGL(k_reduce, grid, block, 0, s.stream, s.part, h->ntiles, h->W,
                      s.ab + static_cast<int64_t>(s.slot) * 2 * h->W, st);
 }
@@ -303,38 +319,81 @@ int exchange(Ctx* h) {
   return 0;
 }
 
-// one pass over M on vector `x` of every shard: afterwards every shard's `ab` is complete
-int enqueue_pass(Ctx* h, bool use_state) {
+SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm) {
+  SolveArgs a;
+  a.st = s.st;
+  a.prm = prm;
+  a.m = h->m;
+  a.W = h->W;
+  a.u0 = s.u0;
+  for (int k = 0; k < 2; ++k) {
+    a.U[k] = s.U[k];
+    a.G[k] = s.G[k];
+    a.T[k] = s.T[k];
+  }
+  a.ab = s.ab;
+  a.part = s.part;
+  a.ntiles = h->ntiles;
+  a.scal = s.scal;
+  a.nwg = static_cast<int>(ceil_div(h->m, TAIL_THREADS));
+  return a;
+}
+
+// the mat-vec kernel of every local shard (optionally bracketed by timing events)
+int enqueue_gemv(Ctx* h, bool use_state) {
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     const SolverState* st = use_state ? s.st : nullptr;
-    const bool prof = h->profiling && (&s == &h->sh[0]) && h->ev_used < MAX_EVENT_PAIRS;
+    // timing events cost ~5 us of stream time each: sample every 4th launch only
+    const bool prof = h->profiling && use_state && (&s == &h->sh[0]) &&
+                      (h->launch_counter % PROFILE_EVERY == 0) && h->ev_used < MAX_EVENT_PAIRS;
     if (prof) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
-    launch_gemv(h, s, s.x, st);
+    launch_gemv(h, s, s.T[0], s.T[1], st);
     if (prof) {
       HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used + 1], s.stream));
+      h->ev_launch_index[h->ev_used] = h->launch_counter;
       ++h->ev_used;
     }
-    launch_reduce(h, s, st);
+  }
+  if (use_state) ++h->launch_counter;
+  return 0;
+}
+
+// raw (un-normalised) sums of the partials into every shard's gathered `ab`
+int enqueue_reduce_exchange(Ctx* h, bool use_state) {
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    launch_reduce(h, s, use_state ? s.st : nullptr);
   }
   return exchange(h);
 }
 
-int enqueue_vec(Ctx* h, const SolverParams& prm) {
+// one full solver iteration: pass over M, element-wise tail, decisions
+int enqueue_iteration(Ctx* h, const SolverParams& prm) {
+  int rc = enqueue_gemv(h, true);
+  if (rc) return rc;
+  if (h->world == 1) {
+    Shard& s = h->sh[0];
+    SolveArgs a = solve_args(h, s, prm);
+    hipLaunchKernelGGL(k_tail<true>, dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, s.stream, a);
+    return 0;
+  }
+  if ((rc = enqueue_reduce_exchange(h, true))) return rc;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    VecArgs a;
-    a.st = s.st;
-    a.prm = prm;
-    a.m = h->m;
-    a.W = h->W;
-    a.u0 = s.u0;
-    a.u = s.u;
-    a.g = s.g;
-    a.x = s.x;
-    a.gnew = s.gnew;
-    a.ab = s.ab;
-    hipLaunchKernelGGL(k_vec, dim3(1), dim3(1024), 0, s.stream, a);
+    SolveArgs a = solve_args(h, s, prm);
+    hipLaunchKernelGGL(k_tail<false>, dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, s.stream, a);
+  }
+  return 0;
+}
+
+int enqueue_decide_only(Ctx* h, const SolverParams& prm) {
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    SolveArgs a = solve_args(h, s, prm);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, s.stream, a);
   }
   return 0;
 }
@@ -979,9 +1038,11 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   if (h->profiling && h->ev_pairs.empty()) {
     HIPCHK(hipSetDevice(h->sh[0].device));
     h->ev_pairs.resize(2 * MAX_EVENT_PAIRS);
+    h->ev_launch_index.assign(MAX_EVENT_PAIRS, 0);
     for (auto& e : h->ev_pairs) HIPCHK(hipEventCreate(&e));
   }
   h->ev_used = 0;
+  h->launch_counter = 0;
 
   SolverParams prm;
   prm.tol_u = P->tol_u;
@@ -995,28 +1056,28 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   SolverState init;
   std::memset(&init, 0, sizeof(init));
   init.alpha = 1.0;
+  init.nrm = 1.0;
   init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    HIPCHK(hipMemcpyAsync(s.x, s.u0, vbytes, hipMemcpyDeviceToDevice, s.stream));
+    // first pass (if any) runs on x = u0: T[0] = u0, nrm = 1
+    HIPCHK(hipMemcpyAsync(s.T[0], s.u0, vbytes, hipMemcpyDeviceToDevice, s.stream));
     HIPCHK(hipMemcpyAsync(s.st, &init, sizeof(init), hipMemcpyHostToDevice, s.stream));
   }
   int rc = 0;
   if (!P->rescale_u0) {
-    if ((rc = enqueue_vec(h, prm))) return rc;  // PH_NORMALIZE consumes no pass
+    if ((rc = enqueue_decide_only(h, prm))) return rc;  // PH_NORMALIZE consumes no pass
   }
 
   // Batched, pipelined enqueue: batch n+1 is queued before the host looks at the state
   // snapshot taken after batch n.
   Shard& s0 = h->sh[0];
-  int batch = 8;
   int slot = 0;
   bool have_prev = false;
   bool done = false;
   while (!done) {
-    for (int it = 0; it < batch; ++it) {
-      if ((rc = enqueue_pass(h, true))) return rc;
-      if ((rc = enqueue_vec(h, prm))) return rc;
+    for (int it = 0; it < SOLVE_BATCH; ++it) {
+      if ((rc = enqueue_iteration(h, prm))) return rc;
     }
     HIPCHK(hipSetDevice(s0.device));
     HIPCHK(hipMemcpyAsync(&h->host_state[slot], s0.st, sizeof(SolverState),
@@ -1028,9 +1089,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     }
     have_prev = true;
     slot ^= 1;
-    if (batch < 32) batch *= 2;
     if (done) break;
-    // with a single batch in flight and nothing queued behind it, peek without waiting
+    // the batch just queued may already be finished (launch-bound small problems): peek
     if (hipEventQuery(h->ev_poll[slot ^ 1]) == hipSuccess) {
       if (h->host_state[slot ^ 1].done) done = true;
     } else {
@@ -1043,7 +1103,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipMemcpy(&fin, s0.st, sizeof(fin), hipMemcpyDeviceToHost));
   std::vector<double> u(static_cast<size_t>(m));
-  HIPCHK(hipMemcpy(u.data(), s0.u, vbytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(u.data(), s0.U[fin.ub & 1], vbytes, hipMemcpyDeviceToHost));
 
   // rounding — clipper.cpp:287-310 with utils.cpp:33-68, on the host
   std::vector<int32_t> nodes;
@@ -1075,14 +1135,16 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   h->tm.gemv_launches = 0;
   h->tm.gemv_bytes = algorithmic_gemv_bytes(h);
   if (h->profiling && h->ev_used > 0) {
-    // only launches that did real work count: the first n_passes of them
-    const int64_t nreal = std::min<int64_t>(h->ev_used, fin.n_passes);
+    // only launches that did real work count: launch index < n_passes
     double sum = 0.0, mn = 1e30;
-    for (int64_t k = 0; k < nreal; ++k) {
+    int64_t nreal = 0;
+    for (int k = 0; k < h->ev_used; ++k) {
+      if (h->ev_launch_index[static_cast<size_t>(k)] >= fin.n_passes) continue;
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, h->ev_pairs[2 * k], h->ev_pairs[2 * k + 1]));
       sum += ms;
       mn = std::min<double>(mn, ms);
+      ++nreal;
     }
     if (nreal > 0) {
       h->tm.gemv_avg_us = sum / static_cast<double>(nreal) * 1e3;
@@ -1124,14 +1186,12 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
   const int64_t m = h->m, W = h->W;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    HIPCHK(hipMemcpyAsync(s.x, x, static_cast<size_t>(m) * sizeof(double),
+    HIPCHK(hipMemcpyAsync(s.T[0], x, static_cast<size_t>(m) * sizeof(double),
                           hipMemcpyHostToDevice, s.stream));
   }
-  const bool prof = h->profiling;
-  h->profiling = false;
-  int rc = enqueue_pass(h, false);
-  h->profiling = prof;
+  int rc = enqueue_gemv(h, false);
   if (rc) return rc;
+  if ((rc = enqueue_reduce_exchange(h, false))) return rc;
   if ((rc = sync_all(h))) return rc;
   std::vector<double> ab(static_cast<size_t>(h->world) * 2 * W);
   Shard& s0 = h->sh[0];
@@ -1167,9 +1227,9 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) launch_gemv(h, s, s.x, nullptr);
+  for (int w = 0; w < 3; ++w) launch_gemv(h, s, s.T[0], s.T[1], nullptr);
   HIPCHK(hipEventRecord(e0, s.stream));
-  for (int r = 0; r < reps; ++r) launch_gemv(h, s, s.x, nullptr);
+  for (int r = 0; r < reps; ++r) launch_gemv(h, s, s.T[0], s.T[1], nullptr);
   HIPCHK(hipEventRecord(e1, s.stream));
   HIPCHK(hipStreamSynchronize(s.stream));
   float ms = 0.f;

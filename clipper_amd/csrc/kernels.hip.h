@@ -18,7 +18,7 @@
 //                   src/invariants/pointnormal_distance.cpp:13-35
 //   k_gemv        : every `M_.selfadjointView<Upper>() * v` / `C_...* v` in
 //                   src/clipper.cpp:194,202,205,219,240-241,268,271 (one fused pass gives both)
-//   k_vec         : the O(m) algebra and control flow of findDenseClique,
+//   k_tail+k_decide: the O(m) algebra and control flow of findDenseClique,
 //                   src/clipper.cpp:193-209 (init), :219-220 (gradient), :226-262 (step,
 //                   projection, line search), :268-280 (penalty update)
 #pragma once
@@ -39,12 +39,18 @@ enum Phase : int32_t {
   PH_TRIAL = 3       // pass was on x = unew: line-search bookkeeping     (clipper.cpp:234-262)
 };
 
+// The vector a pass runs on is kept UN-normalised: x = T[sel] / nrm. k_gemv multiplies M by
+// T[sel]; k_tail divides the two sums by nrm (one division per column instead of one per
+// element of x before the pass) and materialises x where it is needed.
 struct SolverState {
   double d;       // penalty
   double F;       // objective at u
   double alpha;   // current step size
   double s;       // sum(u)
   double sx;      // sum(x) of the pending trial vector
+  double nrm;     // ||T[sel]|| (1 when the pending vector is already normalised / raw u0)
+  int32_t sel;    // which of T[0], T[1] holds the pending trial vector
+  int32_t ub;     // which of U[0]/G[0], U[1]/G[1] holds the current (u, gradF)
   int32_t phase;
   int32_t i, j, k;  // outer / inner / line-search counters (clipper.cpp:217)
   int32_t done;
@@ -58,17 +64,23 @@ struct SolverParams {
   int32_t maxiniters, maxoliters, maxlsiters;
 };
 
-struct VecArgs {
+constexpr int TAIL_THREADS = 256;
+constexpr int NSCAL = 6;  // per-workgroup partial scalars written by k_tail
+
+struct SolveArgs {
   SolverState* st;
   SolverParams prm;
   int64_t m;   // problem size
   int64_t W;   // shard pitch: element i lives in block p = i / W of `ab`
   const double* u0;
-  double* u;
-  double* g;     // gradF at u
-  double* x;     // vector the next / last pass runs on (unew)
-  double* gnew;  // gradF at x
-  const double* ab;  // [P][2][W]: a = M_off x, b = C_off x, gathered from all shards
+  double* U[2];   // current point u (double-buffered: accepted x becomes u by flipping `ub`)
+  double* G[2];   // gradF at u / at the trial vector
+  double* T[2];   // un-normalised trial vectors: T[0] = "if accepted", T[1] = "if rejected"
+  double* ab;     // [P][2][W]: a = M_off x, b = C_off x (raw sums in, normalised out)
+  const double* part;  // [ntiles][2][W] row-tile partials of this shard (fused reduce only)
+  int ntiles;
+  double* scal;   // [nwg][NSCAL] partial scalars of k_tail
+  int nwg;        // workgroups of k_tail = ceil(m / TAIL_THREADS)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -82,18 +94,43 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   return __hiloint2double(hi, lo);
 }
 
-// Deterministic block reduction of N doubles over a 1024-thread block (16 waves):
-// xor-butterfly inside each wave, then every thread sums the 16 wave partials in index
-// order, so all threads hold the identical result and the summation tree is fixed.
-template <int N>
-__device__ __forceinline__ void block_reduce_1024(double (&v)[N], double* lds /* [16*N] */) {
+__device__ __forceinline__ void ab_at(const double* ab, int64_t W, int64_t i, double& a,
+                                      double& b) {
+  // block p = i / W of the gathered [P][2][W] layout; 32-bit division (m < 2^31)
+  const uint32_t p = static_cast<uint32_t>(i) / static_cast<uint32_t>(W);
+  const int64_t off = i - static_cast<int64_t>(p) * W;
+  const double* blk = ab + static_cast<int64_t>(p) * 2 * W;
+  a = blk[off];
+  b = blk[W + off];
+}
+
+// ------------------------------------------------------------------------------------------
+// The O(m) part of one solver iteration, split so that it parallelises:
+//
+//   k_tail   (ceil(m/256) workgroups, one thread per element) — everything element-wise that
+//            follows a pass on the trial vector x (clipper.cpp:238-242, 253): a = M_off x,
+//            b = C_off x (sum of the row-tile partials, divided by nrm), gradFnew, and the
+//            per-workgroup partial sums of Fnew = x.gradFnew and ||x-u||^2. It also prepares
+//            BOTH possible next trial vectors (clipper.cpp:235-236) speculatively —
+//            T[0] = max(x + gradFnew, 0) if the step is accepted (alpha resets to 1),
+//            T[1] = max(u + alpha*beta*gradF, 0) if it is rejected — with the partial sums of
+//            their squared norms and of their entries, so that the only serial work left is
+//   k_decide (one workgroup) — adds the partial scalars in a fixed order, takes the
+//            reference's decisions (clipper.cpp:244-251, 261) and updates the state. Only
+//            the rare transitions (initialisation :193-220, penalty update :268-280, a new
+//            outer iteration :219-220) sweep over the m-vectors here.
+// All sums have a fixed shape, so results are bit-reproducible run to run and rank to rank.
+// ------------------------------------------------------------------------------------------
+
+template <int N, int NWAVES>
+__device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWAVES*N] */) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
     for (int q = 0; q < N; ++q) v[q] += shfl_xor_f64(v[q], off);
   }
   const int wave = threadIdx.x >> 6;
-  __syncthreads();  // previous users of `lds` are done
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int q = 0; q < N; ++q) lds[wave * N + q] = v[q];
@@ -103,121 +140,188 @@ __device__ __forceinline__ void block_reduce_1024(double (&v)[N], double* lds /*
   for (int q = 0; q < N; ++q) {
     double acc = lds[q];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) acc += lds[w * N + q];
+    for (int w = 1; w < NWAVES; ++w) acc += lds[w * N + q];
     v[q] = acc;
   }
 }
 
-__device__ __forceinline__ void ab_at(const double* ab, int64_t W, int64_t i, double& a,
-                                      double& b) {
-  const int64_t p = i / W;
-  const int64_t off = i - p * W;
-  const double* blk = ab + p * 2 * W;
-  a = blk[off];
-  b = blk[W + off];
+template <bool FUSED_REDUCE>
+__global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
+  const SolverState* st = A.st;
+  if (st->done) return;
+  __shared__ double red[(TAIL_THREADS / 64) * NSCAL];
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
+  const int64_t m = A.m;
+  const bool valid = i < m;
+  const double nrm = st->nrm;
+  const int phase = st->phase;
+
+  // (a, b) for the pending vector x = T[sel]/nrm
+  double a = 0.0, b = 0.0;
+  if (valid) {
+    if (FUSED_REDUCE) {  // single shard: W >= m, block 0
+      const double* p = A.part + i;
+      const int64_t ts = 2 * A.W;
+      for (int t = 0; t < A.ntiles; ++t) {
+        a += p[static_cast<int64_t>(t) * ts];
+        b += p[static_cast<int64_t>(t) * ts + A.W];
+      }
+    } else {
+      ab_at(A.ab, A.W, i, a, b);
+    }
+    a = a / nrm;
+    b = b / nrm;
+    // normalised pair back into the gathered layout (read again only by k_decide's rare sweeps)
+    const uint32_t pblk = static_cast<uint32_t>(i) / static_cast<uint32_t>(A.W);
+    const int64_t off = i - static_cast<int64_t>(pblk) * A.W;
+    A.ab[static_cast<int64_t>(pblk) * 2 * A.W + off] = a;
+    A.ab[static_cast<int64_t>(pblk) * 2 * A.W + A.W + off] = b;
+  }
+  if (phase != PH_TRIAL) return;  // initialisation phases are handled by k_decide alone
+
+  const int ub = st->ub;
+  const double d = st->d, sx = st->sx, alpha = st->alpha;
+  double r[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (valid) {
+    const double xi = A.T[st->sel][i] / nrm;  // clipper.cpp:237
+    const double ui = A.U[ub][i];
+    const double gi = A.G[ub][i];
+    const double gn = (1 + d) * xi - d * sx + a + b * d;  // :238-241
+    A.U[ub ^ 1][i] = xi;                                   // becomes u if accepted
+    A.G[ub ^ 1][i] = gn;
+    r[0] = xi * gn;  // :242
+    const double du = xi - ui;
+    r[1] = du * du;  // :253
+    double ta = xi + gn;  // next trial if accepted: alpha = 1 (:227, :235)
+    ta = (ta > 0.0) ? ta : 0.0;  // :236
+    double tr = ui + (alpha * A.prm.beta) * gi;  // next trial if rejected: alpha*beta (:248)
+    tr = (tr > 0.0) ? tr : 0.0;
+    A.T[0][i] = ta;
+    A.T[1][i] = tr;
+    r[2] = ta * ta;
+    r[3] = ta;
+    r[4] = tr * tr;
+    r[5] = tr;
+  }
+  block_reduce<NSCAL, TAIL_THREADS / 64>(r, red);
+  if (threadIdx.x < NSCAL) A.scal[static_cast<int64_t>(blockIdx.x) * NSCAL + threadIdx.x] = r[threadIdx.x];
 }
 
-// ------------------------------------------------------------------------------------------
-// k_vec — all O(m) vector algebra and every branch decision of findDenseClique, on device.
-// One 1024-thread workgroup; thread t owns elements t, t+1024, ... in every sweep, so the
-// sweeps need no synchronisation between them apart from the reductions.
-// ------------------------------------------------------------------------------------------
+constexpr int VU = 8;
+#define VEC_CHUNKS(base) for (int64_t base = tid; base < m; base += 1024 * VU)
+#define VEC_EACH(k, i, base)            \
+  _Pragma("unroll") for (int k = 0; k < VU; ++k) \
+    if (const int64_t i = base + static_cast<int64_t>(k) * 1024; i < m)
 
-__global__ __launch_bounds__(1024) void k_vec(VecArgs A) {
+__global__ __launch_bounds__(1024) void k_decide(SolveArgs A) {
   SolverState* st = A.st;
   if (st->done) return;
 
-  __shared__ double red[16 * 2];
+  __shared__ double red[16 * NSCAL];
   const int tid = threadIdx.x;
   const int64_t m = A.m;
   const SolverParams P = A.prm;
 
   const int phase = st->phase;
-  double d = st->d, F = st->F, alpha = st->alpha, s = st->s;
-  int i_ = st->i, j_ = st->j, k_ = st->k;
+  double d = st->d, F = st->F, alpha = st->alpha, s = st->s, sx = st->sx, nrm = st->nrm;
+  int i_ = st->i, j_ = st->j, k_ = st->k, ub = st->ub, sel = st->sel;
   int64_t n_passes = st->n_passes, n_trials = st->n_trials;
   if (phase != PH_NORMALIZE) ++n_passes;
 
   if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
     // clipper.cpp:193-198 — u = M_off*u0 + u0 (or u0), then u /= u.norm()
+    double* u = A.U[ub];
     double z[1] = {0.0};
-    for (int64_t i = tid; i < m; i += 1024) {
-      double ui = A.u0[i];
-      if (phase == PH_RESCALE) {
-        double a, b;
-        ab_at(A.ab, A.W, i, a, b);
-        ui = a + ui;
+    VEC_CHUNKS(base) {
+      double uv[VU], av[VU];
+      VEC_EACH(k, i, base) {
+        uv[k] = A.u0[i];
+        double b;
+        if (phase == PH_RESCALE) ab_at(A.ab, A.W, i, av[k], b);
       }
-      A.u[i] = ui;
-      z[0] += ui * ui;
+      VEC_EACH(k, i, base) {
+        const double ui = (phase == PH_RESCALE) ? av[k] + uv[k] : uv[k];
+        u[i] = ui;
+        z[0] += ui * ui;
+      }
     }
-    block_reduce_1024<1>(z, red);
-    const double nrm = sqrt(z[0]);
-    for (int64_t i = tid; i < m; i += 1024) {
-      const double ui = A.u[i] / nrm;
-      A.u[i] = ui;
-      A.x[i] = ui;
+    block_reduce<1, 16>(z, red);
+    const double n0 = sqrt(z[0]);
+    VEC_CHUNKS(base) {
+      double uv[VU];
+      VEC_EACH(k, i, base) uv[k] = u[i];
+      VEC_EACH(k, i, base) {
+        const double ui = uv[k] / n0;
+        u[i] = ui;
+        A.T[0][i] = ui;  // next pass runs on x = u (already normalised: nrm = 1)
+      }
     }
     if (tid == 0) {
       st->phase = PH_INIT;
+      st->sel = 0;
+      st->nrm = 1.0;
       st->n_passes = n_passes;
     }
     return;
   }
 
   bool begin_outer = false, end_inner = false, finished = false;
+  bool need_trial_vector = false;  // a sweep must build T[0] from (u, g): after a transition
 
   if (phase == PH_INIT) {
     // clipper.cpp:200-209 — initial d from the pass on u
+    const double* u = A.U[ub];
     double sv[1] = {0.0};
-    for (int64_t i = tid; i < m; i += 1024) sv[0] += A.u[i];
-    block_reduce_1024<1>(sv, red);
+    VEC_CHUNKS(base) {
+      double uv[VU];
+      VEC_EACH(k, i, base) uv[k] = u[i];
+      VEC_EACH(k, i, base) sv[0] += uv[k];
+    }
+    block_reduce<1, 16>(sv, red);
     s = sv[0];
     double ca[2] = {0.0, 0.0};  // count, sum of ratios
-    for (int64_t i = tid; i < m; i += 1024) {
-      double a, b;
-      ab_at(A.ab, A.W, i, a, b);
-      const double ui = A.u[i];
-      const double cbu = s - b - ui;  // :202
-      if (cbu > P.eps && ui > P.eps) {  // :203
-        ca[0] += 1.0;
-        ca[1] += (a + ui) / cbu;  // :205-208
+    VEC_CHUNKS(base) {
+      double uv[VU], av[VU], bv[VU];
+      VEC_EACH(k, i, base) {
+        uv[k] = u[i];
+        ab_at(A.ab, A.W, i, av[k], bv[k]);
+      }
+      VEC_EACH(k, i, base) {
+        const double cbu = s - bv[k] - uv[k];  // :202
+        if (cbu > P.eps && uv[k] > P.eps) {    // :203
+          ca[0] += 1.0;
+          ca[1] += (av[k] + uv[k]) / cbu;  // :205-208
+        }
       }
     }
-    block_reduce_1024<2>(ca, red);
+    block_reduce<2, 16>(ca, red);
     d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
     i_ = 0;
     begin_outer = true;
-  } else {  // PH_TRIAL — clipper.cpp:238-262 for the trial vector x = unew
+  } else {  // PH_TRIAL — the decisions of clipper.cpp:244-262 from k_tail's partial scalars
     ++n_trials;
-    const double sx = st->sx;
-    double r[2] = {0.0, 0.0};  // Fnew, ||x-u||^2
-    for (int64_t i = tid; i < m; i += 1024) {
-      double a, b;
-      ab_at(A.ab, A.W, i, a, b);
-      const double xi = A.x[i];
-      const double gn = (1 + d) * xi - d * sx + a + b * d;  // :238-241
-      A.gnew[i] = gn;
-      r[0] += xi * gn;  // :242
-      const double t = xi - A.u[i];
-      r[1] += t * t;  // :253
+    double r[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int w = tid; w < A.nwg; w += 1024) {
+#pragma unroll
+      for (int q = 0; q < NSCAL; ++q) r[q] += A.scal[static_cast<int64_t>(w) * NSCAL + q];
     }
-    block_reduce_1024<2>(r, red);
+    block_reduce<NSCAL, 16>(r, red);
     const double Fnew = r[0];
     const double deltaF = Fnew - F;  // :244
     bool accept = true;
     if (deltaF < -P.eps) {  // :246-248
       alpha = alpha * P.beta;
       ++k_;
-      if (k_ < P.maxlsiters) accept = false;  // :234 loop bound; last trial is kept
+      if (k_ < P.maxlsiters) accept = false;  // :234 loop bound; the last trial is kept
     }
-    if (accept) {
+    if (!accept) {
+      sel = 1;  // k_tail already built max(u + alpha*beta*g, 0) in T[1]
+      nrm = (r[4] > 0.0) ? sqrt(r[4]) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
+      sx = r[5] / nrm;
+    } else {
       const double deltau = sqrt(r[1]);
-      F = Fnew;  // :256-258
-      for (int64_t i = tid; i < m; i += 1024) {
-        A.u[i] = A.x[i];
-        A.g[i] = A.gnew[i];
-      }
+      F = Fnew;  // :256-258 — u <- x, gradF <- gradFnew by flipping the buffer index
+      ub ^= 1;
       s = sx;
       ++j_;
       if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
@@ -225,6 +329,9 @@ __global__ __launch_bounds__(1024) void k_vec(VecArgs A) {
       } else {
         alpha = 1.0;  // :227
         k_ = 0;
+        sel = 0;  // k_tail already built max(x + gradFnew, 0) in T[0]
+        nrm = (r[2] > 0.0) ? sqrt(r[2]) : 1.0;
+        sx = r[3] / nrm;
       }
     }
   }
@@ -233,18 +340,23 @@ __global__ __launch_bounds__(1024) void k_vec(VecArgs A) {
   // start of the next outer iteration (:219-220) reuse (a, b) of the accepted vector.
   while (true) {
     if (end_inner) {
+      const double* u = A.U[ub];
       double ca[2] = {0.0, 0.0};
-      for (int64_t i = tid; i < m; i += 1024) {
-        double a, b;
-        ab_at(A.ab, A.W, i, a, b);
-        const double ui = A.u[i];
-        const double cbu = s - b - ui;  // :268
-        if (cbu > P.eps && ui > P.eps) {  // :269
-          ca[0] += 1.0;
-          ca[1] += fabs((a + ui) / cbu);  // :271-274
+      VEC_CHUNKS(base) {
+        double uv[VU], av[VU], bv[VU];
+        VEC_EACH(k, i, base) {
+          uv[k] = u[i];
+          ab_at(A.ab, A.W, i, av[k], bv[k]);
+        }
+        VEC_EACH(k, i, base) {
+          const double cbu = s - bv[k] - uv[k];  // :268
+          if (cbu > P.eps && uv[k] > P.eps) {    // :269
+            ca[0] += 1.0;
+            ca[1] += fabs((av[k] + uv[k]) / cbu);  // :271-274
+          }
         }
       }
-      block_reduce_1024<2>(ca, red);
+      block_reduce<2, 16>(ca, red);
       end_inner = false;
       if (ca[0] > 0.0) {
         d += ca[1] / ca[0];  // :276
@@ -261,16 +373,22 @@ __global__ __launch_bounds__(1024) void k_vec(VecArgs A) {
         finished = true;
         break;
       }
+      const double* u = A.U[ub];
+      double* g = A.G[ub];
       double f[1] = {0.0};
-      for (int64_t i = tid; i < m; i += 1024) {
-        double a, b;
-        ab_at(A.ab, A.W, i, a, b);
-        const double ui = A.u[i];
-        const double gi = (1 + d) * ui - d * s + a + b * d;  // :219
-        A.g[i] = gi;
-        f[0] += ui * gi;  // :220
+      VEC_CHUNKS(base) {
+        double uv[VU], av[VU], bv[VU];
+        VEC_EACH(k, i, base) {
+          uv[k] = u[i];
+          ab_at(A.ab, A.W, i, av[k], bv[k]);
+        }
+        VEC_EACH(k, i, base) {
+          const double gi = (1 + d) * uv[k] - d * s + av[k] + bv[k] * d;  // :219
+          g[i] = gi;
+          f[0] += uv[k] * gi;  // :220
+        }
       }
-      block_reduce_1024<1>(f, red);
+      block_reduce<1, 16>(f, red);
       F = f[0];
       j_ = 0;
       if (P.maxiniters <= 0) {
@@ -279,32 +397,34 @@ __global__ __launch_bounds__(1024) void k_vec(VecArgs A) {
       }
       alpha = 1.0;
       k_ = 0;
+      need_trial_vector = true;
     }
     break;
   }
 
-  double sx_new = 0.0;
-  if (!finished) {
-    // :235-237 — gradient step, projection onto the positive orthant, normalisation
-    double z[1] = {0.0};
-    for (int64_t i = tid; i < m; i += 1024) {
-      double t = A.u[i] + alpha * A.g[i];
-      t = (t > 0.0) ? t : 0.0;
-      A.x[i] = t;
-      z[0] += t * t;
-    }
-    block_reduce_1024<1>(z, red);
-    double sxv[1] = {0.0};
-    if (z[0] > 0.0) {  // Eigen's normalize(): only when squaredNorm() > 0
-      const double nrm = sqrt(z[0]);
-      for (int64_t i = tid; i < m; i += 1024) {
-        const double xi = A.x[i] / nrm;
-        A.x[i] = xi;
-        sxv[0] += xi;
+  if (!finished && need_trial_vector) {
+    // :235-236 with alpha = 1 — gradient step and projection; normalisation is deferred (nrm)
+    const double* u = A.U[ub];
+    const double* g = A.G[ub];
+    double zs[2] = {0.0, 0.0};
+    VEC_CHUNKS(base) {
+      double uv[VU], gv[VU];
+      VEC_EACH(k, i, base) {
+        uv[k] = u[i];
+        gv[k] = g[i];
+      }
+      VEC_EACH(k, i, base) {
+        double t = uv[k] + alpha * gv[k];
+        t = (t > 0.0) ? t : 0.0;
+        A.T[0][i] = t;
+        zs[0] += t * t;
+        zs[1] += t;
       }
     }
-    block_reduce_1024<1>(sxv, red);
-    sx_new = sxv[0];
+    block_reduce<2, 16>(zs, red);
+    sel = 0;
+    nrm = (zs[0] > 0.0) ? sqrt(zs[0]) : 1.0;
+    sx = zs[1] / nrm;
   }
 
   if (tid == 0) {
@@ -312,7 +432,10 @@ __global__ __launch_bounds__(1024) void k_vec(VecArgs A) {
     st->F = F;
     st->alpha = alpha;
     st->s = s;
-    st->sx = sx_new;
+    st->sx = sx;
+    st->nrm = nrm;
+    st->sel = sel;
+    st->ub = ub;
     st->phase = PH_TRIAL;
     st->i = i_;
     st->j = j_;
@@ -325,6 +448,8 @@ __global__ __launch_bounds__(1024) void k_vec(VecArgs A) {
     }
   }
 }
+#undef VEC_CHUNKS
+#undef VEC_EACH
 
 // ------------------------------------------------------------------------------------------
 // k_gemv — the fused symmetric mat-vec pair  a = M_off x,  b = C_off x  in ONE pass over M.
@@ -361,10 +486,13 @@ template <typename T, bool HASC, int NW, int UNR>
 __global__ __launch_bounds__(NW * 64) void k_gemv(const T* __restrict__ S,
                                                    const T* __restrict__ Cs, int64_t ld,
                                                    int64_t m, int rows_per_tile,
-                                                   const double* __restrict__ x,
+                                                   const double* __restrict__ x0,
+                                                   const double* __restrict__ x1,
                                                    double* __restrict__ part,
                                                    const SolverState* __restrict__ st) {
   if (st != nullptr && st->done) return;
+  // driven by the solver: the pending trial vector is T[sel] (un-normalised, see SolverState)
+  const double* __restrict__ x = (st != nullptr && st->sel) ? x1 : x0;
 
   __shared__ double lds[NW * 2 * 256];
   const int lane = threadIdx.x & 63;
@@ -458,20 +586,28 @@ __global__ __launch_bounds__(NW * 64) void k_gemv(const T* __restrict__ S,
 }
 
 // k_reduce — adds the row-tile partials in tile order and writes this shard's block of the
-// gathered vector pair: ab_block = [a (W) | b (W)].
+// gathered vector pair: ab_block = [a (W) | b (W)]. One thread per output element; the
+// loads of 8 tiles are issued before they are summed (the partials sit in L2 / MALL).
 __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ part, int ntiles,
                                                  int64_t ld, double* __restrict__ ab_block,
                                                  const SolverState* __restrict__ st) {
   if (st != nullptr && st->done) return;
-  const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (c >= ld) return;
-  double a = 0.0, b = 0.0;
-  for (int t = 0; t < ntiles; ++t) {
-    a += part[(static_cast<int64_t>(t) * 2 + 0) * ld + c];
-    b += part[(static_cast<int64_t>(t) * 2 + 1) * ld + c];
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;  // in [0, 2*ld)
+  if (e >= 2 * ld) return;
+  const int64_t which = e / ld, c = e - which * ld;
+  const double* p = part + which * ld + c;
+  const int64_t tstride = 2 * ld;
+  double acc = 0.0;
+  int t = 0;
+  for (; t + 8 <= ntiles; t += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p[static_cast<int64_t>(t + q) * tstride];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc += v[q];
   }
-  ab_block[c] = a;
-  ab_block[ld + c] = b;
+  for (; t < ntiles; ++t) acc += p[static_cast<int64_t>(t) * tstride];
+  ab_block[e] = acc;  // e = which*ld + c: exactly the [a | b] block layout
 }
 
 // ------------------------------------------------------------------------------------------
