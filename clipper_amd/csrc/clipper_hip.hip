@@ -376,7 +376,7 @@ int enqueue_iteration(Ctx* h, const SolverParams& prm) {
     Shard& s = h->sh[0];
     SolveArgs a = solve_args(h, s, prm);
     hipLaunchKernelGGL(k_tail<true>, dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, s.stream, a);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(DECIDE_THREADS), 0, s.stream, a);
     return 0;
   }
   if ((rc = enqueue_reduce_exchange(h, true))) return rc;
@@ -384,7 +384,7 @@ int enqueue_iteration(Ctx* h, const SolverParams& prm) {
     HIPCHK(hipSetDevice(s.device));
     SolveArgs a = solve_args(h, s, prm);
     hipLaunchKernelGGL(k_tail<false>, dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, s.stream, a);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(DECIDE_THREADS), 0, s.stream, a);
   }
   return 0;
 }
@@ -393,7 +393,7 @@ int enqueue_decide_only(Ctx* h, const SolverParams& prm) {
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     SolveArgs a = solve_args(h, s, prm);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, s.stream, a);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(DECIDE_THREADS), 0, s.stream, a);
   }
   return 0;
 }

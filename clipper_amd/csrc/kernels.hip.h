@@ -147,28 +147,54 @@ __device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWA
 
 template <bool FUSED_REDUCE>
 __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
-  const SolverState* st = A.st;
-  if (st->done) return;
   __shared__ double red[(TAIL_THREADS / 64) * NSCAL];
   const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
   const int64_t m = A.m;
   const bool valid = i < m;
-  const double nrm = st->nrm;
-  const int phase = st->phase;
 
-  // (a, b) for the pending vector x = T[sel]/nrm
+  // Everything that does not depend on the solver state is loaded first, so that the state,
+  // the partials and both buffer candidates share ONE memory round trip instead of chaining.
+  const SolverState stv = *A.st;  // one 128-byte read
   double a = 0.0, b = 0.0;
+  double t0 = 0.0, t1 = 0.0, u0v = 0.0, u1v = 0.0, g0v = 0.0, g1v = 0.0;
   if (valid) {
-    if (FUSED_REDUCE) {  // single shard: W >= m, block 0
+    t0 = A.T[0][i];
+    t1 = A.T[1][i];
+    u0v = A.U[0][i];
+    u1v = A.U[1][i];
+    g0v = A.G[0][i];
+    g1v = A.G[1][i];
+    if (FUSED_REDUCE) {  // single shard: W >= m, block 0; 8 tiles of loads in flight at a time
       const double* p = A.part + i;
       const int64_t ts = 2 * A.W;
-      for (int t = 0; t < A.ntiles; ++t) {
+      int t = 0;
+      for (; t + 8 <= A.ntiles; t += 8) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          va[q] = p[static_cast<int64_t>(t + q) * ts];
+          vb[q] = p[static_cast<int64_t>(t + q) * ts + A.W];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          a += va[q];
+          b += vb[q];
+        }
+      }
+      for (; t < A.ntiles; ++t) {
         a += p[static_cast<int64_t>(t) * ts];
         b += p[static_cast<int64_t>(t) * ts + A.W];
       }
     } else {
       ab_at(A.ab, A.W, i, a, b);
     }
+  }
+  if (stv.done) return;
+  const double nrm = stv.nrm;
+  const int phase = stv.phase;
+
+  // (a, b) for the pending vector x = T[sel]/nrm
+  if (valid) {
     a = a / nrm;
     b = b / nrm;
     // normalised pair back into the gathered layout (read again only by k_decide's rare sweeps)
@@ -179,13 +205,13 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
   }
   if (phase != PH_TRIAL) return;  // initialisation phases are handled by k_decide alone
 
-  const int ub = st->ub;
-  const double d = st->d, sx = st->sx, alpha = st->alpha;
+  const int ub = stv.ub;
+  const double d = stv.d, sx = stv.sx, alpha = stv.alpha;
   double r[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (valid) {
-    const double xi = A.T[st->sel][i] / nrm;  // clipper.cpp:237
-    const double ui = A.U[ub][i];
-    const double gi = A.G[ub][i];
+    const double xi = (stv.sel ? t1 : t0) / nrm;  // clipper.cpp:237
+    const double ui = ub ? u1v : u0v;
+    const double gi = ub ? g1v : g0v;
     const double gn = (1 + d) * xi - d * sx + a + b * d;  // :238-241
     A.U[ub ^ 1][i] = xi;                                   // becomes u if accepted
     A.G[ub ^ 1][i] = gn;
@@ -208,24 +234,33 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
 }
 
 constexpr int VU = 8;
-#define VEC_CHUNKS(base) for (int64_t base = tid; base < m; base += 1024 * VU)
+constexpr int DECIDE_THREADS = 256;
+constexpr int DECIDE_WAVES = DECIDE_THREADS / 64;
+#define VEC_CHUNKS(base) for (int64_t base = tid; base < m; base += DECIDE_THREADS * VU)
 #define VEC_EACH(k, i, base)            \
   _Pragma("unroll") for (int k = 0; k < VU; ++k) \
-    if (const int64_t i = base + static_cast<int64_t>(k) * 1024; i < m)
+    if (const int64_t i = base + static_cast<int64_t>(k) * DECIDE_THREADS; i < m)
 
-__global__ __launch_bounds__(1024) void k_decide(SolveArgs A) {
+__global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
   SolverState* st = A.st;
-  if (st->done) return;
-
-  __shared__ double red[16 * NSCAL];
+  __shared__ double red[DECIDE_WAVES * NSCAL];
   const int tid = threadIdx.x;
   const int64_t m = A.m;
   const SolverParams P = A.prm;
 
-  const int phase = st->phase;
-  double d = st->d, F = st->F, alpha = st->alpha, s = st->s, sx = st->sx, nrm = st->nrm;
-  int i_ = st->i, j_ = st->j, k_ = st->k, ub = st->ub, sel = st->sel;
-  int64_t n_passes = st->n_passes, n_trials = st->n_trials;
+  // state and k_tail's partial scalars in one memory round trip
+  const SolverState stv = *st;
+  double r[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int w = tid; w < A.nwg; w += DECIDE_THREADS) {
+#pragma unroll
+    for (int q = 0; q < NSCAL; ++q) r[q] += A.scal[static_cast<int64_t>(w) * NSCAL + q];
+  }
+  if (stv.done) return;
+
+  const int phase = stv.phase;
+  double d = stv.d, F = stv.F, alpha = stv.alpha, s = stv.s, sx = stv.sx, nrm = stv.nrm;
+  int i_ = stv.i, j_ = stv.j, k_ = stv.k, ub = stv.ub, sel = stv.sel;
+  int64_t n_passes = stv.n_passes, n_trials = stv.n_trials;
   if (phase != PH_NORMALIZE) ++n_passes;
 
   if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
@@ -245,7 +280,7 @@ __global__ __launch_bounds__(1024) void k_decide(SolveArgs A) {
         z[0] += ui * ui;
       }
     }
-    block_reduce<1, 16>(z, red);
+    block_reduce<1, DECIDE_WAVES>(z, red);
     const double n0 = sqrt(z[0]);
     VEC_CHUNKS(base) {
       double uv[VU];
@@ -277,7 +312,7 @@ __global__ __launch_bounds__(1024) void k_decide(SolveArgs A) {
       VEC_EACH(k, i, base) uv[k] = u[i];
       VEC_EACH(k, i, base) sv[0] += uv[k];
     }
-    block_reduce<1, 16>(sv, red);
+    block_reduce<1, DECIDE_WAVES>(sv, red);
     s = sv[0];
     double ca[2] = {0.0, 0.0};  // count, sum of ratios
     VEC_CHUNKS(base) {
@@ -294,18 +329,13 @@ __global__ __launch_bounds__(1024) void k_decide(SolveArgs A) {
         }
       }
     }
-    block_reduce<2, 16>(ca, red);
+    block_reduce<2, DECIDE_WAVES>(ca, red);
     d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
     i_ = 0;
     begin_outer = true;
   } else {  // PH_TRIAL — the decisions of clipper.cpp:244-262 from k_tail's partial scalars
     ++n_trials;
-    double r[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int w = tid; w < A.nwg; w += 1024) {
-#pragma unroll
-      for (int q = 0; q < NSCAL; ++q) r[q] += A.scal[static_cast<int64_t>(w) * NSCAL + q];
-    }
-    block_reduce<NSCAL, 16>(r, red);
+    block_reduce<NSCAL, DECIDE_WAVES>(r, red);
     const double Fnew = r[0];
     const double deltaF = Fnew - F;  // :244
     bool accept = true;
@@ -356,7 +386,7 @@ __global__ __launch_bounds__(1024) void k_decide(SolveArgs A) {
           }
         }
       }
-      block_reduce<2, 16>(ca, red);
+      block_reduce<2, DECIDE_WAVES>(ca, red);
       end_inner = false;
       if (ca[0] > 0.0) {
         d += ca[1] / ca[0];  // :276
@@ -388,7 +418,7 @@ __global__ __launch_bounds__(1024) void k_decide(SolveArgs A) {
           f[0] += uv[k] * gi;  // :220
         }
       }
-      block_reduce<1, 16>(f, red);
+      block_reduce<1, DECIDE_WAVES>(f, red);
       F = f[0];
       j_ = 0;
       if (P.maxiniters <= 0) {
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_decide(SolveArgs A) {
         zs[1] += t;
       }
     }
-    block_reduce<2, 16>(zs, red);
+    block_reduce<2, DECIDE_WAVES>(zs, red);
     sel = 0;
     nrm = (zs[0] > 0.0) ? sqrt(zs[0]) : 1.0;
     sx = zs[1] / nrm;
