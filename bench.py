@@ -98,10 +98,11 @@ def main():
 
     abi.load_library()
 
+    from clipper_amd import dist as cdist
+
     if N > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=N)
+        cdist.init_process_group("cpu:gloo,cuda:nccl")
 
     def barrier_sync():
         if N > 1:
@@ -112,11 +113,8 @@ def main():
     problem = synth.make_euclidean_problem(args.m, rho, seed=args.seed)  # identical on every rank
     if N > 1:
         g = abi.HipClipper(device=local_rank, storage=storage, rank=rank, world=N)
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(g.unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(uid, src=0)
-        g.comm_init(bytes(uid.numpy().tobytes()))
+        uid = cdist.broadcast_bytes(g.unique_id() if rank == 0 else None, 128, src=0)
+        g.comm_init(uid)   # ncclCommInitRank inside libclipper_hip.so (RCCL over xGMI)
     else:
         g = abi.HipClipper(device=local_rank, storage=storage)
 
@@ -153,9 +151,7 @@ def main():
     g.set_profiling(False)
 
     if N > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = cdist.max_over_ranks(elapsed)
 
     tm = g.timings()
     ms_per_step = elapsed * 1e3 / args.steps

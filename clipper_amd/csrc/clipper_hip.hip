@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <queue>
@@ -276,7 +277,7 @@ void launch_reduce(Ctx* h, Shard& s, const SolverState* st) {
 
 // exchange of the per-shard [a|b] blocks so that every shard holds the full gathered pair
 int exchange(Ctx* h) {
-  if (h->world == 1) return 0;
+  if (h->world == 1 && !h->multiproc) return 0;
   const size_t blk = static_cast<size_t>(2 * h->W) * sizeof(double);
   if (h->multiproc) {
     if (!h->comm) return fail(CLIPPER_HIP_E_COMM, "clipper_hip_comm_init was not called");
@@ -372,7 +373,7 @@ int enqueue_reduce_exchange(Ctx* h, bool use_state) {
 int enqueue_iteration(Ctx* h, const SolverParams& prm) {
   int rc = enqueue_gemv(h, true);
   if (rc) return rc;
-  if (h->world == 1) {
+  if (h->world == 1 && !h->multiproc) {
     Shard& s = h->sh[0];
     SolveArgs a = solve_args(h, s, prm);
     hipLaunchKernelGGL(k_tail<true>, dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
@@ -646,7 +647,11 @@ clipper_hip_t* clipper_hip_create_rank(int device, int storage, int rank, int wo
     fail(CLIPPER_HIP_E_INVALID, "rank %d / world %d invalid", rank, world);
     return nullptr;
   }
-  return make_ctx(&device, 1, storage, world, rank, world > 1);
+  // CLIPPER_HIP_FORCE_RCCL=1 routes even a 1-rank world through ncclAllGather, so that the
+  // communicator plumbing can be exercised on a single-GPU box
+  const char* force = std::getenv("CLIPPER_HIP_FORCE_RCCL");
+  const bool multiproc = world > 1 || (force && force[0] == '1');
+  return make_ctx(&device, 1, storage, world, rank, multiproc);
 }
 
 int clipper_hip_comm_unique_id(void* id128) {
@@ -1090,7 +1095,11 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     have_prev = true;
     slot ^= 1;
     if (done) break;
-    // the batch just queued may already be finished (launch-bound small problems): peek
+    // the batch just queued may already be finished (launch-bound small problems): peek.
+    // Never across processes: every rank must queue the same number of batches (each holds
+    // collective calls), so there the decision rests on snapshot contents only, which are
+    // bit-identical on all ranks.
+    if (h->multiproc) continue;
     if (hipEventQuery(h->ev_poll[slot ^ 1]) == hipSuccess) {
       if (h->host_state[slot ^ 1].done) done = true;
     } else {

@@ -357,13 +357,28 @@ def numpy_k_largest(x, k):
     return np.array(out, dtype=np.int32)
 
 
-def numpy_solve(Mup, Cup, u0, p: Params | None = None):
-    """findDenseClique (clipper.cpp:172-323) on dense strict-upper M, C (numpy, fp64)."""
+class _Op:
+    """`op @ x` through a callable, so that numpy_solve can run on a distributed mat-vec."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __matmul__(self, x):
+        return self.fn(x)
+
+
+def numpy_solve(Mup, Cup, u0, p: Params | None = None, matvec=None):
+    """findDenseClique (clipper.cpp:172-323) on dense strict-upper M, C (numpy, fp64).
+    `matvec(x) -> (M_off x, C_off x)`, when given, replaces the dense products (used by the
+    world_size-2 gloo test to run the same loop on a column-sharded, all-gathered mat-vec)."""
     p = p or Params()
-    Ms = Mup + Mup.T  # selfadjointView<Upper> of the strict upper part
-    Cs = Cup + Cup.T
-    n = Ms.shape[0]
+    if matvec is None:
+        Ms = Mup + Mup.T  # selfadjointView<Upper> of the strict upper part
+        Cs = Cup + Cup.T
+    else:
+        Ms, Cs = _Op(lambda x: matvec(x)[0]), _Op(lambda x: matvec(x)[1])
     u0 = np.asarray(u0, float)
+    n = u0.shape[0]
     u = Ms @ u0 + u0 if p.rescale_u0 else u0.copy()
     u = u / np.linalg.norm(u)
     d = 0.0

@@ -306,6 +306,26 @@ def test_in_process_shards_on_one_device(nshards):
         _check_solution(g.solve(p.u0), sr)
 
 
+def test_rccl_exchange_with_a_one_rank_world(monkeypatch):
+    # CLIPPER_HIP_FORCE_RCCL=1 routes the per-pass exchange of a 1-rank world through
+    # ncclAllGather: exercises dlopen(librccl), ncclGetUniqueId, ncclCommInitRank and the
+    # in-place all-gather on the one GPU of the test box.
+    monkeypatch.setenv("CLIPPER_HIP_FORCE_RCCL", "1")
+    p = synth.make_euclidean_problem(1200, 0.9, seed=3)
+    g = abi.HipClipper(storage=abi.STORE_F32, rank=0, world=1)
+    g.comm_init(g.unique_id())
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    sg = g.solve(p.u0)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    _check_solution(sg, r.solve(p.u0))
+    monkeypatch.delenv("CLIPPER_HIP_FORCE_RCCL")
+    s1 = abi.HipClipper(storage=abi.STORE_F32)
+    s1.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    ss = s1.solve(p.u0)
+    assert ss.nodes.tolist() == sg.nodes.tolist() and ss.score == sg.score   # bit-identical
+
+
 # ------------------------------------------------------------------------------------------
 # BASELINE.json full size (m = 10k): oracle comparison + size-independent properties
 # ------------------------------------------------------------------------------------------
