@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Runs the BASELINE.json configurations on one MI355X next to the CPU oracle and prints one
+JSON row per configuration (the table of BASELINE.md section 3).
+  python tools/run_configs.py [--configs 1k,10k,pn5k,100k] [--reps 5] [--no-cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from clipper_amd import _abi as abi  # noqa: E402
+from clipper_amd import synth  # noqa: E402
+
+CONFIGS = {
+    "1k": dict(kind="euclid", m=1000, rho=0.90),
+    "10k": dict(kind="euclid", m=10000, rho=0.95),
+    "pn5k": dict(kind="pointnormal", m=5000, rho=0.90),
+    "30k": dict(kind="euclid", m=30000, rho=0.95),
+    "100k": dict(kind="euclid", m=100000, rho=0.95),
+}
+
+
+def run(name, cfg, reps, storage, with_cpu):
+    m, rho = cfg["m"], cfg["rho"]
+    if cfg["kind"] == "euclid":
+        p = synth.make_euclidean_problem(m, rho)
+        inv = synth.EUCLID_BENCH_PARAMS
+    else:
+        p = synth.make_pointnormal_problem(m, rho)
+        inv = p.meta["invariant"]
+    g = abi.HipClipper(storage=storage)
+    g.stage_inputs(p.D1, p.D2, p.A)
+
+    def affinity():
+        if cfg["kind"] == "euclid":
+            g.affinity_euclidean_staged(**inv)
+        else:
+            g.affinity_pointnormal_staged(**inv)
+
+    affinity()
+    g.stage_u0(p.u0)
+    g.solve_staged()
+    g.set_profiling(True)
+    ta, ts, gemv = [], [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        affinity()
+        t1 = time.perf_counter()
+        sol = g.solve_staged()
+        t2 = time.perf_counter()
+        ta.append((t1 - t0) * 1e3)
+        ts.append((t2 - t1) * 1e3)
+        gemv.append(g.timings().gemv_avg_us)
+    tm = g.timings()
+    row = dict(config=name, kind=cfg["kind"], m=m, rho=rho,
+               storage="f32" if storage == abi.STORE_F32 else "f64",
+               gpu_affinity_ms=round(float(np.median(ta)), 4), gpu_solve_ms=round(float(np.median(ts)), 4),
+               passes=int(sol.n_passes), gemv_us=round(float(np.median(gemv)), 2),
+               gemv_GBps=round(tm.gemv_bytes / (float(np.median(gemv)) * 1e-6) / 1e9, 1),
+               frac_of_8TBps=round(tm.gemv_bytes / (float(np.median(gemv)) * 1e-6) / 8e12, 4),
+               score=sol.score, nodes=int(len(sol.nodes)), ifinal=int(sol.ifinal))
+    prec, rec = synth.precision_recall(g.get_selected_associations(), p.Agt)
+    row.update(precision=round(prec, 4), recall=round(rec, 4))
+    if with_cpu:
+        from oracle import clipper_ref as ref
+        r = ref.RefClipper()
+        t0 = time.perf_counter()
+        if cfg["kind"] == "euclid":
+            r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **inv)
+        else:
+            r.score_pairwise_consistency_pointnormal(p.D1, p.D2, p.A, **inv)
+        t1 = time.perf_counter()
+        sr = r.solve(p.u0)
+        t2 = time.perf_counter()
+        row.update(cpu_affinity_ms=round((t1 - t0) * 1e3, 2), cpu_threads=ref.omp_threads(),
+                   cpu_solve_ms=round((t2 - t1) * 1e3, 2), cpu_passes=int(sr.n_passes),
+                   nnz_upper=int(r.nnz), density=round(r.nnz / (m * (m - 1) / 2), 4),
+                   set_identical=bool(sr.nodes.tolist() == sol.nodes.tolist()),
+                   rel_dscore=abs(sr.score - sol.score) / abs(sr.score))
+    g.close()
+    print(json.dumps(row), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="1k,10k,pn5k")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--storage", default="f32")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    storage = abi.STORE_F32 if a.storage == "f32" else abi.STORE_F64
+    for name in a.configs.split(","):
+        run(name, CONFIGS[name], a.reps, storage, not a.no_cpu)
+
+
+if __name__ == "__main__":
+    main()
