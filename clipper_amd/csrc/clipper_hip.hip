@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <queue>
 #include <string>
 #include <utility>
@@ -117,6 +118,8 @@ struct Shard {
   SolverState* st = nullptr;
   // affinity inputs (staged once, reused while the sizes fit)
   double *P1 = nullptr, *P2 = nullptr;  // gathered point tables [d][pstride]
+  float *P1f = nullptr, *P2f = nullptr; // the same, rounded to fp32 (prefilter input)
+  size_t capPf = 0;
   int32_t* Adev = nullptr;              // [2][m]
   double *dD1 = nullptr, *dD2 = nullptr;  // raw D1, D2 as uploaded
   size_t capP = 0, capA = 0, capD1 = 0, capD2 = 0;
@@ -139,6 +142,8 @@ struct clipper_hip_ctx {
   bool has_matrix = false;
   bool explicitC = false;
   int staged_d = 0;          // dimension of the staged point tables (0 = nothing staged)
+  double staged_maxabs = 0;  // max |coordinate| of D1, D2: bounds the fp32 prefilter's error
+  bool plain_affinity = false;  // CLIPPER_HIP_AFFINITY=plain: non-compacting fill kernels
   int64_t staged_pstride = 0;
   bool u0_staged = false;
   int ntiles = 1, rows_per_tile = 0, nstrips = 0;
@@ -184,6 +189,9 @@ int free_shard_buffers(Shard& s) {
   fr(s.st);
   fr(s.P1);
   fr(s.P2);
+  fr(s.P1f);
+  fr(s.P2f);
+  s.capPf = 0;
   fr(s.Adev);
   fr(s.dD1);
   fr(s.dD2);
@@ -518,14 +526,17 @@ int upload_points(Ctx* h, Shard& s, const double* D1, const double* D2, int d, i
   if ((rc = ensure_cap(s.P1, s.capP, bp))) return rc;
   if ((rc = ensure_cap(s.P2, capP2, bp))) return rc;
   if ((rc = ensure_cap(s.Adev, s.capA, ba))) return rc;
+  size_t capPf2 = s.capPf;
+  if ((rc = ensure_cap(s.P1f, s.capPf, bp / 2))) return rc;
+  if ((rc = ensure_cap(s.P2f, capPf2, bp / 2))) return rc;
   HIPCHK(hipMemcpyAsync(s.dD1, D1, b1, hipMemcpyHostToDevice, s.stream));
   HIPCHK(hipMemcpyAsync(s.dD2, D2, b2, hipMemcpyHostToDevice, s.stream));
   HIPCHK(hipMemcpyAsync(s.Adev, h->A.data(), ba, hipMemcpyHostToDevice, s.stream));
   dim3 grid(static_cast<unsigned>(ceil_div(pstride, 256))), block(256);
   hipLaunchKernelGGL(k_gather_points, grid, block, 0, s.stream, s.dD1, d, s.Adev, h->m, pstride,
-                     s.P1);
+                     s.P1, s.P1f);
   hipLaunchKernelGGL(k_gather_points, grid, block, 0, s.stream, s.dD2, d, s.Adev + h->m, h->m,
-                     pstride, s.P2);
+                     pstride, s.P2, s.P2f);
   HIPCHK(hipStreamSynchronize(s.stream));
   return 0;
 }
@@ -564,7 +575,24 @@ int stage_inputs(Ctx* h, const double* D1, int d, int64_t n1, const double* D2, 
   }
   h->staged_d = d;
   h->staged_pstride = pstride;
+  double mx = 0.0;
+  for (int64_t i = 0; i < static_cast<int64_t>(d) * n1; ++i) mx = std::max(mx, std::fabs(D1[i]));
+  for (int64_t i = 0; i < static_cast<int64_t>(d) * n2; ++i) mx = std::max(mx, std::fabs(D2[i]));
+  h->staged_maxabs = mx;
+  const char* mode = std::getenv("CLIPPER_HIP_AFFINITY");
+  h->plain_affinity = (mode && std::strcmp(mode, "plain") == 0);
   return 0;
+}
+
+// Threshold of the conservative fp32 prefilter: eps + a bound on the fp32 evaluation error of
+// | ||pr-pc|| - ||qr-qc|| | for coordinates of magnitude <= maxabs in dimension d
+// (input rounding 2^-24 each, d+2 roundings in the norm, both norms, the subtraction:
+// < 50 * 2^-24 * maxabs at d = 3; 128*(d+1) * 2^-24 leaves a 10x margin), rounded up.
+float guarded_threshold(double eps, double maxabs, int d) {
+  const double guard = std::ldexp(128.0 * (d + 1), -24) * maxabs;
+  const double t = eps + guard;
+  if (!(t < 3.0e38)) return std::numeric_limits<float>::infinity();
+  return std::nextafter(static_cast<float>(t), std::numeric_limits<float>::infinity());
 }
 
 template <typename Launch>
@@ -727,15 +755,26 @@ int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double
   hipLaunchKernelGGL((k_affinity_euclid<T, D>), grid, block, 0, s.stream,                   \
                      static_cast<T*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, d, s.P1, s.P2, pstride, \
                      A0, A1, prm)
+#define LAUNCH_EUCLID_COMPACT(T, D)                                                         \
+  hipLaunchKernelGGL((k_affinity_euclid_compact<T, D>), grid, block, 0, s.stream,           \
+                     static_cast<T*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2, s.P1f,  \
+                     s.P2f, pstride, A0, A1, prm, thr)
+    const float thr = guarded_threshold(epsilon, h->staged_maxabs, d);
+    const bool compact = !h->plain_affinity && (d == 2 || d == 3);
     if (h->storage == CLIPPER_HIP_STORE_F64) {
-      if (d == 3) LAUNCH_EUCLID(double, 3);
+      if (compact && d == 3) LAUNCH_EUCLID_COMPACT(double, 3);
+      else if (compact && d == 2) LAUNCH_EUCLID_COMPACT(double, 2);
+      else if (d == 3) LAUNCH_EUCLID(double, 3);
       else if (d == 2) LAUNCH_EUCLID(double, 2);
       else LAUNCH_EUCLID(double, 0);
     } else {
-      if (d == 3) LAUNCH_EUCLID(float, 3);
+      if (compact && d == 3) LAUNCH_EUCLID_COMPACT(float, 3);
+      else if (compact && d == 2) LAUNCH_EUCLID_COMPACT(float, 2);
+      else if (d == 3) LAUNCH_EUCLID(float, 3);
       else if (d == 2) LAUNCH_EUCLID(float, 2);
       else LAUNCH_EUCLID(float, 0);
     }
+#undef LAUNCH_EUCLID_COMPACT
 #undef LAUNCH_EUCLID
   });
 }
@@ -752,14 +791,26 @@ int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, doubl
               static_cast<unsigned>(ceil_div(mm, AFF_ROWS_PER_BLK))),
         block(256);
     const int64_t c0 = static_cast<int64_t>(s.slot) * W;
-    if (h->storage == CLIPPER_HIP_STORE_F64)
-      hipLaunchKernelGGL((k_affinity_pointnormal<double>), grid, block, 0, s.stream,
-                         static_cast<double*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2,
-                         pstride, s.Adev, s.Adev + mm, prm);
-    else
-      hipLaunchKernelGGL((k_affinity_pointnormal<float>), grid, block, 0, s.stream,
-                         static_cast<float*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2,
-                         pstride, s.Adev, s.Adev + mm, prm);
+    const float thr = guarded_threshold(epsp, h->staged_maxabs, 3);
+    if (h->plain_affinity) {
+      if (h->storage == CLIPPER_HIP_STORE_F64)
+        hipLaunchKernelGGL((k_affinity_pointnormal<double>), grid, block, 0, s.stream,
+                           static_cast<double*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2,
+                           pstride, s.Adev, s.Adev + mm, prm);
+      else
+        hipLaunchKernelGGL((k_affinity_pointnormal<float>), grid, block, 0, s.stream,
+                           static_cast<float*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2,
+                           pstride, s.Adev, s.Adev + mm, prm);
+    } else {
+      if (h->storage == CLIPPER_HIP_STORE_F64)
+        hipLaunchKernelGGL((k_affinity_pointnormal_compact<double>), grid, block, 0, s.stream,
+                           static_cast<double*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2,
+                           s.P1f, s.P2f, pstride, s.Adev, s.Adev + mm, prm, thr);
+      else
+        hipLaunchKernelGGL((k_affinity_pointnormal_compact<float>), grid, block, 0, s.stream,
+                           static_cast<float*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2,
+                           s.P1f, s.P2f, pstride, s.Adev, s.Adev + mm, prm, thr);
+    }
   });
 }
 

@@ -645,15 +645,21 @@ __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ part,
 // ------------------------------------------------------------------------------------------
 
 // P[k * pstride + i] = D[k + d * idx[i]] : per-association point table, structure of arrays,
-// so that column data loads in the fill kernels are contiguous across lanes.
+// so that column data loads in the fill kernels are contiguous across lanes. Pf is the same
+// table rounded to fp32 (input of the conservative prefilter of the compacting fill kernels).
 __global__ __launch_bounds__(256) void k_gather_points(const double* __restrict__ D, int d,
                                                         const int32_t* __restrict__ idx,
                                                         int64_t m, int64_t pstride,
-                                                        double* __restrict__ P) {
+                                                        double* __restrict__ P,
+                                                        float* __restrict__ Pf) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= pstride) return;
   const int64_t src = (i < m) ? idx[i] : 0;
-  for (int k = 0; k < d; ++k) P[k * pstride + i] = (i < m) ? D[k + d * src] : 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double v = (i < m) ? D[k + d * src] : 0.0;
+    P[k * pstride + i] = v;
+    Pf[k * pstride + i] = static_cast<float>(v);
+  }
 }
 
 template <typename T>
@@ -832,6 +838,289 @@ __global__ __launch_bounds__(256) void k_affinity_pointnormal(
       out[q] = store_score<T>(scr, prm.affinityeps);
     }
     store4<T>(S + r * ld + c, out[0], out[1], out[2], out[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Compacting fill kernels.
+//
+// The exact score costs ~150 fp64-rate instructions per pair (two correctly rounded sqrt, one
+// division, exp / acos), yet on registration data only ~10 % of the pairs pass `c < epsilon`
+// — and with 64-lane waves a plain branch saves nothing. So every pair first goes through a
+// CONSERVATIVE fp32 prefilter (|l1f - l2f| >= epsilon + guard  =>  certainly c >= epsilon; the
+// guard bounds the fp32 error from the data's magnitude, incl. the 1-ulp raw v_sqrt_f32), survivors are compacted into a
+// per-wave LDS queue with ballot/mbcnt (no atomics, no workgroup barrier), and only they are
+// evaluated exactly in fp64 — with the same instruction sequence as the plain kernels, so the
+// results are bit-identical to them. Scores are scattered into an LDS staging tile and leave
+// as whole 1 KiB row segments, so the HBM store pattern is unchanged.
+// Geometry: 4 waves per workgroup, wave w owns 256 columns (4 per lane); rows are processed in
+// groups of AFF_RG = 8: queue 8 KiB + staging 8 (fp32) / 16 (fp64) KiB per wave.
+// ------------------------------------------------------------------------------------------
+
+constexpr int AFF_RG = 8;
+
+__device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+template <typename T, int D>
+__device__ __forceinline__ double exact_euclid_score(const double* __restrict__ P1,
+                                                     const double* __restrict__ P2,
+                                                     int64_t pstride, int64_t r, int64_t g,
+                                                     const EuclidParams& prm) {
+  double s1 = 0.0, s2 = 0.0;  // euclidean_distance.cpp:18-19, sequential fma chain
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double t1 = P1[k * pstride + r] - P1[k * pstride + g];
+    const double t2 = P2[k * pstride + r] - P2[k * pstride + g];
+    s1 = fma(t1, t1, s1);
+    s2 = fma(t2, t2, s2);
+  }
+  const double l1 = sqrt(s1), l2 = sqrt(s2);
+  if (prm.mindist > 0 && (l1 < prm.mindist || l2 < prm.mindist)) return 0.0;  // :23-25
+  const double cc = fabs(l1 - l2);                                            // :28
+  return (cc < prm.epsilon) ? exp(-0.5 * cc * cc / (prm.sigma * prm.sigma)) : 0.0;  // :30
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_affinity_euclid_compact(
+    T* __restrict__ S, int64_t ld, int64_t m, int64_t c0, int rows_per_blk,
+    const double* __restrict__ P1, const double* __restrict__ P2,
+    const float* __restrict__ P1f, const float* __restrict__ P2f, int64_t pstride,
+    const int32_t* __restrict__ A0, const int32_t* __restrict__ A1, EuclidParams prm,
+    float eps_guarded) {
+  __shared__ uint32_t queue[4][AFF_RG * 256];
+  __shared__ T stage[4][AFF_RG][256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t cw = static_cast<int64_t>(blockIdx.x) * 1024 + wave * 256;  // wave's first column
+  const int64_t c = cw + lane * 4;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_blk;
+  const int64_t r1 = (r0 + rows_per_blk < m) ? r0 + rows_per_blk : m;
+  if (cw >= ld) return;  // whole wave outside the slice (wave-uniform)
+
+  // column data (fp32) in registers for the prefilter
+  bool valid[4];
+  int32_t a0c[4], a1c[4];
+  float p1c[4][D], p2c[4][D];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t g = c0 + c + q;
+    valid[q] = (g < m) && (c + q < ld);
+    const int64_t gi = (g < m) ? g : (m - 1);
+    a0c[q] = A0[gi];
+    a1c[q] = A1[gi];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      p1c[q][k] = P1f[k * pstride + gi];
+      p2c[q][k] = P2f[k * pstride + gi];
+    }
+  }
+#pragma unroll
+  for (int r8 = 0; r8 < AFF_RG; ++r8)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage[wave][r8][lane * 4 + q] = T(0);
+
+  for (int64_t base = r0; base < r1; base += AFF_RG) {
+    // ---- phase A: fp32 prefilter + compaction of the surviving (row, column) pairs --------
+    uint32_t count = 0;  // wave-uniform
+#pragma unroll
+    for (int r8 = 0; r8 < AFF_RG; ++r8) {
+      const int64_t r = base + r8;
+      if (r < r1) {  // uniform
+        const int32_t a0r = A0[r], a1r = A1[r];
+        float p1r[D], p2r[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          p1r[k] = P1f[k * pstride + r];
+          p2r[k] = P2f[k * pstride + r];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const float t1 = p1r[k] - p1c[q][k];
+            const float t2 = p2r[k] - p2c[q][k];
+            s1 = fmaf(t1, t1, s1);
+            s2 = fmaf(t2, t2, s2);
+          }
+          const float cf = fabsf(__builtin_amdgcn_sqrtf(s1) - __builtin_amdgcn_sqrtf(s2));
+          // clipper.cpp:35-38 distinctness (also removes the diagonal) + conservative c < eps
+          const bool cand = valid[q] && (a0r != a0c[q]) && (a1r != a1c[q]) && (cf < eps_guarded);
+          const uint64_t mask = __ballot(cand);
+          if (mask != 0) {  // uniform
+            if (cand) queue[wave][count + lane_prefix(mask)] =
+                (static_cast<uint32_t>(r8) << 16) | static_cast<uint32_t>(lane * 4 + q);
+            count += static_cast<uint32_t>(__popcll(mask));
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase B: exact fp64 score of the survivors, scattered into the staging tile -------
+    for (uint32_t e = lane; e < count; e += 64) {
+      const uint32_t code = queue[wave][e];
+      const int r8 = static_cast<int>(code >> 16);
+      const int cl = static_cast<int>(code & 0xffffu);
+      const double scr = exact_euclid_score<T, D>(P1, P2, pstride, base + r8, c0 + cw + cl, prm);
+      stage[wave][r8][cl] = store_score<T>(scr, prm.affinityeps);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase C: whole row segments leave for HBM; the staging tile is re-zeroed ----------
+    if (c < ld) {
+#pragma unroll
+      for (int r8 = 0; r8 < AFF_RG; ++r8) {
+        const int64_t r = base + r8;
+        if (r < r1) {
+          T* sp = &stage[wave][r8][lane * 4];
+          store4<T>(S + r * ld + c, sp[0], sp[1], sp[2], sp[3]);
+          sp[0] = sp[1] = sp[2] = sp[3] = T(0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ double exact_pointnormal_score(const double* __restrict__ P1,
+                                                          const double* __restrict__ P2,
+                                                          int64_t pstride, int64_t r, int64_t g,
+                                                          const PointNormalParams& prm) {
+  double p1r[6], p1g[6], p2r[6], p2g[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    p1r[k] = P1[k * pstride + r];
+    p1g[k] = P1[k * pstride + g];
+    p2r[k] = P2[k * pstride + r];
+    p2g[k] = P2[k * pstride + g];
+  }
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double t1 = p1r[k] - p1g[k];
+    const double t2 = p2r[k] - p2g[k];
+    s1 = fma(t1, t1, s1);
+    s2 = fma(t2, t2, s2);
+  }
+  const double l1 = sqrt(s1), l2 = sqrt(s2);  // :17-18
+  const double dot1 = fma(p1r[5], p1g[5], fma(p1r[4], p1g[4], p1r[3] * p1g[3]));
+  const double dot2 = fma(p2r[5], p2g[5], fma(p2r[4], p2g[4], p2r[3] * p2g[3]));
+  const double alpha1 = acos(dot1);  // :21
+  const double alpha2 = acos(dot2);  // :22
+  const double dp = fabs(l1 - l2);          // :25
+  const double dn = fabs(alpha1 - alpha2);  // :26
+  if (dp < prm.epsp && dn < prm.epsn) {     // :28
+    const double sp = exp(-0.5 * dp * dp / (prm.sigp * prm.sigp));  // :29
+    const double sn = exp(-0.5 * dn * dn / (prm.sign * prm.sign));  // :30
+    return sp * sn;                                                 // :31
+  }
+  return 0.0;
+}
+
+// PointNormalDistance: the prefilter tests only the point-distance residual dp (the normal
+// residual needs acos); survivors get the full exact evaluation.
+template <typename T>
+__global__ __launch_bounds__(256) void k_affinity_pointnormal_compact(
+    T* __restrict__ S, int64_t ld, int64_t m, int64_t c0, int rows_per_blk,
+    const double* __restrict__ P1, const double* __restrict__ P2,
+    const float* __restrict__ P1f, const float* __restrict__ P2f, int64_t pstride,
+    const int32_t* __restrict__ A0, const int32_t* __restrict__ A1, PointNormalParams prm,
+    float eps_guarded) {
+  __shared__ uint32_t queue[4][AFF_RG * 256];
+  __shared__ T stage[4][AFF_RG][256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t cw = static_cast<int64_t>(blockIdx.x) * 1024 + wave * 256;
+  const int64_t c = cw + lane * 4;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_blk;
+  const int64_t r1 = (r0 + rows_per_blk < m) ? r0 + rows_per_blk : m;
+  if (cw >= ld) return;
+
+  bool valid[4];
+  int32_t a0c[4], a1c[4];
+  float p1c[4][3], p2c[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t g = c0 + c + q;
+    valid[q] = (g < m) && (c + q < ld);
+    const int64_t gi = (g < m) ? g : (m - 1);
+    a0c[q] = A0[gi];
+    a1c[q] = A1[gi];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p1c[q][k] = P1f[k * pstride + gi];
+      p2c[q][k] = P2f[k * pstride + gi];
+    }
+  }
+#pragma unroll
+  for (int r8 = 0; r8 < AFF_RG; ++r8)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage[wave][r8][lane * 4 + q] = T(0);
+
+  for (int64_t base = r0; base < r1; base += AFF_RG) {
+    uint32_t count = 0;
+#pragma unroll
+    for (int r8 = 0; r8 < AFF_RG; ++r8) {
+      const int64_t r = base + r8;
+      if (r < r1) {
+        const int32_t a0r = A0[r], a1r = A1[r];
+        float p1r[3], p2r[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          p1r[k] = P1f[k * pstride + r];
+          p2r[k] = P2f[k * pstride + r];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float t1 = p1r[k] - p1c[q][k];
+            const float t2 = p2r[k] - p2c[q][k];
+            s1 = fmaf(t1, t1, s1);
+            s2 = fmaf(t2, t2, s2);
+          }
+          const float dpf = fabsf(__builtin_amdgcn_sqrtf(s1) - __builtin_amdgcn_sqrtf(s2));
+          const bool cand = valid[q] && (a0r != a0c[q]) && (a1r != a1c[q]) && (dpf < eps_guarded);
+          const uint64_t mask = __ballot(cand);
+          if (mask != 0) {
+            if (cand) queue[wave][count + lane_prefix(mask)] =
+                (static_cast<uint32_t>(r8) << 16) | static_cast<uint32_t>(lane * 4 + q);
+            count += static_cast<uint32_t>(__popcll(mask));
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = lane; e < count; e += 64) {
+      const uint32_t code = queue[wave][e];
+      const int r8 = static_cast<int>(code >> 16);
+      const int cl = static_cast<int>(code & 0xffffu);
+      const double scr = exact_pointnormal_score<T>(P1, P2, pstride, base + r8, c0 + cw + cl, prm);
+      stage[wave][r8][cl] = store_score<T>(scr, prm.affinityeps);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (c < ld) {
+#pragma unroll
+      for (int r8 = 0; r8 < AFF_RG; ++r8) {
+        const int64_t r = base + r8;
+        if (r < r1) {
+          T* sp = &stage[wave][r8][lane * 4];
+          store4<T>(S + r * ld + c, sp[0], sp[1], sp[2], sp[3]);
+          sp[0] = sp[1] = sp[2] = sp[3] = T(0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
