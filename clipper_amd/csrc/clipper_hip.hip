@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -65,7 +66,9 @@ constexpr int GEMV_NW = 8;      // waves per workgroup
 constexpr int GEMV_UNR_F32 = 8; // rows in flight per wave, fp32 storage (8 x 16 B per lane)
 constexpr int GEMV_UNR_F64 = 4; // fp64 storage (4 x 32 B per lane)
 constexpr int GEMV_WG_PER_CU = 2;
-constexpr int SOLVE_BATCH = 16;  // solver iterations queued between two looks at the done flag
+constexpr int SOLVE_BATCH = 16;  // multi-process: iterations queued between two state snapshots
+constexpr int RUN_AHEAD = 4;     // one process: iterations kept queued ahead of the device
+constexpr int64_t FUSED_PASS_MAX_M = 4096;  // up to here one launch per iteration (k_pass FUSED)
 constexpr int MAX_EVENT_PAIRS = 4096;
 constexpr int PROFILE_EVERY = 4;  // time every 4th mat-vec launch (events perturb the stream)
 
@@ -112,7 +115,9 @@ struct Shard {
   void* Cs = nullptr;  // explicit constraint matrix, same shape (only when C != pattern(M))
   double* part = nullptr;  // [ntiles][2][W]
   double* u0 = nullptr;
-  double *U[2] = {nullptr, nullptr}, *G[2] = {nullptr, nullptr}, *T[2] = {nullptr, nullptr};
+  double *U[2] = {nullptr, nullptr}, *G[2] = {nullptr, nullptr};
+  double* T[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [pair][candidate], see SolveArgs
+  int* cnt = nullptr;      // arrival counters [nstrips + 1]
   double* ab = nullptr;    // [P][2][W]
   double* scal = nullptr;  // [nwg][NSCAL] partial scalars of k_tail
   SolverState* st = nullptr;
@@ -152,8 +157,14 @@ struct clipper_hip_ctx {
   std::vector<int32_t> A;  // column-major m x 2 (host copy)
   std::vector<int32_t> nodes;
 
-  SolverState* host_state = nullptr;  // pinned, 2 slots
+  SolverState* host_state = nullptr;  // pinned, 2 slots (multi-process snapshots)
   hipEvent_t ev_poll[2] = {nullptr, nullptr};
+  HostMirror* mirror = nullptr;      // pinned + coherent: progress record written by the device
+  HostMirror* mirror_dev = nullptr;  // its device address
+  double* u_pinned = nullptr;        // pinned staging of the final u
+  size_t u_pinned_cap = 0;
+  int pass_mode = 0;   // 0 auto, 1 split (k_gemv + k_tail), 2 fused (k_pass), 3 legacy 3 launches
+  int par = 0;         // which T pair the next launch reads
 
   bool profiling = false;
   std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created lazily
@@ -182,8 +193,10 @@ int free_shard_buffers(Shard& s) {
   for (int k = 0; k < 2; ++k) {
     fr(s.U[k]);
     fr(s.G[k]);
-    fr(s.T[k]);
+    fr(s.T[k][0]);
+    fr(s.T[k][1]);
   }
+  fr(s.cnt);
   fr(s.ab);
   fr(s.scal);
   fr(s.st);
@@ -235,9 +248,13 @@ int ensure_problem(Ctx* h, int64_t m) {
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipMalloc(&s.U[k], nvec));
       HIPCHK(hipMalloc(&s.G[k], nvec));
-      HIPCHK(hipMalloc(&s.T[k], nvec));
-      HIPCHK(hipMemsetAsync(s.T[k], 0, nvec, s.stream));
+      for (int c = 0; c < 2; ++c) {
+        HIPCHK(hipMalloc(&s.T[k][c], nvec));
+        HIPCHK(hipMemsetAsync(s.T[k][c], 0, nvec, s.stream));
+      }
     }
+    HIPCHK(hipMalloc(&s.cnt, static_cast<size_t>(h->nstrips + 1) * sizeof(int)));
+    HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(h->nstrips + 1) * sizeof(int), s.stream));
     HIPCHK(hipMalloc(&s.scal, static_cast<size_t>(ceil_div(m, TAIL_THREADS)) * NSCAL *
                                   sizeof(double)));
     HIPCHK(hipMalloc(&s.ab, 2 * nvec));
@@ -266,7 +283,7 @@ void launch_gemv_t(Ctx* h, Shard& s, const double* x0, const double* x1, const S
                      h->rows_per_tile, x0, x1, s.part, st);
 }
 
-// x = T[st->sel] when `st` is given (solver), else x0
+// x = x1 when `st` is given and st->sel is set (solver), else x0
 void launch_gemv(Ctx* h, Shard& s, const double* x0, const double* x1, const SolverState* st) {
   if (h->storage == CLIPPER_HIP_STORE_F64) {
     if (h->explicitC) launch_gemv_t<double, true>(h, s, x0, x1, st);
@@ -274,6 +291,27 @@ void launch_gemv(Ctx* h, Shard& s, const double* x0, const double* x1, const Sol
   } else {
     if (h->explicitC) launch_gemv_t<float, true>(h, s, x0, x1, st);
     else launch_gemv_t<float, false>(h, s, x0, x1, st);
+  }
+}
+
+template <typename T, bool HASC, int MODE>
+void launch_pass_t(Ctx* h, Shard& s, const SolveArgs& a) {
+  constexpr int UNR = (sizeof(T) == 8) ? GEMV_UNR_F64 : GEMV_UNR_F32;
+  dim3 grid(h->nstrips, h->ntiles), block(GEMV_NW * 64);
+  hipLaunchKernelGGL((k_pass<T, HASC, GEMV_NW, UNR, MODE>), grid, block, 0, s.stream,
+                     static_cast<const T*>(s.S), static_cast<const T*>(s.Cs), h->rows_per_tile,
+                     a);
+}
+
+// the mat-vec with the epilogue `MODE` (PASS_FUSED / PASS_REDUCE) folded in
+template <int MODE>
+void launch_pass(Ctx* h, Shard& s, const SolveArgs& a) {
+  if (h->storage == CLIPPER_HIP_STORE_F64) {
+    if (h->explicitC) launch_pass_t<double, true, MODE>(h, s, a);
+    else launch_pass_t<double, false, MODE>(h, s, a);
+  } else {
+    if (h->explicitC) launch_pass_t<float, true, MODE>(h, s, a);
+    else launch_pass_t<float, false, MODE>(h, s, a);
   }
 }
 
@@ -317,7 +355,7 @@ int exchange(Ctx* h) {
     }
     HIPCHK(hipEventRecord(q.ev_copied, q.stream));
   }
-  // a producer may not overwrite its block (next k_reduce) before every consumer copied it
+  // a producer may not overwrite its block (next reduce) before every consumer copied it
   for (auto& p : h->sh) {
     HIPCHK(hipSetDevice(p.device));
     for (auto& q : h->sh) {
@@ -328,9 +366,12 @@ int exchange(Ctx* h) {
   return 0;
 }
 
-SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm) {
+// arguments of the launches of ONE solver iteration: reads the pending vector from T pair
+// `par`, writes the next candidates to pair `par ^ 1`
+SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   SolveArgs a;
   a.st = s.st;
+  a.host = (&s == &h->sh[0]) ? h->mirror_dev : nullptr;
   a.prm = prm;
   a.m = h->m;
   a.W = h->W;
@@ -338,73 +379,114 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm) {
   for (int k = 0; k < 2; ++k) {
     a.U[k] = s.U[k];
     a.G[k] = s.G[k];
-    a.T[k] = s.T[k];
+    a.Tin[k] = s.T[par][k];
+    a.Tout[k] = s.T[par ^ 1][k];
   }
   a.ab = s.ab;
   a.part = s.part;
   a.ntiles = h->ntiles;
+  a.slot = s.slot;
   a.scal = s.scal;
   a.nwg = static_cast<int>(ceil_div(h->m, TAIL_THREADS));
+  a.cnt = s.cnt;
+  a.nstrips = h->nstrips;
   return a;
 }
 
-// the mat-vec kernel of every local shard (optionally bracketed by timing events)
-int enqueue_gemv(Ctx* h, bool use_state) {
+enum { MODE_AUTO = 0, MODE_SPLIT = 1, MODE_FUSED = 2, MODE_LEGACY = 3 };
+
+int effective_pass_mode(const Ctx* h) {
+  if (h->pass_mode != MODE_AUTO) return h->pass_mode;
+  return (h->m <= FUSED_PASS_MAX_M) ? MODE_FUSED : MODE_SPLIT;
+}
+
+// One full solver iteration: pass over M, element-wise tail, decision.
+//   one shard, fused : k_pass<FUSED>                                  (1 launch)
+//   one shard, split : k_gemv -> k_tail<true, true>                   (2 launches; the mat-vec
+//                      stays a pure streaming kernel — what bench.py's roofline times)
+//   sharded          : k_pass<REDUCE> -> exchange -> k_tail<false, true>
+//   legacy           : k_gemv -> [k_reduce -> exchange] -> k_tail<., false> -> k_decide
+int enqueue_iteration(Ctx* h, const SolverParams& prm) {
+  const int par = h->par;
+  h->par ^= 1;
+  const bool sharded = !(h->world == 1 && !h->multiproc);
+  const int mode = effective_pass_mode(h);
+  // timing events cost ~5 us of stream time each: sample every 4th launch only
+  Shard& s0 = h->sh[0];
+  const bool prof = h->profiling && (h->launch_counter % PROFILE_EVERY == 0) &&
+                    h->ev_used < MAX_EVENT_PAIRS;
+  int rc = 0;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    const SolverState* st = use_state ? s.st : nullptr;
-    // timing events cost ~5 us of stream time each: sample every 4th launch only
-    const bool prof = h->profiling && use_state && (&s == &h->sh[0]) &&
-                      (h->launch_counter % PROFILE_EVERY == 0) && h->ev_used < MAX_EVENT_PAIRS;
-    if (prof) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
-    launch_gemv(h, s, s.T[0], s.T[1], st);
-    if (prof) {
+    const SolveArgs a = solve_args(h, s, prm, par);
+    if (prof && &s == &s0) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
+    if (mode == MODE_LEGACY || (!sharded && mode == MODE_SPLIT)) {
+      launch_gemv(h, s, a.Tin[0], a.Tin[1], s.st);
+    } else if (sharded) {
+      launch_pass<PASS_REDUCE>(h, s, a);
+    } else {
+      launch_pass<PASS_FUSED>(h, s, a);
+    }
+    if (prof && &s == &s0) {
       HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used + 1], s.stream));
       h->ev_launch_index[h->ev_used] = h->launch_counter;
       ++h->ev_used;
     }
   }
-  if (use_state) ++h->launch_counter;
-  return 0;
-}
-
-// raw (un-normalised) sums of the partials into every shard's gathered `ab`
-int enqueue_reduce_exchange(Ctx* h, bool use_state) {
+  ++h->launch_counter;
+  if (sharded) {
+    if (mode == MODE_LEGACY)
+      for (auto& s : h->sh) {
+        HIPCHK(hipSetDevice(s.device));
+        launch_reduce(h, s, s.st);
+      }
+    if ((rc = exchange(h))) return rc;
+  }
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    launch_reduce(h, s, use_state ? s.st : nullptr);
-  }
-  return exchange(h);
-}
-
-// one full solver iteration: pass over M, element-wise tail, decisions
-int enqueue_iteration(Ctx* h, const SolverParams& prm) {
-  int rc = enqueue_gemv(h, true);
-  if (rc) return rc;
-  if (h->world == 1 && !h->multiproc) {
-    Shard& s = h->sh[0];
-    SolveArgs a = solve_args(h, s, prm);
-    hipLaunchKernelGGL(k_tail<true>, dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(DECIDE_THREADS), 0, s.stream, a);
-    return 0;
-  }
-  if ((rc = enqueue_reduce_exchange(h, true))) return rc;
-  for (auto& s : h->sh) {
-    HIPCHK(hipSetDevice(s.device));
-    SolveArgs a = solve_args(h, s, prm);
-    hipLaunchKernelGGL(k_tail<false>, dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(DECIDE_THREADS), 0, s.stream, a);
+    const SolveArgs a = solve_args(h, s, prm, par);
+    if (mode == MODE_LEGACY) {
+      if (sharded) hipLaunchKernelGGL((k_tail<false, false>), dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
+      else hipLaunchKernelGGL((k_tail<true, false>), dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
+      hipLaunchKernelGGL(k_decide, dim3(1), dim3(DECIDE_THREADS), 0, s.stream, a);
+    } else if (sharded) {
+      hipLaunchKernelGGL((k_tail<false, true>), dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
+    } else if (mode == MODE_SPLIT) {
+      hipLaunchKernelGGL((k_tail<true, true>), dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
+    }
   }
   return 0;
 }
 
 int enqueue_decide_only(Ctx* h, const SolverParams& prm) {
+  const int par = h->par;
+  h->par ^= 1;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    SolveArgs a = solve_args(h, s, prm);
+    SolveArgs a = solve_args(h, s, prm, par);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(DECIDE_THREADS), 0, s.stream, a);
   }
   return 0;
+}
+
+// plain mat-vec of every local shard on x (matvec API / micro-benchmark)
+int enqueue_gemv_plain(Ctx* h, const double* const* x_per_shard) {
+  size_t k = 0;
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    launch_gemv(h, s, x_per_shard[k], x_per_shard[k], nullptr);
+    ++k;
+  }
+  return 0;
+}
+
+// raw (un-normalised) sums of the partials into every shard's gathered `ab`
+int enqueue_reduce_exchange(Ctx* h) {
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    launch_reduce(h, s, nullptr);
+  }
+  return exchange(h);
 }
 
 int sync_all(Ctx* h) {
@@ -497,6 +579,22 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     fail(CLIPPER_HIP_E_HIP, "cannot allocate pinned solver state");
     delete h;
     return nullptr;
+  }
+  // progress record the deciding workgroup writes straight into host memory (coherent, mapped)
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->mirror), sizeof(HostMirror),
+                    hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&h->mirror_dev), h->mirror, 0) !=
+          hipSuccess) {
+    fail(CLIPPER_HIP_E_HIP, "cannot allocate the pinned progress record");
+    delete h;
+    return nullptr;
+  }
+  std::memset(h->mirror, 0, sizeof(HostMirror));
+  // CLIPPER_HIP_PASS = split | fused | legacy overrides the per-size choice of launch shape
+  if (const char* pm = std::getenv("CLIPPER_HIP_PASS")) {
+    if (!std::strcmp(pm, "split")) h->pass_mode = MODE_SPLIT;
+    else if (!std::strcmp(pm, "fused")) h->pass_mode = MODE_FUSED;
+    else if (!std::strcmp(pm, "legacy")) h->pass_mode = MODE_LEGACY;
   }
   return h;
 }
@@ -727,6 +825,8 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   if (h->ev_poll[0]) hipEventDestroy(h->ev_poll[0]);
   if (h->ev_poll[1]) hipEventDestroy(h->ev_poll[1]);
   if (h->host_state) hipHostFree(h->host_state);
+  if (h->mirror) hipHostFree(h->mirror);
+  if (h->u_pinned) hipHostFree(h->u_pinned);
   delete h;
 }
 
@@ -1114,56 +1214,93 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   init.alpha = 1.0;
   init.nrm = 1.0;
   init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
+  // prologue, one launch per shard: pending vector = u0 (T pair 0, nrm = 1), state, counters
+  h->par = 0;
+  std::memset(h->mirror, 0, sizeof(HostMirror));
+  std::atomic_thread_fence(std::memory_order_seq_cst);
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    // first pass (if any) runs on x = u0: T[0] = u0, nrm = 1
-    HIPCHK(hipMemcpyAsync(s.T[0], s.u0, vbytes, hipMemcpyDeviceToDevice, s.stream));
-    HIPCHK(hipMemcpyAsync(s.st, &init, sizeof(init), hipMemcpyHostToDevice, s.stream));
+    const SolveArgs a = solve_args(h, s, prm, 0);
+    hipLaunchKernelGGL(k_init, dim3(static_cast<unsigned>(ceil_div(m, 256))), dim3(256), 0,
+                       s.stream, a, init, s.T[0][0]);
   }
   int rc = 0;
   if (!P->rescale_u0) {
     if ((rc = enqueue_decide_only(h, prm))) return rc;  // PH_NORMALIZE consumes no pass
   }
 
-  // Batched, pipelined enqueue: batch n+1 is queued before the host looks at the state
-  // snapshot taken after batch n.
   Shard& s0 = h->sh[0];
-  int slot = 0;
-  bool have_prev = false;
-  bool done = false;
-  while (!done) {
-    for (int it = 0; it < SOLVE_BATCH; ++it) {
-      if ((rc = enqueue_iteration(h, prm))) return rc;
-    }
-    HIPCHK(hipSetDevice(s0.device));
-    HIPCHK(hipMemcpyAsync(&h->host_state[slot], s0.st, sizeof(SolverState),
-                          hipMemcpyDeviceToHost, s0.stream));
-    HIPCHK(hipEventRecord(h->ev_poll[slot], s0.stream));
-    if (have_prev) {
-      HIPCHK(hipEventSynchronize(h->ev_poll[slot ^ 1]));
-      if (h->host_state[slot ^ 1].done) done = true;
-    }
-    have_prev = true;
-    slot ^= 1;
-    if (done) break;
-    // the batch just queued may already be finished (launch-bound small problems): peek.
-    // Never across processes: every rank must queue the same number of batches (each holds
-    // collective calls), so there the decision rests on snapshot contents only, which are
-    // bit-identical on all ranks.
-    if (h->multiproc) continue;
-    if (hipEventQuery(h->ev_poll[slot ^ 1]) == hipSuccess) {
-      if (h->host_state[slot ^ 1].done) done = true;
-    } else {
-      (void)hipGetLastError();  // hipErrorNotReady is not a failure
-    }
-  }
-  if ((rc = sync_all(h))) return rc;
-
   SolverState fin;
+  std::memset(&fin, 0, sizeof(fin));
+  if (!h->multiproc) {
+    // One process: the deciding workgroup reports progress into pinned host memory; the host
+    // keeps RUN_AHEAD iterations queued ahead of what the device has retired and stops
+    // queueing the moment `done` shows up — no memcpy, no event, no host wait in the loop.
+    volatile HostMirror* hm = h->mirror;
+    int64_t queued = P->rescale_u0 ? 0 : 1;  // the decide-only launch counts as an iteration
+    uint64_t spins = 0;
+    while (!hm->done) {
+      if (queued - hm->iters < RUN_AHEAD) {
+        if ((rc = enqueue_iteration(h, prm))) return rc;
+        ++queued;
+        spins = 0;
+      } else if ((++spins & 0xfffff) == 0) {
+        // the device has not retired an iteration for a long time: make sure it is still alive
+        hipError_t q = hipStreamQuery(s0.stream);
+        if (q != hipSuccess && q != hipErrorNotReady)
+          return fail(CLIPPER_HIP_E_HIP, "solver stream failed: %s", hipGetErrorString(q));
+        if (q == hipSuccess && !hm->done && queued - hm->iters >= RUN_AHEAD)
+          return fail(CLIPPER_HIP_E_HIP, "solver made no progress (iters %lld of %lld queued)",
+                      static_cast<long long>(hm->iters), static_cast<long long>(queued));
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    fin.F = hm->F;
+    fin.d = hm->d;
+    fin.n_passes = hm->n_passes;
+    fin.n_trials = hm->n_trials;
+    fin.ifinal = hm->ifinal;
+    fin.ub = hm->ub;
+  } else {
+    // Multi-process: every rank must queue the same number of iterations (each holds a
+    // collective), so the decision to stop rests on state snapshots only, which are
+    // bit-identical on all ranks. Batch n+1 is queued before the snapshot after batch n is read.
+    int slot = 0;
+    bool have_prev = false;
+    bool done = false;
+    while (!done) {
+      for (int it = 0; it < SOLVE_BATCH; ++it) {
+        if ((rc = enqueue_iteration(h, prm))) return rc;
+      }
+      HIPCHK(hipSetDevice(s0.device));
+      HIPCHK(hipMemcpyAsync(&h->host_state[slot], s0.st, sizeof(SolverState),
+                            hipMemcpyDeviceToHost, s0.stream));
+      HIPCHK(hipEventRecord(h->ev_poll[slot], s0.stream));
+      if (have_prev) {
+        HIPCHK(hipEventSynchronize(h->ev_poll[slot ^ 1]));
+        if (h->host_state[slot ^ 1].done) done = true;
+      }
+      have_prev = true;
+      slot ^= 1;
+    }
+    if ((rc = sync_all(h))) return rc;
+    HIPCHK(hipSetDevice(s0.device));
+    HIPCHK(hipMemcpy(&fin, s0.st, sizeof(fin), hipMemcpyDeviceToHost));
+  }
+
+  // final u: one D2H copy into pinned staging (also drains the few no-op launches queued
+  // past convergence)
+  if (h->u_pinned_cap < vbytes) {
+    if (h->u_pinned) hipHostFree(h->u_pinned);
+    h->u_pinned = nullptr;
+    h->u_pinned_cap = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->u_pinned), vbytes, hipHostMallocDefault));
+    h->u_pinned_cap = vbytes;
+  }
   HIPCHK(hipSetDevice(s0.device));
-  HIPCHK(hipMemcpy(&fin, s0.st, sizeof(fin), hipMemcpyDeviceToHost));
-  std::vector<double> u(static_cast<size_t>(m));
-  HIPCHK(hipMemcpy(u.data(), s0.U[fin.ub & 1], vbytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(h->u_pinned, s0.U[fin.ub & 1], vbytes, hipMemcpyDeviceToHost, s0.stream));
+  if ((rc = sync_all(h))) return rc;
+  std::vector<double> u(h->u_pinned, h->u_pinned + m);
 
   // rounding — clipper.cpp:287-310 with utils.cpp:33-68, on the host
   std::vector<int32_t> nodes;
@@ -1246,12 +1383,14 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
   const int64_t m = h->m, W = h->W;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    HIPCHK(hipMemcpyAsync(s.T[0], x, static_cast<size_t>(m) * sizeof(double),
+    HIPCHK(hipMemcpyAsync(s.T[0][0], x, static_cast<size_t>(m) * sizeof(double),
                           hipMemcpyHostToDevice, s.stream));
   }
-  int rc = enqueue_gemv(h, false);
+  std::vector<const double*> xs;
+  for (auto& s : h->sh) xs.push_back(s.T[0][0]);
+  int rc = enqueue_gemv_plain(h, xs.data());
   if (rc) return rc;
-  if ((rc = enqueue_reduce_exchange(h, false))) return rc;
+  if ((rc = enqueue_reduce_exchange(h))) return rc;
   if ((rc = sync_all(h))) return rc;
   std::vector<double> ab(static_cast<size_t>(h->world) * 2 * W);
   Shard& s0 = h->sh[0];
@@ -1287,9 +1426,9 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) launch_gemv(h, s, s.T[0], s.T[1], nullptr);
+  for (int w = 0; w < 3; ++w) launch_gemv(h, s, s.T[0][0], s.T[0][0], nullptr);
   HIPCHK(hipEventRecord(e0, s.stream));
-  for (int r = 0; r < reps; ++r) launch_gemv(h, s, s.T[0], s.T[1], nullptr);
+  for (int r = 0; r < reps; ++r) launch_gemv(h, s, s.T[0][0], s.T[0][0], nullptr);
   HIPCHK(hipEventRecord(e1, s.stream));
   HIPCHK(hipStreamSynchronize(s.stream));
   float ms = 0.f;

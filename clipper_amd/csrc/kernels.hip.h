@@ -29,7 +29,8 @@
 namespace clipper_hip {
 
 // ------------------------------------------------------------------------------------------
-// solver state that lives in device memory for the whole solve (the host only polls `done`)
+// solver state that lives in device memory for the whole solve (the host only watches the
+// pinned HostMirror)
 // ------------------------------------------------------------------------------------------
 
 enum Phase : int32_t {
@@ -39,17 +40,17 @@ enum Phase : int32_t {
   PH_TRIAL = 3       // pass was on x = unew: line-search bookkeeping     (clipper.cpp:234-262)
 };
 
-// The vector a pass runs on is kept UN-normalised: x = T[sel] / nrm. k_gemv multiplies M by
-// T[sel]; k_tail divides the two sums by nrm (one division per column instead of one per
-// element of x before the pass) and materialises x where it is needed.
+// The vector a pass runs on is kept UN-normalised: x = Tin[sel] / nrm. The mat-vec multiplies
+// M by Tin[sel]; the tail divides the two sums by nrm (one division per column instead of one
+// per element of x before the pass) and materialises x where it is needed.
 struct SolverState {
   double d;       // penalty
   double F;       // objective at u
   double alpha;   // current step size
   double s;       // sum(u)
   double sx;      // sum(x) of the pending trial vector
-  double nrm;     // ||T[sel]|| (1 when the pending vector is already normalised / raw u0)
-  int32_t sel;    // which of T[0], T[1] holds the pending trial vector
+  double nrm;     // ||Tin[sel]|| (1 when the pending vector is already normalised / raw u0)
+  int32_t sel;    // which of Tin[0], Tin[1] holds the pending trial vector
   int32_t ub;     // which of U[0]/G[0], U[1]/G[1] holds the current (u, gradF)
   int32_t phase;
   int32_t i, j, k;  // outer / inner / line-search counters (clipper.cpp:217)
@@ -57,6 +58,19 @@ struct SolverState {
   int32_t ifinal;
   int64_t n_passes;
   int64_t n_trials;
+  int64_t n_iters;  // decisions taken so far (= solver iterations the device has retired)
+};
+
+// Host-visible progress record in pinned, coherent host memory. The deciding workgroup writes
+// it with system-scope stores; the host spins on `iters` / `done` instead of issuing
+// memcpy + event round trips, and keeps only a few iterations queued ahead of the device.
+struct HostMirror {
+  double F, d;
+  int64_t n_passes, n_trials;
+  int64_t iters;
+  int32_t ifinal, ub;
+  int32_t done;
+  int32_t pad_;
 };
 
 struct SolverParams {
@@ -65,22 +79,31 @@ struct SolverParams {
 };
 
 constexpr int TAIL_THREADS = 256;
-constexpr int NSCAL = 6;  // per-workgroup partial scalars written by k_tail
+constexpr int NSCAL = 6;  // per-workgroup partial scalars written by the tail
 
 struct SolveArgs {
   SolverState* st;
+  HostMirror* host;  // device address of the pinned progress record (may be null)
   SolverParams prm;
   int64_t m;   // problem size
   int64_t W;   // shard pitch: element i lives in block p = i / W of `ab`
   const double* u0;
   double* U[2];   // current point u (double-buffered: accepted x becomes u by flipping `ub`)
   double* G[2];   // gradF at u / at the trial vector
-  double* T[2];   // un-normalised trial vectors: T[0] = "if accepted", T[1] = "if rejected"
+  // un-normalised trial vectors, [0] = "if accepted", [1] = "if rejected". A launch READS the
+  // pending vector from Tin and WRITES the two candidates of the next pass to Tout; the host
+  // swaps the pairs from launch to launch, so that a workgroup that finishes its columns early
+  // can never overwrite an x another workgroup of the same launch is still multiplying by.
+  const double* Tin[2];
+  double* Tout[2];
   double* ab;     // [P][2][W]: a = M_off x, b = C_off x (raw sums in, normalised out)
-  const double* part;  // [ntiles][2][W] row-tile partials of this shard (fused reduce only)
+  double* part;   // [ntiles][2][W] row-tile partials of this shard
   int ntiles;
-  double* scal;   // [nwg][NSCAL] partial scalars of k_tail
-  int nwg;        // workgroups of k_tail = ceil(m / TAIL_THREADS)
+  int slot;       // this shard's block of `ab`
+  double* scal;   // [nwg][NSCAL] partial scalars of the tail
+  int nwg;        // workgroups of the tail = ceil(m / TAIL_THREADS)
+  int* cnt;       // arrival counters: [0, nstrips) one per column strip, [nstrips] the tail's
+  int nstrips;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -104,24 +127,60 @@ __device__ __forceinline__ void ab_at(const double* ab, int64_t W, int64_t i, do
   b = blk[W + off];
 }
 
+// Last-arriver hand-off inside one launch (CDNA guide, section 6 guideline 16, counter form;
+// the split-K recipe): every workgroup publishes what it stored — each wave drains its own
+// stores, one lane issues the agent-scope release and draws a ticket — and the workgroup that
+// draws the last ticket acquires at agent scope and continues with plain loads. Correct for
+// any placement of the workgroups over the 8 XCDs (their L2s are not coherent with each other).
+// The counter is zeroed before the first launch of a solve (k_init) and re-armed by the last
+// arriver. Returns true in every thread of the last workgroup. `flag` is one int of LDS.
+__device__ __forceinline__ bool arrive_last(int* counter, int expected, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop the fence's own wait
+    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == expected - 1) ? 1 : 0;
+    if (last) {
+      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  const bool last = (*flag != 0);
+  __syncthreads();  // the flag word is free again
+  return last;
+}
+
 // ------------------------------------------------------------------------------------------
 // The O(m) part of one solver iteration, split so that it parallelises:
 //
-//   k_tail   (ceil(m/256) workgroups, one thread per element) — everything element-wise that
-//            follows a pass on the trial vector x (clipper.cpp:238-242, 253): a = M_off x,
-//            b = C_off x (sum of the row-tile partials, divided by nrm), gradFnew, and the
-//            per-workgroup partial sums of Fnew = x.gradFnew and ||x-u||^2. It also prepares
-//            BOTH possible next trial vectors (clipper.cpp:235-236) speculatively —
-//            T[0] = max(x + gradFnew, 0) if the step is accepted (alpha resets to 1),
-//            T[1] = max(u + alpha*beta*gradF, 0) if it is rejected — with the partial sums of
-//            their squared norms and of their entries, so that the only serial work left is
-//   k_decide (one workgroup) — adds the partial scalars in a fixed order, takes the
-//            reference's decisions (clipper.cpp:244-251, 261) and updates the state. Only
-//            the rare transitions (initialisation :193-220, penalty update :268-280, a new
-//            outer iteration :219-220) sweep over the m-vectors here.
-// All sums have a fixed shape, so results are bit-reproducible run to run and rank to rank.
+//   tail    (one workgroup per 256 elements, one thread per element) — everything element-wise
+//           that follows a pass on the trial vector x (clipper.cpp:238-242, 253): a = M_off x,
+//           b = C_off x (sum of the row-tile partials, divided by nrm), gradFnew, and the
+//           per-workgroup partial sums of Fnew = x.gradFnew and ||x-u||^2. It also prepares
+//           BOTH possible next trial vectors (clipper.cpp:235-236) speculatively —
+//           Tout[0] = max(x + gradFnew, 0) if the step is accepted (alpha resets to 1),
+//           Tout[1] = max(u + alpha*beta*gradF, 0) if it is rejected — with the partial sums
+//           of their squared norms and of their entries, so that the only serial work left is
+//   decide  (one workgroup) — adds the partial scalars in a fixed order, takes the
+//           reference's decisions (clipper.cpp:244-251, 261) and updates the state. Only
+//           the rare transitions (initialisation :193-220, penalty update :268-280, a new
+//           outer iteration :219-220) sweep over the m-vectors here.
+//
+// Both are device functions shared by three launch shapes:
+//   k_gemv -> k_tail<.., true>            two launches per pass: the last tail workgroup decides
+//   k_pass<.., PASS_FUSED>                one launch per pass: the last workgroup of a column
+//                                         strip runs that strip's tail, the last strip decides
+//   k_pass<.., PASS_REDUCE> -> exchange -> k_tail<false, true>    column-sharded M
+// All sums have a fixed shape (256 data-carrying threads, partials in workgroup order), so the
+// results are bit-identical across the three shapes, from run to run and from rank to rank.
 // ------------------------------------------------------------------------------------------
 
+// Sum over the first NWAVES waves of the workgroup; every thread of the workgroup must call it
+// (waves beyond NWAVES only take part in the barriers) and every thread gets the totals.
 template <int N, int NWAVES>
 __device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWAVES*N] */) {
 #pragma unroll
@@ -131,7 +190,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWA
   }
   const int wave = threadIdx.x >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0 && wave < NWAVES) {
 #pragma unroll
     for (int q = 0; q < N; ++q) lds[wave * N + q] = v[q];
   }
@@ -145,73 +204,77 @@ __device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWA
   }
 }
 
-template <bool FUSED_REDUCE>
-__global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
-  __shared__ double red[(TAIL_THREADS / 64) * NSCAL];
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
-  const int64_t m = A.m;
-  const bool valid = i < m;
+constexpr int TAIL_WAVES = TAIL_THREADS / 64;
+constexpr int RED_DOUBLES = TAIL_WAVES * NSCAL + 2;  // reduction scratch + the arrival flag
 
-  // Everything that does not depend on the solver state is loaded first, so that the state,
-  // the partials and both buffer candidates share ONE memory round trip instead of chaining.
-  const SolverState stv = *A.st;  // one 128-byte read
-  double a = 0.0, b = 0.0;
-  double t0 = 0.0, t1 = 0.0, u0v = 0.0, u1v = 0.0, g0v = 0.0, g1v = 0.0;
+struct TailLoads {  // everything element i needs that does not depend on the state
+  double t0, t1, u0v, u1v, g0v, g1v;
+};
+
+__device__ __forceinline__ TailLoads tail_loads(const SolveArgs& A, int64_t i, bool valid) {
+  TailLoads L = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (valid) {
-    t0 = A.T[0][i];
-    t1 = A.T[1][i];
-    u0v = A.U[0][i];
-    u1v = A.U[1][i];
-    g0v = A.G[0][i];
-    g1v = A.G[1][i];
-    if (FUSED_REDUCE) {  // single shard: W >= m, block 0; 8 tiles of loads in flight at a time
-      const double* p = A.part + i;
-      const int64_t ts = 2 * A.W;
-      int t = 0;
-      for (; t + 8 <= A.ntiles; t += 8) {
-        double va[8], vb[8];
+    L.t0 = A.Tin[0][i];
+    L.t1 = A.Tin[1][i];
+    L.u0v = A.U[0][i];
+    L.u1v = A.U[1][i];
+    L.g0v = A.G[0][i];
+    L.g1v = A.G[1][i];
+  }
+  return L;
+}
+
+// partial sums of element i over the row tiles, in tile order (single shard: W >= m, block 0);
+// 8 tiles of loads in flight at a time
+__device__ __forceinline__ void sum_partials(const SolveArgs& A, int64_t i, double& a, double& b) {
+  const double* p = A.part + i;
+  const int64_t ts = 2 * A.W;
+  int t = 0;
+  for (; t + 8 <= A.ntiles; t += 8) {
+    double va[8], vb[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          va[q] = p[static_cast<int64_t>(t + q) * ts];
-          vb[q] = p[static_cast<int64_t>(t + q) * ts + A.W];
-        }
+    for (int q = 0; q < 8; ++q) {
+      va[q] = p[static_cast<int64_t>(t + q) * ts];
+      vb[q] = p[static_cast<int64_t>(t + q) * ts + A.W];
+    }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          a += va[q];
-          b += vb[q];
-        }
-      }
-      for (; t < A.ntiles; ++t) {
-        a += p[static_cast<int64_t>(t) * ts];
-        b += p[static_cast<int64_t>(t) * ts + A.W];
-      }
-    } else {
-      ab_at(A.ab, A.W, i, a, b);
+    for (int q = 0; q < 8; ++q) {
+      a += va[q];
+      b += vb[q];
     }
   }
-  if (stv.done) return;
-  const double nrm = stv.nrm;
-  const int phase = stv.phase;
+  for (; t < A.ntiles; ++t) {
+    a += p[static_cast<int64_t>(t) * ts];
+    b += p[static_cast<int64_t>(t) * ts + A.W];
+  }
+}
 
-  // (a, b) for the pending vector x = T[sel]/nrm
+// Element-wise tail of element i (raw sums a, b in). `valid` = this thread carries an element
+// (one of the first 256 threads of the workgroup and i < m). Writes scal[slot][0..5].
+// Returns false when the state says there is nothing to do after the normalisation.
+__device__ __forceinline__ void tail_elements(const SolveArgs& A, const SolverState& stv,
+                                              int64_t i, bool valid, double a, double b,
+                                              const TailLoads& L, double* red, int64_t slot) {
+  const double nrm = stv.nrm;
+  // (a, b) for the pending vector x = Tin[sel]/nrm
   if (valid) {
     a = a / nrm;
     b = b / nrm;
-    // normalised pair back into the gathered layout (read again only by k_decide's rare sweeps)
+    // normalised pair back into the gathered layout (read again only by decide's rare sweeps)
     const uint32_t pblk = static_cast<uint32_t>(i) / static_cast<uint32_t>(A.W);
     const int64_t off = i - static_cast<int64_t>(pblk) * A.W;
     A.ab[static_cast<int64_t>(pblk) * 2 * A.W + off] = a;
     A.ab[static_cast<int64_t>(pblk) * 2 * A.W + A.W + off] = b;
   }
-  if (phase != PH_TRIAL) return;  // initialisation phases are handled by k_decide alone
+  if (stv.phase != PH_TRIAL) return;  // initialisation phases are handled by decide alone
 
   const int ub = stv.ub;
   const double d = stv.d, sx = stv.sx, alpha = stv.alpha;
   double r[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (valid) {
-    const double xi = (stv.sel ? t1 : t0) / nrm;  // clipper.cpp:237
-    const double ui = ub ? u1v : u0v;
-    const double gi = ub ? g1v : g0v;
+    const double xi = (stv.sel ? L.t1 : L.t0) / nrm;  // clipper.cpp:237
+    const double ui = ub ? L.u1v : L.u0v;
+    const double gi = ub ? L.g1v : L.g0v;
     const double gn = (1 + d) * xi - d * sx + a + b * d;  // :238-241
     A.U[ub ^ 1][i] = xi;                                   // becomes u if accepted
     A.G[ub ^ 1][i] = gn;
@@ -222,45 +285,50 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
     ta = (ta > 0.0) ? ta : 0.0;  // :236
     double tr = ui + (alpha * A.prm.beta) * gi;  // next trial if rejected: alpha*beta (:248)
     tr = (tr > 0.0) ? tr : 0.0;
-    A.T[0][i] = ta;
-    A.T[1][i] = tr;
+    A.Tout[0][i] = ta;
+    A.Tout[1][i] = tr;
     r[2] = ta * ta;
     r[3] = ta;
     r[4] = tr * tr;
     r[5] = tr;
   }
-  block_reduce<NSCAL, TAIL_THREADS / 64>(r, red);
-  if (threadIdx.x < NSCAL) A.scal[static_cast<int64_t>(blockIdx.x) * NSCAL + threadIdx.x] = r[threadIdx.x];
+  block_reduce<NSCAL, TAIL_WAVES>(r, red);
+  if (threadIdx.x < NSCAL) A.scal[slot * NSCAL + threadIdx.x] = r[threadIdx.x];
 }
 
-constexpr int VU = 8;
+constexpr int VU = 4;  // elements per thread per sweep step (register budget of the fused epilogue)
 constexpr int DECIDE_THREADS = 256;
 constexpr int DECIDE_WAVES = DECIDE_THREADS / 64;
-#define VEC_CHUNKS(base) for (int64_t base = tid; base < m; base += DECIDE_THREADS * VU)
+// only the first DECIDE_THREADS threads of the workgroup carry elements
+#define VEC_CHUNKS(base) \
+  for (int64_t base = (tid < DECIDE_THREADS) ? tid : m; base < m; base += DECIDE_THREADS * VU)
 #define VEC_EACH(k, i, base)            \
   _Pragma("unroll") for (int k = 0; k < VU; ++k) \
     if (const int64_t i = base + static_cast<int64_t>(k) * DECIDE_THREADS; i < m)
 
-__global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
+// One decision of the solver's state machine, by ONE workgroup (all of its threads must call
+// this; the first 256 carry data). `stv` is the state as read at the start of the launch.
+__device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverState& stv,
+                                            double* red) {
   SolverState* st = A.st;
-  __shared__ double red[DECIDE_WAVES * NSCAL];
   const int tid = threadIdx.x;
   const int64_t m = A.m;
   const SolverParams P = A.prm;
 
-  // state and k_tail's partial scalars in one memory round trip
-  const SolverState stv = *st;
+  // the tail's partial scalars, one workgroup-strided sweep
   double r[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int w = tid; w < A.nwg; w += DECIDE_THREADS) {
+  if (tid < DECIDE_THREADS) {
+    for (int w = tid; w < A.nwg; w += DECIDE_THREADS) {
 #pragma unroll
-    for (int q = 0; q < NSCAL; ++q) r[q] += A.scal[static_cast<int64_t>(w) * NSCAL + q];
+      for (int q = 0; q < NSCAL; ++q) r[q] += A.scal[static_cast<int64_t>(w) * NSCAL + q];
+    }
   }
-  if (stv.done) return;
 
   const int phase = stv.phase;
   double d = stv.d, F = stv.F, alpha = stv.alpha, s = stv.s, sx = stv.sx, nrm = stv.nrm;
   int i_ = stv.i, j_ = stv.j, k_ = stv.k, ub = stv.ub, sel = stv.sel;
   int64_t n_passes = stv.n_passes, n_trials = stv.n_trials;
+  const int64_t n_iters = stv.n_iters + 1;
   if (phase != PH_NORMALIZE) ++n_passes;
 
   if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
@@ -288,7 +356,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
       VEC_EACH(k, i, base) {
         const double ui = uv[k] / n0;
         u[i] = ui;
-        A.T[0][i] = ui;  // next pass runs on x = u (already normalised: nrm = 1)
+        A.Tout[0][i] = ui;  // next pass runs on x = u (already normalised: nrm = 1)
       }
     }
     if (tid == 0) {
@@ -296,12 +364,15 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
       st->sel = 0;
       st->nrm = 1.0;
       st->n_passes = n_passes;
+      st->n_iters = n_iters;
+      if (A.host != nullptr)
+        __hip_atomic_store(&A.host->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return;
   }
 
   bool begin_outer = false, end_inner = false, finished = false;
-  bool need_trial_vector = false;  // a sweep must build T[0] from (u, g): after a transition
+  bool need_trial_vector = false;  // a sweep must build Tout[0] from (u, g): after a transition
 
   if (phase == PH_INIT) {
     // clipper.cpp:200-209 — initial d from the pass on u
@@ -333,7 +404,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
     d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
     i_ = 0;
     begin_outer = true;
-  } else {  // PH_TRIAL — the decisions of clipper.cpp:244-262 from k_tail's partial scalars
+  } else {  // PH_TRIAL — the decisions of clipper.cpp:244-262 from the tail's partial scalars
     ++n_trials;
     block_reduce<NSCAL, DECIDE_WAVES>(r, red);
     const double Fnew = r[0];
@@ -345,7 +416,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
       if (k_ < P.maxlsiters) accept = false;  // :234 loop bound; the last trial is kept
     }
     if (!accept) {
-      sel = 1;  // k_tail already built max(u + alpha*beta*g, 0) in T[1]
+      sel = 1;  // the tail already built max(u + alpha*beta*g, 0) in Tout[1]
       nrm = (r[4] > 0.0) ? sqrt(r[4]) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
       sx = r[5] / nrm;
     } else {
@@ -359,7 +430,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
       } else {
         alpha = 1.0;  // :227
         k_ = 0;
-        sel = 0;  // k_tail already built max(x + gradFnew, 0) in T[0]
+        sel = 0;  // the tail already built max(x + gradFnew, 0) in Tout[0]
         nrm = (r[2] > 0.0) ? sqrt(r[2]) : 1.0;
         sx = r[3] / nrm;
       }
@@ -446,7 +517,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
       VEC_EACH(k, i, base) {
         double t = uv[k] + alpha * gv[k];
         t = (t > 0.0) ? t : 0.0;
-        A.T[0][i] = t;
+        A.Tout[0][i] = t;
         zs[0] += t * t;
         zs[1] += t;
       }
@@ -472,14 +543,75 @@ __global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
     st->k = k_;
     st->n_passes = n_passes;
     st->n_trials = n_trials;
+    st->n_iters = n_iters;
     if (finished) {
       st->ifinal = i_;
       st->done = 1;
+    }
+    if (A.host != nullptr) {
+      HostMirror* hm = A.host;
+      if (finished) {
+        __hip_atomic_store(&hm->F, F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->d, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->n_passes, n_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->n_trials, n_trials, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->ifinal, i_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->ub, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // every store above (and the vectors this workgroup wrote) before the flag
+        __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
 #undef VEC_CHUNKS
 #undef VEC_EACH
+
+// Solve prologue, one launch: pending vector = u0 (un-normalised, nrm = 1), initial state,
+// arrival counters zeroed.
+__global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, double* T0) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < A.m) T0[i] = A.u0[i];
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c <= A.nstrips; c += 256) A.cnt[c] = 0;
+    if (threadIdx.x == 0) *A.st = init;
+  }
+}
+
+// The tail as its own launch (one workgroup per 256 elements).
+//   FUSED_REDUCE: sum the row-tile partials of the single shard here (else `ab` holds the
+//                 gathered raw sums of all shards);
+//   FUSED_DECIDE: the last workgroup to arrive takes the decision (else k_decide follows).
+template <bool FUSED_REDUCE, bool FUSED_DECIDE>
+__global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
+  __shared__ double red[RED_DOUBLES];
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
+  const bool valid = i < A.m;
+
+  // Everything that does not depend on the solver state is loaded first, so that the state,
+  // the partials and both buffer candidates share ONE memory round trip instead of chaining.
+  const SolverState stv = *A.st;  // one 128-byte read
+  const TailLoads L = tail_loads(A, i, valid);
+  double a = 0.0, b = 0.0;
+  if (valid) {
+    if (FUSED_REDUCE) sum_partials(A, i, a, b);
+    else ab_at(A.ab, A.W, i, a, b);
+  }
+  if (stv.done) return;
+  tail_elements(A, stv, i, valid, a, b, L, red, blockIdx.x);
+  if (FUSED_DECIDE) {
+    if (!arrive_last(A.cnt + A.nstrips, gridDim.x, reinterpret_cast<int*>(red + RED_DOUBLES - 1)))
+      return;
+    decide_body(A, stv, red);
+  }
+}
+
+__global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
+  __shared__ double red[RED_DOUBLES];
+  const SolverState stv = *A.st;
+  if (stv.done) return;
+  decide_body(A, stv, red);
+}
 
 // ------------------------------------------------------------------------------------------
 // k_gemv — the fused symmetric mat-vec pair  a = M_off x,  b = C_off x  in ONE pass over M.
@@ -512,19 +644,12 @@ __device__ __forceinline__ typename Vec4<T>::type load4(const T* p) {
   return *reinterpret_cast<const typename Vec4<T>::type*>(p);
 }
 
+// The streaming part: this workgroup's (strip, row tile) partial sums -> part[tile][2][ld].
 template <typename T, bool HASC, int NW, int UNR>
-__global__ __launch_bounds__(NW * 64) void k_gemv(const T* __restrict__ S,
-                                                   const T* __restrict__ Cs, int64_t ld,
-                                                   int64_t m, int rows_per_tile,
-                                                   const double* __restrict__ x0,
-                                                   const double* __restrict__ x1,
-                                                   double* __restrict__ part,
-                                                   const SolverState* __restrict__ st) {
-  if (st != nullptr && st->done) return;
-  // driven by the solver: the pending trial vector is T[sel] (un-normalised, see SolverState)
-  const double* __restrict__ x = (st != nullptr && st->sel) ? x1 : x0;
-
-  __shared__ double lds[NW * 2 * 256];
+__device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __restrict__ Cs,
+                                          int64_t ld, int64_t m, int rows_per_tile,
+                                          const double* __restrict__ x,
+                                          double* __restrict__ part, double* lds) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t col = static_cast<int64_t>(blockIdx.x) * 256 + lane * 4;
@@ -613,6 +738,85 @@ __global__ __launch_bounds__(NW * 64) void k_gemv(const T* __restrict__ S,
     const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
     if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * 2 + which) * ld + c] = acc;
   }
+}
+
+
+constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * 2 * 256 + 2; }  // + the arrival flag
+
+template <typename T, bool HASC, int NW, int UNR>
+__global__ __launch_bounds__(NW * 64) void k_gemv(const T* __restrict__ S,
+                                                   const T* __restrict__ Cs, int64_t ld,
+                                                   int64_t m, int rows_per_tile,
+                                                   const double* __restrict__ x0,
+                                                   const double* __restrict__ x1,
+                                                   double* __restrict__ part,
+                                                   const SolverState* __restrict__ st) {
+  if (st != nullptr && st->done) return;
+  // driven by the solver: the pending trial vector is Tin[sel] (un-normalised, see SolverState)
+  const double* __restrict__ x = (st != nullptr && st->sel) ? x1 : x0;
+  __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
+  gemv_core<T, HASC, NW, UNR>(S, Cs, ld, m, rows_per_tile, x, part, lds);
+}
+
+// k_pass — the mat-vec with the rest of the solver iteration folded into its epilogue.
+//   PASS_FUSED  (one shard): the LAST row-tile workgroup of a column strip (arrival counter per
+//               strip) sums that strip's partials in tile order and runs the element-wise tail
+//               for its 256 columns while the other strips are still streaming; the last strip
+//               to finish (second counter) takes the decision. One launch per solver iteration.
+//   PASS_REDUCE (column-sharded M): the last workgroup of a strip writes the strip's raw sums
+//               into this shard's [a | b] block (what k_reduce did in a launch of its own); the
+//               exchange and k_tail<false, true> follow.
+// The strip tail writes the NEXT pass's candidates to Tout, never to the Tin other workgroups
+// of this launch are still reading.
+enum PassMode : int { PASS_FUSED = 1, PASS_REDUCE = 2 };
+
+// two workgroups per CU (NW*64/256 * 2 waves per SIMD): caps the epilogue's register appetite
+template <typename T, bool HASC, int NW, int UNR, int MODE>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ S,
+                                                   const T* __restrict__ Cs,
+                                                   int rows_per_tile, SolveArgs A) {
+  static_assert(NW * 64 >= TAIL_THREADS, "the strip tail needs 256 threads");
+  __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
+  const SolverState stv = *A.st;
+  if (stv.done) return;
+  const int64_t ld = A.W;
+  gemv_core<T, HASC, NW, UNR>(S, Cs, ld, A.m, rows_per_tile, stv.sel ? A.Tin[1] : A.Tin[0],
+                              A.part, lds);
+  int* flag = reinterpret_cast<int*>(lds + GEMV_LDS_DOUBLES(NW) - 1);
+  if (!arrive_last(A.cnt + blockIdx.x, gridDim.y, flag)) return;
+
+  // ---- last workgroup of this column strip ------------------------------------------------
+  if (MODE == PASS_REDUCE) {
+    double* ab_block = A.ab + static_cast<int64_t>(A.slot) * 2 * ld;
+    for (int t = threadIdx.x; t < 512; t += NW * 64) {
+      const int which = t >> 8;
+      const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
+      if (c < ld) {
+        const double* p = A.part + which * ld + c;
+        double acc = 0.0;
+        int tt = 0;
+        for (; tt + 8 <= A.ntiles; tt += 8) {
+          double v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = p[static_cast<int64_t>(tt + q) * 2 * ld];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; tt < A.ntiles; ++tt) acc += p[static_cast<int64_t>(tt) * 2 * ld];
+        ab_block[which * ld + c] = acc;
+      }
+    }
+    return;
+  }
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const bool valid = (threadIdx.x < TAIL_THREADS) && (i < A.m);
+  const TailLoads L = tail_loads(A, i, valid);
+  double a = 0.0, b = 0.0;
+  if (valid) sum_partials(A, i, a, b);
+  tail_elements(A, stv, i, valid, a, b, L, lds, blockIdx.x);
+  if (!arrive_last(A.cnt + A.nstrips, gridDim.x, flag)) return;
+  // ---- last strip: the decision -------------------------------------------------------------
+  decide_body(A, stv, lds);
 }
 
 // k_reduce — adds the row-tile partials in tile order and writes this shard's block of the

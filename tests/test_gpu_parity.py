@@ -367,3 +367,66 @@ def test_full_size_10k_properties_and_parity():
     # the objective recomputed from the returned u on the device matrix: u'(M+I)u
     a, _ = c.matvec(s1.u)
     assert abs((s1.u @ a + s1.u @ s1.u) - sr.u @ (r.matvec(sr.u)[0] + sr.u)) <= 1e-6 * sr.score
+
+
+# ------------------------------------------------------------------------------------------
+# launch shapes of one solver iteration: legacy (k_gemv, k_tail, k_decide), split (k_gemv,
+# k_tail + last-arriver decision), fused (k_pass: strip-last tail + last-strip decision) — all
+# sums have one fixed shape, so the three must agree to the last bit
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("m,rho,seed", [(600, 0.9, 1), (1037, 0.8, 7), (3000, 0.9, 5), (5200, 0.95, 11)])
+def test_launch_shapes_are_bit_identical(monkeypatch, m, rho, seed):
+    p = synth.make_euclidean_problem(m, rho, seed=seed)
+    sols = {}
+    for mode in ("legacy", "split", "fused"):
+        monkeypatch.setenv("CLIPPER_HIP_PASS", mode)
+        for storage in STORAGES:
+            g = abi.HipClipper(storage=storage)
+            g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+            for rep in range(3):   # repeated solves on one context: counters re-arm themselves
+                sols[(mode, storage, rep)] = g.solve(p.u0)
+            g.close()
+    monkeypatch.delenv("CLIPPER_HIP_PASS")
+    for storage in STORAGES:
+        base = sols[("legacy", storage, 0)]
+        for mode in ("legacy", "split", "fused"):
+            for rep in range(3):
+                s = sols[(mode, storage, rep)]
+                assert s.nodes.tolist() == base.nodes.tolist(), (mode, storage, rep)
+                assert s.score == base.score and s.ifinal == base.ifinal, (mode, storage, rep)
+                assert s.n_passes == base.n_passes and s.n_trials == base.n_trials
+                assert np.array_equal(s.u, base.u), (mode, storage, rep)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    _check_solution(sols[("fused", abi.STORE_F32, 0)], r.solve(p.u0))
+
+
+@pytest.mark.parametrize("mode", ["legacy", "split"])
+def test_sharded_launch_shapes(monkeypatch, mode):
+    # sharded: legacy = k_gemv, k_reduce, exchange, k_tail, k_decide;
+    #          otherwise k_pass<REDUCE>, exchange, k_tail + last-arriver decision
+    p = synth.make_euclidean_problem(1500, 0.9, seed=77)
+    monkeypatch.setenv("CLIPPER_HIP_PASS", "legacy")
+    g1 = abi.HipClipper(storage=abi.STORE_F32)
+    g1.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    s1 = g1.solve(p.u0)
+    monkeypatch.setenv("CLIPPER_HIP_PASS", mode)
+    g = abi.HipClipper(storage=abi.STORE_F32, group=[0] * 3)
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    for rep in range(2):
+        s = g.solve(p.u0)
+        assert s.nodes.tolist() == s1.nodes.tolist() and s.n_passes == s1.n_passes
+        assert abs(s.score - s1.score) <= 1e-12 * abs(s1.score)
+
+
+def test_no_rescale_and_nonzero_rounding_in_every_shape(monkeypatch):
+    p = synth.make_euclidean_problem(900, 0.85, seed=21)
+    r = ref.RefClipper(ref.Params(rescale_u0=False, rounding=ref.ROUNDING_NONZERO))
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    sr = r.solve(p.u0)
+    for mode in ("legacy", "split", "fused"):
+        monkeypatch.setenv("CLIPPER_HIP_PASS", mode)
+        g = abi.HipClipper(abi.Params(rescale_u0=False, rounding=abi.ROUNDING_NONZERO))
+        g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+        _check_solution(g.solve(p.u0), sr)
