@@ -5,11 +5,12 @@
 // entry points return an error.
 //
 // Solve loop (CLIPPER::solve -> findDenseClique, /root/reference/src/clipper.cpp:172-323):
-// the whole state machine — line search, convergence tests, penalty homotopy — lives in
-// device memory (SolverState) and is advanced by k_vec. The host only enqueues
-// [k_gemv, k_reduce, (exchange), k_vec] iterations in batches and polls the `done` flag
-// of the previous batch while the next one is already queued, so the GPU never waits for
-// the host; kernels launched after convergence return immediately.
+// the whole state machine — windowed line search, convergence tests, penalty homotopy — lives
+// in device memory (SolverState). One solver iteration = k_gemv over a window of V candidate
+// vectors, then k_tail (grid: blocks x V) whose last workgroup takes the decision. The host
+// only enqueues iterations, a few ahead of what the device reports as retired in a pinned
+// progress record, and stops when `done` shows up there; kernels launched after convergence
+// return immediately.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -27,6 +28,7 @@
 #include <limits>
 #include <queue>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -63,12 +65,19 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // mat-vec kernel geometry (tuned on MI355X)
 constexpr int GEMV_NW = 8;      // waves per workgroup
-constexpr int GEMV_UNR_F32 = 8; // rows in flight per wave, fp32 storage (8 x 16 B per lane)
-constexpr int GEMV_UNR_F64 = 4; // fp64 storage (4 x 32 B per lane)
 constexpr int GEMV_WG_PER_CU = 2;
+// rows in flight per wave: 8 x 16 B per lane for fp32 storage and windows up to 4 vectors; the
+// 6-vector window needs 96 accumulator registers and keeps 4 rows in flight (tools/mv_tune.hip);
+// halved for fp64 storage (32 B per lane and row) and again with an explicit C matrix
+constexpr int gemv_unr(int V, int esize, bool hasc) {
+  int u = (V <= 4) ? 8 : 4;
+  if (esize == 8) u /= 2;
+  if (hasc) u /= 2;
+  return u < 1 ? 1 : u;
+}
+constexpr int DEFAULT_WINDOW = 6;  // line-search candidates per pass (CLIPPER_HIP_WINDOW = 1|4|6)
 constexpr int SOLVE_BATCH = 16;  // multi-process: iterations queued between two state snapshots
 constexpr int RUN_AHEAD = 4;     // one process: iterations kept queued ahead of the device
-constexpr int64_t FUSED_PASS_MAX_M = 4096;  // up to here one launch per iteration (k_pass FUSED)
 constexpr int MAX_EVENT_PAIRS = 4096;
 constexpr int PROFILE_EVERY = 4;  // time every 4th mat-vec launch (events perturb the stream)
 
@@ -115,11 +124,11 @@ struct Shard {
   void* Cs = nullptr;  // explicit constraint matrix, same shape (only when C != pattern(M))
   double* part = nullptr;  // [ntiles][2][W]
   double* u0 = nullptr;
-  double *U[2] = {nullptr, nullptr}, *G[2] = {nullptr, nullptr};
-  double* T[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [pair][candidate], see SolveArgs
+  double* pt = nullptr;    // point slots [2][V][4][mp]
+  double* X[2] = {nullptr, nullptr};  // candidate tables [V+1][mp][VS], see SolveArgs
   int* cnt = nullptr;      // arrival counters [nstrips + 1]
-  double* ab = nullptr;    // [P][2][W]
-  double* scal = nullptr;  // [nwg][NSCAL] partial scalars of k_tail
+  double* ab = nullptr;    // [P][V][2][W]
+  double* scal = nullptr;  // [nwg][Q] partial scalars of k_tail
   SolverState* st = nullptr;
   // affinity inputs (staged once, reused while the sizes fit)
   double *P1 = nullptr, *P2 = nullptr;  // gathered point tables [d][pstride]
@@ -163,8 +172,9 @@ struct clipper_hip_ctx {
   HostMirror* mirror_dev = nullptr;  // its device address
   double* u_pinned = nullptr;        // pinned staging of the final u
   size_t u_pinned_cap = 0;
-  int pass_mode = 0;   // 0 auto, 1 split (k_gemv + k_tail), 2 fused (k_pass), 3 legacy 3 launches
-  int par = 0;         // which T pair the next launch reads
+  int V = DEFAULT_WINDOW;  // line-search window: candidate vectors per pass
+  int64_t mp = 0;          // rows of a candidate table
+  int par = 0;             // which table set the next launch reads
 
   bool profiling = false;
   std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created lazily
@@ -190,12 +200,9 @@ int free_shard_buffers(Shard& s) {
   fr(s.Cs);
   fr(s.part);
   fr(s.u0);
-  for (int k = 0; k < 2; ++k) {
-    fr(s.U[k]);
-    fr(s.G[k]);
-    fr(s.T[k][0]);
-    fr(s.T[k][1]);
-  }
+  fr(s.pt);
+  fr(s.X[0]);
+  fr(s.X[1]);
   fr(s.cnt);
   fr(s.ab);
   fr(s.scal);
@@ -213,19 +220,29 @@ int free_shard_buffers(Shard& s) {
   return 0;
 }
 
+int plan_unr(const Ctx* h) {
+  return gemv_unr(h->V, static_cast<int>(h->esize()), h->explicitC);
+}
+
 void plan_tiles(Ctx* h) {
-  const int unr = (h->storage == CLIPPER_HIP_STORE_F64) ? GEMV_UNR_F64 : GEMV_UNR_F32;
+  const int unr = plan_unr(h);
   const int64_t chunk = static_cast<int64_t>(GEMV_NW) * unr;
   h->nstrips = static_cast<int>(ceil_div(h->W, 256));
-  // two 8-wave workgroups per CU (16 waves x 8 rows x 16 B = 2 KiB per lane-row in flight per
-  // CU... measured with tools/gemv_tune.hip: at m = 10k this geometry sits at the box's pure
-  // streaming-read ceiling while needing only ~13 row tiles, i.e. few partials for k_reduce)
+  // two 8-wave workgroups per CU: measured with tools/gemv_tune.hip / mv_tune.hip, at m = 10k
+  // this geometry sits at the box's pure streaming-read ceiling while needing only ~13 row
+  // tiles, i.e. few partials for the tail
   const int64_t target = static_cast<int64_t>(h->cus) * GEMV_WG_PER_CU;
   int64_t nt = std::max<int64_t>(1, ceil_div(target, h->nstrips));
   nt = std::min<int64_t>(nt, std::max<int64_t>(1, ceil_div(h->m, chunk)));
   int64_t rpt = round_up(ceil_div(h->m, nt), chunk);
   h->rows_per_tile = static_cast<int>(rpt);
   h->ntiles = static_cast<int>(ceil_div(h->m, rpt));
+}
+
+int64_t max_tiles(const Ctx* h) {
+  // upper bound of ntiles over every unroll plan_tiles may pick for this (m, W)
+  const int64_t target = static_cast<int64_t>(h->cus) * GEMV_WG_PER_CU;
+  return std::max<int64_t>(1, ceil_div(target, std::max(1, h->nstrips))) + 1;
 }
 
 // (re)allocate everything for an m x m problem
@@ -235,6 +252,7 @@ int ensure_problem(Ctx* h, int64_t m) {
   const int64_t W = round_up(ceil_div(m, P), 64);
   h->m = m;
   h->W = W;
+  h->mp = P * W;
   plan_tiles(h);
   if (h->alloc_m == m && h->alloc_W == W) return 0;
   for (auto& s : h->sh) {
@@ -244,24 +262,20 @@ int ensure_problem(Ctx* h, int64_t m) {
     HIPCHK(hipMalloc(&s.S, bytesS));
     s.bytes_S = bytesS;
     const size_t nvec = static_cast<size_t>(P * W) * sizeof(double);
+    const size_t V = static_cast<size_t>(h->V);
     HIPCHK(hipMalloc(&s.u0, nvec));
+    HIPCHK(hipMalloc(&s.pt, 2 * V * 4 * nvec));
     for (int k = 0; k < 2; ++k) {
-      HIPCHK(hipMalloc(&s.U[k], nvec));
-      HIPCHK(hipMalloc(&s.G[k], nvec));
-      for (int c = 0; c < 2; ++c) {
-        HIPCHK(hipMalloc(&s.T[k][c], nvec));
-        HIPCHK(hipMemsetAsync(s.T[k][c], 0, nvec, s.stream));
-      }
+      HIPCHK(hipMalloc(&s.X[k], (V + 1) * VS * nvec));
+      HIPCHK(hipMemsetAsync(s.X[k], 0, (V + 1) * VS * nvec, s.stream));
     }
     HIPCHK(hipMalloc(&s.cnt, static_cast<size_t>(h->nstrips + 1) * sizeof(int)));
     HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(h->nstrips + 1) * sizeof(int), s.stream));
-    HIPCHK(hipMalloc(&s.scal, static_cast<size_t>(ceil_div(m, TAIL_THREADS)) * NSCAL *
-                                  sizeof(double)));
-    HIPCHK(hipMalloc(&s.ab, 2 * nvec));
-    HIPCHK(hipMemsetAsync(s.ab, 0, 2 * nvec, s.stream));
-    // the tile plan depends only on (m, W, storage): size for the worst case of both
-    const int64_t max_tiles = std::max<int64_t>(h->ntiles, 1);
-    HIPCHK(hipMalloc(&s.part, static_cast<size_t>(max_tiles) * 2 * W * sizeof(double)));
+    const size_t Q = V * (2 + 2 * V) + 2 * V;
+    HIPCHK(hipMalloc(&s.scal, static_cast<size_t>(ceil_div(m, TAIL_THREADS)) * Q * sizeof(double)));
+    HIPCHK(hipMalloc(&s.ab, V * 2 * nvec));
+    HIPCHK(hipMemsetAsync(s.ab, 0, V * 2 * nvec, s.stream));
+    HIPCHK(hipMalloc(&s.part, static_cast<size_t>(max_tiles(h)) * V * 2 * W * sizeof(double)));
     HIPCHK(hipMalloc(&s.st, sizeof(SolverState)));
     HIPCHK(hipMemsetAsync(s.st, 0, sizeof(SolverState), s.stream));
   }
@@ -269,67 +283,86 @@ int ensure_problem(Ctx* h, int64_t m) {
   h->alloc_W = W;
   h->has_matrix = false;
   h->explicitC = false;
+  plan_tiles(h);
   h->u0_staged = false;
   h->staged_d = 0;
   return 0;
 }
 
-template <typename T, bool HASC>
-void launch_gemv_t(Ctx* h, Shard& s, const double* x0, const double* x1, const SolverState* st) {
-  constexpr int UNR = (sizeof(T) == 8) ? GEMV_UNR_F64 : GEMV_UNR_F32;
+// ---- kernel dispatch over (storage type, explicit C, window size) -------------------------
+template <typename T, bool HASC, int V>
+void launch_gemv_tv(Ctx* h, Shard& s, const double* Xtab, const SolverState* st) {
+  constexpr int UNR = gemv_unr(V, sizeof(T), HASC);
   dim3 grid(h->nstrips, h->ntiles), block(GEMV_NW * 64);
-  hipLaunchKernelGGL((k_gemv<T, HASC, GEMV_NW, UNR>), grid, block, 0, s.stream,
+  hipLaunchKernelGGL((k_gemv<T, HASC, V, GEMV_NW, UNR>), grid, block, 0, s.stream,
                      static_cast<const T*>(s.S), static_cast<const T*>(s.Cs), h->W, h->m,
-                     h->rows_per_tile, x0, x1, s.part, st);
+                     h->rows_per_tile, Xtab, h->mp, s.part, st);
 }
 
-// x = x1 when `st` is given and st->sel is set (solver), else x0
-void launch_gemv(Ctx* h, Shard& s, const double* x0, const double* x1, const SolverState* st) {
-  if (h->storage == CLIPPER_HIP_STORE_F64) {
-    if (h->explicitC) launch_gemv_t<double, true>(h, s, x0, x1, st);
-    else launch_gemv_t<double, false>(h, s, x0, x1, st);
-  } else {
-    if (h->explicitC) launch_gemv_t<float, true>(h, s, x0, x1, st);
-    else launch_gemv_t<float, false>(h, s, x0, x1, st);
-  }
-}
-
-template <typename T, bool HASC, int MODE>
-void launch_pass_t(Ctx* h, Shard& s, const SolveArgs& a) {
-  constexpr int UNR = (sizeof(T) == 8) ? GEMV_UNR_F64 : GEMV_UNR_F32;
+template <typename T, bool HASC, int V>
+void launch_pass_tv(Ctx* h, Shard& s, const SolveArgs& a) {
+  constexpr int UNR = gemv_unr(V, sizeof(T), HASC);
   dim3 grid(h->nstrips, h->ntiles), block(GEMV_NW * 64);
-  hipLaunchKernelGGL((k_pass<T, HASC, GEMV_NW, UNR, MODE>), grid, block, 0, s.stream,
+  hipLaunchKernelGGL((k_pass<T, HASC, V, GEMV_NW, UNR>), grid, block, 0, s.stream,
                      static_cast<const T*>(s.S), static_cast<const T*>(s.Cs), h->rows_per_tile,
                      a);
 }
 
-// the mat-vec with the epilogue `MODE` (PASS_FUSED / PASS_REDUCE) folded in
-template <int MODE>
-void launch_pass(Ctx* h, Shard& s, const SolveArgs& a) {
+// calls f(type tag, HASC tag) for the context's storage type and constraint mode
+template <int V, typename F>
+void dispatch_storage(Ctx* h, F&& f) {
   if (h->storage == CLIPPER_HIP_STORE_F64) {
-    if (h->explicitC) launch_pass_t<double, true, MODE>(h, s, a);
-    else launch_pass_t<double, false, MODE>(h, s, a);
+    if (h->explicitC) f(double{}, std::true_type{});
+    else f(double{}, std::false_type{});
   } else {
-    if (h->explicitC) launch_pass_t<float, true, MODE>(h, s, a);
-    else launch_pass_t<float, false, MODE>(h, s, a);
+    if (h->explicitC) f(float{}, std::true_type{});
+    else f(float{}, std::false_type{});
   }
 }
 
-void launch_reduce(Ctx* h, Shard& s, const SolverState* st) {
-  dim3 grid(static_cast<unsigned>(ceil_div(2 * h->W, 256))), block(256);
-  hipLaunchKernelGGL(k_reduce, grid, block, 0, s.stream, s.part, h->ntiles, h->W,
-                     s.ab + static_cast<int64_t>(s.slot) * 2 * h->W, st);
+// the mat-vec of the pending window of the solver (table st->sel of Xtab)
+template <int V>
+void launch_gemv(Ctx* h, Shard& s, const double* Xtab, const SolverState* st) {
+  dispatch_storage<V>(h, [&](auto t, auto c) {
+    launch_gemv_tv<decltype(t), decltype(c)::value, V>(h, s, Xtab, st);
+  });
 }
 
-// exchange of the per-shard [a|b] blocks so that every shard holds the full gathered pair
-int exchange(Ctx* h) {
+// the same with the reduction of the partials folded in (column-sharded M)
+template <int V>
+void launch_pass(Ctx* h, Shard& s, const SolveArgs& a) {
+  dispatch_storage<V>(h, [&](auto t, auto c) {
+    launch_pass_tv<decltype(t), decltype(c)::value, V>(h, s, a);
+  });
+}
+
+// calls f(integral_constant<V>) for the context's window size
+template <typename F>
+void dispatch_window(const Ctx* h, F&& f) {
+  switch (h->V) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    default: f(std::integral_constant<int, 6>{}); break;
+  }
+}
+
+// plain reduction of the partials of `nvec` vectors into this shard's block (matvec API)
+void launch_reduce(Ctx* h, Shard& s, int nvec) {
+  dim3 grid(static_cast<unsigned>(ceil_div(static_cast<int64_t>(nvec) * 2 * h->W, 256))), block(256);
+  hipLaunchKernelGGL(k_reduce, grid, block, 0, s.stream, s.part, h->ntiles, nvec, h->W,
+                     s.ab + static_cast<int64_t>(s.slot) * nvec * 2 * h->W);
+}
+
+// exchange of the per-shard blocks [nvec][2][W] so that every shard holds the gathered sums
+int exchange(Ctx* h, int nvec) {
   if (h->world == 1 && !h->multiproc) return 0;
-  const size_t blk = static_cast<size_t>(2 * h->W) * sizeof(double);
+  const int64_t blk_elems = static_cast<int64_t>(nvec) * 2 * h->W;
+  const size_t blk = static_cast<size_t>(blk_elems) * sizeof(double);
   if (h->multiproc) {
     if (!h->comm) return fail(CLIPPER_HIP_E_COMM, "clipper_hip_comm_init was not called");
     Shard& s = h->sh[0];
-    ncclResult_t r = g_rccl.AllGather(s.ab + static_cast<int64_t>(s.slot) * 2 * h->W, s.ab,
-                                      static_cast<size_t>(2 * h->W), ncclDouble, h->comm,
+    ncclResult_t r = g_rccl.AllGather(s.ab + static_cast<int64_t>(s.slot) * blk_elems, s.ab,
+                                      static_cast<size_t>(blk_elems), ncclDouble, h->comm,
                                       s.stream);
     if (r != ncclSuccess)
       return fail(CLIPPER_HIP_E_COMM, "ncclAllGather: %s",
@@ -346,7 +379,7 @@ int exchange(Ctx* h) {
     for (auto& p : h->sh) {
       if (p.slot == q.slot) continue;
       HIPCHK(hipStreamWaitEvent(q.stream, p.ev_reduced, 0));
-      const int64_t off = static_cast<int64_t>(p.slot) * 2 * h->W;
+      const int64_t off = static_cast<int64_t>(p.slot) * blk_elems;
       if (p.device == q.device) {
         HIPCHK(hipMemcpyAsync(q.ab + off, p.ab + off, blk, hipMemcpyDeviceToDevice, q.stream));
       } else {
@@ -366,8 +399,8 @@ int exchange(Ctx* h) {
   return 0;
 }
 
-// arguments of the launches of ONE solver iteration: reads the pending vector from T pair
-// `par`, writes the next candidates to pair `par ^ 1`
+// arguments of the launches of ONE solver iteration: reads the pending window from table set
+// `par`, writes the windows of every outcome to set `par ^ 1`
 SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   SolveArgs a;
   a.st = s.st;
@@ -375,13 +408,11 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.prm = prm;
   a.m = h->m;
   a.W = h->W;
+  a.mp = h->mp;
   a.u0 = s.u0;
-  for (int k = 0; k < 2; ++k) {
-    a.U[k] = s.U[k];
-    a.G[k] = s.G[k];
-    a.Tin[k] = s.T[par][k];
-    a.Tout[k] = s.T[par ^ 1][k];
-  }
+  a.pt = s.pt;
+  a.Xin = s.X[par];
+  a.Xout = s.X[par ^ 1];
   a.ab = s.ab;
   a.part = s.part;
   a.ntiles = h->ntiles;
@@ -393,40 +424,26 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   return a;
 }
 
-enum { MODE_AUTO = 0, MODE_SPLIT = 1, MODE_FUSED = 2, MODE_LEGACY = 3 };
-
-int effective_pass_mode(const Ctx* h) {
-  if (h->pass_mode != MODE_AUTO) return h->pass_mode;
-  return (h->m <= FUSED_PASS_MAX_M) ? MODE_FUSED : MODE_SPLIT;
-}
-
-// One full solver iteration: pass over M, element-wise tail, decision.
-//   one shard, fused : k_pass<FUSED>                                  (1 launch)
-//   one shard, split : k_gemv -> k_tail<true, true>                   (2 launches; the mat-vec
-//                      stays a pure streaming kernel — what bench.py's roofline times)
-//   sharded          : k_pass<REDUCE> -> exchange -> k_tail<false, true>
-//   legacy           : k_gemv -> [k_reduce -> exchange] -> k_tail<., false> -> k_decide
-int enqueue_iteration(Ctx* h, const SolverParams& prm) {
+// One full solver iteration: pass over M with the pending window, element-wise tail per
+// candidate, decision by the tail's last workgroup.
+//   one shard : k_gemv -> k_tail<V, true>       (the mat-vec stays a pure streaming kernel —
+//               what bench.py's roofline times)
+//   sharded   : k_pass (reduction folded in) -> exchange -> k_tail<V, false>
+template <int V>
+int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   const int par = h->par;
   h->par ^= 1;
   const bool sharded = !(h->world == 1 && !h->multiproc);
-  const int mode = effective_pass_mode(h);
   // timing events cost ~5 us of stream time each: sample every 4th launch only
   Shard& s0 = h->sh[0];
   const bool prof = h->profiling && (h->launch_counter % PROFILE_EVERY == 0) &&
                     h->ev_used < MAX_EVENT_PAIRS;
-  int rc = 0;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, par);
     if (prof && &s == &s0) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
-    if (mode == MODE_LEGACY || (!sharded && mode == MODE_SPLIT)) {
-      launch_gemv(h, s, a.Tin[0], a.Tin[1], s.st);
-    } else if (sharded) {
-      launch_pass<PASS_REDUCE>(h, s, a);
-    } else {
-      launch_pass<PASS_FUSED>(h, s, a);
-    }
+    if (sharded) launch_pass<V>(h, s, a);
+    else launch_gemv<V>(h, s, a.Xin, s.st);
     if (prof && &s == &s0) {
       HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used + 1], s.stream));
       h->ev_launch_index[h->ev_used] = h->launch_counter;
@@ -435,27 +452,23 @@ int enqueue_iteration(Ctx* h, const SolverParams& prm) {
   }
   ++h->launch_counter;
   if (sharded) {
-    if (mode == MODE_LEGACY)
-      for (auto& s : h->sh) {
-        HIPCHK(hipSetDevice(s.device));
-        launch_reduce(h, s, s.st);
-      }
-    if ((rc = exchange(h))) return rc;
+    int rc = exchange(h, V);
+    if (rc) return rc;
   }
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, par);
-    if (mode == MODE_LEGACY) {
-      if (sharded) hipLaunchKernelGGL((k_tail<false, false>), dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
-      else hipLaunchKernelGGL((k_tail<true, false>), dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
-      hipLaunchKernelGGL(k_decide, dim3(1), dim3(DECIDE_THREADS), 0, s.stream, a);
-    } else if (sharded) {
-      hipLaunchKernelGGL((k_tail<false, true>), dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
-    } else if (mode == MODE_SPLIT) {
-      hipLaunchKernelGGL((k_tail<true, true>), dim3(a.nwg), dim3(TAIL_THREADS), 0, s.stream, a);
-    }
+    dim3 grid(static_cast<unsigned>(a.nwg), V), block(TAIL_THREADS);
+    if (sharded) hipLaunchKernelGGL((k_tail<V, false>), grid, block, 0, s.stream, a);
+    else hipLaunchKernelGGL((k_tail<V, true>), grid, block, 0, s.stream, a);
   }
   return 0;
+}
+
+int enqueue_iteration(Ctx* h, const SolverParams& prm) {
+  int rc = 0;
+  dispatch_window(h, [&](auto v) { rc = enqueue_iteration_v<decltype(v)::value>(h, prm); });
+  return rc;
 }
 
 int enqueue_decide_only(Ctx* h, const SolverParams& prm) {
@@ -464,29 +477,29 @@ int enqueue_decide_only(Ctx* h, const SolverParams& prm) {
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     SolveArgs a = solve_args(h, s, prm, par);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(DECIDE_THREADS), 0, s.stream, a);
+    dispatch_window(h, [&](auto v) {
+      hipLaunchKernelGGL((k_decide<decltype(v)::value>), dim3(1), dim3(TAIL_THREADS), 0, s.stream, a);
+    });
   }
   return 0;
 }
 
-// plain mat-vec of every local shard on x (matvec API / micro-benchmark)
-int enqueue_gemv_plain(Ctx* h, const double* const* x_per_shard) {
-  size_t k = 0;
+// plain single-vector mat-vec of every local shard on table X[0] (matvec API / micro-benchmark)
+int enqueue_gemv_plain(Ctx* h) {
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    launch_gemv(h, s, x_per_shard[k], x_per_shard[k], nullptr);
-    ++k;
+    launch_gemv<1>(h, s, s.X[0], nullptr);
   }
   return 0;
 }
 
-// raw (un-normalised) sums of the partials into every shard's gathered `ab`
+// raw (un-normalised) sums of the single-vector partials into every shard's gathered `ab`
 int enqueue_reduce_exchange(Ctx* h) {
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    launch_reduce(h, s, nullptr);
+    launch_reduce(h, s, 1);
   }
-  return exchange(h);
+  return exchange(h, 1);
 }
 
 int sync_all(Ctx* h) {
@@ -590,11 +603,10 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     return nullptr;
   }
   std::memset(h->mirror, 0, sizeof(HostMirror));
-  // CLIPPER_HIP_PASS = split | fused | legacy overrides the per-size choice of launch shape
-  if (const char* pm = std::getenv("CLIPPER_HIP_PASS")) {
-    if (!std::strcmp(pm, "split")) h->pass_mode = MODE_SPLIT;
-    else if (!std::strcmp(pm, "fused")) h->pass_mode = MODE_FUSED;
-    else if (!std::strcmp(pm, "legacy")) h->pass_mode = MODE_LEGACY;
+  // CLIPPER_HIP_WINDOW = 1 | 4 | 6: line-search candidates multiplied per pass over M
+  if (const char* w = std::getenv("CLIPPER_HIP_WINDOW")) {
+    const int v = std::atoi(w);
+    if (v == 1 || v == 4 || v == 6) h->V = v;
   }
   return h;
 }
@@ -704,6 +716,7 @@ int run_affinity(Ctx* h, Launch launch) {
     }
   }
   h->explicitC = false;
+  plan_tiles(h);
   hipEvent_t e0, e1;
   Shard& s0 = h->sh[0];
   HIPCHK(hipSetDevice(s0.device));
@@ -1011,6 +1024,7 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
       }
   }
   h->explicitC = (mismatch != 0);
+  plan_tiles(h);
   if (h->explicitC) {
     for (size_t k = 0; k < h->sh.size(); ++k) {
       Shard& s = h->sh[k];
@@ -1056,6 +1070,7 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
                  std::equal(Mrow, Mrow + nnzM, Crow);
   for (int64_t p = 0; pattern && p < nnzM; ++p) pattern = (Cval[p] == 1.0) && (Mval[p] != 0.0);
   h->explicitC = !pattern;
+  plan_tiles(h);
   const int64_t W = h->W;
   auto scatter = [&](Shard& s, void* dst, const int64_t* cp, const int32_t* ri, const double* va,
                      int64_t nnz) -> int {
@@ -1212,7 +1227,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   SolverState init;
   std::memset(&init, 0, sizeof(init));
   init.alpha = 1.0;
-  init.nrm = 1.0;
+  for (int l = 0; l < VS; ++l) init.nrm[l] = 1.0;
   init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
   // prologue, one launch per shard: pending vector = u0 (T pair 0, nrm = 1), state, counters
   h->par = 0;
@@ -1222,7 +1237,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, 0);
     hipLaunchKernelGGL(k_init, dim3(static_cast<unsigned>(ceil_div(m, 256))), dim3(256), 0,
-                       s.stream, a, init, s.T[0][0]);
+                       s.stream, a, init, s.X[0]);
   }
   int rc = 0;
   if (!P->rescale_u0) {
@@ -1260,7 +1275,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     fin.n_passes = hm->n_passes;
     fin.n_trials = hm->n_trials;
     fin.ifinal = hm->ifinal;
-    fin.ub = hm->ub;
+    fin.ubp = hm->ubp;
+    fin.ubv = hm->ubv;
   } else {
     // Multi-process: every rank must queue the same number of iterations (each holds a
     // collective), so the decision to stop rests on state snapshots only, which are
@@ -1298,7 +1314,9 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     h->u_pinned_cap = vbytes;
   }
   HIPCHK(hipSetDevice(s0.device));
-  HIPCHK(hipMemcpyAsync(h->u_pinned, s0.U[fin.ub & 1], vbytes, hipMemcpyDeviceToHost, s0.stream));
+  const double* u_dev =
+      s0.pt + ((static_cast<int64_t>(fin.ubp & 1) * h->V + fin.ubv) * 4 + 0) * h->mp;
+  HIPCHK(hipMemcpyAsync(h->u_pinned, u_dev, vbytes, hipMemcpyDeviceToHost, s0.stream));
   if ((rc = sync_all(h))) return rc;
   std::vector<double> u(h->u_pinned, h->u_pinned + m);
 
@@ -1383,12 +1401,14 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
   const int64_t m = h->m, W = h->W;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    HIPCHK(hipMemcpyAsync(s.T[0][0], x, static_cast<size_t>(m) * sizeof(double),
+    // x -> candidate 0 of table 0 (staged through the u0 buffer)
+    HIPCHK(hipMemcpyAsync(s.u0, x, static_cast<size_t>(m) * sizeof(double),
                           hipMemcpyHostToDevice, s.stream));
+    hipLaunchKernelGGL(k_spread, dim3(static_cast<unsigned>(ceil_div(m, 256))), dim3(256), 0,
+                       s.stream, s.u0, m, s.X[0]);
   }
-  std::vector<const double*> xs;
-  for (auto& s : h->sh) xs.push_back(s.T[0][0]);
-  int rc = enqueue_gemv_plain(h, xs.data());
+  h->u0_staged = false;
+  int rc = enqueue_gemv_plain(h);
   if (rc) return rc;
   if ((rc = enqueue_reduce_exchange(h))) return rc;
   if ((rc = sync_all(h))) return rc;
@@ -1426,9 +1446,9 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) launch_gemv(h, s, s.T[0][0], s.T[0][0], nullptr);
+  for (int w = 0; w < 3; ++w) launch_gemv<1>(h, s, s.X[0], nullptr);
   HIPCHK(hipEventRecord(e0, s.stream));
-  for (int r = 0; r < reps; ++r) launch_gemv(h, s, s.T[0][0], s.T[0][0], nullptr);
+  for (int r = 0; r < reps; ++r) launch_gemv<1>(h, s, s.X[0], nullptr);
   HIPCHK(hipEventRecord(e1, s.stream));
   HIPCHK(hipStreamSynchronize(s.stream));
   float ms = 0.f;

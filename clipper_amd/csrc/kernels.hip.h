@@ -18,7 +18,7 @@
 //                   src/invariants/pointnormal_distance.cpp:13-35
 //   k_gemv        : every `M_.selfadjointView<Upper>() * v` / `C_...* v` in
 //                   src/clipper.cpp:194,202,205,219,240-241,268,271 (one fused pass gives both)
-//   k_tail+k_decide: the O(m) algebra and control flow of findDenseClique,
+//   k_tail (+ the decision of its last workgroup): the O(m) algebra and control flow of findDenseClique,
 //                   src/clipper.cpp:193-209 (init), :219-220 (gradient), :226-262 (step,
 //                   projection, line search), :268-280 (penalty update)
 #pragma once
@@ -29,36 +29,59 @@
 namespace clipper_hip {
 
 // ------------------------------------------------------------------------------------------
-// solver state that lives in device memory for the whole solve (the host only watches the
-// pinned HostMirror)
+// The line-search WINDOW (what makes this solver an MI355X design rather than a port)
+//
+// One pass over M costs s*m^2 bytes of HBM traffic and, for a single vector, ~20 % of the
+// fp64 VALU time that fits under it. The reference's backtracking line search
+// (clipper.cpp:234-251) tries alpha = 1, beta, beta^2, ... one mat-vec pair at a time — at
+// m = 10k half of all passes are rejected trials. Every one of those candidates
+//     c_l = max(u + alpha*beta^l * gradF, 0)                         (clipper.cpp:235-236)
+// is known BEFORE the first of them is evaluated, so a pass here multiplies M by a window of
+// V consecutive candidates at once (V accumulator sets per lane, one read of M): the decision
+// then walks the window in the reference's order and takes the first candidate the reference
+// would have accepted. Same trials, same arithmetic per trial, same result — in 1/2 to 2/3 of
+// the passes. Candidates live interleaved in "tables" X[row][VS] (64-byte rows) so that the
+// V wave-uniform multipliers of a row arrive with one scalar load.
+//
+// After a pass the element-wise tail runs once per candidate v (grid = blocks x V): it forms
+// gradFnew_v, the partial sums of Fnew_v and ||x_v - u||^2, stores (x_v, gradFnew_v, a_v, b_v)
+// into point slot (ubp^1, v), and speculatively builds the NEXT window for the outcome
+// "candidate v was accepted" (table v of Xout: max(x_v + beta^l gradFnew_v, 0), l < V) with
+// the partial sums of its norms; the v = 0 workgroups also build the outcome "all V rejected"
+// (table V: the next V step sizes from the unchanged (u, gradF)). The deciding workgroup then
+// only adds partial scalars, picks the outcome and publishes which table is pending.
 // ------------------------------------------------------------------------------------------
+
+constexpr int VS = 8;       // doubles per table row; window sizes V <= VS
+constexpr int QMAX = 128;   // upper bound of partial scalars per tail workgroup, V*(2+2V)+2V
 
 enum Phase : int32_t {
   PH_NORMALIZE = 0,  // no rescale: u = u0/||u0||, no pass consumed       (clipper.cpp:196-198)
   PH_RESCALE = 1,    // pass was on x = u0: u = M_off u0 + u0, normalise  (clipper.cpp:193-198)
   PH_INIT = 2,       // pass was on x = u: initial d, first gradient      (clipper.cpp:200-220)
-  PH_TRIAL = 3       // pass was on x = unew: line-search bookkeeping     (clipper.cpp:234-262)
+  PH_TRIAL = 3       // pass was on a window of trial vectors             (clipper.cpp:234-262)
 };
 
-// The vector a pass runs on is kept UN-normalised: x = Tin[sel] / nrm. The mat-vec multiplies
-// M by Tin[sel]; the tail divides the two sums by nrm (one division per column instead of one
-// per element of x before the pass) and materialises x where it is needed.
+// Candidates are kept UN-normalised: x_l = Xin[sel][.][l] / nrm[l]. The mat-vec multiplies M
+// by the raw table; the tail divides the sums by nrm[l].
 struct SolverState {
-  double d;       // penalty
-  double F;       // objective at u
-  double alpha;   // current step size
-  double s;       // sum(u)
-  double sx;      // sum(x) of the pending trial vector
-  double nrm;     // ||Tin[sel]|| (1 when the pending vector is already normalised / raw u0)
-  int32_t sel;    // which of Tin[0], Tin[1] holds the pending trial vector
-  int32_t ub;     // which of U[0]/G[0], U[1]/G[1] holds the current (u, gradF)
+  double d;        // penalty
+  double F;        // objective at u
+  double alpha;    // step size of candidate 0 of the pending window
+  double s;        // sum(u)
+  double nrm[VS];  // ||candidate l|| of the pending window (1 for an already normalised vector)
+  double sx[VS];   // sum(x_l)
+  int32_t sel;     // which table of Xin holds the pending window
+  int32_t ubp, ubv;  // point slot that holds the current (u, gradF, M_off u, C_off u)
   int32_t phase;
   int32_t i, j, k;  // outer / inner / line-search counters (clipper.cpp:217)
   int32_t done;
   int32_t ifinal;
+  int32_t pad_;
   int64_t n_passes;
-  int64_t n_trials;
-  int64_t n_iters;  // decisions taken so far (= solver iterations the device has retired)
+  int64_t n_trials;  // trials the reference would have evaluated (window slots past the
+                     // accepted candidate do not count)
+  int64_t n_iters;   // decisions taken so far (= solver iterations the device has retired)
 };
 
 // Host-visible progress record in pinned, coherent host memory. The deciding workgroup writes
@@ -68,9 +91,8 @@ struct HostMirror {
   double F, d;
   int64_t n_passes, n_trials;
   int64_t iters;
-  int32_t ifinal, ub;
+  int32_t ifinal, ubp, ubv;
   int32_t done;
-  int32_t pad_;
 };
 
 struct SolverParams {
@@ -79,29 +101,32 @@ struct SolverParams {
 };
 
 constexpr int TAIL_THREADS = 256;
-constexpr int NSCAL = 6;  // per-workgroup partial scalars written by the tail
+constexpr int TAIL_WAVES = TAIL_THREADS / 64;
+// LDS of the tail / decide kernels (doubles): [0,256) partial-scalar sums and reduction scratch
+// of the tail, [256,312) reduction scratch of the decision, [319] the arrival flag
+constexpr int SOLVE_LDS = 320;
+constexpr int LDS_SCRATCH = 256;
+constexpr int LDS_FLAG = 319;
 
 struct SolveArgs {
   SolverState* st;
   HostMirror* host;  // device address of the pinned progress record (may be null)
   SolverParams prm;
-  int64_t m;   // problem size
-  int64_t W;   // shard pitch: element i lives in block p = i / W of `ab`
+  int64_t m;    // problem size
+  int64_t W;    // shard pitch: element i lives in block p = i / W of `ab`
+  int64_t mp;   // rows of a candidate table / pitch of a point-slot array (>= m)
   const double* u0;
-  double* U[2];   // current point u (double-buffered: accepted x becomes u by flipping `ub`)
-  double* G[2];   // gradF at u / at the trial vector
-  // un-normalised trial vectors, [0] = "if accepted", [1] = "if rejected". A launch READS the
-  // pending vector from Tin and WRITES the two candidates of the next pass to Tout; the host
-  // swaps the pairs from launch to launch, so that a workgroup that finishes its columns early
-  // can never overwrite an x another workgroup of the same launch is still multiplying by.
-  const double* Tin[2];
-  double* Tout[2];
-  double* ab;     // [P][2][W]: a = M_off x, b = C_off x (raw sums in, normalised out)
-  double* part;   // [ntiles][2][W] row-tile partials of this shard
+  double* pt;   // point slots [2][V][4][mp]: u, gradF, a = M_off u, b = C_off u
+  // candidate tables [V+1][mp][VS]. A launch READS the pending window from Xin and WRITES the
+  // windows of every outcome to Xout; the host swaps the two from launch to launch.
+  const double* Xin;
+  double* Xout;
+  double* ab;     // column-sharded M: gathered RAW sums [P][V][2][W]
+  double* part;   // [ntiles][V][2][W] row-tile partials of this shard
   int ntiles;
   int slot;       // this shard's block of `ab`
-  double* scal;   // [nwg][NSCAL] partial scalars of the tail
-  int nwg;        // workgroups of the tail = ceil(m / TAIL_THREADS)
+  double* scal;   // [nwg][Q] partial scalars of the tail, Q = V*(2+2V) + 2V
+  int nwg;        // tail workgroups per candidate = ceil(m / TAIL_THREADS)
   int* cnt;       // arrival counters: [0, nstrips) one per column strip, [nstrips] the tail's
   int nstrips;
 };
@@ -117,14 +142,9 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ void ab_at(const double* ab, int64_t W, int64_t i, double& a,
-                                      double& b) {
-  // block p = i / W of the gathered [P][2][W] layout; 32-bit division (m < 2^31)
-  const uint32_t p = static_cast<uint32_t>(i) / static_cast<uint32_t>(W);
-  const int64_t off = i - static_cast<int64_t>(p) * W;
-  const double* blk = ab + static_cast<int64_t>(p) * 2 * W;
-  a = blk[off];
-  b = blk[W + off];
+// array k (0 = u, 1 = gradF, 2 = a, 3 = b) of point slot (p, v)
+__device__ __forceinline__ double* pt_arr(const SolveArgs& A, int V, int p, int v, int k) {
+  return A.pt + ((static_cast<int64_t>(p) * V + v) * 4 + k) * A.mp;
 }
 
 // Last-arriver hand-off inside one launch (CDNA guide, section 6 guideline 16, counter form;
@@ -154,33 +174,8 @@ __device__ __forceinline__ bool arrive_last(int* counter, int expected, int* fla
   return last;
 }
 
-// ------------------------------------------------------------------------------------------
-// The O(m) part of one solver iteration, split so that it parallelises:
-//
-//   tail    (one workgroup per 256 elements, one thread per element) — everything element-wise
-//           that follows a pass on the trial vector x (clipper.cpp:238-242, 253): a = M_off x,
-//           b = C_off x (sum of the row-tile partials, divided by nrm), gradFnew, and the
-//           per-workgroup partial sums of Fnew = x.gradFnew and ||x-u||^2. It also prepares
-//           BOTH possible next trial vectors (clipper.cpp:235-236) speculatively —
-//           Tout[0] = max(x + gradFnew, 0) if the step is accepted (alpha resets to 1),
-//           Tout[1] = max(u + alpha*beta*gradF, 0) if it is rejected — with the partial sums
-//           of their squared norms and of their entries, so that the only serial work left is
-//   decide  (one workgroup) — adds the partial scalars in a fixed order, takes the
-//           reference's decisions (clipper.cpp:244-251, 261) and updates the state. Only
-//           the rare transitions (initialisation :193-220, penalty update :268-280, a new
-//           outer iteration :219-220) sweep over the m-vectors here.
-//
-// Both are device functions shared by three launch shapes:
-//   k_gemv -> k_tail<.., true>            two launches per pass: the last tail workgroup decides
-//   k_pass<.., PASS_FUSED>                one launch per pass: the last workgroup of a column
-//                                         strip runs that strip's tail, the last strip decides
-//   k_pass<.., PASS_REDUCE> -> exchange -> k_tail<false, true>    column-sharded M
-// All sums have a fixed shape (256 data-carrying threads, partials in workgroup order), so the
-// results are bit-identical across the three shapes, from run to run and from rank to rank.
-// ------------------------------------------------------------------------------------------
-
-// Sum over the first NWAVES waves of the workgroup; every thread of the workgroup must call it
-// (waves beyond NWAVES only take part in the barriers) and every thread gets the totals.
+// Sum over the NWAVES waves of the workgroup; every thread must call it, every thread gets the
+// totals. Fixed tree: bit-reproducible.
 template <int N, int NWAVES>
 __device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWAVES*N] */) {
 #pragma unroll
@@ -190,7 +185,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWA
   }
   const int wave = threadIdx.x >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0 && wave < NWAVES) {
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int q = 0; q < N; ++q) lds[wave * N + q] = v[q];
   }
@@ -204,143 +199,83 @@ __device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWA
   }
 }
 
-constexpr int TAIL_WAVES = TAIL_THREADS / 64;
-constexpr int RED_DOUBLES = TAIL_WAVES * NSCAL + 2;  // reduction scratch + the arrival flag
-
-struct TailLoads {  // everything element i needs that does not depend on the state
-  double t0, t1, u0v, u1v, g0v, g1v;
-};
-
-__device__ __forceinline__ TailLoads tail_loads(const SolveArgs& A, int64_t i, bool valid) {
-  TailLoads L = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if (valid) {
-    L.t0 = A.Tin[0][i];
-    L.t1 = A.Tin[1][i];
-    L.u0v = A.U[0][i];
-    L.u1v = A.U[1][i];
-    L.g0v = A.G[0][i];
-    L.g1v = A.G[1][i];
-  }
-  return L;
-}
-
-// partial sums of element i over the row tiles, in tile order (single shard: W >= m, block 0);
-// 8 tiles of loads in flight at a time
-__device__ __forceinline__ void sum_partials(const SolveArgs& A, int64_t i, double& a, double& b) {
-  const double* p = A.part + i;
-  const int64_t ts = 2 * A.W;
-  int t = 0;
-  for (; t + 8 <= A.ntiles; t += 8) {
-    double va[8], vb[8];
+// The same sums, left in LDS: thread t < N returns total t (its own registers are never indexed
+// at run time, which would push the array to scratch), other threads return 0.
+template <int N, int NWAVES>
+__device__ __forceinline__ double block_reduce_pick(double (&v)[N], double* lds) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      va[q] = p[static_cast<int64_t>(t + q) * ts];
-      vb[q] = p[static_cast<int64_t>(t + q) * ts + A.W];
-    }
+  for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      a += va[q];
-      b += vb[q];
-    }
+    for (int q = 0; q < N; ++q) v[q] += shfl_xor_f64(v[q], off);
   }
-  for (; t < A.ntiles; ++t) {
-    a += p[static_cast<int64_t>(t) * ts];
-    b += p[static_cast<int64_t>(t) * ts + A.W];
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) lds[wave * N + q] = v[q];
   }
+  __syncthreads();
+  double acc = 0.0;
+  if (threadIdx.x < N) {
+    acc = lds[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < NWAVES; ++w) acc += lds[w * N + threadIdx.x];
+  }
+  return acc;
 }
 
-// Element-wise tail of element i (raw sums a, b in). `valid` = this thread carries an element
-// (one of the first 256 threads of the workgroup and i < m). Writes scal[slot][0..5].
-// Returns false when the state says there is nothing to do after the normalisation.
-__device__ __forceinline__ void tail_elements(const SolveArgs& A, const SolverState& stv,
-                                              int64_t i, bool valid, double a, double b,
-                                              const TailLoads& L, double* red, int64_t slot) {
-  const double nrm = stv.nrm;
-  // (a, b) for the pending vector x = Tin[sel]/nrm
-  if (valid) {
-    a = a / nrm;
-    b = b / nrm;
-    // normalised pair back into the gathered layout (read again only by decide's rare sweeps)
-    const uint32_t pblk = static_cast<uint32_t>(i) / static_cast<uint32_t>(A.W);
-    const int64_t off = i - static_cast<int64_t>(pblk) * A.W;
-    A.ab[static_cast<int64_t>(pblk) * 2 * A.W + off] = a;
-    A.ab[static_cast<int64_t>(pblk) * 2 * A.W + A.W + off] = b;
-  }
-  if (stv.phase != PH_TRIAL) return;  // initialisation phases are handled by decide alone
-
-  const int ub = stv.ub;
-  const double d = stv.d, sx = stv.sx, alpha = stv.alpha;
-  double r[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if (valid) {
-    const double xi = (stv.sel ? L.t1 : L.t0) / nrm;  // clipper.cpp:237
-    const double ui = ub ? L.u1v : L.u0v;
-    const double gi = ub ? L.g1v : L.g0v;
-    const double gn = (1 + d) * xi - d * sx + a + b * d;  // :238-241
-    A.U[ub ^ 1][i] = xi;                                   // becomes u if accepted
-    A.G[ub ^ 1][i] = gn;
-    r[0] = xi * gn;  // :242
-    const double du = xi - ui;
-    r[1] = du * du;  // :253
-    double ta = xi + gn;  // next trial if accepted: alpha = 1 (:227, :235)
-    ta = (ta > 0.0) ? ta : 0.0;  // :236
-    double tr = ui + (alpha * A.prm.beta) * gi;  // next trial if rejected: alpha*beta (:248)
-    tr = (tr > 0.0) ? tr : 0.0;
-    A.Tout[0][i] = ta;
-    A.Tout[1][i] = tr;
-    r[2] = ta * ta;
-    r[3] = ta;
-    r[4] = tr * tr;
-    r[5] = tr;
-  }
-  block_reduce<NSCAL, TAIL_WAVES>(r, red);
-  if (threadIdx.x < NSCAL) A.scal[slot * NSCAL + threadIdx.x] = r[threadIdx.x];
+__device__ __forceinline__ void store_row(double* row, const double (&c)[VS]) {
+  double4* q = reinterpret_cast<double4*>(row);
+  q[0] = make_double4(c[0], c[1], c[2], c[3]);
+  q[1] = make_double4(c[4], c[5], c[6], c[7]);
 }
 
-constexpr int VU = 4;  // elements per thread per sweep step (register budget of the fused epilogue)
-constexpr int DECIDE_THREADS = 256;
-constexpr int DECIDE_WAVES = DECIDE_THREADS / 64;
-// only the first DECIDE_THREADS threads of the workgroup carry elements
-#define VEC_CHUNKS(base) \
-  for (int64_t base = (tid < DECIDE_THREADS) ? tid : m; base < m; base += DECIDE_THREADS * VU)
+// ------------------------------------------------------------------------------------------
+// decide — ONE workgroup of 256 threads: adds the tail's partial scalars in a fixed order,
+// takes the reference's decisions (clipper.cpp:244-251, 261) for the candidates of the window
+// in order, and updates the state. Only the rare transitions (initialisation :193-220, penalty
+// update :268-280, a new outer iteration :219-220) sweep over the m-vectors here.
+// ------------------------------------------------------------------------------------------
+
+constexpr int VU = 4;  // elements per thread per sweep step
+#define VEC_CHUNKS(base) for (int64_t base = tid; base < m; base += TAIL_THREADS * VU)
 #define VEC_EACH(k, i, base)            \
   _Pragma("unroll") for (int k = 0; k < VU; ++k) \
-    if (const int64_t i = base + static_cast<int64_t>(k) * DECIDE_THREADS; i < m)
+    if (const int64_t i = base + static_cast<int64_t>(k) * TAIL_THREADS; i < m)
 
-// One decision of the solver's state machine, by ONE workgroup (all of its threads must call
-// this; the first 256 carry data). `stv` is the state as read at the start of the launch.
-__device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverState& stv,
-                                            double* red) {
+template <int V>
+__device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
+  constexpr int NR = 2 + 2 * V;
+  constexpr int Q = V * NR + 2 * V;
+  static_assert(Q <= QMAX && V <= VS, "window too large");
   SolverState* st = A.st;
   const int tid = threadIdx.x;
   const int64_t m = A.m;
   const SolverParams P = A.prm;
 
-  // the tail's partial scalars, one workgroup-strided sweep
-  double r[NSCAL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if (tid < DECIDE_THREADS) {
-    for (int w = tid; w < A.nwg; w += DECIDE_THREADS) {
-#pragma unroll
-      for (int q = 0; q < NSCAL; ++q) r[q] += A.scal[static_cast<int64_t>(w) * NSCAL + q];
-    }
-  }
-
-  const int phase = stv.phase;
-  double d = stv.d, F = stv.F, alpha = stv.alpha, s = stv.s, sx = stv.sx, nrm = stv.nrm;
-  int i_ = stv.i, j_ = stv.j, k_ = stv.k, ub = stv.ub, sel = stv.sel;
-  int64_t n_passes = stv.n_passes, n_trials = stv.n_trials;
-  const int64_t n_iters = stv.n_iters + 1;
+  const int phase = st->phase;
+  double d = st->d, F = st->F, alpha = st->alpha, s = st->s;
+  int i_ = st->i, j_ = st->j, k_ = st->k, ubp = st->ubp, ubv = st->ubv, sel = st->sel;
+  int64_t n_passes = st->n_passes, n_trials = st->n_trials;
+  const int64_t n_iters = st->n_iters + 1;
   if (phase != PH_NORMALIZE) ++n_passes;
+  double nrm[V], sx[V];
+#pragma unroll
+  for (int l = 0; l < V; ++l) {
+    nrm[l] = 1.0;
+    sx[l] = 0.0;
+  }
 
   if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
     // clipper.cpp:193-198 — u = M_off*u0 + u0 (or u0), then u /= u.norm()
-    double* u = A.U[ub];
+    double* u = pt_arr(A, V, ubp, ubv, 0);
+    const double* av_ = pt_arr(A, V, ubp, ubv, 2);
     double z[1] = {0.0};
     VEC_CHUNKS(base) {
       double uv[VU], av[VU];
       VEC_EACH(k, i, base) {
         uv[k] = A.u0[i];
-        double b;
-        if (phase == PH_RESCALE) ab_at(A.ab, A.W, i, av[k], b);
+        if (phase == PH_RESCALE) av[k] = av_[i];
       }
       VEC_EACH(k, i, base) {
         const double ui = (phase == PH_RESCALE) ? av[k] + uv[k] : uv[k];
@@ -348,7 +283,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
         z[0] += ui * ui;
       }
     }
-    block_reduce<1, DECIDE_WAVES>(z, red);
+    block_reduce<1, TAIL_WAVES>(z, red + LDS_SCRATCH);
     const double n0 = sqrt(z[0]);
     VEC_CHUNKS(base) {
       double uv[VU];
@@ -356,13 +291,15 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
       VEC_EACH(k, i, base) {
         const double ui = uv[k] / n0;
         u[i] = ui;
-        A.Tout[0][i] = ui;  // next pass runs on x = u (already normalised: nrm = 1)
+        // next pass runs on x = u (already normalised: nrm = 1), candidate 0 of table 0
+        const double row[VS] = {ui, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        store_row(A.Xout + i * VS, row);
       }
     }
     if (tid == 0) {
       st->phase = PH_INIT;
       st->sel = 0;
-      st->nrm = 1.0;
+      st->nrm[0] = 1.0;
       st->n_passes = n_passes;
       st->n_iters = n_iters;
       if (A.host != nullptr)
@@ -372,25 +309,28 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
   }
 
   bool begin_outer = false, end_inner = false, finished = false;
-  bool need_trial_vector = false;  // a sweep must build Tout[0] from (u, g): after a transition
+  bool need_window = false;  // a sweep must build the window from (u, g): after a transition
 
   if (phase == PH_INIT) {
     // clipper.cpp:200-209 — initial d from the pass on u
-    const double* u = A.U[ub];
+    const double* u = pt_arr(A, V, ubp, ubv, 0);
+    const double* ua = pt_arr(A, V, ubp, ubv, 2);
+    const double* ub_ = pt_arr(A, V, ubp, ubv, 3);
     double sv[1] = {0.0};
     VEC_CHUNKS(base) {
       double uv[VU];
       VEC_EACH(k, i, base) uv[k] = u[i];
       VEC_EACH(k, i, base) sv[0] += uv[k];
     }
-    block_reduce<1, DECIDE_WAVES>(sv, red);
+    block_reduce<1, TAIL_WAVES>(sv, red + LDS_SCRATCH);
     s = sv[0];
     double ca[2] = {0.0, 0.0};  // count, sum of ratios
     VEC_CHUNKS(base) {
       double uv[VU], av[VU], bv[VU];
       VEC_EACH(k, i, base) {
         uv[k] = u[i];
-        ab_at(A.ab, A.W, i, av[k], bv[k]);
+        av[k] = ua[i];
+        bv[k] = ub_[i];
       }
       VEC_EACH(k, i, base) {
         const double cbu = s - bv[k] - uv[k];  // :202
@@ -400,39 +340,83 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
         }
       }
     }
-    block_reduce<2, DECIDE_WAVES>(ca, red);
+    block_reduce<2, TAIL_WAVES>(ca, red + LDS_SCRATCH);
     d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
     i_ = 0;
     begin_outer = true;
   } else {  // PH_TRIAL — the decisions of clipper.cpp:244-262 from the tail's partial scalars
-    ++n_trials;
-    block_reduce<NSCAL, DECIDE_WAVES>(r, red);
-    const double Fnew = r[0];
-    const double deltaF = Fnew - F;  // :244
-    bool accept = true;
-    if (deltaF < -P.eps) {  // :246-248
-      alpha = alpha * P.beta;
-      ++k_;
-      if (k_ < P.maxlsiters) accept = false;  // :234 loop bound; the last trial is kept
+    // sums[q] = sum over the tail workgroups w of scal[w][q]: two interleaved chains (even /
+    // odd w) per quantity, the same shape for every window size
+    {
+      const int q = tid & (QMAX - 1), h = tid >> 7;
+      double acc = 0.0;
+      if (q < Q) {
+        const double* p = A.scal + q;
+        int w = h;
+        for (; w + 6 < A.nwg; w += 8) {
+          const double v0 = p[static_cast<int64_t>(w) * Q], v1 = p[static_cast<int64_t>(w + 2) * Q],
+                       v2 = p[static_cast<int64_t>(w + 4) * Q], v3 = p[static_cast<int64_t>(w + 6) * Q];
+          acc += v0;
+          acc += v1;
+          acc += v2;
+          acc += v3;
+        }
+        for (; w < A.nwg; w += 2) acc += p[static_cast<int64_t>(w) * Q];
+      }
+      red[tid] = acc;
+      __syncthreads();
+      const double tot = (tid < QMAX) ? red[tid] + red[tid + QMAX] : 0.0;
+      __syncthreads();
+      if (tid < QMAX) red[tid] = tot;
+      __syncthreads();
     }
-    if (!accept) {
-      sel = 1;  // the tail already built max(u + alpha*beta*g, 0) in Tout[1]
-      nrm = (r[4] > 0.0) ? sqrt(r[4]) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
-      sx = r[5] / nrm;
+    const double* sums = red;
+    int jstar = -1;
+    double Fnew = 0.0, deltaF = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if (jstar < 0) {
+        ++n_trials;
+        Fnew = sums[v * NR + 0];
+        deltaF = Fnew - F;  // :244
+        bool accept = true;
+        if (deltaF < -P.eps) {  // :246-248
+          alpha = alpha * P.beta;
+          ++k_;
+          if (k_ < P.maxlsiters) accept = false;  // :234 loop bound; the last trial is kept
+        }
+        if (accept) jstar = v;
+      }
+    }
+    if (jstar < 0) {
+      // all V candidates rejected: the v = 0 tail already built the next V step sizes from
+      // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
+      sel = V;
+#pragma unroll
+      for (int l = 0; l < V; ++l) {
+        const double z = sums[V * NR + 2 * l];
+        nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
+        sx[l] = sums[V * NR + 2 * l + 1] / nrm[l];
+      }
     } else {
-      const double deltau = sqrt(r[1]);
-      F = Fnew;  // :256-258 — u <- x, gradF <- gradFnew by flipping the buffer index
-      ub ^= 1;
-      s = sx;
+      const double deltau = sqrt(sums[jstar * NR + 1]);
+      s = st->sx[jstar];
+      F = Fnew;  // :256-258 — u <- x, gradF <- gradFnew: the point slot the tail filled
+      ubp ^= 1;
+      ubv = jstar;
       ++j_;
       if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
         end_inner = true;
       } else {
         alpha = 1.0;  // :227
         k_ = 0;
-        sel = 0;  // the tail already built max(x + gradFnew, 0) in Tout[0]
-        nrm = (r[2] > 0.0) ? sqrt(r[2]) : 1.0;
-        sx = r[3] / nrm;
+        sel = jstar;  // the tail already built max(x + beta^l gradFnew, 0) in table jstar
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          const double z = sums[jstar * NR + 2 + 2 * l];
+          nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
+          sx[l] = sums[jstar * NR + 3 + 2 * l] / nrm[l];
+        }
       }
     }
   }
@@ -441,13 +425,16 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
   // start of the next outer iteration (:219-220) reuse (a, b) of the accepted vector.
   while (true) {
     if (end_inner) {
-      const double* u = A.U[ub];
+      const double* u = pt_arr(A, V, ubp, ubv, 0);
+      const double* ua = pt_arr(A, V, ubp, ubv, 2);
+      const double* ub_ = pt_arr(A, V, ubp, ubv, 3);
       double ca[2] = {0.0, 0.0};
       VEC_CHUNKS(base) {
         double uv[VU], av[VU], bv[VU];
         VEC_EACH(k, i, base) {
           uv[k] = u[i];
-          ab_at(A.ab, A.W, i, av[k], bv[k]);
+          av[k] = ua[i];
+          bv[k] = ub_[i];
         }
         VEC_EACH(k, i, base) {
           const double cbu = s - bv[k] - uv[k];  // :268
@@ -457,7 +444,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
           }
         }
       }
-      block_reduce<2, DECIDE_WAVES>(ca, red);
+      block_reduce<2, TAIL_WAVES>(ca, red + LDS_SCRATCH);
       end_inner = false;
       if (ca[0] > 0.0) {
         d += ca[1] / ca[0];  // :276
@@ -474,14 +461,17 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
         finished = true;
         break;
       }
-      const double* u = A.U[ub];
-      double* g = A.G[ub];
+      const double* u = pt_arr(A, V, ubp, ubv, 0);
+      double* g = pt_arr(A, V, ubp, ubv, 1);
+      const double* ua = pt_arr(A, V, ubp, ubv, 2);
+      const double* ub_ = pt_arr(A, V, ubp, ubv, 3);
       double f[1] = {0.0};
       VEC_CHUNKS(base) {
         double uv[VU], av[VU], bv[VU];
         VEC_EACH(k, i, base) {
           uv[k] = u[i];
-          ab_at(A.ab, A.W, i, av[k], bv[k]);
+          av[k] = ua[i];
+          bv[k] = ub_[i];
         }
         VEC_EACH(k, i, base) {
           const double gi = (1 + d) * uv[k] - d * s + av[k] + bv[k] * d;  // :219
@@ -489,7 +479,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
           f[0] += uv[k] * gi;  // :220
         }
       }
-      block_reduce<1, DECIDE_WAVES>(f, red);
+      block_reduce<1, TAIL_WAVES>(f, red + LDS_SCRATCH);
       F = f[0];
       j_ = 0;
       if (P.maxiniters <= 0) {
@@ -498,16 +488,19 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
       }
       alpha = 1.0;
       k_ = 0;
-      need_trial_vector = true;
+      need_window = true;
     }
     break;
   }
 
-  if (!finished && need_trial_vector) {
-    // :235-236 with alpha = 1 — gradient step and projection; normalisation is deferred (nrm)
-    const double* u = A.U[ub];
-    const double* g = A.G[ub];
-    double zs[2] = {0.0, 0.0};
+  if (!finished && need_window) {
+    // :235-236 for alpha = 1, beta, beta^2, ... — gradient step and projection of the whole
+    // window; normalisation is deferred (nrm)
+    const double* u = pt_arr(A, V, ubp, ubv, 0);
+    const double* g = pt_arr(A, V, ubp, ubv, 1);
+    double zs[2 * V];
+#pragma unroll
+    for (int q = 0; q < 2 * V; ++q) zs[q] = 0.0;
     VEC_CHUNKS(base) {
       double uv[VU], gv[VU];
       VEC_EACH(k, i, base) {
@@ -515,17 +508,27 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
         gv[k] = g[i];
       }
       VEC_EACH(k, i, base) {
-        double t = uv[k] + alpha * gv[k];
-        t = (t > 0.0) ? t : 0.0;
-        A.Tout[0][i] = t;
-        zs[0] += t * t;
-        zs[1] += t;
+        double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double al = alpha;
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          double t = uv[k] + al * gv[k];
+          t = (t > 0.0) ? t : 0.0;
+          row[l] = t;
+          zs[2 * l] += t * t;
+          zs[2 * l + 1] += t;
+          al = al * P.beta;
+        }
+        store_row(A.Xout + i * VS, row);
       }
     }
-    block_reduce<2, DECIDE_WAVES>(zs, red);
+    block_reduce<2 * V, TAIL_WAVES>(zs, red + LDS_SCRATCH);
     sel = 0;
-    nrm = (zs[0] > 0.0) ? sqrt(zs[0]) : 1.0;
-    sx = zs[1] / nrm;
+#pragma unroll
+    for (int l = 0; l < V; ++l) {
+      nrm[l] = (zs[2 * l] > 0.0) ? sqrt(zs[2 * l]) : 1.0;
+      sx[l] = zs[2 * l + 1] / nrm[l];
+    }
   }
 
   if (tid == 0) {
@@ -533,10 +536,14 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
     st->F = F;
     st->alpha = alpha;
     st->s = s;
-    st->sx = sx;
-    st->nrm = nrm;
+#pragma unroll
+    for (int l = 0; l < V; ++l) {
+      st->nrm[l] = nrm[l];
+      st->sx[l] = sx[l];
+    }
     st->sel = sel;
-    st->ub = ub;
+    st->ubp = ubp;
+    st->ubv = ubv;
     st->phase = PH_TRIAL;
     st->i = i_;
     st->j = j_;
@@ -556,7 +563,8 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
         __hip_atomic_store(&hm->n_passes, n_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->n_trials, n_trials, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->ifinal, i_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&hm->ub, ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->ubp, ubp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->ubv, ubv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // every store above (and the vectors this workgroup wrote) before the flag
         __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -567,65 +575,166 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, const SolverStat
 #undef VEC_CHUNKS
 #undef VEC_EACH
 
-// Solve prologue, one launch: pending vector = u0 (un-normalised, nrm = 1), initial state,
-// arrival counters zeroed.
-__global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, double* T0) {
+// Solve prologue, one launch: pending window = {u0} (candidate 0 of table 0, un-normalised,
+// nrm = 1), initial state, arrival counters zeroed.
+__global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, double* X0) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i < A.m) T0[i] = A.u0[i];
+  if (i < A.m) {
+    const double row[VS] = {A.u0[i], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    store_row(X0 + i * VS, row);
+  }
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c <= A.nstrips; c += 256) A.cnt[c] = 0;
     if (threadIdx.x == 0) *A.st = init;
   }
 }
 
-// The tail as its own launch (one workgroup per 256 elements).
+// ------------------------------------------------------------------------------------------
+// tail — grid (ceil(m/256), V): workgroup (blk, v) handles candidate v of 256 elements.
 //   FUSED_REDUCE: sum the row-tile partials of the single shard here (else `ab` holds the
-//                 gathered raw sums of all shards);
-//   FUSED_DECIDE: the last workgroup to arrive takes the decision (else k_decide follows).
-template <bool FUSED_REDUCE, bool FUSED_DECIDE>
+//                 gathered raw sums of all shards).
+// The last workgroup to arrive takes the decision (arrive_last).
+// ------------------------------------------------------------------------------------------
+template <int V, bool FUSED_REDUCE>
 __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
-  __shared__ double red[RED_DOUBLES];
+  constexpr int NR = 2 + 2 * V;
+  constexpr int Q = V * NR + 2 * V;
+  __shared__ double red[SOLVE_LDS];
+  const int v = blockIdx.y;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
   const bool valid = i < A.m;
+  const SolverState* st = A.st;
 
-  // Everything that does not depend on the solver state is loaded first, so that the state,
-  // the partials and both buffer candidates share ONE memory round trip instead of chaining.
-  const SolverState stv = *A.st;  // one 128-byte read
-  const TailLoads L = tail_loads(A, i, valid);
+  // raw sums of candidate v: these loads do not depend on the solver state
   double a = 0.0, b = 0.0;
   if (valid) {
-    if (FUSED_REDUCE) sum_partials(A, i, a, b);
-    else ab_at(A.ab, A.W, i, a, b);
+    if (FUSED_REDUCE) {  // single shard: W >= m; partials in tile order, 8 tiles in flight
+      const double* p = A.part + static_cast<int64_t>(v) * 2 * A.W + i;
+      const int64_t ts = static_cast<int64_t>(V) * 2 * A.W;
+      int t = 0;
+      for (; t + 8 <= A.ntiles; t += 8) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          va[q] = p[static_cast<int64_t>(t + q) * ts];
+          vb[q] = p[static_cast<int64_t>(t + q) * ts + A.W];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          a += va[q];
+          b += vb[q];
+        }
+      }
+      for (; t < A.ntiles; ++t) {
+        a += p[static_cast<int64_t>(t) * ts];
+        b += p[static_cast<int64_t>(t) * ts + A.W];
+      }
+    } else {  // block p = i / W of the gathered [P][V][2][W] layout (32-bit division, m < 2^31)
+      const uint32_t pb = static_cast<uint32_t>(i) / static_cast<uint32_t>(A.W);
+      const int64_t off = i - static_cast<int64_t>(pb) * A.W;
+      const double* blk = A.ab + ((static_cast<int64_t>(pb) * V + v) * 2) * A.W;
+      a = blk[off];
+      b = blk[A.W + off];
+    }
   }
-  if (stv.done) return;
-  tail_elements(A, stv, i, valid, a, b, L, red, blockIdx.x);
-  if (FUSED_DECIDE) {
-    if (!arrive_last(A.cnt + A.nstrips, gridDim.x, reinterpret_cast<int*>(red + RED_DOUBLES - 1)))
-      return;
-    decide_body(A, stv, red);
+  if (st->done) return;
+  const int phase = st->phase;
+  const int ubp = st->ubp, ubv = st->ubv;
+
+  if (phase != PH_TRIAL) {
+    // initialisation passes carry one vector (candidate 0, nrm = 1): its (a, b) go to the
+    // current point slot, where the decision reads them
+    if (v == 0 && valid) {
+      pt_arr(A, V, ubp, ubv, 2)[i] = a;
+      pt_arr(A, V, ubp, ubv, 3)[i] = b;
+    }
+  } else {
+    const double nrmv = st->nrm[v], sxv = st->sx[v];
+    const double d = st->d, alpha = st->alpha, beta = A.prm.beta;
+    double r[NR + 2 * V];
+#pragma unroll
+    for (int q = 0; q < NR + 2 * V; ++q) r[q] = 0.0;
+    if (valid) {
+      const double xraw = A.Xin[(static_cast<int64_t>(st->sel) * A.mp + i) * VS + v];
+      const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
+      const double xi = xraw / nrmv;  // clipper.cpp:237
+      a = a / nrmv;
+      b = b / nrmv;
+      const double gn = (1 + d) * xi - d * sxv + a + b * d;  // :238-241
+      pt_arr(A, V, ubp ^ 1, v, 0)[i] = xi;  // becomes (u, gradF, a, b) if candidate v is accepted
+      pt_arr(A, V, ubp ^ 1, v, 1)[i] = gn;
+      pt_arr(A, V, ubp ^ 1, v, 2)[i] = a;
+      pt_arr(A, V, ubp ^ 1, v, 3)[i] = b;
+      r[0] = xi * gn;  // :242
+      const double du = xi - ui;
+      r[1] = du * du;  // :253
+      // next window if candidate v is accepted: alpha = 1, beta, beta^2, ... (:227, :235-236)
+      double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      double al = 1.0;
+#pragma unroll
+      for (int l = 0; l < V; ++l) {
+        double t = xi + al * gn;
+        t = (t > 0.0) ? t : 0.0;
+        row[l] = t;
+        r[2 + 2 * l] = t * t;
+        r[3 + 2 * l] = t;
+        al = al * beta;
+      }
+      store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
+      if (v == 0) {
+        // next window if all V candidates are rejected: V more factors of beta (:248)
+        const double gi = pt_arr(A, V, ubp, ubv, 1)[i];
+        double row2[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        al = alpha;
+#pragma unroll
+        for (int l = 0; l < V; ++l) al = al * beta;
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          double t = ui + al * gi;
+          t = (t > 0.0) ? t : 0.0;
+          row2[l] = t;
+          r[NR + 2 * l] = t * t;
+          r[NR + 2 * l + 1] = t;
+          al = al * beta;
+        }
+        store_row(A.Xout + (static_cast<int64_t>(V) * A.mp + i) * VS, row2);
+      }
+    }
+    const double tot = block_reduce_pick<NR + 2 * V, TAIL_WAVES>(r, red);
+    double* out = A.scal + static_cast<int64_t>(blockIdx.x) * Q;
+    if (threadIdx.x < NR) out[v * NR + threadIdx.x] = tot;
+    if (v == 0 && threadIdx.x >= NR && threadIdx.x < NR + 2 * V)
+      out[V * NR + (threadIdx.x - NR)] = tot;
   }
+  if (!arrive_last(A.cnt + A.nstrips, gridDim.x * gridDim.y, reinterpret_cast<int*>(red + LDS_FLAG)))
+    return;
+  decide_body<V>(A, red);
 }
 
-__global__ __launch_bounds__(DECIDE_THREADS) void k_decide(SolveArgs A) {
-  __shared__ double red[RED_DOUBLES];
-  const SolverState stv = *A.st;
-  if (stv.done) return;
-  decide_body(A, stv, red);
+// the decision alone (PH_NORMALIZE consumes no pass)
+template <int V>
+__global__ __launch_bounds__(TAIL_THREADS) void k_decide(SolveArgs A) {
+  __shared__ double red[SOLVE_LDS];
+  if (A.st->done) return;
+  decide_body<V>(A, red);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_gemv — the fused symmetric mat-vec pair  a = M_off x,  b = C_off x  in ONE pass over M.
+// k_gemv — the symmetric mat-vec pairs  a_v = M_off x_v,  b_v = C_off x_v  of a window of V
+// vectors in ONE pass over M.
 //
 // grid = (strips of 256 columns, row tiles). A workgroup of NW waves shares one column
 // strip; wave w takes rows r0 + w*UNR + k*NW*UNR ... of its tile, UNR rows per iteration
-// so UNR independent 16-byte loads per lane are in flight. x[row] is wave-uniform: the
-// compiler turns it into scalar loads. Per-wave partials are combined through LDS in wave
-// order and written to part[tile][2][ld]; k_reduce adds the tiles in tile order. Nothing
-// is atomic: the result is bit-reproducible from run to run and from rank to rank.
+// so UNR independent 16-byte loads per lane are in flight. The V multipliers of a row are
+// wave-uniform and contiguous (one 64-byte table row): scalar loads. Per-wave partials are
+// combined through LDS in wave order and written to part[tile][v][2][ld]; the tail adds the
+// tiles in tile order. Nothing is atomic: bit-reproducible from run to run and rank to rank.
+// C_off x: without an explicit C, C == pattern(M) and b_v += (M != 0) * x_v — as an fma with
+// the 0/1 indicator, which rounds exactly like the addition it replaces.
 //
-// HBM-bound: s*m*W bytes per launch (s = sizeof(T)); per element one cvt, one fma, one
-// compare/select, one add — far below the fp64 vector rate, MFMA has nothing to offer a
-// rank-1 product.
+// HBM-bound: s*m*W bytes per launch (s = sizeof(T)); per element one cvt, one compare/select
+// and 2V fma — V = 1: ~20 %, V = 6: ~60 % of the fp64 vector rate at HBM speed; MFMA has
+// nothing to offer a product whose inner dimension is read exactly once.
 // ------------------------------------------------------------------------------------------
 
 template <typename T>
@@ -644,11 +753,42 @@ __device__ __forceinline__ typename Vec4<T>::type load4(const T* p) {
   return *reinterpret_cast<const typename Vec4<T>::type*>(p);
 }
 
-// The streaming part: this workgroup's (strip, row tile) partial sums -> part[tile][2][ld].
-template <typename T, bool HASC, int NW, int UNR>
+template <typename T, bool HASC, int V>
+__device__ __forceinline__ void gemv_row(const typename Vec4<T>::type& mv,
+                                         const typename Vec4<T>::type& cv,
+                                         const double* __restrict__ xr, double (&aa)[V][4],
+                                         double (&bb)[V][4]) {
+  const double mm[4] = {static_cast<double>(mv.x), static_cast<double>(mv.y),
+                        static_cast<double>(mv.z), static_cast<double>(mv.w)};
+  double ii[4];
+  if (HASC) {
+    ii[0] = static_cast<double>(cv.x);
+    ii[1] = static_cast<double>(cv.y);
+    ii[2] = static_cast<double>(cv.z);
+    ii[3] = static_cast<double>(cv.w);
+  } else {
+    ii[0] = (mv.x != T(0)) ? 1.0 : 0.0;
+    ii[1] = (mv.y != T(0)) ? 1.0 : 0.0;
+    ii[2] = (mv.z != T(0)) ? 1.0 : 0.0;
+    ii[3] = (mv.w != T(0)) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const double xv = xr[v];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      aa[v][e] = fma(mm[e], xv, aa[v][e]);
+      bb[v][e] = fma(ii[e], xv, bb[v][e]);
+    }
+  }
+}
+
+// The streaming part: this workgroup's (strip, row tile) partial sums -> part[tile][v][2][ld].
+// X: the pending table, X[row][VS].
+template <typename T, bool HASC, int V, int NW, int UNR>
 __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __restrict__ Cs,
                                           int64_t ld, int64_t m, int rows_per_tile,
-                                          const double* __restrict__ x,
+                                          const double* __restrict__ X,
                                           double* __restrict__ part, double* lds) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -656,181 +796,133 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
   const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_tile;
   const int64_t r1 = (r0 + rows_per_tile < m) ? r0 + rows_per_tile : m;
 
-  double aa[4] = {0.0, 0.0, 0.0, 0.0};
-  double bb[4] = {0.0, 0.0, 0.0, 0.0};
+  double aa[V][4], bb[V][4];
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) aa[v][e] = bb[v][e] = 0.0;
 
   if (col < ld) {
     const T* p = S + col;
-    const T* pc = HASC ? Cs + col : nullptr;
+    const T* pc = HASC ? Cs + col : S + col;
     int64_t r = r0 + static_cast<int64_t>(wave) * UNR;
     for (; r + UNR <= r1; r += static_cast<int64_t>(NW) * UNR) {
-      typename Vec4<T>::type v[UNR];
-      typename Vec4<T>::type c[UNR];
+      typename Vec4<T>::type mv[UNR];
+      typename Vec4<T>::type cv[HASC ? UNR : 1];
 #pragma unroll
       for (int q = 0; q < UNR; ++q) {
-        v[q] = load4(p + (r + q) * ld);
-        if (HASC) c[q] = load4(pc + (r + q) * ld);
+        mv[q] = load4(p + (r + q) * ld);
+        if (HASC) cv[q] = load4(pc + (r + q) * ld);
       }
 #pragma unroll
-      for (int q = 0; q < UNR; ++q) {
-        const double xr = x[r + q];
-        const double m0 = static_cast<double>(v[q].x), m1 = static_cast<double>(v[q].y),
-                     m2 = static_cast<double>(v[q].z), m3 = static_cast<double>(v[q].w);
-        aa[0] = fma(m0, xr, aa[0]);
-        aa[1] = fma(m1, xr, aa[1]);
-        aa[2] = fma(m2, xr, aa[2]);
-        aa[3] = fma(m3, xr, aa[3]);
-        if (HASC) {
-          bb[0] = fma(static_cast<double>(c[q].x), xr, bb[0]);
-          bb[1] = fma(static_cast<double>(c[q].y), xr, bb[1]);
-          bb[2] = fma(static_cast<double>(c[q].z), xr, bb[2]);
-          bb[3] = fma(static_cast<double>(c[q].w), xr, bb[3]);
-        } else {
-          bb[0] += (v[q].x != T(0)) ? xr : 0.0;
-          bb[1] += (v[q].y != T(0)) ? xr : 0.0;
-          bb[2] += (v[q].z != T(0)) ? xr : 0.0;
-          bb[3] += (v[q].w != T(0)) ? xr : 0.0;
-        }
-      }
+      for (int q = 0; q < UNR; ++q)
+        gemv_row<T, HASC, V>(mv[q], cv[HASC ? q : 0], X + (r + q) * VS, aa, bb);
     }
     // tail rows of this wave's last chunk
     for (int q = 0; q < UNR; ++q) {
       const int64_t rr = r + q;
       if (rr < r1) {
-        const typename Vec4<T>::type v = load4(p + rr * ld);
-        const double xr = x[rr];
-        const double mm[4] = {static_cast<double>(v.x), static_cast<double>(v.y),
-                              static_cast<double>(v.z), static_cast<double>(v.w)};
-        double cc[4];
-        if (HASC) {
-          const typename Vec4<T>::type c = load4(pc + rr * ld);
-          cc[0] = static_cast<double>(c.x);
-          cc[1] = static_cast<double>(c.y);
-          cc[2] = static_cast<double>(c.z);
-          cc[3] = static_cast<double>(c.w);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          aa[e] = fma(mm[e], xr, aa[e]);
-          if (HASC) {
-            bb[e] = fma(cc[e], xr, bb[e]);
-          } else {
-            bb[e] += (mm[e] != 0.0) ? xr : 0.0;
-          }
-        }
+        const typename Vec4<T>::type mv = load4(p + rr * ld);
+        const typename Vec4<T>::type cv = load4(pc + rr * ld);
+        gemv_row<T, HASC, V>(mv, cv, X + rr * VS, aa, bb);
       }
     }
   }
 
-  // cross-wave combine in wave order (fixed summation tree)
-  double* mine = lds + wave * 512 + lane * 4;
+  // cross-wave combine in wave order (fixed summation tree), one candidate at a time
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    mine[e] = aa[e];
-    mine[256 + e] = bb[e];
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < 512; t += NW * 64) {
-    double acc = lds[t];
+  for (int v = 0; v < V; ++v) {
+    double* mine = lds + wave * 512 + lane * 4;
 #pragma unroll
-    for (int w = 1; w < NW; ++w) acc += lds[w * 512 + t];
-    const int which = t >> 8;  // 0 = a, 1 = b
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
-    if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * 2 + which) * ld + c] = acc;
+    for (int e = 0; e < 4; ++e) {
+      mine[e] = aa[v][e];
+      mine[256 + e] = bb[v][e];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 512; t += NW * 64) {
+      double acc = lds[t];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) acc += lds[w * 512 + t];
+      const int which = t >> 8;  // 0 = a, 1 = b
+      const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
+      if (c < ld)
+        part[((static_cast<int64_t>(blockIdx.y) * V + v) * 2 + which) * ld + c] = acc;
+    }
+    if (v + 1 < V) __syncthreads();
   }
 }
-
 
 constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * 2 * 256 + 2; }  // + the arrival flag
 
-template <typename T, bool HASC, int NW, int UNR>
-__global__ __launch_bounds__(NW * 64) void k_gemv(const T* __restrict__ S,
-                                                   const T* __restrict__ Cs, int64_t ld,
-                                                   int64_t m, int rows_per_tile,
-                                                   const double* __restrict__ x0,
-                                                   const double* __restrict__ x1,
-                                                   double* __restrict__ part,
-                                                   const SolverState* __restrict__ st) {
-  if (st != nullptr && st->done) return;
-  // driven by the solver: the pending trial vector is Tin[sel] (un-normalised, see SolverState)
-  const double* __restrict__ x = (st != nullptr && st->sel) ? x1 : x0;
+// two workgroups per CU (NW/2 waves per SIMD each): caps the registers at 128 per lane
+template <typename T, bool HASC, int V, int NW, int UNR>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv(const T* __restrict__ S,
+                                                           const T* __restrict__ Cs, int64_t ld,
+                                                           int64_t m, int rows_per_tile,
+                                                           const double* __restrict__ Xtab,
+                                                           int64_t mp, double* __restrict__ part,
+                                                           const SolverState* __restrict__ st) {
+  int sel = 0;
+  if (st != nullptr) {
+    if (st->done) return;
+    sel = st->sel;  // driven by the solver: the pending window is table `sel`
+  }
   __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
-  gemv_core<T, HASC, NW, UNR>(S, Cs, ld, m, rows_per_tile, x, part, lds);
+  gemv_core<T, HASC, V, NW, UNR>(S, Cs, ld, m, rows_per_tile,
+                                 Xtab + static_cast<int64_t>(sel) * mp * VS, part, lds);
 }
 
-// k_pass — the mat-vec with the rest of the solver iteration folded into its epilogue.
-//   PASS_FUSED  (one shard): the LAST row-tile workgroup of a column strip (arrival counter per
-//               strip) sums that strip's partials in tile order and runs the element-wise tail
-//               for its 256 columns while the other strips are still streaming; the last strip
-//               to finish (second counter) takes the decision. One launch per solver iteration.
-//   PASS_REDUCE (column-sharded M): the last workgroup of a strip writes the strip's raw sums
-//               into this shard's [a | b] block (what k_reduce did in a launch of its own); the
-//               exchange and k_tail<false, true> follow.
-// The strip tail writes the NEXT pass's candidates to Tout, never to the Tin other workgroups
-// of this launch are still reading.
-enum PassMode : int { PASS_FUSED = 1, PASS_REDUCE = 2 };
-
-// two workgroups per CU (NW*64/256 * 2 waves per SIMD): caps the epilogue's register appetite
-template <typename T, bool HASC, int NW, int UNR, int MODE>
+// k_pass — the mat-vec of a column-sharded M with the reduction of its row-tile partials folded
+// into the epilogue: the LAST row-tile workgroup of a column strip (arrival counter per strip)
+// adds the strip's partials in tile order into this shard's block of the gathered layout
+// ab[P][V][2][W] — what k_reduce would do in a launch of its own. The exchange and
+// k_tail<V, false> follow.
+template <typename T, bool HASC, int V, int NW, int UNR>
 __global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ S,
-                                                   const T* __restrict__ Cs,
-                                                   int rows_per_tile, SolveArgs A) {
-  static_assert(NW * 64 >= TAIL_THREADS, "the strip tail needs 256 threads");
+                                                           const T* __restrict__ Cs,
+                                                           int rows_per_tile, SolveArgs A) {
   __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
-  const SolverState stv = *A.st;
-  if (stv.done) return;
+  const SolverState* st = A.st;
+  if (st->done) return;
   const int64_t ld = A.W;
-  gemv_core<T, HASC, NW, UNR>(S, Cs, ld, A.m, rows_per_tile, stv.sel ? A.Tin[1] : A.Tin[0],
-                              A.part, lds);
+  gemv_core<T, HASC, V, NW, UNR>(S, Cs, ld, A.m, rows_per_tile,
+                                 A.Xin + static_cast<int64_t>(st->sel) * A.mp * VS, A.part, lds);
   int* flag = reinterpret_cast<int*>(lds + GEMV_LDS_DOUBLES(NW) - 1);
   if (!arrive_last(A.cnt + blockIdx.x, gridDim.y, flag)) return;
-
   // ---- last workgroup of this column strip ------------------------------------------------
-  if (MODE == PASS_REDUCE) {
-    double* ab_block = A.ab + static_cast<int64_t>(A.slot) * 2 * ld;
-    for (int t = threadIdx.x; t < 512; t += NW * 64) {
-      const int which = t >> 8;
-      const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
-      if (c < ld) {
-        const double* p = A.part + which * ld + c;
-        double acc = 0.0;
-        int tt = 0;
-        for (; tt + 8 <= A.ntiles; tt += 8) {
-          double v[8];
+  double* ab_block = A.ab + static_cast<int64_t>(A.slot) * V * 2 * ld;
+  const int64_t ts = static_cast<int64_t>(V) * 2 * ld;
+  for (int t = threadIdx.x; t < V * 512; t += NW * 64) {
+    const int vw = t >> 8;  // v*2 + which
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
+    if (c < ld) {
+      const double* p = A.part + vw * ld + c;
+      double acc = 0.0;
+      int tt = 0;
+      for (; tt + 8 <= A.ntiles; tt += 8) {
+        double x[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = p[static_cast<int64_t>(tt + q) * 2 * ld];
+        for (int q = 0; q < 8; ++q) x[q] = p[static_cast<int64_t>(tt + q) * ts];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) acc += v[q];
-        }
-        for (; tt < A.ntiles; ++tt) acc += p[static_cast<int64_t>(tt) * 2 * ld];
-        ab_block[which * ld + c] = acc;
+        for (int q = 0; q < 8; ++q) acc += x[q];
       }
+      for (; tt < A.ntiles; ++tt) acc += p[static_cast<int64_t>(tt) * ts];
+      ab_block[vw * ld + c] = acc;
     }
-    return;
   }
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const bool valid = (threadIdx.x < TAIL_THREADS) && (i < A.m);
-  const TailLoads L = tail_loads(A, i, valid);
-  double a = 0.0, b = 0.0;
-  if (valid) sum_partials(A, i, a, b);
-  tail_elements(A, stv, i, valid, a, b, L, lds, blockIdx.x);
-  if (!arrive_last(A.cnt + A.nstrips, gridDim.x, flag)) return;
-  // ---- last strip: the decision -------------------------------------------------------------
-  decide_body(A, stv, lds);
 }
 
 // k_reduce — adds the row-tile partials in tile order and writes this shard's block of the
-// gathered vector pair: ab_block = [a (W) | b (W)]. One thread per output element; the
-// loads of 8 tiles are issued before they are summed (the partials sit in L2 / MALL).
+// gathered layout (matvec API only: the solver folds this into k_pass / k_tail). One thread per
+// output element e = (v*2 + which)*ld + c; the loads of 8 tiles are issued before they are
+// summed (the partials sit in L2 / MALL).
 __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ part, int ntiles,
-                                                 int64_t ld, double* __restrict__ ab_block,
-                                                 const SolverState* __restrict__ st) {
-  if (st != nullptr && st->done) return;
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;  // in [0, 2*ld)
-  if (e >= 2 * ld) return;
-  const int64_t which = e / ld, c = e - which * ld;
-  const double* p = part + which * ld + c;
-  const int64_t tstride = 2 * ld;
+                                                 int nvec, int64_t ld,
+                                                 double* __restrict__ ab_block) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t tstride = static_cast<int64_t>(nvec) * 2 * ld;
+  if (e >= tstride) return;
+  const double* p = part + e;
   double acc = 0.0;
   int t = 0;
   for (; t + 8 <= ntiles; t += 8) {
@@ -841,7 +933,17 @@ __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ part,
     for (int q = 0; q < 8; ++q) acc += v[q];
   }
   for (; t < ntiles; ++t) acc += p[static_cast<int64_t>(t) * tstride];
-  ab_block[e] = acc;  // e = which*ld + c: exactly the [a | b] block layout
+  ab_block[e] = acc;
+}
+
+// x[i] -> candidate 0 of a table row (matvec API)
+__global__ __launch_bounds__(256) void k_spread(const double* __restrict__ x, int64_t m,
+                                                 double* __restrict__ X) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < m) {
+    const double row[VS] = {x[i], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    store_row(X + i * VS, row);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -167,8 +167,9 @@ def test_euclidean_parity(storage, m, rho, seed):
     if storage == abi.STORE_F64:
         assert abs(sg.score - sr.score) <= 1e-9 * abs(sr.score)
         assert np.allclose(sg.u, sr.u, rtol=0, atol=1e-9)
-    # every pass is a line-search trial except the (<=2) initial ones
-    assert sg.n_passes == sg.n_trials + 2
+    # a pass evaluates a window of line-search trials: never more passes than trials (+ the 2
+    # initial passes), and no fewer than trials / window
+    assert (sg.n_trials + 5) // 6 + 2 <= sg.n_passes <= sg.n_trials + 2
     prec, rec = synth.precision_recall(c.get_selected_associations(), p.Agt)
     assert prec >= 0.95
 
@@ -370,63 +371,71 @@ def test_full_size_10k_properties_and_parity():
 
 
 # ------------------------------------------------------------------------------------------
-# launch shapes of one solver iteration: legacy (k_gemv, k_tail, k_decide), split (k_gemv,
-# k_tail + last-arriver decision), fused (k_pass: strip-last tail + last-strip decision) — all
-# sums have one fixed shape, so the three must agree to the last bit
+# line-search window: V candidates per pass over M (CLIPPER_HIP_WINDOW = 1 | 4 | 6). The window
+# only changes HOW MANY passes evaluate the reference's trial sequence, never which trials are
+# accepted: every window size must reproduce the oracle's trial count and selection.
 # ------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("m,rho,seed", [(600, 0.9, 1), (1037, 0.8, 7), (3000, 0.9, 5), (5200, 0.95, 11)])
-def test_launch_shapes_are_bit_identical(monkeypatch, m, rho, seed):
+def test_window_sizes_agree(monkeypatch, m, rho, seed):
     p = synth.make_euclidean_problem(m, rho, seed=seed)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    sr = r.solve(p.u0)
     sols = {}
-    for mode in ("legacy", "split", "fused"):
-        monkeypatch.setenv("CLIPPER_HIP_PASS", mode)
+    for V in (1, 4, 6):
+        monkeypatch.setenv("CLIPPER_HIP_WINDOW", str(V))
         for storage in STORAGES:
             g = abi.HipClipper(storage=storage)
             g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
-            for rep in range(3):   # repeated solves on one context: counters re-arm themselves
-                sols[(mode, storage, rep)] = g.solve(p.u0)
+            for rep in range(2):   # repeated solves on one context: counters re-arm themselves
+                s = g.solve(p.u0)
+                sols[(V, storage, rep)] = s
+                _check_solution(s, sr, exact_counts=(storage == abi.STORE_F64))
             g.close()
-    monkeypatch.delenv("CLIPPER_HIP_PASS")
+    monkeypatch.delenv("CLIPPER_HIP_WINDOW")
     for storage in STORAGES:
-        base = sols[("legacy", storage, 0)]
-        for mode in ("legacy", "split", "fused"):
-            for rep in range(3):
-                s = sols[(mode, storage, rep)]
-                assert s.nodes.tolist() == base.nodes.tolist(), (mode, storage, rep)
-                assert s.score == base.score and s.ifinal == base.ifinal, (mode, storage, rep)
-                assert s.n_passes == base.n_passes and s.n_trials == base.n_trials
-                assert np.array_equal(s.u, base.u), (mode, storage, rep)
-    r = ref.RefClipper()
-    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
-    _check_solution(sols[("fused", abi.STORE_F32, 0)], r.solve(p.u0))
+        base = sols[(1, storage, 0)]
+        assert base.n_passes == base.n_trials + 2        # window 1: one trial per pass
+        for V in (1, 4, 6):
+            for rep in range(2):
+                s = sols[(V, storage, rep)]
+                assert s.nodes.tolist() == base.nodes.tolist(), (V, storage, rep)
+                assert s.ifinal == base.ifinal and s.n_trials == base.n_trials, (V, storage, rep)
+                assert abs(s.score - base.score) <= 1e-12 * abs(base.score)
+                assert np.allclose(s.u, base.u, rtol=0, atol=1e-12)
+                assert s.n_passes <= base.n_passes
+                assert np.array_equal(s.u, sols[(V, storage, 0)].u)   # run-to-run bit-identical
 
 
-@pytest.mark.parametrize("mode", ["legacy", "split"])
-def test_sharded_launch_shapes(monkeypatch, mode):
-    # sharded: legacy = k_gemv, k_reduce, exchange, k_tail, k_decide;
-    #          otherwise k_pass<REDUCE>, exchange, k_tail + last-arriver decision
+@pytest.mark.parametrize("V", [1, 4, 6])
+def test_window_with_line_search_limits(monkeypatch, V):
+    # maxlsiters cuts the backtracking inside a window (the last allowed trial is accepted
+    # unconditionally, clipper.cpp:234), beta != 1/4 changes the step sizes of the window
+    monkeypatch.setenv("CLIPPER_HIP_WINDOW", str(V))
+    p = synth.make_euclidean_problem(1500, 0.93, seed=8)
+    for kw in (dict(maxlsiters=1), dict(maxlsiters=2), dict(maxlsiters=3), dict(maxlsiters=5),
+               dict(beta=0.5), dict(beta=0.1, maxlsiters=7), dict(maxiniters=3), dict(maxoliters=2),
+               dict(rescale_u0=False), dict(rounding=abi.ROUNDING_NONZERO)):
+        g, r = _pair(abi.STORE_F64, **kw)
+        g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+        r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+        _check_solution(g.solve(p.u0), r.solve(p.u0), exact_counts=True)
+        g.close()
+
+
+@pytest.mark.parametrize("V", [1, 4, 6])
+def test_window_sharded(monkeypatch, V):
+    # column-sharded M: k_pass (reduction folded in), exchange of [V][2][W] blocks, k_tail
+    monkeypatch.setenv("CLIPPER_HIP_WINDOW", str(V))
     p = synth.make_euclidean_problem(1500, 0.9, seed=77)
-    monkeypatch.setenv("CLIPPER_HIP_PASS", "legacy")
     g1 = abi.HipClipper(storage=abi.STORE_F32)
     g1.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
     s1 = g1.solve(p.u0)
-    monkeypatch.setenv("CLIPPER_HIP_PASS", mode)
     g = abi.HipClipper(storage=abi.STORE_F32, group=[0] * 3)
     g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
     for rep in range(2):
         s = g.solve(p.u0)
         assert s.nodes.tolist() == s1.nodes.tolist() and s.n_passes == s1.n_passes
+        assert s.n_trials == s1.n_trials
         assert abs(s.score - s1.score) <= 1e-12 * abs(s1.score)
-
-
-def test_no_rescale_and_nonzero_rounding_in_every_shape(monkeypatch):
-    p = synth.make_euclidean_problem(900, 0.85, seed=21)
-    r = ref.RefClipper(ref.Params(rescale_u0=False, rounding=ref.ROUNDING_NONZERO))
-    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
-    sr = r.solve(p.u0)
-    for mode in ("legacy", "split", "fused"):
-        monkeypatch.setenv("CLIPPER_HIP_PASS", mode)
-        g = abi.HipClipper(abi.Params(rescale_u0=False, rounding=abi.ROUNDING_NONZERO))
-        g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
-        _check_solution(g.solve(p.u0), sr)
