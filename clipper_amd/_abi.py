@@ -17,7 +17,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libclipper_hip.so")
+# CLIPPER_HIP_LIB: alternate build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("CLIPPER_HIP_LIB") or os.path.join(_HERE, "lib", "libclipper_hip.so")
 
 STORE_F32, STORE_F64 = 0, 1
 ROUNDING_NONZERO, ROUNDING_DSD, ROUNDING_DSD_HEU = 0, 1, 2

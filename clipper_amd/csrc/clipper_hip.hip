@@ -66,16 +66,19 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // mat-vec kernel geometry (tuned on MI355X)
 constexpr int GEMV_NW = 8;      // waves per workgroup
 constexpr int GEMV_WG_PER_CU = 2;
-// rows in flight per wave: 8 x 16 B per lane for fp32 storage and windows up to 4 vectors; the
-// 6-vector window needs 96 accumulator registers and keeps 4 rows in flight (tools/mv_tune.hip);
-// halved for fp64 storage (32 B per lane and row) and again with an explicit C matrix
+// rows in flight per wave: 8 x 16 B per lane for fp32 storage and windows up to 6 vectors (one
+// accumulator set per candidate: 48 registers at V = 6); the 8-vector window keeps 4 rows in
+// flight (tools/mv_tune.hip); halved for fp64 storage (32 B per lane and row) and again with an
+// explicit C matrix
 constexpr int gemv_unr(int V, int esize, bool hasc) {
-  int u = (V <= 4) ? 8 : 4;
+  int u = (V <= 6) ? 8 : 4;
   if (esize == 8) u /= 2;
   if (hasc) u /= 2;
   return u < 1 ? 1 : u;
 }
-constexpr int DEFAULT_WINDOW = 6;  // line-search candidates per pass (CLIPPER_HIP_WINDOW = 1|4|6)
+// line-search candidates per pass: 6 from this size on, else 1 (below, a pass is latency-bound and
+// the V-fold tail costs more than the saved passes); CLIPPER_HIP_WINDOW = 1|4|6|8 overrides
+constexpr int64_t WINDOW_MIN_M = 6000;
 constexpr int SOLVE_BATCH = 16;  // multi-process: iterations queued between two state snapshots
 constexpr int RUN_AHEAD = 4;     // one process: iterations kept queued ahead of the device
 constexpr int MAX_EVENT_PAIRS = 4096;
@@ -124,10 +127,11 @@ struct Shard {
   void* Cs = nullptr;  // explicit constraint matrix, same shape (only when C != pattern(M))
   double* part = nullptr;  // [ntiles][2][W]
   double* u0 = nullptr;
-  double* pt = nullptr;    // point slots [2][V][4][mp]
+  double* pt = nullptr;    // point slots [2][V][2][mp]
+  double* cab = nullptr;   // (a, b) of the last pair-mode pass [2][mp]
   double* X[2] = {nullptr, nullptr};  // candidate tables [V+1][mp][VS], see SolveArgs
   int* cnt = nullptr;      // arrival counters [nstrips + 1]
-  double* ab = nullptr;    // [P][V][2][W]
+  double* ab = nullptr;    // [P][NSLOT][W]
   double* scal = nullptr;  // [nwg][Q] partial scalars of k_tail
   SolverState* st = nullptr;
   // affinity inputs (staged once, reused while the sizes fit)
@@ -172,7 +176,8 @@ struct clipper_hip_ctx {
   HostMirror* mirror_dev = nullptr;  // its device address
   double* u_pinned = nullptr;        // pinned staging of the final u
   size_t u_pinned_cap = 0;
-  int V = DEFAULT_WINDOW;  // line-search window: candidate vectors per pass
+  int V = 6;               // line-search window: candidate vectors per pass
+  int V_forced = 0;        // CLIPPER_HIP_WINDOW
   int64_t mp = 0;          // rows of a candidate table
   int par = 0;             // which table set the next launch reads
 
@@ -201,6 +206,7 @@ int free_shard_buffers(Shard& s) {
   fr(s.part);
   fr(s.u0);
   fr(s.pt);
+  fr(s.cab);
   fr(s.X[0]);
   fr(s.X[1]);
   fr(s.cnt);
@@ -253,8 +259,11 @@ int ensure_problem(Ctx* h, int64_t m) {
   h->m = m;
   h->W = W;
   h->mp = P * W;
+  const int V = h->V_forced ? h->V_forced : (m >= WINDOW_MIN_M ? 6 : 1);
+  const bool same = (h->alloc_m == m && h->alloc_W == W && h->V == V);
+  h->V = V;
   plan_tiles(h);
-  if (h->alloc_m == m && h->alloc_W == W) return 0;
+  if (same) return 0;
   for (auto& s : h->sh) {
     free_shard_buffers(s);
     HIPCHK(hipSetDevice(s.device));
@@ -264,7 +273,9 @@ int ensure_problem(Ctx* h, int64_t m) {
     const size_t nvec = static_cast<size_t>(P * W) * sizeof(double);
     const size_t V = static_cast<size_t>(h->V);
     HIPCHK(hipMalloc(&s.u0, nvec));
-    HIPCHK(hipMalloc(&s.pt, 2 * V * 4 * nvec));
+    const size_t NSLOT = static_cast<size_t>(nslot(h->V));
+    HIPCHK(hipMalloc(&s.pt, 2 * V * 2 * nvec));
+    HIPCHK(hipMalloc(&s.cab, 2 * nvec));
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipMalloc(&s.X[k], (V + 1) * VS * nvec));
       HIPCHK(hipMemsetAsync(s.X[k], 0, (V + 1) * VS * nvec, s.stream));
@@ -273,9 +284,9 @@ int ensure_problem(Ctx* h, int64_t m) {
     HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(h->nstrips + 1) * sizeof(int), s.stream));
     const size_t Q = V * (2 + 2 * V) + 2 * V;
     HIPCHK(hipMalloc(&s.scal, static_cast<size_t>(ceil_div(m, TAIL_THREADS)) * Q * sizeof(double)));
-    HIPCHK(hipMalloc(&s.ab, V * 2 * nvec));
-    HIPCHK(hipMemsetAsync(s.ab, 0, V * 2 * nvec, s.stream));
-    HIPCHK(hipMalloc(&s.part, static_cast<size_t>(max_tiles(h)) * V * 2 * W * sizeof(double)));
+    HIPCHK(hipMalloc(&s.ab, NSLOT * nvec));
+    HIPCHK(hipMemsetAsync(s.ab, 0, NSLOT * nvec, s.stream));
+    HIPCHK(hipMalloc(&s.part, static_cast<size_t>(max_tiles(h)) * NSLOT * W * sizeof(double)));
     HIPCHK(hipMalloc(&s.st, sizeof(SolverState)));
     HIPCHK(hipMemsetAsync(s.st, 0, sizeof(SolverState), s.stream));
   }
@@ -342,21 +353,22 @@ void dispatch_window(const Ctx* h, F&& f) {
   switch (h->V) {
     case 1: f(std::integral_constant<int, 1>{}); break;
     case 4: f(std::integral_constant<int, 4>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
     default: f(std::integral_constant<int, 6>{}); break;
   }
 }
 
-// plain reduction of the partials of `nvec` vectors into this shard's block (matvec API)
-void launch_reduce(Ctx* h, Shard& s, int nvec) {
-  dim3 grid(static_cast<unsigned>(ceil_div(static_cast<int64_t>(nvec) * 2 * h->W, 256))), block(256);
-  hipLaunchKernelGGL(k_reduce, grid, block, 0, s.stream, s.part, h->ntiles, nvec, h->W,
-                     s.ab + static_cast<int64_t>(s.slot) * nvec * 2 * h->W);
+// plain reduction of `nslots` partial slots into this shard's block (matvec API)
+void launch_reduce(Ctx* h, Shard& s, int nslots) {
+  dim3 grid(static_cast<unsigned>(ceil_div(static_cast<int64_t>(nslots) * h->W, 256))), block(256);
+  hipLaunchKernelGGL(k_reduce, grid, block, 0, s.stream, s.part, h->ntiles, nslots, h->W,
+                     s.ab + static_cast<int64_t>(s.slot) * nslots * h->W);
 }
 
-// exchange of the per-shard blocks [nvec][2][W] so that every shard holds the gathered sums
-int exchange(Ctx* h, int nvec) {
+// exchange of the per-shard blocks [nslots][W] so that every shard holds the gathered sums
+int exchange(Ctx* h, int nslots) {
   if (h->world == 1 && !h->multiproc) return 0;
-  const int64_t blk_elems = static_cast<int64_t>(nvec) * 2 * h->W;
+  const int64_t blk_elems = static_cast<int64_t>(nslots) * h->W;
   const size_t blk = static_cast<size_t>(blk_elems) * sizeof(double);
   if (h->multiproc) {
     if (!h->comm) return fail(CLIPPER_HIP_E_COMM, "clipper_hip_comm_init was not called");
@@ -411,6 +423,7 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.mp = h->mp;
   a.u0 = s.u0;
   a.pt = s.pt;
+  a.cab = s.cab;
   a.Xin = s.X[par];
   a.Xout = s.X[par ^ 1];
   a.ab = s.ab;
@@ -452,7 +465,7 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   }
   ++h->launch_counter;
   if (sharded) {
-    int rc = exchange(h, V);
+    int rc = exchange(h, nslot(V));
     if (rc) return rc;
   }
   for (auto& s : h->sh) {
@@ -497,9 +510,9 @@ int enqueue_gemv_plain(Ctx* h) {
 int enqueue_reduce_exchange(Ctx* h) {
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    launch_reduce(h, s, 1);
+    launch_reduce(h, s, 2);
   }
-  return exchange(h, 1);
+  return exchange(h, 2);
 }
 
 int sync_all(Ctx* h) {
@@ -603,10 +616,10 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     return nullptr;
   }
   std::memset(h->mirror, 0, sizeof(HostMirror));
-  // CLIPPER_HIP_WINDOW = 1 | 4 | 6: line-search candidates multiplied per pass over M
+  // CLIPPER_HIP_WINDOW = 1 | 4 | 6 | 8: line-search candidates multiplied per pass over M
   if (const char* w = std::getenv("CLIPPER_HIP_WINDOW")) {
     const int v = std::atoi(w);
-    if (v == 1 || v == 4 || v == 6) h->V = v;
+    if (v == 1 || v == 4 || v == 6 || v == 8) h->V_forced = v;
   }
   return h;
 }
@@ -1315,7 +1328,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   }
   HIPCHK(hipSetDevice(s0.device));
   const double* u_dev =
-      s0.pt + ((static_cast<int64_t>(fin.ubp & 1) * h->V + fin.ubv) * 4 + 0) * h->mp;
+      s0.pt + ((static_cast<int64_t>(fin.ubp & 1) * h->V + fin.ubv) * 2 + 0) * h->mp;
   HIPCHK(hipMemcpyAsync(h->u_pinned, u_dev, vbytes, hipMemcpyDeviceToHost, s0.stream));
   if ((rc = sync_all(h))) return rc;
   std::vector<double> u(h->u_pinned, h->u_pinned + m);

@@ -44,7 +44,7 @@ namespace clipper_hip {
 // V wave-uniform multipliers of a row arrive with one scalar load.
 //
 // After a pass the element-wise tail runs once per candidate v (grid = blocks x V): it forms
-// gradFnew_v, the partial sums of Fnew_v and ||x_v - u||^2, stores (x_v, gradFnew_v, a_v, b_v)
+// gradFnew_v, the partial sums of Fnew_v and ||x_v - u||^2, stores (x_v, gradFnew_v)
 // into point slot (ubp^1, v), and speculatively builds the NEXT window for the outcome
 // "candidate v was accepted" (table v of Xout: max(x_v + beta^l gradFnew_v, 0), l < V) with
 // the partial sums of its norms; the v = 0 workgroups also build the outcome "all V rejected"
@@ -53,14 +53,17 @@ namespace clipper_hip {
 // ------------------------------------------------------------------------------------------
 
 constexpr int VS = 8;       // doubles per table row; window sizes V <= VS
-constexpr int QMAX = 128;   // upper bound of partial scalars per tail workgroup, V*(2+2V)+2V
+constexpr int nslot(int V) { return V < 2 ? 2 : V; }  // partial-sum slots per row tile: V candidates, or (a, b)
 
 enum Phase : int32_t {
   PH_NORMALIZE = 0,  // no rescale: u = u0/||u0||, no pass consumed       (clipper.cpp:196-198)
   PH_RESCALE = 1,    // pass was on x = u0: u = M_off u0 + u0, normalise  (clipper.cpp:193-198)
   PH_INIT = 2,       // pass was on x = u: initial d, first gradient      (clipper.cpp:200-220)
-  PH_TRIAL = 3       // pass was on a window of trial vectors             (clipper.cpp:234-262)
+  PH_TRIAL = 3,      // pass was on a window of trial vectors             (clipper.cpp:234-262)
+  PH_PENALTY = 4     // pass was on x = the inner loop's final u: penalty update (:268-280)
 };
+// PH_TRIAL passes run the mat-vec in window mode (g_v = (M_off + d*C_off) x_v), all others in
+// pair mode (a = M_off x, b = C_off x of candidate 0) — see k_gemv.
 
 // Candidates are kept UN-normalised: x_l = Xin[sel][.][l] / nrm[l]. The mat-vec multiplies M
 // by the raw table; the tail divides the sums by nrm[l].
@@ -72,7 +75,7 @@ struct SolverState {
   double nrm[VS];  // ||candidate l|| of the pending window (1 for an already normalised vector)
   double sx[VS];   // sum(x_l)
   int32_t sel;     // which table of Xin holds the pending window
-  int32_t ubp, ubv;  // point slot that holds the current (u, gradF, M_off u, C_off u)
+  int32_t ubp, ubv;  // point slot that holds the current (u, gradF)
   int32_t phase;
   int32_t i, j, k;  // outer / inner / line-search counters (clipper.cpp:217)
   int32_t done;
@@ -116,13 +119,14 @@ struct SolveArgs {
   int64_t W;    // shard pitch: element i lives in block p = i / W of `ab`
   int64_t mp;   // rows of a candidate table / pitch of a point-slot array (>= m)
   const double* u0;
-  double* pt;   // point slots [2][V][4][mp]: u, gradF, a = M_off u, b = C_off u
+  double* pt;   // point slots [2][V][2][mp]: u, gradF
+  double* cab;  // [2][mp]: a = M_off x, b = C_off x of the last pair-mode pass
   // candidate tables [V+1][mp][VS]. A launch READS the pending window from Xin and WRITES the
   // windows of every outcome to Xout; the host swaps the two from launch to launch.
   const double* Xin;
   double* Xout;
-  double* ab;     // column-sharded M: gathered RAW sums [P][V][2][W]
-  double* part;   // [ntiles][V][2][W] row-tile partials of this shard
+  double* ab;     // column-sharded M: gathered RAW sums [P][NSLOT][W], NSLOT = max(V, 2)
+  double* part;   // [ntiles][NSLOT][W] row-tile partials of this shard
   int ntiles;
   int slot;       // this shard's block of `ab`
   double* scal;   // [nwg][Q] partial scalars of the tail, Q = V*(2+2V) + 2V
@@ -142,9 +146,9 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   return __hiloint2double(hi, lo);
 }
 
-// array k (0 = u, 1 = gradF, 2 = a, 3 = b) of point slot (p, v)
+// array k (0 = u, 1 = gradF) of point slot (p, v)
 __device__ __forceinline__ double* pt_arr(const SolveArgs& A, int V, int p, int v, int k) {
-  return A.pt + ((static_cast<int64_t>(p) * V + v) * 4 + k) * A.mp;
+  return A.pt + ((static_cast<int64_t>(p) * V + v) * 2 + k) * A.mp;
 }
 
 // Last-arriver hand-off inside one launch (CDNA guide, section 6 guideline 16, counter form;
@@ -174,18 +178,34 @@ __device__ __forceinline__ bool arrive_last(int* counter, int expected, int* fla
   return last;
 }
 
+// Wave-level sum with DPP moves (VALU speed, no LDS crossbar): after the six steps lane 63
+// holds the total of the 64 lanes; the order of the additions is fixed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v += dpp_f64<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_f64<0x140, 0xf>(v);  // row_mirror: every lane holds the sum of its row of 16
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast15 into rows 1, 3
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast31 into rows 2, 3: lane 63 holds the wave total
+  return v;
+}
+
 // Sum over the NWAVES waves of the workgroup; every thread must call it, every thread gets the
 // totals. Fixed tree: bit-reproducible.
 template <int N, int NWAVES>
 __device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWAVES*N] */) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-    for (int q = 0; q < N; ++q) v[q] += shfl_xor_f64(v[q], off);
-  }
+  for (int q = 0; q < N; ++q) v[q] = wave_sum_to_lane63(v[q]);
   const int wave = threadIdx.x >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 63) {
 #pragma unroll
     for (int q = 0; q < N; ++q) lds[wave * N + q] = v[q];
   }
@@ -204,13 +224,10 @@ __device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWA
 template <int N, int NWAVES>
 __device__ __forceinline__ double block_reduce_pick(double (&v)[N], double* lds) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-    for (int q = 0; q < N; ++q) v[q] += shfl_xor_f64(v[q], off);
-  }
+  for (int q = 0; q < N; ++q) v[q] = wave_sum_to_lane63(v[q]);
   const int wave = threadIdx.x >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 63) {
 #pragma unroll
     for (int q = 0; q < N; ++q) lds[wave * N + q] = v[q];
   }
@@ -243,11 +260,19 @@ constexpr int VU = 4;  // elements per thread per sweep step
   _Pragma("unroll") for (int k = 0; k < VU; ++k) \
     if (const int64_t i = base + static_cast<int64_t>(k) * TAIL_THREADS; i < m)
 
+constexpr int pow2_at_least(int x) {
+  int p = 1;
+  while (p < x) p *= 2;
+  return p;
+}
+
 template <int V>
 __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
   constexpr int NR = 2 + 2 * V;
   constexpr int Q = V * NR + 2 * V;
-  static_assert(Q <= QMAX && V <= VS, "window too large");
+  constexpr int QPAD = pow2_at_least(Q);
+  constexpr int NCH = TAIL_THREADS / QPAD;  // interleaved summation chains per quantity
+  static_assert(QPAD <= TAIL_THREADS && V <= VS, "window too large");
   SolverState* st = A.st;
   const int tid = threadIdx.x;
   const int64_t m = A.m;
@@ -259,23 +284,25 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
   int64_t n_passes = st->n_passes, n_trials = st->n_trials;
   const int64_t n_iters = st->n_iters + 1;
   if (phase != PH_NORMALIZE) ++n_passes;
+  int next_phase = PH_TRIAL;
   double nrm[V], sx[V];
 #pragma unroll
   for (int l = 0; l < V; ++l) {
     nrm[l] = 1.0;
     sx[l] = 0.0;
   }
+  const double* ca_ = A.cab;           // a = M_off x of the last pair-mode pass
+  const double* cb_ = A.cab + A.mp;    // b = C_off x
 
   if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
     // clipper.cpp:193-198 — u = M_off*u0 + u0 (or u0), then u /= u.norm()
     double* u = pt_arr(A, V, ubp, ubv, 0);
-    const double* av_ = pt_arr(A, V, ubp, ubv, 2);
     double z[1] = {0.0};
     VEC_CHUNKS(base) {
       double uv[VU], av[VU];
       VEC_EACH(k, i, base) {
         uv[k] = A.u0[i];
-        if (phase == PH_RESCALE) av[k] = av_[i];
+        if (phase == PH_RESCALE) av[k] = ca_[i];
       }
       VEC_EACH(k, i, base) {
         const double ui = (phase == PH_RESCALE) ? av[k] + uv[k] : uv[k];
@@ -291,7 +318,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
       VEC_EACH(k, i, base) {
         const double ui = uv[k] / n0;
         u[i] = ui;
-        // next pass runs on x = u (already normalised: nrm = 1), candidate 0 of table 0
+        // next pass (pair mode) runs on x = u, already normalised: candidate 0 of table 0
         const double row[VS] = {ui, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         store_row(A.Xout + i * VS, row);
       }
@@ -308,14 +335,13 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
     return;
   }
 
-  bool begin_outer = false, end_inner = false, finished = false;
+  bool begin_outer = false, penalty = false, finished = false;
   bool need_window = false;  // a sweep must build the window from (u, g): after a transition
+  bool need_pair = false;    // a pair-mode pass on u must come first: end of an inner loop
 
   if (phase == PH_INIT) {
-    // clipper.cpp:200-209 — initial d from the pass on u
+    // clipper.cpp:200-209 — initial d from the pair-mode pass on u
     const double* u = pt_arr(A, V, ubp, ubv, 0);
-    const double* ua = pt_arr(A, V, ubp, ubv, 2);
-    const double* ub_ = pt_arr(A, V, ubp, ubv, 3);
     double sv[1] = {0.0};
     VEC_CHUNKS(base) {
       double uv[VU];
@@ -329,8 +355,8 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
       double uv[VU], av[VU], bv[VU];
       VEC_EACH(k, i, base) {
         uv[k] = u[i];
-        av[k] = ua[i];
-        bv[k] = ub_[i];
+        av[k] = ca_[i];
+        bv[k] = cb_[i];
       }
       VEC_EACH(k, i, base) {
         const double cbu = s - bv[k] - uv[k];  // :202
@@ -344,30 +370,37 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
     d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
     i_ = 0;
     begin_outer = true;
+  } else if (phase == PH_PENALTY) {
+    penalty = true;  // (a, b) of the inner loop's final u have just arrived
   } else {  // PH_TRIAL — the decisions of clipper.cpp:244-262 from the tail's partial scalars
-    // sums[q] = sum over the tail workgroups w of scal[w][q]: two interleaved chains (even /
-    // odd w) per quantity, the same shape for every window size
+    // sums[q] = sum over the tail workgroups w of scal[w][q]: NCH interleaved chains per
+    // quantity (w = c, c + NCH, ...), added in chain order
     {
-      const int q = tid & (QMAX - 1), h = tid >> 7;
+      const int q = tid & (QPAD - 1), c = tid / QPAD;
       double acc = 0.0;
       if (q < Q) {
+        constexpr int U = 10;  // loads in flight per chain
         const double* p = A.scal + q;
-        int w = h;
-        for (; w + 6 < A.nwg; w += 8) {
-          const double v0 = p[static_cast<int64_t>(w) * Q], v1 = p[static_cast<int64_t>(w + 2) * Q],
-                       v2 = p[static_cast<int64_t>(w + 4) * Q], v3 = p[static_cast<int64_t>(w + 6) * Q];
-          acc += v0;
-          acc += v1;
-          acc += v2;
-          acc += v3;
+        int w = c;
+        for (; w + NCH * (U - 1) < A.nwg; w += NCH * U) {
+          double x[U];
+#pragma unroll
+          for (int k = 0; k < U; ++k) x[k] = p[static_cast<int64_t>(w + NCH * k) * Q];
+#pragma unroll
+          for (int k = 0; k < U; ++k) acc += x[k];
         }
-        for (; w < A.nwg; w += 2) acc += p[static_cast<int64_t>(w) * Q];
+        for (; w < A.nwg; w += NCH) acc += p[static_cast<int64_t>(w) * Q];
       }
       red[tid] = acc;
       __syncthreads();
-      const double tot = (tid < QMAX) ? red[tid] + red[tid + QMAX] : 0.0;
+      double tot = 0.0;
+      if (tid < QPAD) {
+        tot = red[tid];
+#pragma unroll
+        for (int c2 = 1; c2 < NCH; ++c2) tot += red[c2 * QPAD + tid];
+      }
       __syncthreads();
-      if (tid < QMAX) red[tid] = tot;
+      if (tid < QPAD) red[tid] = tot;
       __syncthreads();
     }
     const double* sums = red;
@@ -406,7 +439,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
       ubv = jstar;
       ++j_;
       if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
-        end_inner = true;
+        need_pair = true;  // the penalty update needs M_off u and C_off u apart (:268, :271)
       } else {
         alpha = 1.0;  // :227
         k_ = 0;
@@ -421,20 +454,18 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
     }
   }
 
-  // Transitions that need no pass over M: penalty update (:268-280) and the gradient at the
-  // start of the next outer iteration (:219-220) reuse (a, b) of the accepted vector.
+  // Transitions that need no further pass: penalty update (:268-280) and the gradient at the
+  // start of the next outer iteration (:219-220), from (a, b) of the last pair-mode pass.
   while (true) {
-    if (end_inner) {
+    if (penalty) {
       const double* u = pt_arr(A, V, ubp, ubv, 0);
-      const double* ua = pt_arr(A, V, ubp, ubv, 2);
-      const double* ub_ = pt_arr(A, V, ubp, ubv, 3);
       double ca[2] = {0.0, 0.0};
       VEC_CHUNKS(base) {
         double uv[VU], av[VU], bv[VU];
         VEC_EACH(k, i, base) {
           uv[k] = u[i];
-          av[k] = ua[i];
-          bv[k] = ub_[i];
+          av[k] = ca_[i];
+          bv[k] = cb_[i];
         }
         VEC_EACH(k, i, base) {
           const double cbu = s - bv[k] - uv[k];  // :268
@@ -445,7 +476,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
         }
       }
       block_reduce<2, TAIL_WAVES>(ca, red + LDS_SCRATCH);
-      end_inner = false;
+      penalty = false;
       if (ca[0] > 0.0) {
         d += ca[1] / ca[0];  // :276
         ++i_;                // :218 loop increment
@@ -463,15 +494,13 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
       }
       const double* u = pt_arr(A, V, ubp, ubv, 0);
       double* g = pt_arr(A, V, ubp, ubv, 1);
-      const double* ua = pt_arr(A, V, ubp, ubv, 2);
-      const double* ub_ = pt_arr(A, V, ubp, ubv, 3);
       double f[1] = {0.0};
       VEC_CHUNKS(base) {
         double uv[VU], av[VU], bv[VU];
         VEC_EACH(k, i, base) {
           uv[k] = u[i];
-          av[k] = ua[i];
-          bv[k] = ub_[i];
+          av[k] = ca_[i];
+          bv[k] = cb_[i];
         }
         VEC_EACH(k, i, base) {
           const double gi = (1 + d) * uv[k] - d * s + av[k] + bv[k] * d;  // :219
@@ -483,7 +512,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
       F = f[0];
       j_ = 0;
       if (P.maxiniters <= 0) {
-        end_inner = true;
+        penalty = true;  // empty inner loop: u is unchanged, its (a, b) are still valid
         continue;
       }
       alpha = 1.0;
@@ -491,6 +520,21 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
       need_window = true;
     }
     break;
+  }
+
+  if (!finished && need_pair) {
+    // the next pass runs in pair mode on x = u (normalised): candidate 0 of table 0
+    const double* u = pt_arr(A, V, ubp, ubv, 0);
+    VEC_CHUNKS(base) {
+      double uv[VU];
+      VEC_EACH(k, i, base) uv[k] = u[i];
+      VEC_EACH(k, i, base) {
+        const double row[VS] = {uv[k], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        store_row(A.Xout + i * VS, row);
+      }
+    }
+    sel = 0;
+    next_phase = PH_PENALTY;
   }
 
   if (!finished && need_window) {
@@ -544,7 +588,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
     st->sel = sel;
     st->ubp = ubp;
     st->ubv = ubv;
-    st->phase = PH_TRIAL;
+    st->phase = next_phase;
     st->i = i_;
     st->j = j_;
     st->k = k_;
@@ -590,7 +634,8 @@ __global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, dou
 }
 
 // ------------------------------------------------------------------------------------------
-// tail — grid (ceil(m/256), V): workgroup (blk, v) handles candidate v of 256 elements.
+// tail — grid (ceil(m/256), V): workgroup (blk, v) handles candidate v of 256 elements
+// (one element per thread: more elements per thread only lengthens the latency chain — measured).
 //   FUSED_REDUCE: sum the row-tile partials of the single shard here (else `ab` holds the
 //                 gathered raw sums of all shards).
 // The last workgroup to arrive takes the decision (arrive_last).
@@ -599,42 +644,45 @@ template <int V, bool FUSED_REDUCE>
 __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
   constexpr int NR = 2 + 2 * V;
   constexpr int Q = V * NR + 2 * V;
+  constexpr int NSLOT = nslot(V);
   __shared__ double red[SOLVE_LDS];
   const int v = blockIdx.y;
+  const SolverState* st = A.st;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
   const bool valid = i < A.m;
-  const SolverState* st = A.st;
 
-  // raw sums of candidate v: these loads do not depend on the solver state
-  double a = 0.0, b = 0.0;
+  // raw sums of slot v (and of slot 1 for the v = 0 workgroups: the b of a pair-mode pass):
+  // these loads do not depend on the solver state
+  double p0 = 0.0, p1 = 0.0;
   if (valid) {
     if (FUSED_REDUCE) {  // single shard: W >= m; partials in tile order, 8 tiles in flight
-      const double* p = A.part + static_cast<int64_t>(v) * 2 * A.W + i;
-      const int64_t ts = static_cast<int64_t>(V) * 2 * A.W;
+      const double* p = A.part + static_cast<int64_t>(v) * A.W + i;
+      const int64_t ts = static_cast<int64_t>(NSLOT) * A.W;
+      const int64_t o1 = (v == 0) ? A.W : 0;  // slot 1 sits one pitch after slot 0
       int t = 0;
       for (; t + 8 <= A.ntiles; t += 8) {
         double va[8], vb[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           va[q] = p[static_cast<int64_t>(t + q) * ts];
-          vb[q] = p[static_cast<int64_t>(t + q) * ts + A.W];
+          vb[q] = p[static_cast<int64_t>(t + q) * ts + o1];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          a += va[q];
-          b += vb[q];
+          p0 += va[q];
+          p1 += vb[q];
         }
       }
       for (; t < A.ntiles; ++t) {
-        a += p[static_cast<int64_t>(t) * ts];
-        b += p[static_cast<int64_t>(t) * ts + A.W];
+        p0 += p[static_cast<int64_t>(t) * ts];
+        p1 += p[static_cast<int64_t>(t) * ts + o1];
       }
-    } else {  // block p = i / W of the gathered [P][V][2][W] layout (32-bit division, m < 2^31)
+    } else {  // block pb = i / W of the gathered [P][NSLOT][W] layout (32-bit division)
       const uint32_t pb = static_cast<uint32_t>(i) / static_cast<uint32_t>(A.W);
       const int64_t off = i - static_cast<int64_t>(pb) * A.W;
-      const double* blk = A.ab + ((static_cast<int64_t>(pb) * V + v) * 2) * A.W;
-      a = blk[off];
-      b = blk[A.W + off];
+      const double* blk = A.ab + (static_cast<int64_t>(pb) * NSLOT) * A.W;
+      p0 = blk[static_cast<int64_t>(v) * A.W + off];
+      p1 = blk[((v == 0) ? A.W : 0) + off];
     }
   }
   if (st->done) return;
@@ -642,11 +690,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
   const int ubp = st->ubp, ubv = st->ubv;
 
   if (phase != PH_TRIAL) {
-    // initialisation passes carry one vector (candidate 0, nrm = 1): its (a, b) go to the
-    // current point slot, where the decision reads them
+    // pair-mode passes carry one vector (candidate 0, nrm = 1): a = M_off x, b = C_off x
     if (v == 0 && valid) {
-      pt_arr(A, V, ubp, ubv, 2)[i] = a;
-      pt_arr(A, V, ubp, ubv, 3)[i] = b;
+      A.cab[i] = p0;
+      A.cab[A.mp + i] = p1;
     }
   } else {
     const double nrmv = st->nrm[v], sxv = st->sx[v];
@@ -658,13 +705,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
       const double xraw = A.Xin[(static_cast<int64_t>(st->sel) * A.mp + i) * VS + v];
       const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
       const double xi = xraw / nrmv;  // clipper.cpp:237
-      a = a / nrmv;
-      b = b / nrmv;
-      const double gn = (1 + d) * xi - d * sxv + a + b * d;  // :238-241
-      pt_arr(A, V, ubp ^ 1, v, 0)[i] = xi;  // becomes (u, gradF, a, b) if candidate v is accepted
+      const double gs = p0 / nrmv;    // (M_off + d*C_off) x
+      const double gn = (1 + d) * xi - d * sxv + gs;  // :238-241
+      pt_arr(A, V, ubp ^ 1, v, 0)[i] = xi;  // becomes (u, gradF) if candidate v is accepted
       pt_arr(A, V, ubp ^ 1, v, 1)[i] = gn;
-      pt_arr(A, V, ubp ^ 1, v, 2)[i] = a;
-      pt_arr(A, V, ubp ^ 1, v, 3)[i] = b;
       r[0] = xi * gn;  // :242
       const double du = xi - ui;
       r[1] = du * du;  // :253
@@ -720,21 +764,31 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_decide(SolveArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_gemv — the symmetric mat-vec pairs  a_v = M_off x_v,  b_v = C_off x_v  of a window of V
-// vectors in ONE pass over M.
+// k_gemv — ONE pass over the symmetric matrix, in one of two modes chosen by the solver state:
+//
+//   window mode (PH_TRIAL): the line search only ever needs a_v + d*b_v (clipper.cpp:238-241:
+//     gradFnew = (1+d)x - d*sum(x) + M_off x + d * C_off x), and d is fixed during a pass. So
+//     every element is turned ONCE into w = M + d*C (one fma with the 0/1 pattern indicator,
+//     or with the explicit C value) and each of the V candidates costs ONE fma per element:
+//         g_v[c] = sum_r w[r][c] * x_v[r]                        4 + V fp64 ops per element
+//     which keeps a window of 6 under the HBM roofline (a separate a/b pair would be 3 + 2V
+//     ops: VALU-bound from V = 5 on — measured, tools/mv_tune.hip).
+//   pair mode (initialisation, penalty update; matvec API): a = M_off x and b = C_off x of ONE
+//     vector separately — the products clipper.cpp:194,202,205,268,271 need them apart. Without
+//     an explicit C, b += (M != 0) * x as an fma with the 0/1 indicator, which rounds exactly
+//     like the addition it replaces.
 //
 // grid = (strips of 256 columns, row tiles). A workgroup of NW waves shares one column
 // strip; wave w takes rows r0 + w*UNR + k*NW*UNR ... of its tile, UNR rows per iteration
-// so UNR independent 16-byte loads per lane are in flight. The V multipliers of a row are
+// so UNR independent 16-byte loads per lane are in flight. The multipliers of a row are
 // wave-uniform and contiguous (one 64-byte table row): scalar loads. Per-wave partials are
-// combined through LDS in wave order and written to part[tile][v][2][ld]; the tail adds the
-// tiles in tile order. Nothing is atomic: bit-reproducible from run to run and rank to rank.
-// C_off x: without an explicit C, C == pattern(M) and b_v += (M != 0) * x_v — as an fma with
-// the 0/1 indicator, which rounds exactly like the addition it replaces.
+// combined through LDS in wave order and written to part[tile][slot][ld] (slot = candidate v,
+// or 0 = a, 1 = b); the tail adds the tiles in tile order. Nothing is atomic: bit-reproducible
+// from run to run and rank to rank.
 //
-// HBM-bound: s*m*W bytes per launch (s = sizeof(T)); per element one cvt, one compare/select
-// and 2V fma — V = 1: ~20 %, V = 6: ~60 % of the fp64 vector rate at HBM speed; MFMA has
-// nothing to offer a product whose inner dimension is read exactly once.
+// HBM-bound: s*m*W bytes per launch (s = sizeof(T)). MFMA has nothing to offer a product
+// whose inner dimension is read exactly once (a 16x16x4 f64 tile would run 6/16 full and the
+// operands would need a cross-lane transpose first).
 // ------------------------------------------------------------------------------------------
 
 template <typename T>
@@ -753,14 +807,11 @@ __device__ __forceinline__ typename Vec4<T>::type load4(const T* p) {
   return *reinterpret_cast<const typename Vec4<T>::type*>(p);
 }
 
-template <typename T, bool HASC, int V>
-__device__ __forceinline__ void gemv_row(const typename Vec4<T>::type& mv,
-                                         const typename Vec4<T>::type& cv,
-                                         const double* __restrict__ xr, double (&aa)[V][4],
-                                         double (&bb)[V][4]) {
-  const double mm[4] = {static_cast<double>(mv.x), static_cast<double>(mv.y),
-                        static_cast<double>(mv.z), static_cast<double>(mv.w)};
-  double ii[4];
+
+// 0/1 pattern indicator, or the explicit constraint value, of the 4 elements of a lane
+template <typename T, bool HASC>
+__device__ __forceinline__ void indicator(const typename Vec4<T>::type& mv,
+                                          const typename Vec4<T>::type& cv, double (&ii)[4]) {
   if (HASC) {
     ii[0] = static_cast<double>(cv.x);
     ii[1] = static_cast<double>(cv.y);
@@ -772,22 +823,49 @@ __device__ __forceinline__ void gemv_row(const typename Vec4<T>::type& mv,
     ii[2] = (mv.z != T(0)) ? 1.0 : 0.0;
     ii[3] = (mv.w != T(0)) ? 1.0 : 0.0;
   }
+}
+
+// window mode: acc[v][e] += (M + d*C)[e] * x_v
+template <typename T, bool HASC, int V>
+__device__ __forceinline__ void row_window(const typename Vec4<T>::type& mv,
+                                           const typename Vec4<T>::type& cv, double d,
+                                           const double* __restrict__ xr, double (&acc)[V][4]) {
+  const double mm[4] = {static_cast<double>(mv.x), static_cast<double>(mv.y),
+                        static_cast<double>(mv.z), static_cast<double>(mv.w)};
+  double ii[4];
+  indicator<T, HASC>(mv, cv, ii);
+  double w[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w[e] = fma(d, ii[e], mm[e]);
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     const double xv = xr[v];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      aa[v][e] = fma(mm[e], xv, aa[v][e]);
-      bb[v][e] = fma(ii[e], xv, bb[v][e]);
-    }
+    for (int e = 0; e < 4; ++e) acc[v][e] = fma(w[e], xv, acc[v][e]);
   }
 }
 
-// The streaming part: this workgroup's (strip, row tile) partial sums -> part[tile][v][2][ld].
-// X: the pending table, X[row][VS].
-template <typename T, bool HASC, int V, int NW, int UNR>
+// pair mode: acc[0][e] += M[e] * x, acc[1][e] += C[e] * x
+template <typename T, bool HASC>
+__device__ __forceinline__ void row_pair(const typename Vec4<T>::type& mv,
+                                         const typename Vec4<T>::type& cv, double xv,
+                                         double (&acc)[2][4]) {
+  const double mm[4] = {static_cast<double>(mv.x), static_cast<double>(mv.y),
+                        static_cast<double>(mv.z), static_cast<double>(mv.w)};
+  double ii[4];
+  indicator<T, HASC>(mv, cv, ii);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    acc[0][e] = fma(mm[e], xv, acc[0][e]);
+    acc[1][e] = fma(ii[e], xv, acc[1][e]);
+  }
+}
+
+// The streaming part: this workgroup's (strip, row tile) partial sums -> part[tile][slot][ld].
+// X: the pending table, X[row][VS]. NS accumulator sets: V (window mode) or 2 (pair mode).
+template <typename T, bool HASC, bool WINDOW, int NS, int NSLOT, int NW, int UNR>
 __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __restrict__ Cs,
-                                          int64_t ld, int64_t m, int rows_per_tile,
+                                          int64_t ld, int64_t m, int rows_per_tile, double d,
                                           const double* __restrict__ X,
                                           double* __restrict__ part, double* lds) {
   const int lane = threadIdx.x & 63;
@@ -796,11 +874,11 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
   const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_tile;
   const int64_t r1 = (r0 + rows_per_tile < m) ? r0 + rows_per_tile : m;
 
-  double aa[V][4], bb[V][4];
+  double acc[NS][4];
 #pragma unroll
-  for (int v = 0; v < V; ++v)
+  for (int v = 0; v < NS; ++v)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) aa[v][e] = bb[v][e] = 0.0;
+    for (int e = 0; e < 4; ++e) acc[v][e] = 0.0;
 
   if (col < ld) {
     const T* p = S + col;
@@ -815,8 +893,10 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
         if (HASC) cv[q] = load4(pc + (r + q) * ld);
       }
 #pragma unroll
-      for (int q = 0; q < UNR; ++q)
-        gemv_row<T, HASC, V>(mv[q], cv[HASC ? q : 0], X + (r + q) * VS, aa, bb);
+      for (int q = 0; q < UNR; ++q) {
+        if constexpr (WINDOW) row_window<T, HASC, NS>(mv[q], cv[HASC ? q : 0], d, X + (r + q) * VS, acc);
+        else row_pair<T, HASC>(mv[q], cv[HASC ? q : 0], X[(r + q) * VS], acc);
+      }
     }
     // tail rows of this wave's last chunk
     for (int q = 0; q < UNR; ++q) {
@@ -824,35 +904,49 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
       if (rr < r1) {
         const typename Vec4<T>::type mv = load4(p + rr * ld);
         const typename Vec4<T>::type cv = load4(pc + rr * ld);
-        gemv_row<T, HASC, V>(mv, cv, X + rr * VS, aa, bb);
+        if constexpr (WINDOW) row_window<T, HASC, NS>(mv, cv, d, X + rr * VS, acc);
+        else row_pair<T, HASC>(mv, cv, X[rr * VS], acc);
       }
     }
   }
 
-  // cross-wave combine in wave order (fixed summation tree), one candidate at a time
+  // cross-wave combine in wave order (fixed summation tree), one slot at a time
 #pragma unroll
-  for (int v = 0; v < V; ++v) {
-    double* mine = lds + wave * 512 + lane * 4;
+  for (int v = 0; v < NS; ++v) {
+    double* mine = lds + wave * 256 + lane * 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      mine[e] = aa[v][e];
-      mine[256 + e] = bb[v][e];
-    }
+    for (int e = 0; e < 4; ++e) mine[e] = acc[v][e];
     __syncthreads();
-    for (int t = threadIdx.x; t < 512; t += NW * 64) {
-      double acc = lds[t];
+    for (int t = threadIdx.x; t < 256; t += NW * 64) {
+      double sum = lds[t];
 #pragma unroll
-      for (int w = 1; w < NW; ++w) acc += lds[w * 512 + t];
-      const int which = t >> 8;  // 0 = a, 1 = b
-      const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
-      if (c < ld)
-        part[((static_cast<int64_t>(blockIdx.y) * V + v) * 2 + which) * ld + c] = acc;
+      for (int w = 1; w < NW; ++w) sum += lds[w * 256 + t];
+      const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + t;
+      if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * NSLOT + v) * ld + c] = sum;
     }
-    if (v + 1 < V) __syncthreads();
+    if (v + 1 < NS) __syncthreads();
   }
 }
 
-constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * 2 * 256 + 2; }  // + the arrival flag
+constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * 256 + 2; }  // + the arrival flag
+
+// window or pair mode by the solver phase; st == nullptr: pair mode on table 0 (matvec API)
+template <typename T, bool HASC, int V, int NW, int UNR>
+__device__ __forceinline__ void gemv_by_phase(const T* __restrict__ S, const T* __restrict__ Cs,
+                                              int64_t ld, int64_t m, int rows_per_tile,
+                                              const double* __restrict__ Xtab, int64_t mp,
+                                              double* __restrict__ part,
+                                              const SolverState* __restrict__ st, double* lds) {
+  if (st != nullptr && st->phase == PH_TRIAL) {
+    gemv_core<T, HASC, true, V, nslot(V), NW, UNR>(
+        S, Cs, ld, m, rows_per_tile, st->d, Xtab + static_cast<int64_t>(st->sel) * mp * VS, part,
+        lds);
+  } else {
+    const int sel = (st != nullptr) ? st->sel : 0;
+    gemv_core<T, HASC, false, 2, nslot(V), NW, UNR>(
+        S, Cs, ld, m, rows_per_tile, 0.0, Xtab + static_cast<int64_t>(sel) * mp * VS, part, lds);
+  }
+}
 
 // two workgroups per CU (NW/2 waves per SIMD each): caps the registers at 128 per lane
 template <typename T, bool HASC, int V, int NW, int UNR>
@@ -862,41 +956,36 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv(const T* __restrict__ 
                                                            const double* __restrict__ Xtab,
                                                            int64_t mp, double* __restrict__ part,
                                                            const SolverState* __restrict__ st) {
-  int sel = 0;
-  if (st != nullptr) {
-    if (st->done) return;
-    sel = st->sel;  // driven by the solver: the pending window is table `sel`
-  }
+  if (st != nullptr && st->done) return;
   __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
-  gemv_core<T, HASC, V, NW, UNR>(S, Cs, ld, m, rows_per_tile,
-                                 Xtab + static_cast<int64_t>(sel) * mp * VS, part, lds);
+  gemv_by_phase<T, HASC, V, NW, UNR>(S, Cs, ld, m, rows_per_tile, Xtab, mp, part, st, lds);
 }
 
 // k_pass — the mat-vec of a column-sharded M with the reduction of its row-tile partials folded
 // into the epilogue: the LAST row-tile workgroup of a column strip (arrival counter per strip)
 // adds the strip's partials in tile order into this shard's block of the gathered layout
-// ab[P][V][2][W] — what k_reduce would do in a launch of its own. The exchange and
+// ab[P][NSLOT][W] — what k_reduce would do in a launch of its own. The exchange and
 // k_tail<V, false> follow.
 template <typename T, bool HASC, int V, int NW, int UNR>
 __global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ S,
                                                            const T* __restrict__ Cs,
                                                            int rows_per_tile, SolveArgs A) {
+  constexpr int NSLOT = nslot(V);
   __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
   const SolverState* st = A.st;
   if (st->done) return;
   const int64_t ld = A.W;
-  gemv_core<T, HASC, V, NW, UNR>(S, Cs, ld, A.m, rows_per_tile,
-                                 A.Xin + static_cast<int64_t>(st->sel) * A.mp * VS, A.part, lds);
+  gemv_by_phase<T, HASC, V, NW, UNR>(S, Cs, ld, A.m, rows_per_tile, A.Xin, A.mp, A.part, st, lds);
   int* flag = reinterpret_cast<int*>(lds + GEMV_LDS_DOUBLES(NW) - 1);
   if (!arrive_last(A.cnt + blockIdx.x, gridDim.y, flag)) return;
   // ---- last workgroup of this column strip ------------------------------------------------
-  double* ab_block = A.ab + static_cast<int64_t>(A.slot) * V * 2 * ld;
-  const int64_t ts = static_cast<int64_t>(V) * 2 * ld;
-  for (int t = threadIdx.x; t < V * 512; t += NW * 64) {
-    const int vw = t >> 8;  // v*2 + which
+  double* ab_block = A.ab + static_cast<int64_t>(A.slot) * NSLOT * ld;
+  const int64_t ts = static_cast<int64_t>(NSLOT) * ld;
+  for (int t = threadIdx.x; t < NSLOT * 256; t += NW * 64) {
+    const int sl = t >> 8;
     const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
     if (c < ld) {
-      const double* p = A.part + vw * ld + c;
+      const double* p = A.part + sl * ld + c;
       double acc = 0.0;
       int tt = 0;
       for (; tt + 8 <= A.ntiles; tt += 8) {
@@ -907,20 +996,20 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ 
         for (int q = 0; q < 8; ++q) acc += x[q];
       }
       for (; tt < A.ntiles; ++tt) acc += p[static_cast<int64_t>(tt) * ts];
-      ab_block[vw * ld + c] = acc;
+      ab_block[sl * ld + c] = acc;
     }
   }
 }
 
 // k_reduce — adds the row-tile partials in tile order and writes this shard's block of the
 // gathered layout (matvec API only: the solver folds this into k_pass / k_tail). One thread per
-// output element e = (v*2 + which)*ld + c; the loads of 8 tiles are issued before they are
-// summed (the partials sit in L2 / MALL).
+// output element e = slot*ld + c; the loads of 8 tiles are issued before they are summed (the
+// partials sit in L2 / MALL).
 __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ part, int ntiles,
-                                                 int nvec, int64_t ld,
+                                                 int nslots, int64_t ld,
                                                  double* __restrict__ ab_block) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const int64_t tstride = static_cast<int64_t>(nvec) * 2 * ld;
+  const int64_t tstride = static_cast<int64_t>(nslots) * ld;
   if (e >= tstride) return;
   const double* p = part + e;
   double acc = 0.0;

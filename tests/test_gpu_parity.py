@@ -87,10 +87,16 @@ def test_golden_solve_known_answer(golden, storage):
     u0s = [np.ones(12) / np.sqrt(12)] + [rng.random(12) for _ in range(12)]
     for k, u0 in enumerate(u0s):
         sg, sr = c.solve(u0), r.solve(u0)
-        _check_solution(sg, sr, exact_counts=True)
+        # k == 0: uniform u0 on this symmetric toy problem — the three selected entries of u are
+        # structurally tied, their heap order (utils.cpp:33-55) rests on last-bit rounding
+        _check_solution(sg, sr, exact_counts=True, ordered=(k != 0))
         assert np.allclose(sg.u, sr.u, rtol=0, atol=1e-9)
         Ain = c.get_selected_associations()
-        assert np.array_equal(Ain, r.get_selected_associations())
+        Aref = r.get_selected_associations()
+        if k == 0:
+            assert sorted(map(tuple, Ain)) == sorted(map(tuple, Aref))
+        else:
+            assert np.array_equal(Ain, Aref)
         if k == 0:   # clipper_test.cpp:62-66
             assert Ain.shape[0] == 3 and np.all(Ain[:, 0] == Ain[:, 1])
             assert sorted(sg.nodes.tolist()) == g["expected_inlier_nodes"]
@@ -168,8 +174,8 @@ def test_euclidean_parity(storage, m, rho, seed):
         assert abs(sg.score - sr.score) <= 1e-9 * abs(sr.score)
         assert np.allclose(sg.u, sr.u, rtol=0, atol=1e-9)
     # a pass evaluates a window of line-search trials: never more passes than trials (+ the 2
-    # initial passes), and no fewer than trials / window
-    assert (sg.n_trials + 5) // 6 + 2 <= sg.n_passes <= sg.n_trials + 2
+    # initial passes + one pair-mode pass per penalty update), no fewer than trials / window
+    assert (sg.n_trials + 7) // 8 + 2 <= sg.n_passes <= sg.n_trials + 3 + sg.ifinal
     prec, rec = synth.precision_recall(c.get_selected_associations(), p.Agt)
     assert prec >= 0.95
 
@@ -383,7 +389,7 @@ def test_window_sizes_agree(monkeypatch, m, rho, seed):
     r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
     sr = r.solve(p.u0)
     sols = {}
-    for V in (1, 4, 6):
+    for V in (1, 4, 6, 8):
         monkeypatch.setenv("CLIPPER_HIP_WINDOW", str(V))
         for storage in STORAGES:
             g = abi.HipClipper(storage=storage)
@@ -396,8 +402,9 @@ def test_window_sizes_agree(monkeypatch, m, rho, seed):
     monkeypatch.delenv("CLIPPER_HIP_WINDOW")
     for storage in STORAGES:
         base = sols[(1, storage, 0)]
-        assert base.n_passes == base.n_trials + 2        # window 1: one trial per pass
-        for V in (1, 4, 6):
+        # window 1: one trial per pass, + the 2 initial passes + one pair pass per penalty update
+        assert base.n_trials + 2 <= base.n_passes <= base.n_trials + 3 + base.ifinal
+        for V in (1, 4, 6, 8):
             for rep in range(2):
                 s = sols[(V, storage, rep)]
                 assert s.nodes.tolist() == base.nodes.tolist(), (V, storage, rep)
@@ -408,7 +415,7 @@ def test_window_sizes_agree(monkeypatch, m, rho, seed):
                 assert np.array_equal(s.u, sols[(V, storage, 0)].u)   # run-to-run bit-identical
 
 
-@pytest.mark.parametrize("V", [1, 4, 6])
+@pytest.mark.parametrize("V", [1, 4, 6, 8])
 def test_window_with_line_search_limits(monkeypatch, V):
     # maxlsiters cuts the backtracking inside a window (the last allowed trial is accepted
     # unconditionally, clipper.cpp:234), beta != 1/4 changes the step sizes of the window
@@ -416,6 +423,7 @@ def test_window_with_line_search_limits(monkeypatch, V):
     p = synth.make_euclidean_problem(1500, 0.93, seed=8)
     for kw in (dict(maxlsiters=1), dict(maxlsiters=2), dict(maxlsiters=3), dict(maxlsiters=5),
                dict(beta=0.5), dict(beta=0.1, maxlsiters=7), dict(maxiniters=3), dict(maxoliters=2),
+               dict(maxiniters=0), dict(maxoliters=0), dict(maxiniters=1, maxoliters=1),
                dict(rescale_u0=False), dict(rounding=abi.ROUNDING_NONZERO)):
         g, r = _pair(abi.STORE_F64, **kw)
         g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
@@ -424,7 +432,7 @@ def test_window_with_line_search_limits(monkeypatch, V):
         g.close()
 
 
-@pytest.mark.parametrize("V", [1, 4, 6])
+@pytest.mark.parametrize("V", [1, 4, 6, 8])
 def test_window_sharded(monkeypatch, V):
     # column-sharded M: k_pass (reduction folded in), exchange of [V][2][W] blocks, k_tail
     monkeypatch.setenv("CLIPPER_HIP_WINDOW", str(V))

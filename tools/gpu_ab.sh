@@ -3,7 +3,7 @@
 TAG=${1:-ab}; shift; SIZES=${@:-"1000 10000"}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 ( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > $OUT/pytest.log
-for V in 1 4 6; do
+for V in 1 4 6 8; do
   for m in $SIZES; do
     CLIPPER_HIP_WINDOW=$V timeout 300 python bench.py --m $m --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys,json
