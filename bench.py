@@ -14,9 +14,10 @@ the full solver. With N > 1 the SAME problem is column-sharded over the N GPUs (
 per GPU, per-pass RCCL all-gather of the (M_off x, C_off x) slices): strong scaling.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement), extended with
-  "roofline"     achieved HBM GB/s of the dominant kernel (the fused mat-vec k_gemv), from
-                 HIP events recorded on the solver stream around every launch in the timed
-                 region; algorithmic bytes per launch = s*m*W (s = 4, fp32 storage)
+  "roofline"     achieved HBM GB/s of the dominant kernel (the mat-vec k_gemv: one pass over M
+                 for a whole line-search window), from HIP events recorded on the solver stream
+                 around every 4th launch in the timed region; algorithmic bytes per launch =
+                 s*m*W (s = 4, fp32 storage)
   "cpu_baseline" the oracle (oracle/libclipper_ref.so, a port of the reference) timed on
                  this box's host cores on the same problem (rank 0, N = 1 only).
 """
@@ -46,6 +47,8 @@ def parse():
                     help="element type of the dense M in HBM (vectors/accumulators are always f64)")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="do not bracket mat-vec launches with HIP events (roofline fields become 0)")
     return ap.parse_args()
 
 
@@ -131,7 +134,7 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    g.set_profiling(True)
+    g.set_profiling(not args.no_profile)
     aff_ms, solve_ms, gemv_us, gemv_n = [], [], [], []
     barrier_sync()
     t0 = time.perf_counter()
@@ -203,6 +206,8 @@ def main():
             "solve_ms": round(sum(solve_ms) / len(solve_ms), 4),
             "affinity_kernel_ms": round(tm.affinity_kernel_ms, 4),
             "gemv_passes_per_solve": int(sol.n_passes),
+            "line_search_trials_per_solve": int(sol.n_trials),
+            "line_search_window": g.window,
             "gemv_avg_us": round(gemv_avg_us, 3),
             "gemv_min_us": round(tm.gemv_min_us, 3),
             "ms_per_step_host_buffers": round(host_ms, 4),

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_get_associations", "clipper_hip_set_matrix", "clipper_hip_set_sparse",
     "clipper_hip_get_matrix", "clipper_hip_solve", "clipper_hip_get_nodes",
     "clipper_hip_get_selected_associations", "clipper_hip_matvec", "clipper_hip_set_profiling",
+    "clipper_hip_set_window", "clipper_hip_window",
     "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
     "clipper_hip_affinity_pointnormal_staged", "clipper_hip_stage_u0",
@@ -137,6 +138,8 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_get_nodes.argtypes = [vp, ip, C.c_int32]
     L.clipper_hip_get_selected_associations.argtypes = [vp, ip, C.c_int32]
     L.clipper_hip_matvec.argtypes = [vp, dp, dp, dp]
+    L.clipper_hip_set_window.argtypes = [vp, C.c_int]
+    L.clipper_hip_window.argtypes = [vp]
     L.clipper_hip_set_profiling.argtypes = [vp, C.c_int]
     L.clipper_hip_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.clipper_hip_bench_matvec.argtypes = [vp, C.c_int, dp]
@@ -349,6 +352,14 @@ class HipClipper:
         return np.stack([buf[:kk], buf[kk:2 * kk]], axis=1)
 
     # ---- measurement ------------------------------------------------------------------------
+    def set_window(self, window: int):
+        """Line-search window (0 = automatic, 1 | 4 | 6 | 8); effective from the next build."""
+        self._check(self.L.clipper_hip_set_window(self.h, int(window)))
+
+    @property
+    def window(self) -> int:
+        return int(self.L.clipper_hip_window(self.h))
+
     def set_profiling(self, on: bool):
         self._check(self.L.clipper_hip_set_profiling(self.h, int(on)))
 

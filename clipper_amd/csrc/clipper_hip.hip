@@ -6,11 +6,11 @@
 //
 // Solve loop (CLIPPER::solve -> findDenseClique, /root/reference/src/clipper.cpp:172-323):
 // the whole state machine — windowed line search, convergence tests, penalty homotopy — lives
-// in device memory (SolverState). One solver iteration = k_gemv over a window of V candidate
-// vectors, then k_tail (grid: blocks x V) whose last workgroup takes the decision. The host
-// only enqueues iterations, a few ahead of what the device reports as retired in a pinned
-// progress record, and stops when `done` shows up there; kernels launched after convergence
-// return immediately.
+// in device memory (SolverState). One solver iteration = k_gemv (every workgroup decides what
+// the previous iteration's results mean, then streams M against a window of V candidate
+// vectors), then k_tail (grid: blocks x V). The host only enqueues iterations, a few ahead of
+// what the device reports as started in a pinned progress record, and stops when `done` shows
+// up there; kernels launched after convergence return immediately.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -133,7 +133,8 @@ struct Shard {
   int* cnt = nullptr;      // arrival counters [nstrips + 1]
   double* ab = nullptr;    // [P][NSLOT][W]
   double* scal = nullptr;  // [nwg][Q] partial scalars of k_tail
-  SolverState* st = nullptr;
+  SolverState* st = nullptr;      // ST[2], see SolverState
+  SolveShared* shared = nullptr;
   // affinity inputs (staged once, reused while the sizes fit)
   double *P1 = nullptr, *P2 = nullptr;  // gathered point tables [d][pstride]
   float *P1f = nullptr, *P2f = nullptr; // the same, rounded to fp32 (prefilter input)
@@ -170,10 +171,12 @@ struct clipper_hip_ctx {
   std::vector<int32_t> A;  // column-major m x 2 (host copy)
   std::vector<int32_t> nodes;
 
-  SolverState* host_state = nullptr;  // pinned, 2 slots (multi-process snapshots)
+  SolveShared* host_state = nullptr;  // pinned, 2 slots (multi-process snapshots)
   hipEvent_t ev_poll[2] = {nullptr, nullptr};
   HostMirror* mirror = nullptr;      // pinned + coherent: progress record written by the device
   HostMirror* mirror_dev = nullptr;  // its device address
+  uint8_t* kind = nullptr;           // pinned + coherent: per-iteration pass / transition marks
+  uint8_t* kind_dev = nullptr;       // (profiling only), written by the device
   double* u_pinned = nullptr;        // pinned staging of the final u
   size_t u_pinned_cap = 0;
   int V = 6;               // line-search window: candidate vectors per pass
@@ -213,6 +216,7 @@ int free_shard_buffers(Shard& s) {
   fr(s.ab);
   fr(s.scal);
   fr(s.st);
+  fr(s.shared);
   fr(s.P1);
   fr(s.P2);
   fr(s.P1f);
@@ -280,15 +284,17 @@ int ensure_problem(Ctx* h, int64_t m) {
       HIPCHK(hipMalloc(&s.X[k], (V + 1) * VS * nvec));
       HIPCHK(hipMemsetAsync(s.X[k], 0, (V + 1) * VS * nvec, s.stream));
     }
-    HIPCHK(hipMalloc(&s.cnt, static_cast<size_t>(h->nstrips + 1) * sizeof(int)));
-    HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(h->nstrips + 1) * sizeof(int), s.stream));
+    HIPCHK(hipMalloc(&s.cnt, static_cast<size_t>(h->nstrips) * sizeof(int)));
+    HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(h->nstrips) * sizeof(int), s.stream));
     const size_t Q = V * (2 + 2 * V) + 2 * V;
     HIPCHK(hipMalloc(&s.scal, static_cast<size_t>(ceil_div(m, TAIL_THREADS)) * Q * sizeof(double)));
     HIPCHK(hipMalloc(&s.ab, NSLOT * nvec));
     HIPCHK(hipMemsetAsync(s.ab, 0, NSLOT * nvec, s.stream));
     HIPCHK(hipMalloc(&s.part, static_cast<size_t>(max_tiles(h)) * NSLOT * W * sizeof(double)));
-    HIPCHK(hipMalloc(&s.st, sizeof(SolverState)));
-    HIPCHK(hipMemsetAsync(s.st, 0, sizeof(SolverState), s.stream));
+    HIPCHK(hipMalloc(&s.st, 2 * sizeof(SolverState)));
+    HIPCHK(hipMemsetAsync(s.st, 0, 2 * sizeof(SolverState), s.stream));
+    HIPCHK(hipMalloc(&s.shared, sizeof(SolveShared)));
+    HIPCHK(hipMemsetAsync(s.shared, 0, sizeof(SolveShared), s.stream));
   }
   h->alloc_m = m;
   h->alloc_W = W;
@@ -301,26 +307,31 @@ int ensure_problem(Ctx* h, int64_t m) {
 }
 
 // ---- kernel dispatch over (storage type, explicit C, window size) -------------------------
-template <typename T, bool HASC, int V>
-void launch_gemv_tv(Ctx* h, Shard& s, const double* Xtab, const SolverState* st) {
-  constexpr int UNR = gemv_unr(V, sizeof(T), HASC);
-  dim3 grid(h->nstrips, h->ntiles), block(GEMV_NW * 64);
-  hipLaunchKernelGGL((k_gemv<T, HASC, V, GEMV_NW, UNR>), grid, block, 0, s.stream,
-                     static_cast<const T*>(s.S), static_cast<const T*>(s.Cs), h->W, h->m,
-                     h->rows_per_tile, Xtab, h->mp, s.part, st);
-}
-
-template <typename T, bool HASC, int V>
+template <typename T, bool HASC, int V, bool SHARDED>
 void launch_pass_tv(Ctx* h, Shard& s, const SolveArgs& a) {
   constexpr int UNR = gemv_unr(V, sizeof(T), HASC);
   dim3 grid(h->nstrips, h->ntiles), block(GEMV_NW * 64);
-  hipLaunchKernelGGL((k_pass<T, HASC, V, GEMV_NW, UNR>), grid, block, 0, s.stream,
-                     static_cast<const T*>(s.S), static_cast<const T*>(s.Cs), h->rows_per_tile,
-                     a);
+  if (SHARDED)
+    hipLaunchKernelGGL((k_pass<T, HASC, V, GEMV_NW, UNR>), grid, block, 0, s.stream,
+                       static_cast<const T*>(s.S), static_cast<const T*>(s.Cs),
+                       h->rows_per_tile, a);
+  else
+    hipLaunchKernelGGL((k_gemv<T, HASC, V, GEMV_NW, UNR>), grid, block, 0, s.stream,
+                       static_cast<const T*>(s.S), static_cast<const T*>(s.Cs),
+                       h->rows_per_tile, a);
+}
+
+template <typename T, bool HASC>
+void launch_plain_t(Ctx* h, Shard& s, const double* X) {
+  constexpr int UNR = gemv_unr(1, sizeof(T), HASC);
+  dim3 grid(h->nstrips, h->ntiles), block(GEMV_NW * 64);
+  hipLaunchKernelGGL((k_gemv_plain<T, HASC, GEMV_NW, UNR>), grid, block, 0, s.stream,
+                     static_cast<const T*>(s.S), static_cast<const T*>(s.Cs), h->W, h->m,
+                     h->rows_per_tile, X, s.part);
 }
 
 // calls f(type tag, HASC tag) for the context's storage type and constraint mode
-template <int V, typename F>
+template <typename F>
 void dispatch_storage(Ctx* h, F&& f) {
   if (h->storage == CLIPPER_HIP_STORE_F64) {
     if (h->explicitC) f(double{}, std::true_type{});
@@ -331,19 +342,18 @@ void dispatch_storage(Ctx* h, F&& f) {
   }
 }
 
-// the mat-vec of the pending window of the solver (table st->sel of Xtab)
-template <int V>
-void launch_gemv(Ctx* h, Shard& s, const double* Xtab, const SolverState* st) {
-  dispatch_storage<V>(h, [&](auto t, auto c) {
-    launch_gemv_tv<decltype(t), decltype(c)::value, V>(h, s, Xtab, st);
+// G of one solver iteration: decision + mat-vec of the pending window (sharded: + reduction)
+template <int V, bool SHARDED>
+void launch_pass(Ctx* h, Shard& s, const SolveArgs& a) {
+  dispatch_storage(h, [&](auto t, auto c) {
+    launch_pass_tv<decltype(t), decltype(c)::value, V, SHARDED>(h, s, a);
   });
 }
 
-// the same with the reduction of the partials folded in (column-sharded M)
-template <int V>
-void launch_pass(Ctx* h, Shard& s, const SolveArgs& a) {
-  dispatch_storage<V>(h, [&](auto t, auto c) {
-    launch_pass_tv<decltype(t), decltype(c)::value, V>(h, s, a);
+// the pair-mode mat-vec alone on table X (matvec API, micro-benchmark)
+void launch_plain(Ctx* h, Shard& s, const double* X) {
+  dispatch_storage(h, [&](auto t, auto c) {
+    launch_plain_t<decltype(t), decltype(c)::value>(h, s, X);
   });
 }
 
@@ -411,11 +421,14 @@ int exchange(Ctx* h, int nslots) {
   return 0;
 }
 
-// arguments of the launches of ONE solver iteration: reads the pending window from table set
-// `par`, writes the windows of every outcome to set `par ^ 1`
+// arguments of the launches of ONE solver iteration: starts from state copy / table set `par`,
+// records what it decided in state copy `par ^ 1` and writes the windows of every outcome to
+// table set `par ^ 1`
 SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   SolveArgs a;
-  a.st = s.st;
+  a.st_cur = s.st + par;
+  a.st_next = s.st + (par ^ 1);
+  a.shared = s.shared;
   a.host = (&s == &h->sh[0]) ? h->mirror_dev : nullptr;
   a.prm = prm;
   a.m = h->m;
@@ -434,14 +447,13 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.nwg = static_cast<int>(ceil_div(h->m, TAIL_THREADS));
   a.cnt = s.cnt;
   a.nstrips = h->nstrips;
+  a.kind = (h->profiling && &s == &h->sh[0]) ? h->kind_dev : nullptr;
   return a;
 }
 
-// One full solver iteration: pass over M with the pending window, element-wise tail per
-// candidate, decision by the tail's last workgroup.
-//   one shard : k_gemv -> k_tail<V, true>       (the mat-vec stays a pure streaming kernel —
-//               what bench.py's roofline times)
-//   sharded   : k_pass (reduction folded in) -> exchange -> k_tail<V, false>
+// One full solver iteration:
+//   one shard : k_gemv (decision + pass) -> k_tail<V, true>
+//   sharded   : k_pass (decision + pass + reduction) -> exchange -> k_tail<V, false>
 template <int V>
 int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   const int par = h->par;
@@ -455,8 +467,8 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, par);
     if (prof && &s == &s0) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
-    if (sharded) launch_pass<V>(h, s, a);
-    else launch_gemv<V>(h, s, a.Xin, s.st);
+    if (sharded) launch_pass<V, true>(h, s, a);
+    else launch_pass<V, false>(h, s, a);
     if (prof && &s == &s0) {
       HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used + 1], s.stream));
       h->ev_launch_index[h->ev_used] = h->launch_counter;
@@ -484,29 +496,16 @@ int enqueue_iteration(Ctx* h, const SolverParams& prm) {
   return rc;
 }
 
-int enqueue_decide_only(Ctx* h, const SolverParams& prm) {
-  const int par = h->par;
-  h->par ^= 1;
-  for (auto& s : h->sh) {
-    HIPCHK(hipSetDevice(s.device));
-    SolveArgs a = solve_args(h, s, prm, par);
-    dispatch_window(h, [&](auto v) {
-      hipLaunchKernelGGL((k_decide<decltype(v)::value>), dim3(1), dim3(TAIL_THREADS), 0, s.stream, a);
-    });
-  }
-  return 0;
-}
-
-// plain single-vector mat-vec of every local shard on table X[0] (matvec API / micro-benchmark)
+// plain pair-mode mat-vec of every local shard on table X[0] (matvec API)
 int enqueue_gemv_plain(Ctx* h) {
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    launch_gemv<1>(h, s, s.X[0], nullptr);
+    launch_plain(h, s, s.X[0]);
   }
   return 0;
 }
 
-// raw (un-normalised) sums of the single-vector partials into every shard's gathered `ab`
+// raw (un-normalised) sums of the pair partials into every shard's gathered `ab`
 int enqueue_reduce_exchange(Ctx* h) {
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
@@ -598,7 +597,7 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, h->sh[0].device) == hipSuccess)
     h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (hipHostMalloc(reinterpret_cast<void**>(&h->host_state), 2 * sizeof(SolverState),
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->host_state), 2 * sizeof(SolveShared),
                     hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_poll[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_poll[1], hipEventDisableTiming) != hipSuccess) {
@@ -616,6 +615,14 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     return nullptr;
   }
   std::memset(h->mirror, 0, sizeof(HostMirror));
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->kind), KIND_CAP,
+                    hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&h->kind_dev), h->kind, 0) != hipSuccess) {
+    fail(CLIPPER_HIP_E_HIP, "cannot allocate the pinned iteration marks");
+    delete h;
+    return nullptr;
+  }
+  std::memset(h->kind, 0, KIND_CAP);
   // CLIPPER_HIP_WINDOW = 1 | 4 | 6 | 8: line-search candidates multiplied per pass over M
   if (const char* w = std::getenv("CLIPPER_HIP_WINDOW")) {
     const int v = std::atoi(w);
@@ -852,6 +859,7 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   if (h->ev_poll[1]) hipEventDestroy(h->ev_poll[1]);
   if (h->host_state) hipHostFree(h->host_state);
   if (h->mirror) hipHostFree(h->mirror);
+  if (h->kind) hipHostFree(h->kind);
   if (h->u_pinned) hipHostFree(h->u_pinned);
   delete h;
 }
@@ -1226,6 +1234,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     for (auto& e : h->ev_pairs) HIPCHK(hipEventCreate(&e));
   }
   h->ev_used = 0;
+  if (h->profiling)  // marks of the previous solve
+    std::memset(h->kind, 0, static_cast<size_t>(std::min<int64_t>(h->launch_counter + 1, KIND_CAP)));
   h->launch_counter = 0;
 
   SolverParams prm;
@@ -1241,7 +1251,9 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   std::memset(&init, 0, sizeof(init));
   init.alpha = 1.0;
   for (int l = 0; l < VS; ++l) init.nrm[l] = 1.0;
+  // with rescaling the first iteration runs the pair pass on u0; without, it only normalises
   init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
+  init.stage = P->rescale_u0 ? ST_PASS : ST_RESULTS;
   // prologue, one launch per shard: pending vector = u0 (T pair 0, nrm = 1), state, counters
   h->par = 0;
   std::memset(h->mirror, 0, sizeof(HostMirror));
@@ -1250,22 +1262,19 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, 0);
     hipLaunchKernelGGL(k_init, dim3(static_cast<unsigned>(ceil_div(m, 256))), dim3(256), 0,
-                       s.stream, a, init, s.X[0]);
+                       s.stream, a, init, s.st, s.X[0]);
   }
   int rc = 0;
-  if (!P->rescale_u0) {
-    if ((rc = enqueue_decide_only(h, prm))) return rc;  // PH_NORMALIZE consumes no pass
-  }
 
   Shard& s0 = h->sh[0];
-  SolverState fin;
+  SolveShared fin;
   std::memset(&fin, 0, sizeof(fin));
   if (!h->multiproc) {
     // One process: the deciding workgroup reports progress into pinned host memory; the host
     // keeps RUN_AHEAD iterations queued ahead of what the device has retired and stops
     // queueing the moment `done` shows up — no memcpy, no event, no host wait in the loop.
     volatile HostMirror* hm = h->mirror;
-    int64_t queued = P->rescale_u0 ? 0 : 1;  // the decide-only launch counts as an iteration
+    int64_t queued = 0;
     uint64_t spins = 0;
     while (!hm->done) {
       if (queued - hm->iters < RUN_AHEAD) {
@@ -1302,7 +1311,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         if ((rc = enqueue_iteration(h, prm))) return rc;
       }
       HIPCHK(hipSetDevice(s0.device));
-      HIPCHK(hipMemcpyAsync(&h->host_state[slot], s0.st, sizeof(SolverState),
+      HIPCHK(hipMemcpyAsync(&h->host_state[slot], s0.shared, sizeof(SolveShared),
                             hipMemcpyDeviceToHost, s0.stream));
       HIPCHK(hipEventRecord(h->ev_poll[slot], s0.stream));
       if (have_prev) {
@@ -1314,7 +1323,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     }
     if ((rc = sync_all(h))) return rc;
     HIPCHK(hipSetDevice(s0.device));
-    HIPCHK(hipMemcpy(&fin, s0.st, sizeof(fin), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&fin, s0.shared, sizeof(fin), hipMemcpyDeviceToHost));
   }
 
   // final u: one D2H copy into pinned staging (also drains the few no-op launches queued
@@ -1363,11 +1372,15 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   h->tm.gemv_launches = 0;
   h->tm.gemv_bytes = algorithmic_gemv_bytes(h);
   if (h->profiling && h->ev_used > 0) {
-    // only launches that did real work count: launch index < n_passes
+    // only launches that streamed M count: the device marked every iteration as pass (1) or
+    // transition (0); launches queued past convergence have no mark
+    const uint8_t* kind = h->kind;
+    const int64_t iters_run = std::min<int64_t>(h->launch_counter, KIND_CAP);
     double sum = 0.0, mn = 1e30;
     int64_t nreal = 0;
     for (int k = 0; k < h->ev_used; ++k) {
-      if (h->ev_launch_index[static_cast<size_t>(k)] >= fin.n_passes) continue;
+      const int64_t li = h->ev_launch_index[static_cast<size_t>(k)];
+      if (li >= iters_run || !kind[static_cast<size_t>(li)]) continue;
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, h->ev_pairs[2 * k], h->ev_pairs[2 * k + 1]));
       sum += ms;
@@ -1407,6 +1420,16 @@ int clipper_hip_get_selected_associations(const clipper_hip_t* h, int32_t* A_out
   }
   return k;
 }
+
+int clipper_hip_set_window(clipper_hip_t* h, int window) {
+  if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (window != 0 && window != 1 && window != 4 && window != 6 && window != 8)
+    return fail(CLIPPER_HIP_E_INVALID, "window must be 0 (automatic), 1, 4, 6 or 8");
+  h->V_forced = window;
+  return 0;
+}
+
+int clipper_hip_window(const clipper_hip_t* h) { return h ? h->V : 0; }
 
 int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC) {
   if (!h || !x) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
@@ -1459,9 +1482,9 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) launch_gemv<1>(h, s, s.X[0], nullptr);
+  for (int w = 0; w < 3; ++w) launch_plain(h, s, s.X[0]);
   HIPCHK(hipEventRecord(e0, s.stream));
-  for (int r = 0; r < reps; ++r) launch_gemv<1>(h, s, s.X[0], nullptr);
+  for (int r = 0; r < reps; ++r) launch_plain(h, s, s.X[0]);
   HIPCHK(hipEventRecord(e1, s.stream));
   HIPCHK(hipStreamSynchronize(s.stream));
   float ms = 0.f;

@@ -39,17 +39,25 @@ namespace clipper_hip {
 // is known BEFORE the first of them is evaluated, so a pass here multiplies M by a window of
 // V consecutive candidates at once (V accumulator sets per lane, one read of M): the decision
 // then walks the window in the reference's order and takes the first candidate the reference
-// would have accepted. Same trials, same arithmetic per trial, same result — in 1/2 to 2/3 of
+// would have accepted. Same trials, same arithmetic per trial, same result — in 1/2 to 1/3 of
 // the passes. Candidates live interleaved in "tables" X[row][VS] (64-byte rows) so that the
 // V wave-uniform multipliers of a row arrive with one scalar load.
 //
-// After a pass the element-wise tail runs once per candidate v (grid = blocks x V): it forms
-// gradFnew_v, the partial sums of Fnew_v and ||x_v - u||^2, stores (x_v, gradFnew_v)
-// into point slot (ubp^1, v), and speculatively builds the NEXT window for the outcome
-// "candidate v was accepted" (table v of Xout: max(x_v + beta^l gradFnew_v, 0), l < V) with
-// the partial sums of its norms; the v = 0 workgroups also build the outcome "all V rejected"
-// (table V: the next V step sizes from the unchanged (u, gradF)). The deciding workgroup then
-// only adds partial scalars, picks the outcome and publishes which table is pending.
+// One solver ITERATION is two launches, and no workgroup ever waits for another:
+//   G  k_gemv   every workgroup first DECIDES, redundantly and identically, what the results
+//               of the previous iteration mean (a few KB of partial scalars from L2 — the
+//               loads overlap the first rows of M) and then streams its tile of M against the
+//               pending window. Workgroup (0,0) also records the state it decided on.
+//   T  k_tail   once per candidate v (grid = blocks x V): gradFnew_v, the partial sums of
+//               Fnew_v and ||x_v - u||^2, (x_v, gradFnew_v) into point slot (ubp^1, v), and —
+//               speculatively — the NEXT window for the outcome "candidate v was accepted"
+//               (table v of Xout: max(x_v + beta^l gradFnew_v, 0), l < V) with the partial sums
+//               of its norms; the v = 0 workgroups also build the outcome "all V rejected"
+//               (table V: the next V step sizes from the unchanged (u, gradF)).
+// The rare steps that sweep whole vectors (initialisation clipper.cpp:193-220, penalty update
+// :268-280, a new outer iteration :219-220) take an iteration of their own: every workgroup of
+// G sees that the decision needs one, workgroup (0,0) alone performs it, the others exit, and T
+// finds nothing to do.
 // ------------------------------------------------------------------------------------------
 
 constexpr int VS = 8;       // doubles per table row; window sizes V <= VS
@@ -57,16 +65,23 @@ constexpr int nslot(int V) { return V < 2 ? 2 : V; }  // partial-sum slots per r
 
 enum Phase : int32_t {
   PH_NORMALIZE = 0,  // no rescale: u = u0/||u0||, no pass consumed       (clipper.cpp:196-198)
-  PH_RESCALE = 1,    // pass was on x = u0: u = M_off u0 + u0, normalise  (clipper.cpp:193-198)
-  PH_INIT = 2,       // pass was on x = u: initial d, first gradient      (clipper.cpp:200-220)
-  PH_TRIAL = 3,      // pass was on a window of trial vectors             (clipper.cpp:234-262)
-  PH_PENALTY = 4     // pass was on x = the inner loop's final u: penalty update (:268-280)
+  PH_RESCALE = 1,    // pass on x = u0: u = M_off u0 + u0, normalise      (clipper.cpp:193-198)
+  PH_INIT = 2,       // pass on x = u: initial d, first gradient          (clipper.cpp:200-220)
+  PH_TRIAL = 3,      // pass on a window of trial vectors                 (clipper.cpp:234-262)
+  PH_PENALTY = 4     // pass on x = the inner loop's final u: penalty update (:268-280)
 };
 // PH_TRIAL passes run the mat-vec in window mode (g_v = (M_off + d*C_off) x_v), all others in
 // pair mode (a = M_off x, b = C_off x of candidate 0) — see k_gemv.
 
+enum Stage : int32_t {
+  ST_PASS = 0,     // the tables hold the pending vectors of `phase`: run the pass
+  ST_RESULTS = 1   // the pass of `phase` and its tail have run: decide what they mean first
+};
+
 // Candidates are kept UN-normalised: x_l = Xin[sel][.][l] / nrm[l]. The mat-vec multiplies M
 // by the raw table; the tail divides the sums by nrm[l].
+// Two copies ST[2] alternate: iteration k reads ST[k & 1], its workgroup (0,0) writes the state
+// it decided on to ST[(k+1) & 1], which the tail of iteration k and iteration k+1 read.
 struct SolverState {
   double d;        // penalty
   double F;        // objective at u
@@ -77,19 +92,26 @@ struct SolverState {
   int32_t sel;     // which table of Xin holds the pending window
   int32_t ubp, ubv;  // point slot that holds the current (u, gradF)
   int32_t phase;
+  int32_t stage;
   int32_t i, j, k;  // outer / inner / line-search counters (clipper.cpp:217)
-  int32_t done;
-  int32_t ifinal;
-  int32_t pad_;
   int64_t n_passes;
   int64_t n_trials;  // trials the reference would have evaluated (window slots past the
                      // accepted candidate do not count)
-  int64_t n_iters;   // decisions taken so far (= solver iterations the device has retired)
+  int64_t n_iters;   // iterations (G, T) the device has started
 };
 
-// Host-visible progress record in pinned, coherent host memory. The deciding workgroup writes
-// it with system-scope stores; the host spins on `iters` / `done` instead of issuing
-// memcpy + event round trips, and keeps only a few iterations queued ahead of the device.
+// What outlives the alternating state: the end of the solve. Kernels launched after
+// convergence see `done` and return immediately.
+struct SolveShared {
+  double F, d;
+  int64_t n_passes, n_trials;
+  int32_t ifinal, ubp, ubv;
+  int32_t done;
+};
+
+// Host-visible progress record in pinned, coherent host memory. Workgroup (0,0) of G writes it
+// with system-scope stores; the host spins on `iters` / `done` instead of issuing memcpy +
+// event round trips, and keeps only a few iterations queued ahead of the device.
 struct HostMirror {
   double F, d;
   int64_t n_passes, n_trials;
@@ -105,14 +127,11 @@ struct SolverParams {
 
 constexpr int TAIL_THREADS = 256;
 constexpr int TAIL_WAVES = TAIL_THREADS / 64;
-// LDS of the tail / decide kernels (doubles): [0,256) partial-scalar sums and reduction scratch
-// of the tail, [256,312) reduction scratch of the decision, [319] the arrival flag
-constexpr int SOLVE_LDS = 320;
-constexpr int LDS_SCRATCH = 256;
-constexpr int LDS_FLAG = 319;
 
 struct SolveArgs {
-  SolverState* st;
+  const SolverState* st_cur;  // ST[k & 1]: what iteration k starts from
+  SolverState* st_next;       // ST[(k+1) & 1]: what it decided on (read by its tail)
+  SolveShared* shared;
   HostMirror* host;  // device address of the pinned progress record (may be null)
   SolverParams prm;
   int64_t m;    // problem size
@@ -121,8 +140,8 @@ struct SolveArgs {
   const double* u0;
   double* pt;   // point slots [2][V][2][mp]: u, gradF
   double* cab;  // [2][mp]: a = M_off x, b = C_off x of the last pair-mode pass
-  // candidate tables [V+1][mp][VS]. A launch READS the pending window from Xin and WRITES the
-  // windows of every outcome to Xout; the host swaps the two from launch to launch.
+  // candidate tables [V+1][mp][VS]. Iteration k READS the pending window from Xin and WRITES
+  // the windows of every outcome to Xout; the host swaps the two from iteration to iteration.
   const double* Xin;
   double* Xout;
   double* ab;     // column-sharded M: gathered RAW sums [P][NSLOT][W], NSLOT = max(V, 2)
@@ -131,20 +150,15 @@ struct SolveArgs {
   int slot;       // this shard's block of `ab`
   double* scal;   // [nwg][Q] partial scalars of the tail, Q = V*(2+2V) + 2V
   int nwg;        // tail workgroups per candidate = ceil(m / TAIL_THREADS)
-  int* cnt;       // arrival counters: [0, nstrips) one per column strip, [nstrips] the tail's
+  int* cnt;       // column-sharded M: one arrival counter per column strip
   int nstrips;
+  uint8_t* kind;  // pinned host memory [KIND_CAP], profiling only: iteration n_iters ran a pass
 };
+constexpr int KIND_CAP = 1 << 16;
 
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, mask, 64);
-  hi = __shfl_xor(hi, mask, 64);
-  return __hiloint2double(hi, lo);
-}
 
 // array k (0 = u, 1 = gradF) of point slot (p, v)
 __device__ __forceinline__ double* pt_arr(const SolveArgs& A, int V, int p, int v, int k) {
@@ -152,12 +166,13 @@ __device__ __forceinline__ double* pt_arr(const SolveArgs& A, int V, int p, int 
 }
 
 // Last-arriver hand-off inside one launch (CDNA guide, section 6 guideline 16, counter form;
-// the split-K recipe): every workgroup publishes what it stored — each wave drains its own
-// stores, one lane issues the agent-scope release and draws a ticket — and the workgroup that
-// draws the last ticket acquires at agent scope and continues with plain loads. Correct for
-// any placement of the workgroups over the 8 XCDs (their L2s are not coherent with each other).
-// The counter is zeroed before the first launch of a solve (k_init) and re-armed by the last
-// arriver. Returns true in every thread of the last workgroup. `flag` is one int of LDS.
+// the split-K recipe) — used only by k_pass (column-sharded M): every workgroup publishes what
+// it stored — each wave drains its own stores, one lane issues the agent-scope release and
+// draws a ticket — and the workgroup that draws the last ticket acquires at agent scope and
+// continues with plain loads. Correct for any placement of the workgroups over the 8 XCDs
+// (their L2s are not coherent with each other). The counter is zeroed before the first launch
+// of a solve (k_init) and re-armed by the last arriver. Returns true in every thread of the
+// last workgroup. `flag` is one int of LDS.
 __device__ __forceinline__ bool arrive_last(int* counter, int expected, int* flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -247,43 +262,57 @@ __device__ __forceinline__ void store_row(double* row, const double (&c)[VS]) {
   q[1] = make_double4(c[4], c[5], c[6], c[7]);
 }
 
-// ------------------------------------------------------------------------------------------
-// decide — ONE workgroup of 256 threads: adds the tail's partial scalars in a fixed order,
-// takes the reference's decisions (clipper.cpp:244-251, 261) for the candidates of the window
-// in order, and updates the state. Only the rare transitions (initialisation :193-220, penalty
-// update :268-280, a new outer iteration :219-220) sweep over the m-vectors here.
-// ------------------------------------------------------------------------------------------
-
-constexpr int VU = 4;  // elements per thread per sweep step
-#define VEC_CHUNKS(base) for (int64_t base = tid; base < m; base += TAIL_THREADS * VU)
-#define VEC_EACH(k, i, base)            \
-  _Pragma("unroll") for (int k = 0; k < VU; ++k) \
-    if (const int64_t i = base + static_cast<int64_t>(k) * TAIL_THREADS; i < m)
-
 constexpr int pow2_at_least(int x) {
   int p = 1;
   while (p < x) p *= 2;
   return p;
 }
 
-template <int V>
-__device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
+// ------------------------------------------------------------------------------------------
+// decide — the head of every G launch (NT threads per workgroup). Returns true when this
+// iteration performs a pass (plan = what to stream against), false when the workgroup has
+// nothing more to do (transition iteration or end of the solve).
+//
+// Common case (a window pass and its tail have run): EVERY workgroup adds the tail's partial
+// scalars in the same fixed order and walks the window exactly like the reference's line
+// search (clipper.cpp:244-251, 261) — all workgroups reach the same decision on their own, no
+// communication. Workgroup (0,0) records the decided state in st_next.
+// Transitions (everything that sweeps whole vectors): workgroup (0,0) alone, the others leave.
+// ------------------------------------------------------------------------------------------
+
+struct PassPlan {
+  int phase;
+  int sel;
+  double d;
+};
+
+constexpr int VU = 4;  // elements per thread per sweep step (all NT threads of the workgroup sweep)
+#define VEC_CHUNKS(base) for (int64_t base = tid; base < m; base += NT * VU)
+#define VEC_EACH(k, i, base)            \
+  _Pragma("unroll") for (int k = 0; k < VU; ++k) \
+    if (const int64_t i = base + static_cast<int64_t>(k) * NT; i < m)
+
+template <int V, int NT>
+__device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverState* stash,
+                                       PassPlan& plan) {
   constexpr int NR = 2 + 2 * V;
   constexpr int Q = V * NR + 2 * V;
   constexpr int QPAD = pow2_at_least(Q);
-  constexpr int NCH = TAIL_THREADS / QPAD;  // interleaved summation chains per quantity
-  static_assert(QPAD <= TAIL_THREADS && V <= VS, "window too large");
-  SolverState* st = A.st;
+  constexpr int NCH = NT / QPAD;  // interleaved summation chains per quantity
+  constexpr int NWV = NT / 64;
+  static_assert(QPAD <= NT && V <= VS, "window too large");
+  double* scratch = red + NT;     // block_reduce scratch, NWV * 2V doubles at most
+  const SolverState* st = A.st_cur;
   const int tid = threadIdx.x;
   const int64_t m = A.m;
   const SolverParams P = A.prm;
+  const bool writer = (blockIdx.x == 0 && blockIdx.y == 0);
 
   const int phase = st->phase;
   double d = st->d, F = st->F, alpha = st->alpha, s = st->s;
   int i_ = st->i, j_ = st->j, k_ = st->k, ubp = st->ubp, ubv = st->ubv, sel = st->sel;
   int64_t n_passes = st->n_passes, n_trials = st->n_trials;
   const int64_t n_iters = st->n_iters + 1;
-  if (phase != PH_NORMALIZE) ++n_passes;
   int next_phase = PH_TRIAL;
   double nrm[V], sx[V];
 #pragma unroll
@@ -291,88 +320,12 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
     nrm[l] = 1.0;
     sx[l] = 0.0;
   }
-  const double* ca_ = A.cab;           // a = M_off x of the last pair-mode pass
-  const double* cb_ = A.cab + A.mp;    // b = C_off x
-
-  if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
-    // clipper.cpp:193-198 — u = M_off*u0 + u0 (or u0), then u /= u.norm()
-    double* u = pt_arr(A, V, ubp, ubv, 0);
-    double z[1] = {0.0};
-    VEC_CHUNKS(base) {
-      double uv[VU], av[VU];
-      VEC_EACH(k, i, base) {
-        uv[k] = A.u0[i];
-        if (phase == PH_RESCALE) av[k] = ca_[i];
-      }
-      VEC_EACH(k, i, base) {
-        const double ui = (phase == PH_RESCALE) ? av[k] + uv[k] : uv[k];
-        u[i] = ui;
-        z[0] += ui * ui;
-      }
-    }
-    block_reduce<1, TAIL_WAVES>(z, red + LDS_SCRATCH);
-    const double n0 = sqrt(z[0]);
-    VEC_CHUNKS(base) {
-      double uv[VU];
-      VEC_EACH(k, i, base) uv[k] = u[i];
-      VEC_EACH(k, i, base) {
-        const double ui = uv[k] / n0;
-        u[i] = ui;
-        // next pass (pair mode) runs on x = u, already normalised: candidate 0 of table 0
-        const double row[VS] = {ui, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        store_row(A.Xout + i * VS, row);
-      }
-    }
-    if (tid == 0) {
-      st->phase = PH_INIT;
-      st->sel = 0;
-      st->nrm[0] = 1.0;
-      st->n_passes = n_passes;
-      st->n_iters = n_iters;
-      if (A.host != nullptr)
-        __hip_atomic_store(&A.host->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return;
-  }
-
   bool begin_outer = false, penalty = false, finished = false;
   bool need_window = false;  // a sweep must build the window from (u, g): after a transition
   bool need_pair = false;    // a pair-mode pass on u must come first: end of an inner loop
+  bool fast = false;         // the pending window is one of the tables the tail already built
 
-  if (phase == PH_INIT) {
-    // clipper.cpp:200-209 — initial d from the pair-mode pass on u
-    const double* u = pt_arr(A, V, ubp, ubv, 0);
-    double sv[1] = {0.0};
-    VEC_CHUNKS(base) {
-      double uv[VU];
-      VEC_EACH(k, i, base) uv[k] = u[i];
-      VEC_EACH(k, i, base) sv[0] += uv[k];
-    }
-    block_reduce<1, TAIL_WAVES>(sv, red + LDS_SCRATCH);
-    s = sv[0];
-    double ca[2] = {0.0, 0.0};  // count, sum of ratios
-    VEC_CHUNKS(base) {
-      double uv[VU], av[VU], bv[VU];
-      VEC_EACH(k, i, base) {
-        uv[k] = u[i];
-        av[k] = ca_[i];
-        bv[k] = cb_[i];
-      }
-      VEC_EACH(k, i, base) {
-        const double cbu = s - bv[k] - uv[k];  // :202
-        if (cbu > P.eps && uv[k] > P.eps) {    // :203
-          ca[0] += 1.0;
-          ca[1] += (av[k] + uv[k]) / cbu;  // :205-208
-        }
-      }
-    }
-    block_reduce<2, TAIL_WAVES>(ca, red + LDS_SCRATCH);
-    d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
-    i_ = 0;
-    begin_outer = true;
-  } else if (phase == PH_PENALTY) {
-    penalty = true;  // (a, b) of the inner loop's final u have just arrived
-  } else {  // PH_TRIAL — the decisions of clipper.cpp:244-262 from the tail's partial scalars
+  if (phase == PH_TRIAL) {
     // sums[q] = sum over the tail workgroups w of scal[w][q]: NCH interleaved chains per
     // quantity (w = c, c + NCH, ...), added in chain order
     {
@@ -425,6 +378,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
       // all V candidates rejected: the v = 0 tail already built the next V step sizes from
       // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
       sel = V;
+      fast = true;
 #pragma unroll
       for (int l = 0; l < V; ++l) {
         const double z = sums[V * NR + 2 * l];
@@ -444,6 +398,7 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
         alpha = 1.0;  // :227
         k_ = 0;
         sel = jstar;  // the tail already built max(x + beta^l gradFnew, 0) in table jstar
+        fast = true;
 #pragma unroll
         for (int l = 0; l < V; ++l) {
           const double z = sums[jstar * NR + 2 + 2 * l];
@@ -454,12 +409,57 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
     }
   }
 
-  // Transitions that need no further pass: penalty update (:268-280) and the gradient at the
-  // start of the next outer iteration (:219-220), from (a, b) of the last pair-mode pass.
-  while (true) {
-    if (penalty) {
+  if (!fast) {
+    // ---- transition iteration: workgroup (0,0) alone -------------------------------------
+    if (!writer) return false;
+    const double* ca_ = A.cab;         // a = M_off x of the last pair-mode pass
+    const double* cb_ = A.cab + A.mp;  // b = C_off x
+    bool to_init = false;
+
+    if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
+      // clipper.cpp:193-198 — u = M_off*u0 + u0 (or u0), then u /= u.norm()
+      double* u = pt_arr(A, V, ubp, ubv, 0);
+      double z[1] = {0.0};
+      VEC_CHUNKS(base) {
+        double uv[VU], av[VU];
+        VEC_EACH(k, i, base) {
+          uv[k] = A.u0[i];
+          if (phase == PH_RESCALE) av[k] = ca_[i];
+        }
+        VEC_EACH(k, i, base) {
+          const double ui = (phase == PH_RESCALE) ? av[k] + uv[k] : uv[k];
+          u[i] = ui;
+          z[0] += ui * ui;
+        }
+      }
+      block_reduce<1, NWV>(z, scratch);
+      const double n0 = sqrt(z[0]);
+      VEC_CHUNKS(base) {
+        double uv[VU];
+        VEC_EACH(k, i, base) uv[k] = u[i];
+        VEC_EACH(k, i, base) {
+          const double ui = uv[k] / n0;
+          u[i] = ui;
+          // next pass (pair mode) runs on x = u, already normalised: candidate 0 of table 0
+          const double row[VS] = {ui, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          store_row(A.Xout + i * VS, row);
+        }
+      }
+      sel = 0;
+      next_phase = PH_INIT;
+      to_init = true;
+    } else if (phase == PH_INIT) {
+      // clipper.cpp:200-209 — initial d from the pair-mode pass on u
       const double* u = pt_arr(A, V, ubp, ubv, 0);
-      double ca[2] = {0.0, 0.0};
+      double sv[1] = {0.0};
+      VEC_CHUNKS(base) {
+        double uv[VU];
+        VEC_EACH(k, i, base) uv[k] = u[i];
+        VEC_EACH(k, i, base) sv[0] += uv[k];
+      }
+      block_reduce<1, NWV>(sv, scratch);
+      s = sv[0];
+      double ca[2] = {0.0, 0.0};  // count, sum of ratios
       VEC_CHUNKS(base) {
         double uv[VU], av[VU], bv[VU];
         VEC_EACH(k, i, base) {
@@ -468,136 +468,185 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
           bv[k] = cb_[i];
         }
         VEC_EACH(k, i, base) {
-          const double cbu = s - bv[k] - uv[k];  // :268
-          if (cbu > P.eps && uv[k] > P.eps) {    // :269
+          const double cbu = s - bv[k] - uv[k];  // :202
+          if (cbu > P.eps && uv[k] > P.eps) {    // :203
             ca[0] += 1.0;
-            ca[1] += fabs((av[k] + uv[k]) / cbu);  // :271-274
+            ca[1] += (av[k] + uv[k]) / cbu;  // :205-208
           }
         }
       }
-      block_reduce<2, TAIL_WAVES>(ca, red + LDS_SCRATCH);
-      penalty = false;
-      if (ca[0] > 0.0) {
-        d += ca[1] / ca[0];  // :276
-        ++i_;                // :218 loop increment
-        begin_outer = true;
-      } else {
-        finished = true;  // :278-280 break
-        break;
-      }
+      block_reduce<2, NWV>(ca, scratch);
+      d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
+      i_ = 0;
+      begin_outer = true;
+    } else if (phase == PH_PENALTY) {
+      penalty = true;  // (a, b) of the inner loop's final u have just arrived
     }
-    if (begin_outer) {
-      begin_outer = false;
-      if (i_ >= P.maxoliters) {  // :218 loop bound
-        finished = true;
-        break;
+
+    // penalty update (:268-280) and the gradient at the start of the next outer iteration
+    // (:219-220), from (a, b) of the last pair-mode pass
+    while (!to_init) {
+      if (penalty) {
+        const double* u = pt_arr(A, V, ubp, ubv, 0);
+        double ca[2] = {0.0, 0.0};
+        VEC_CHUNKS(base) {
+          double uv[VU], av[VU], bv[VU];
+          VEC_EACH(k, i, base) {
+            uv[k] = u[i];
+            av[k] = ca_[i];
+            bv[k] = cb_[i];
+          }
+          VEC_EACH(k, i, base) {
+            const double cbu = s - bv[k] - uv[k];  // :268
+            if (cbu > P.eps && uv[k] > P.eps) {    // :269
+              ca[0] += 1.0;
+              ca[1] += fabs((av[k] + uv[k]) / cbu);  // :271-274
+            }
+          }
+        }
+        block_reduce<2, NWV>(ca, scratch);
+        penalty = false;
+        if (ca[0] > 0.0) {
+          d += ca[1] / ca[0];  // :276
+          ++i_;                // :218 loop increment
+          begin_outer = true;
+        } else {
+          finished = true;  // :278-280 break
+          break;
+        }
       }
+      if (begin_outer) {
+        begin_outer = false;
+        if (i_ >= P.maxoliters) {  // :218 loop bound
+          finished = true;
+          break;
+        }
+        const double* u = pt_arr(A, V, ubp, ubv, 0);
+        double* g = pt_arr(A, V, ubp, ubv, 1);
+        double f[1] = {0.0};
+        VEC_CHUNKS(base) {
+          double uv[VU], av[VU], bv[VU];
+          VEC_EACH(k, i, base) {
+            uv[k] = u[i];
+            av[k] = ca_[i];
+            bv[k] = cb_[i];
+          }
+          VEC_EACH(k, i, base) {
+            const double gi = (1 + d) * uv[k] - d * s + av[k] + bv[k] * d;  // :219
+            g[i] = gi;
+            f[0] += uv[k] * gi;  // :220
+          }
+        }
+        block_reduce<1, NWV>(f, scratch);
+        F = f[0];
+        j_ = 0;
+        if (P.maxiniters <= 0) {
+          penalty = true;  // empty inner loop: u is unchanged, its (a, b) are still valid
+          continue;
+        }
+        alpha = 1.0;
+        k_ = 0;
+        need_window = true;
+      }
+      break;
+    }
+
+    if (!finished && need_pair) {
+      // the next pass runs in pair mode on x = u (normalised): candidate 0 of table 0
       const double* u = pt_arr(A, V, ubp, ubv, 0);
-      double* g = pt_arr(A, V, ubp, ubv, 1);
-      double f[1] = {0.0};
       VEC_CHUNKS(base) {
-        double uv[VU], av[VU], bv[VU];
+        double uv[VU];
+        VEC_EACH(k, i, base) uv[k] = u[i];
+        VEC_EACH(k, i, base) {
+          const double row[VS] = {uv[k], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          store_row(A.Xout + i * VS, row);
+        }
+      }
+      sel = 0;
+      next_phase = PH_PENALTY;
+    }
+
+    if (!finished && need_window) {
+      // :235-236 for alpha = 1, beta, beta^2, ... — gradient step and projection of the whole
+      // window; normalisation is deferred (nrm)
+      const double* u = pt_arr(A, V, ubp, ubv, 0);
+      const double* g = pt_arr(A, V, ubp, ubv, 1);
+      double zs[2 * V];
+#pragma unroll
+      for (int q = 0; q < 2 * V; ++q) zs[q] = 0.0;
+      VEC_CHUNKS(base) {
+        double uv[VU], gv[VU];
         VEC_EACH(k, i, base) {
           uv[k] = u[i];
-          av[k] = ca_[i];
-          bv[k] = cb_[i];
+          gv[k] = g[i];
         }
         VEC_EACH(k, i, base) {
-          const double gi = (1 + d) * uv[k] - d * s + av[k] + bv[k] * d;  // :219
-          g[i] = gi;
-          f[0] += uv[k] * gi;  // :220
+          double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          double al = alpha;
+#pragma unroll
+          for (int l = 0; l < V; ++l) {
+            double t = uv[k] + al * gv[k];
+            t = (t > 0.0) ? t : 0.0;
+            row[l] = t;
+            zs[2 * l] += t * t;
+            zs[2 * l + 1] += t;
+            al = al * P.beta;
+          }
+          store_row(A.Xout + i * VS, row);
         }
       }
-      block_reduce<1, TAIL_WAVES>(f, red + LDS_SCRATCH);
-      F = f[0];
-      j_ = 0;
-      if (P.maxiniters <= 0) {
-        penalty = true;  // empty inner loop: u is unchanged, its (a, b) are still valid
-        continue;
-      }
-      alpha = 1.0;
-      k_ = 0;
-      need_window = true;
-    }
-    break;
-  }
-
-  if (!finished && need_pair) {
-    // the next pass runs in pair mode on x = u (normalised): candidate 0 of table 0
-    const double* u = pt_arr(A, V, ubp, ubv, 0);
-    VEC_CHUNKS(base) {
-      double uv[VU];
-      VEC_EACH(k, i, base) uv[k] = u[i];
-      VEC_EACH(k, i, base) {
-        const double row[VS] = {uv[k], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        store_row(A.Xout + i * VS, row);
-      }
-    }
-    sel = 0;
-    next_phase = PH_PENALTY;
-  }
-
-  if (!finished && need_window) {
-    // :235-236 for alpha = 1, beta, beta^2, ... — gradient step and projection of the whole
-    // window; normalisation is deferred (nrm)
-    const double* u = pt_arr(A, V, ubp, ubv, 0);
-    const double* g = pt_arr(A, V, ubp, ubv, 1);
-    double zs[2 * V];
+      block_reduce<2 * V, NWV>(zs, scratch);
+      sel = 0;
 #pragma unroll
-    for (int q = 0; q < 2 * V; ++q) zs[q] = 0.0;
-    VEC_CHUNKS(base) {
-      double uv[VU], gv[VU];
-      VEC_EACH(k, i, base) {
-        uv[k] = u[i];
-        gv[k] = g[i];
+      for (int l = 0; l < V; ++l) {
+        nrm[l] = (zs[2 * l] > 0.0) ? sqrt(zs[2 * l]) : 1.0;
+        sx[l] = zs[2 * l + 1] / nrm[l];
       }
-      VEC_EACH(k, i, base) {
-        double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double al = alpha;
-#pragma unroll
-        for (int l = 0; l < V; ++l) {
-          double t = uv[k] + al * gv[k];
-          t = (t > 0.0) ? t : 0.0;
-          row[l] = t;
-          zs[2 * l] += t * t;
-          zs[2 * l + 1] += t;
-          al = al * P.beta;
-        }
-        store_row(A.Xout + i * VS, row);
-      }
-    }
-    block_reduce<2 * V, TAIL_WAVES>(zs, red + LDS_SCRATCH);
-    sel = 0;
-#pragma unroll
-    for (int l = 0; l < V; ++l) {
-      nrm[l] = (zs[2 * l] > 0.0) ? sqrt(zs[2 * l]) : 1.0;
-      sx[l] = zs[2 * l + 1] / nrm[l];
     }
   }
 
-  if (tid == 0) {
-    st->d = d;
-    st->F = F;
-    st->alpha = alpha;
-    st->s = s;
+  // ---- record the decided state (workgroup (0,0), one thread) ------------------------------
+  // A pass iteration parks it in LDS and writes it out AFTER the streaming loop (flush_state):
+  // a global store ahead of the loop would make the compiler treat the table rows as possibly
+  // clobbered and turn their scalar loads into per-lane vector loads.
+  if (writer && tid == 0) {
+    // (two call sites so that each store keeps its address space: LDS or global, never flat)
+    auto record = [&](SolverState* o) {
+      o->d = d;
+      o->F = F;
+      o->alpha = alpha;
+      o->s = s;
 #pragma unroll
-    for (int l = 0; l < V; ++l) {
-      st->nrm[l] = nrm[l];
-      st->sx[l] = sx[l];
-    }
-    st->sel = sel;
-    st->ubp = ubp;
-    st->ubv = ubv;
-    st->phase = next_phase;
-    st->i = i_;
-    st->j = j_;
-    st->k = k_;
-    st->n_passes = n_passes;
-    st->n_trials = n_trials;
-    st->n_iters = n_iters;
+      for (int l = 0; l < V; ++l) {
+        o->nrm[l] = nrm[l];
+        o->sx[l] = sx[l];
+      }
+      o->sel = sel;
+      o->ubp = ubp;
+      o->ubv = ubv;
+      o->phase = next_phase;
+      // fast: this iteration streams the pending window, its results are due next time;
+      // transition: the next iteration runs the pass this one prepared
+      o->stage = fast ? ST_RESULTS : ST_PASS;
+      o->i = i_;
+      o->j = j_;
+      o->k = k_;
+      o->n_passes = n_passes + (fast ? 1 : 0);
+      o->n_trials = n_trials;
+      o->n_iters = n_iters;
+    };
+    if (fast) record(stash);
+    else record(A.st_next);
     if (finished) {
-      st->ifinal = i_;
-      st->done = 1;
+      SolveShared* sh = A.shared;
+      sh->F = F;
+      sh->d = d;
+      sh->n_passes = n_passes;
+      sh->n_trials = n_trials;
+      sh->ifinal = i_;
+      sh->ubp = ubp;
+      sh->ubv = ubv;
+      sh->done = 1;
     }
     if (A.host != nullptr) {
       HostMirror* hm = A.host;
@@ -612,24 +661,71 @@ __device__ __forceinline__ void decide_body(const SolveArgs& A, double* red) {
         // every store above (and the vectors this workgroup wrote) before the flag
         __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (!fast)
+        __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  // the decision came out of LDS reads: tell the compiler it is wave-uniform, so that the
+  // multipliers of the streaming loop stay scalar loads
+  plan.phase = PH_TRIAL;
+  plan.sel = __builtin_amdgcn_readfirstlane(sel);
+  plan.d = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(d)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(d)));
+  return fast;
 }
 #undef VEC_CHUNKS
 #undef VEC_EACH
 
-// Solve prologue, one launch: pending window = {u0} (candidate 0 of table 0, un-normalised,
-// nrm = 1), initial state, arrival counters zeroed.
-__global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, double* X0) {
+// What every G launch starts with. Returns false when this workgroup has nothing to stream.
+// `stash`: LDS copy of the state a pass iteration decided on, see flush_state.
+template <int V, int NT>
+__device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
+                                               SolverState* stash, PassPlan& plan) {
+  if (A.shared->done) return false;
+  const SolverState* st = A.st_cur;
+  if (st->stage == ST_RESULTS) return decide<V, NT>(A, lds, stash, plan);
+  // the pass was prepared by a transition iteration (or by k_init): run it as it stands
+  plan.phase = st->phase;
+  plan.sel = st->sel;
+  plan.d = st->d;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    *stash = *st;
+    stash->stage = ST_RESULTS;
+    stash->n_passes = st->n_passes + 1;
+    stash->n_iters = st->n_iters + 1;
+  }
+  return true;
+}
+
+// End of a pass iteration: workgroup (0,0) writes the state it decided on where the tail and
+// the next iteration read it, marks the iteration as a pass and reports progress to the host.
+__device__ __forceinline__ void flush_state(const SolveArgs& A, const SolverState* stash) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    *A.st_next = *stash;
+    const int64_t n_iters = stash->n_iters;
+    if (A.kind != nullptr && n_iters <= KIND_CAP)
+      __hip_atomic_store(A.kind + (n_iters - 1), static_cast<uint8_t>(1), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if (A.host != nullptr)
+      __hip_atomic_store(&A.host->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Solve prologue, one launch: pending vector = u0 (candidate 0 of table 0, un-normalised,
+// nrm = 1), initial state in ST[0], arrival counters zeroed.
+__global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, SolverState* st0,
+                                               double* X0) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i < A.m) {
     const double row[VS] = {A.u0[i], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     store_row(X0 + i * VS, row);
   }
   if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c <= A.nstrips; c += 256) A.cnt[c] = 0;
-    if (threadIdx.x == 0) *A.st = init;
+    for (int c = threadIdx.x; c < A.nstrips; c += 256) A.cnt[c] = 0;
+    if (threadIdx.x == 0) {
+      *st0 = init;
+      A.shared->done = 0;
+    }
   }
 }
 
@@ -638,16 +734,16 @@ __global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, dou
 // (one element per thread: more elements per thread only lengthens the latency chain — measured).
 //   FUSED_REDUCE: sum the row-tile partials of the single shard here (else `ab` holds the
 //                 gathered raw sums of all shards).
-// The last workgroup to arrive takes the decision (arrive_last).
+// Reads the state G decided on (st_next); communicates with nobody.
 // ------------------------------------------------------------------------------------------
 template <int V, bool FUSED_REDUCE>
 __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
   constexpr int NR = 2 + 2 * V;
   constexpr int Q = V * NR + 2 * V;
   constexpr int NSLOT = nslot(V);
-  __shared__ double red[SOLVE_LDS];
+  __shared__ double red[TAIL_WAVES * (NR + 2 * V)];
   const int v = blockIdx.y;
-  const SolverState* st = A.st;
+  const SolverState* st = A.st_next;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
   const bool valid = i < A.m;
 
@@ -685,7 +781,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
       p1 = blk[((v == 0) ? A.W : 0) + off];
     }
   }
-  if (st->done) return;
+  if (A.shared->done) return;
+  if (st->stage != ST_RESULTS) return;  // transition iteration: no pass was run
   const int phase = st->phase;
   const int ubp = st->ubp, ubv = st->ubv;
 
@@ -695,72 +792,61 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
       A.cab[i] = p0;
       A.cab[A.mp + i] = p1;
     }
-  } else {
-    const double nrmv = st->nrm[v], sxv = st->sx[v];
-    const double d = st->d, alpha = st->alpha, beta = A.prm.beta;
-    double r[NR + 2 * V];
+    return;
+  }
+  const double nrmv = st->nrm[v], sxv = st->sx[v];
+  const double d = st->d, alpha = st->alpha, beta = A.prm.beta;
+  double r[NR + 2 * V];
 #pragma unroll
-    for (int q = 0; q < NR + 2 * V; ++q) r[q] = 0.0;
-    if (valid) {
-      const double xraw = A.Xin[(static_cast<int64_t>(st->sel) * A.mp + i) * VS + v];
-      const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
-      const double xi = xraw / nrmv;  // clipper.cpp:237
-      const double gs = p0 / nrmv;    // (M_off + d*C_off) x
-      const double gn = (1 + d) * xi - d * sxv + gs;  // :238-241
-      pt_arr(A, V, ubp ^ 1, v, 0)[i] = xi;  // becomes (u, gradF) if candidate v is accepted
-      pt_arr(A, V, ubp ^ 1, v, 1)[i] = gn;
-      r[0] = xi * gn;  // :242
-      const double du = xi - ui;
-      r[1] = du * du;  // :253
-      // next window if candidate v is accepted: alpha = 1, beta, beta^2, ... (:227, :235-236)
-      double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      double al = 1.0;
+  for (int q = 0; q < NR + 2 * V; ++q) r[q] = 0.0;
+  if (valid) {
+    const double xraw = A.Xin[(static_cast<int64_t>(st->sel) * A.mp + i) * VS + v];
+    const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
+    const double xi = xraw / nrmv;  // clipper.cpp:237
+    const double gs = p0 / nrmv;    // (M_off + d*C_off) x
+    const double gn = (1 + d) * xi - d * sxv + gs;  // :238-241
+    pt_arr(A, V, ubp ^ 1, v, 0)[i] = xi;  // becomes (u, gradF) if candidate v is accepted
+    pt_arr(A, V, ubp ^ 1, v, 1)[i] = gn;
+    r[0] = xi * gn;  // :242
+    const double du = xi - ui;
+    r[1] = du * du;  // :253
+    // next window if candidate v is accepted: alpha = 1, beta, beta^2, ... (:227, :235-236)
+    double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double al = 1.0;
+#pragma unroll
+    for (int l = 0; l < V; ++l) {
+      double t = xi + al * gn;
+      t = (t > 0.0) ? t : 0.0;
+      row[l] = t;
+      r[2 + 2 * l] = t * t;
+      r[3 + 2 * l] = t;
+      al = al * beta;
+    }
+    store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
+    if (v == 0) {
+      // next window if all V candidates are rejected: V more factors of beta (:248)
+      const double gi = pt_arr(A, V, ubp, ubv, 1)[i];
+      double row2[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      al = alpha;
+#pragma unroll
+      for (int l = 0; l < V; ++l) al = al * beta;
 #pragma unroll
       for (int l = 0; l < V; ++l) {
-        double t = xi + al * gn;
+        double t = ui + al * gi;
         t = (t > 0.0) ? t : 0.0;
-        row[l] = t;
-        r[2 + 2 * l] = t * t;
-        r[3 + 2 * l] = t;
+        row2[l] = t;
+        r[NR + 2 * l] = t * t;
+        r[NR + 2 * l + 1] = t;
         al = al * beta;
       }
-      store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
-      if (v == 0) {
-        // next window if all V candidates are rejected: V more factors of beta (:248)
-        const double gi = pt_arr(A, V, ubp, ubv, 1)[i];
-        double row2[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        al = alpha;
-#pragma unroll
-        for (int l = 0; l < V; ++l) al = al * beta;
-#pragma unroll
-        for (int l = 0; l < V; ++l) {
-          double t = ui + al * gi;
-          t = (t > 0.0) ? t : 0.0;
-          row2[l] = t;
-          r[NR + 2 * l] = t * t;
-          r[NR + 2 * l + 1] = t;
-          al = al * beta;
-        }
-        store_row(A.Xout + (static_cast<int64_t>(V) * A.mp + i) * VS, row2);
-      }
+      store_row(A.Xout + (static_cast<int64_t>(V) * A.mp + i) * VS, row2);
     }
-    const double tot = block_reduce_pick<NR + 2 * V, TAIL_WAVES>(r, red);
-    double* out = A.scal + static_cast<int64_t>(blockIdx.x) * Q;
-    if (threadIdx.x < NR) out[v * NR + threadIdx.x] = tot;
-    if (v == 0 && threadIdx.x >= NR && threadIdx.x < NR + 2 * V)
-      out[V * NR + (threadIdx.x - NR)] = tot;
   }
-  if (!arrive_last(A.cnt + A.nstrips, gridDim.x * gridDim.y, reinterpret_cast<int*>(red + LDS_FLAG)))
-    return;
-  decide_body<V>(A, red);
-}
-
-// the decision alone (PH_NORMALIZE consumes no pass)
-template <int V>
-__global__ __launch_bounds__(TAIL_THREADS) void k_decide(SolveArgs A) {
-  __shared__ double red[SOLVE_LDS];
-  if (A.st->done) return;
-  decide_body<V>(A, red);
+  const double tot = block_reduce_pick<NR + 2 * V, TAIL_WAVES>(r, red);
+  double* out = A.scal + static_cast<int64_t>(blockIdx.x) * Q;
+  if (threadIdx.x < NR) out[v * NR + threadIdx.x] = tot;
+  if (v == 0 && threadIdx.x >= NR && threadIdx.x < NR + 2 * V)
+    out[V * NR + (threadIdx.x - NR)] = tot;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -807,7 +893,6 @@ __device__ __forceinline__ typename Vec4<T>::type load4(const T* p) {
   return *reinterpret_cast<const typename Vec4<T>::type*>(p);
 }
 
-
 // 0/1 pattern indicator, or the explicit constraint value, of the 4 elements of a lane
 template <typename T, bool HASC>
 __device__ __forceinline__ void indicator(const typename Vec4<T>::type& mv,
@@ -825,11 +910,17 @@ __device__ __forceinline__ void indicator(const typename Vec4<T>::type& mv,
   }
 }
 
+// The table rows are read through the CONSTANT address space: a launch never writes the table
+// it reads (Xin; the writes go to Xout), and with a wave-uniform address a constant-space load
+// is always a scalar load — independent of what the compiler can prove about the global stores
+// workgroup (0,0) issues elsewhere in the kernel.
+typedef const __attribute__((address_space(4))) double* const_f64_ptr;
+
 // window mode: acc[v][e] += (M + d*C)[e] * x_v
 template <typename T, bool HASC, int V>
 __device__ __forceinline__ void row_window(const typename Vec4<T>::type& mv,
                                            const typename Vec4<T>::type& cv, double d,
-                                           const double* __restrict__ xr, double (&acc)[V][4]) {
+                                           const_f64_ptr xr, double (&acc)[V][4]) {
   const double mm[4] = {static_cast<double>(mv.x), static_cast<double>(mv.y),
                         static_cast<double>(mv.z), static_cast<double>(mv.w)};
   double ii[4];
@@ -866,8 +957,9 @@ __device__ __forceinline__ void row_pair(const typename Vec4<T>::type& mv,
 template <typename T, bool HASC, bool WINDOW, int NS, int NSLOT, int NW, int UNR>
 __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __restrict__ Cs,
                                           int64_t ld, int64_t m, int rows_per_tile, double d,
-                                          const double* __restrict__ X,
+                                          const double* __restrict__ Xg,
                                           double* __restrict__ part, double* lds) {
+  const const_f64_ptr X = (const_f64_ptr)Xg;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t col = static_cast<int64_t>(blockIdx.x) * 256 + lane * 4;
@@ -911,6 +1003,7 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
   }
 
   // cross-wave combine in wave order (fixed summation tree), one slot at a time
+  __syncthreads();  // the decision at the head of the launch used the same LDS
 #pragma unroll
   for (int v = 0; v < NS; ++v) {
     double* mine = lds + wave * 256 + lane * 4;
@@ -930,52 +1023,56 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
 
 constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * 256 + 2; }  // + the arrival flag
 
-// window or pair mode by the solver phase; st == nullptr: pair mode on table 0 (matvec API)
+// window or pair mode by the plan of this iteration
 template <typename T, bool HASC, int V, int NW, int UNR>
-__device__ __forceinline__ void gemv_by_phase(const T* __restrict__ S, const T* __restrict__ Cs,
-                                              int64_t ld, int64_t m, int rows_per_tile,
-                                              const double* __restrict__ Xtab, int64_t mp,
-                                              double* __restrict__ part,
-                                              const SolverState* __restrict__ st, double* lds) {
-  if (st != nullptr && st->phase == PH_TRIAL) {
-    gemv_core<T, HASC, true, V, nslot(V), NW, UNR>(
-        S, Cs, ld, m, rows_per_tile, st->d, Xtab + static_cast<int64_t>(st->sel) * mp * VS, part,
-        lds);
+__device__ __forceinline__ void gemv_by_plan(const T* __restrict__ S, const T* __restrict__ Cs,
+                                             int64_t ld, int64_t m, int rows_per_tile,
+                                             const double* __restrict__ Xtab, int64_t mp,
+                                             double* __restrict__ part, const PassPlan& plan,
+                                             double* lds) {
+  const double* X = Xtab + static_cast<int64_t>(plan.sel) * mp * VS;
+  if (plan.phase == PH_TRIAL) {
+    gemv_core<T, HASC, true, V, nslot(V), NW, UNR>(S, Cs, ld, m, rows_per_tile, plan.d, X, part,
+                                                   lds);
   } else {
-    const int sel = (st != nullptr) ? st->sel : 0;
-    gemv_core<T, HASC, false, 2, nslot(V), NW, UNR>(
-        S, Cs, ld, m, rows_per_tile, 0.0, Xtab + static_cast<int64_t>(sel) * mp * VS, part, lds);
+    gemv_core<T, HASC, false, 2, nslot(V), NW, UNR>(S, Cs, ld, m, rows_per_tile, 0.0, X, part,
+                                                    lds);
   }
 }
 
 // two workgroups per CU (NW/2 waves per SIMD each): caps the registers at 128 per lane
 template <typename T, bool HASC, int V, int NW, int UNR>
 __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv(const T* __restrict__ S,
-                                                           const T* __restrict__ Cs, int64_t ld,
-                                                           int64_t m, int rows_per_tile,
-                                                           const double* __restrict__ Xtab,
-                                                           int64_t mp, double* __restrict__ part,
-                                                           const SolverState* __restrict__ st) {
-  if (st != nullptr && st->done) return;
+                                                           const T* __restrict__ Cs,
+                                                           int rows_per_tile, SolveArgs A) {
+  static_assert(NW * 64 >= TAIL_THREADS && NW * 256 >= NW * 64 + (NW * 2 * V),
+                "LDS of the mat-vec must hold the decision's scratch");
   __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
-  gemv_by_phase<T, HASC, V, NW, UNR>(S, Cs, ld, m, rows_per_tile, Xtab, mp, part, st, lds);
+  __shared__ SolverState stash;
+  PassPlan plan;
+  if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
+  gemv_by_plan<T, HASC, V, NW, UNR>(S, Cs, A.W, A.m, rows_per_tile, A.Xin, A.mp, A.part, plan,
+                                    lds);
+  flush_state(A, &stash);
 }
 
-// k_pass — the mat-vec of a column-sharded M with the reduction of its row-tile partials folded
+// k_pass — the same for a column-sharded M, with the reduction of the row-tile partials folded
 // into the epilogue: the LAST row-tile workgroup of a column strip (arrival counter per strip)
 // adds the strip's partials in tile order into this shard's block of the gathered layout
 // ab[P][NSLOT][W] — what k_reduce would do in a launch of its own. The exchange and
-// k_tail<V, false> follow.
+// k_tail<V, false> follow. Every rank takes the same decision from the same bits.
 template <typename T, bool HASC, int V, int NW, int UNR>
 __global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ S,
                                                            const T* __restrict__ Cs,
                                                            int rows_per_tile, SolveArgs A) {
   constexpr int NSLOT = nslot(V);
   __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
-  const SolverState* st = A.st;
-  if (st->done) return;
+  __shared__ SolverState stash;
+  PassPlan plan;
+  if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
   const int64_t ld = A.W;
-  gemv_by_phase<T, HASC, V, NW, UNR>(S, Cs, ld, A.m, rows_per_tile, A.Xin, A.mp, A.part, st, lds);
+  gemv_by_plan<T, HASC, V, NW, UNR>(S, Cs, ld, A.m, rows_per_tile, A.Xin, A.mp, A.part, plan, lds);
+  flush_state(A, &stash);
   int* flag = reinterpret_cast<int*>(lds + GEMV_LDS_DOUBLES(NW) - 1);
   if (!arrive_last(A.cnt + blockIdx.x, gridDim.y, flag)) return;
   // ---- last workgroup of this column strip ------------------------------------------------
@@ -999,6 +1096,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ 
       ab_block[sl * ld + c] = acc;
     }
   }
+}
+
+// the pair-mode pass alone, on table 0 (matvec API, micro-benchmark): no solver state
+template <typename T, bool HASC, int NW, int UNR>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_plain(const T* __restrict__ S,
+                                                                 const T* __restrict__ Cs,
+                                                                 int64_t ld, int64_t m,
+                                                                 int rows_per_tile,
+                                                                 const double* __restrict__ X,
+                                                                 double* __restrict__ part) {
+  __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
+  gemv_core<T, HASC, false, 2, 2, NW, UNR>(S, Cs, ld, m, rows_per_tile, 0.0, X, part, lds);
 }
 
 // k_reduce — adds the row-tile partials in tile order and writes this shard's block of the

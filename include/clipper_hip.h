@@ -55,7 +55,8 @@ typedef struct clipper_hip_timings_t {
   double affinity_kernel_ms; /* affinity fill kernel(s) only                           */
   double affinity_total_ms;  /* H2D of D1,D2,A + gather + fill, host wall clock         */
   double solve_total_ms;     /* host wall clock of clipper_hip_solve                    */
-  double gemv_avg_us;        /* mean duration of the mat-vec kernel over the last solve
+  double gemv_avg_us;        /* mean duration of the mat-vec kernel (k_gemv: one pass over
+                                M for a whole line-search window) over the last solve
                                 (only when profiling is on; else 0)                     */
   double gemv_min_us;
   int64_t gemv_launches;     /* number of mat-vec launches that were timed              */
@@ -161,6 +162,15 @@ int clipper_hip_get_nodes(const clipper_hip_t* h, int32_t* nodes_out, int32_t ca
 /* CLIPPER::getSelectedAssociations (clipper.cpp:124-127): column-major k x 2. */
 int clipper_hip_get_selected_associations(const clipper_hip_t* h, int32_t* A_out,
                                           int32_t capacity);
+
+/* Line-search window: how many consecutive step sizes alpha, alpha*beta, ... of the
+ * backtracking line search (clipper.cpp:234-251) one pass over M evaluates at once. The
+ * trial sequence, the accepted trial and the result are those of the reference for every
+ * window; only the number of passes over M changes. 0 = automatic (6 for m >= 6000, else 1);
+ * 1, 4, 6 or 8 forces a size (also: environment CLIPPER_HIP_WINDOW). Takes effect at the next
+ * affinity build / set_matrix. clipper_hip_window returns the size in use. */
+int clipper_hip_set_window(clipper_hip_t* h, int window);
+int clipper_hip_window(const clipper_hip_t* h);
 
 /* One pass of the mat-vec kernel: yM = M_off*x, yC = C_off*x (the products at
  * clipper.cpp:194,202,205,219,240-241,268,271). x, yM, yC: m doubles on the host. */

@@ -87,16 +87,14 @@ def test_golden_solve_known_answer(golden, storage):
     u0s = [np.ones(12) / np.sqrt(12)] + [rng.random(12) for _ in range(12)]
     for k, u0 in enumerate(u0s):
         sg, sr = c.solve(u0), r.solve(u0)
-        # k == 0: uniform u0 on this symmetric toy problem — the three selected entries of u are
-        # structurally tied, their heap order (utils.cpp:33-55) rests on last-bit rounding
-        _check_solution(sg, sr, exact_counts=True, ordered=(k != 0))
+        # the selected clique {0,4,8} has exactly equal affinities, so the three entries of u
+        # converge to the same value: their heap order (utils.cpp:33-55) rests on last-bit
+        # rounding — compare as sets
+        _check_solution(sg, sr, exact_counts=True, ordered=False)
         assert np.allclose(sg.u, sr.u, rtol=0, atol=1e-9)
         Ain = c.get_selected_associations()
         Aref = r.get_selected_associations()
-        if k == 0:
-            assert sorted(map(tuple, Ain)) == sorted(map(tuple, Aref))
-        else:
-            assert np.array_equal(Ain, Aref)
+        assert sorted(map(tuple, Ain)) == sorted(map(tuple, Aref))
         if k == 0:   # clipper_test.cpp:62-66
             assert Ain.shape[0] == 3 and np.all(Ain[:, 0] == Ain[:, 1])
             assert sorted(sg.nodes.tolist()) == g["expected_inlier_nodes"]
