@@ -594,17 +594,26 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(c.X, x.data(), x.size() * 8, hipMemcpyHostToDevice));
   CK(hipDeviceSynchronize());
   printf("m = %lld, %d CUs\n", (long long)c.m, c.cus);
-  run<1, 8, 8, 4>(c, 2, "baseline shape");
-  run<6, 8, 4, 4>(c, 2, "");
+  // (the "check" column compares candidate 0's a-sums with the first variant; the g-mode
+  //  variants accumulate a + d*b instead, so their difference is expected)
+  run<1, 8, 8, 4>(c, 2, "a/b accumulators: baseline shape");
+  run<2, 8, 8, 4>(c, 2, "a/b accumulators");
+  run<3, 8, 8, 4>(c, 2, "a/b accumulators");
+  run<4, 8, 8, 4>(c, 2, "a/b accumulators");
+  run<5, 8, 4, 4>(c, 2, "a/b accumulators");
+  run<6, 8, 4, 4>(c, 2, "a/b accumulators");
+  run<6, 8, 8, 2>(c, 1, "a/b accumulators, 1 wg/cu");
+  run<8, 8, 8, 2>(c, 1, "a/b accumulators, 1 wg/cu");
+  run_k(c, k_mv2<6, 8, 8, 4>, 6, 8, 8, 4, 128, 8, 2, "a/b, 2 col/lane");
+  run_k(c, k_mvs<6, 2, 8, 8, 4>, 6, 8, 8, 4, 256, 4, 2, "a/b, vectors split over 2 wave groups");
+  run_k(c, k_mvp<6, 8, 4, 4>, 6, 8, 4, 4, 256, 8, 2, "a/b, register software pipeline D4");
+  run_k(c, k_mvd<1, 8, 8, 4>, 1, 8, 8, 4, 256, 8, 2, "a/b, lds-dma ring D8");
+  run_k(c, k_mvd<6, 8, 8, 4>, 6, 8, 8, 4, 256, 8, 2, "a/b, lds-dma ring D8");
   run_k(c, k_mvg<1, 8, 8, 4>, 1, 8, 8, 4, 256, 8, 2, "g-mode");
   run_k(c, k_mvg<4, 8, 8, 4>, 4, 8, 8, 4, 256, 8, 2, "g-mode");
-  run_k(c, k_mvg<6, 8, 8, 4>, 6, 8, 8, 4, 256, 8, 2, "g-mode");
+  run_k(c, k_mvg<6, 8, 8, 4>, 6, 8, 8, 4, 256, 8, 2, "g-mode  <- the product kernel's shape");
   run_k(c, k_mvg<6, 8, 4, 4>, 6, 8, 4, 4, 256, 8, 2, "g-mode");
   run_k(c, k_mvg<8, 8, 8, 4>, 8, 8, 8, 4, 256, 8, 2, "g-mode");
   run_k(c, k_mvg<8, 8, 4, 4>, 8, 8, 4, 4, 256, 8, 2, "g-mode");
-  run_k(c, k_mvg<8, 8, 12, 4>, 8, 8, 12, 4, 256, 8, 2, "g-mode");
-  run_k(c, k_mvg<8, 16, 8, 4>, 8, 16, 8, 4, 256, 16, 1, "g-mode NW16");
-  run_k(c, k_mvg<8, 4, 8, 4>, 8, 4, 8, 4, 256, 4, 4, "g-mode NW4 4wg");
-  run_k(c, k_mvg<8, 8, 8, 4>, 8, 8, 8, 4, 256, 8, 3, "g-mode 3wg/cu tiles");
   return 0;
 }
