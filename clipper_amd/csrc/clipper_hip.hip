@@ -243,6 +243,10 @@ void plan_tiles(Ctx* h) {
   // tiles, i.e. few partials for the tail
   const int64_t target = static_cast<int64_t>(h->cus) * GEMV_WG_PER_CU;
   int64_t nt = std::max<int64_t>(1, ceil_div(target, h->nstrips));
+  if (const char* e = std::getenv("CLIPPER_HIP_TILES")) {  // tuning knob (measurements only)
+    const int64_t v = std::atoll(e);
+    if (v > 0) nt = v;
+  }
   nt = std::min<int64_t>(nt, std::max<int64_t>(1, ceil_div(h->m, chunk)));
   int64_t rpt = round_up(ceil_div(h->m, nt), chunk);
   h->rows_per_tile = static_cast<int>(rpt);
@@ -252,7 +256,9 @@ void plan_tiles(Ctx* h) {
 int64_t max_tiles(const Ctx* h) {
   // upper bound of ntiles over every unroll plan_tiles may pick for this (m, W)
   const int64_t target = static_cast<int64_t>(h->cus) * GEMV_WG_PER_CU;
-  return std::max<int64_t>(1, ceil_div(target, std::max(1, h->nstrips))) + 1;
+  int64_t nt = std::max<int64_t>(1, ceil_div(target, std::max(1, h->nstrips))) + 1;
+  if (const char* e = std::getenv("CLIPPER_HIP_TILES")) nt = std::max<int64_t>(nt, std::atoll(e));
+  return nt;
 }
 
 // (re)allocate everything for an m x m problem

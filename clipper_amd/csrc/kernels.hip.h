@@ -282,7 +282,8 @@ constexpr int pow2_at_least(int x) {
 
 struct PassPlan {
   int phase;
-  int sel;
+  int sel;     // table of Xin that holds the pending window, or
+  int from_u;  // -1, or (p*V + v): pair-mode pass straight on the u array of point slot (p, v)
   double d;
 };
 
@@ -393,7 +394,11 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
       ubv = jstar;
       ++j_;
       if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
-        need_pair = true;  // the penalty update needs M_off u and C_off u apart (:268, :271)
+        // the penalty update needs M_off u and C_off u apart (:268, :271): this iteration runs
+        // a pair-mode pass straight on the accepted x (already normalised, in its point slot)
+        need_pair = true;
+        fast = true;
+        next_phase = PH_PENALTY;
       } else {
         alpha = 1.0;  // :227
         k_ = 0;
@@ -551,21 +556,6 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
       break;
     }
 
-    if (!finished && need_pair) {
-      // the next pass runs in pair mode on x = u (normalised): candidate 0 of table 0
-      const double* u = pt_arr(A, V, ubp, ubv, 0);
-      VEC_CHUNKS(base) {
-        double uv[VU];
-        VEC_EACH(k, i, base) uv[k] = u[i];
-        VEC_EACH(k, i, base) {
-          const double row[VS] = {uv[k], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-          store_row(A.Xout + i * VS, row);
-        }
-      }
-      sel = 0;
-      next_phase = PH_PENALTY;
-    }
-
     if (!finished && need_window) {
       // :235-236 for alpha = 1, beta, beta^2, ... — gradient step and projection of the whole
       // window; normalisation is deferred (nrm)
@@ -667,8 +657,9 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
   }
   // the decision came out of LDS reads: tell the compiler it is wave-uniform, so that the
   // multipliers of the streaming loop stay scalar loads
-  plan.phase = PH_TRIAL;
+  plan.phase = __builtin_amdgcn_readfirstlane(next_phase);
   plan.sel = __builtin_amdgcn_readfirstlane(sel);
+  plan.from_u = __builtin_amdgcn_readfirstlane(need_pair ? ubp * V + ubv : -1);
   plan.d = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(d)),
                             __builtin_amdgcn_readfirstlane(__double2loint(d)));
   return fast;
@@ -687,6 +678,7 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
   // the pass was prepared by a transition iteration (or by k_init): run it as it stands
   plan.phase = st->phase;
   plan.sel = st->sel;
+  plan.from_u = -1;
   plan.d = st->d;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     *stash = *st;
@@ -957,8 +949,9 @@ __device__ __forceinline__ void row_pair(const typename Vec4<T>::type& mv,
 template <typename T, bool HASC, bool WINDOW, int NS, int NSLOT, int NW, int UNR>
 __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __restrict__ Cs,
                                           int64_t ld, int64_t m, int rows_per_tile, double d,
-                                          const double* __restrict__ Xg,
+                                          const double* __restrict__ Xg, int xstride,
                                           double* __restrict__ part, double* lds) {
+  // X[row * xstride + v]: a table (xstride = VS) or, pair mode only, a plain vector (1)
   const const_f64_ptr X = (const_f64_ptr)Xg;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -987,7 +980,7 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
 #pragma unroll
       for (int q = 0; q < UNR; ++q) {
         if constexpr (WINDOW) row_window<T, HASC, NS>(mv[q], cv[HASC ? q : 0], d, X + (r + q) * VS, acc);
-        else row_pair<T, HASC>(mv[q], cv[HASC ? q : 0], X[(r + q) * VS], acc);
+        else row_pair<T, HASC>(mv[q], cv[HASC ? q : 0], X[(r + q) * xstride], acc);
       }
     }
     // tail rows of this wave's last chunk
@@ -997,7 +990,7 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
         const typename Vec4<T>::type mv = load4(p + rr * ld);
         const typename Vec4<T>::type cv = load4(pc + rr * ld);
         if constexpr (WINDOW) row_window<T, HASC, NS>(mv, cv, d, X + rr * VS, acc);
-        else row_pair<T, HASC>(mv, cv, X[rr * VS], acc);
+        else row_pair<T, HASC>(mv, cv, X[rr * xstride], acc);
       }
     }
   }
@@ -1027,16 +1020,22 @@ constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * 256 + 2; }  // + the arriva
 template <typename T, bool HASC, int V, int NW, int UNR>
 __device__ __forceinline__ void gemv_by_plan(const T* __restrict__ S, const T* __restrict__ Cs,
                                              int64_t ld, int64_t m, int rows_per_tile,
-                                             const double* __restrict__ Xtab, int64_t mp,
+                                             const double* __restrict__ Xtab,
+                                             const double* __restrict__ pt, int64_t mp,
                                              double* __restrict__ part, const PassPlan& plan,
                                              double* lds) {
-  const double* X = Xtab + static_cast<int64_t>(plan.sel) * mp * VS;
   if (plan.phase == PH_TRIAL) {
-    gemv_core<T, HASC, true, V, nslot(V), NW, UNR>(S, Cs, ld, m, rows_per_tile, plan.d, X, part,
-                                                   lds);
+    gemv_core<T, HASC, true, V, nslot(V), NW, UNR>(
+        S, Cs, ld, m, rows_per_tile, plan.d, Xtab + static_cast<int64_t>(plan.sel) * mp * VS, VS,
+        part, lds);
+  } else if (plan.from_u >= 0) {  // the u array of a point slot, see pt_arr
+    gemv_core<T, HASC, false, 2, nslot(V), NW, UNR>(
+        S, Cs, ld, m, rows_per_tile, 0.0, pt + static_cast<int64_t>(plan.from_u) * 2 * mp, 1,
+        part, lds);
   } else {
-    gemv_core<T, HASC, false, 2, nslot(V), NW, UNR>(S, Cs, ld, m, rows_per_tile, 0.0, X, part,
-                                                    lds);
+    gemv_core<T, HASC, false, 2, nslot(V), NW, UNR>(
+        S, Cs, ld, m, rows_per_tile, 0.0, Xtab + static_cast<int64_t>(plan.sel) * mp * VS, VS,
+        part, lds);
   }
 }
 
@@ -1051,8 +1050,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv(const T* __restrict__ 
   __shared__ SolverState stash;
   PassPlan plan;
   if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
-  gemv_by_plan<T, HASC, V, NW, UNR>(S, Cs, A.W, A.m, rows_per_tile, A.Xin, A.mp, A.part, plan,
-                                    lds);
+  gemv_by_plan<T, HASC, V, NW, UNR>(S, Cs, A.W, A.m, rows_per_tile, A.Xin, A.pt, A.mp, A.part,
+                                    plan, lds);
   flush_state(A, &stash);
 }
 
@@ -1071,7 +1070,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ 
   PassPlan plan;
   if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
   const int64_t ld = A.W;
-  gemv_by_plan<T, HASC, V, NW, UNR>(S, Cs, ld, A.m, rows_per_tile, A.Xin, A.mp, A.part, plan, lds);
+  gemv_by_plan<T, HASC, V, NW, UNR>(S, Cs, ld, A.m, rows_per_tile, A.Xin, A.pt, A.mp, A.part,
+                                    plan, lds);
   flush_state(A, &stash);
   int* flag = reinterpret_cast<int*>(lds + GEMV_LDS_DOUBLES(NW) - 1);
   if (!arrive_last(A.cnt + blockIdx.x, gridDim.y, flag)) return;
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_plain(const T* __restr
                                                                  const double* __restrict__ X,
                                                                  double* __restrict__ part) {
   __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
-  gemv_core<T, HASC, false, 2, 2, NW, UNR>(S, Cs, ld, m, rows_per_tile, 0.0, X, part, lds);
+  gemv_core<T, HASC, false, 2, 2, NW, UNR>(S, Cs, ld, m, rows_per_tile, 0.0, X, VS, part, lds);
 }
 
 // k_reduce — adds the row-tile partials in tile order and writes this shard's block of the

@@ -108,7 +108,9 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
                     u, g = slot_u[jstar].copy(), slot_g[jstar].copy()
                     j_ += 1
                     if deltau < P.tol_u or abs(deltaF) < P.tol_F or j_ >= P.maxiniters:
-                        need_pair = True
+                        # pair-mode pass straight on the accepted x (its point slot), same iteration
+                        need_pair = fast = True
+                        phase = PH_PENALTY
                     else:
                         alpha, k_ = 1.0, 0
                         sel, nrm, sx = jstar, sums["nrm"][jstar], sums["sx"][jstar]
@@ -164,12 +166,6 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
                     break
                 if finished:
                     return Result(u, F, d, i_, n_passes, n_trials, n_iters, accepted)
-                if need_pair:
-                    tab = np.zeros((m, V))
-                    tab[:, 0] = u
-                    new_tables = {0: tab}
-                    sel, nrm = 0, np.ones(V)
-                    next_phase = PH_PENALTY
                 if need_window:
                     tab, nrm, sx = build_window(u, g, alpha)
                     new_tables = {0: tab}
@@ -183,7 +179,8 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
         n_passes += 1
         X = tables[sel]
         if phase != PH_TRIAL:                       # pair mode, candidate 0 (nrm = 1)
-            a, b = Moff @ X[:, 0], Coff @ X[:, 0]
+            x = u if phase == PH_PENALTY else X[:, 0]
+            a, b = Moff @ x, Coff @ x
             results_pending = True
             continue
         W = Moff + d * Coff                         # window mode
