@@ -163,6 +163,8 @@ struct clipper_hip_ctx {
   int staged_d = 0;          // dimension of the staged point tables (0 = nothing staged)
   double staged_maxabs = 0;  // max |coordinate| of D1, D2: bounds the fp32 prefilter's error
   bool plain_affinity = false;  // CLIPPER_HIP_AFFINITY=plain: non-compacting fill kernels
+  bool strip_affinity = false;  // CLIPPER_HIP_AFFINITY=strip: compacting strip kernels even where
+                                // the symmetric tile kernel applies (one shard, fp32 storage)
   int64_t staged_pstride = 0;
   bool u0_staged = false;
   int ntiles = 1, rows_per_tile = 0, nstrips = 0;
@@ -717,6 +719,7 @@ int stage_inputs(Ctx* h, const double* D1, int d, int64_t n1, const double* D2, 
   h->staged_maxabs = mx;
   const char* mode = std::getenv("CLIPPER_HIP_AFFINITY");
   h->plain_affinity = (mode && std::strcmp(mode, "plain") == 0);
+  h->strip_affinity = (mode && std::strcmp(mode, "strip") == 0);
   return 0;
 }
 
@@ -729,6 +732,33 @@ float guarded_threshold(double eps, double maxabs, int d) {
   const double t = eps + guard;
   if (!(t < 3.0e38)) return std::numeric_limits<float>::infinity();
   return std::nextafter(static_cast<float>(t), std::numeric_limits<float>::infinity());
+}
+
+// E^2 for the square-root-free prefilter of k_affinity_sym, rounded up
+float guarded_threshold_sq(float E) {
+  if (!(E < 1.0e19f)) return std::numeric_limits<float>::infinity();
+  const double e2 = static_cast<double>(E) * static_cast<double>(E);
+  return std::nextafter(static_cast<float>(e2), std::numeric_limits<float>::infinity());
+}
+
+bool use_sym_fill(const Ctx* h) {
+  return !h->plain_affinity && !h->strip_affinity && h->world == 1 && !h->multiproc &&
+         h->storage == CLIPPER_HIP_STORE_F32;
+}
+
+// k_affinity_sym needs more dynamic LDS than the 64 KiB a kernel gets by default
+template <typename K>
+void launch_sym(K kernel, dim3 grid, hipStream_t stream, float* S, int64_t W, int64_t mm, int nT,
+                const Shard& s, int64_t pstride, const int32_t* A0, const int32_t* A1,
+                const EuclidParams& e, const PointNormalParams& n, float E2) {
+  static std::vector<const void*> raised;  // once per kernel instantiation and device
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  if (std::find(raised.begin(), raised.end(), fn) == raised.end()) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, AT_SYM_LDS_BYTES);
+    raised.push_back(fn);
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(AT_WAVES * 64), AT_SYM_LDS_BYTES, stream, S, W, mm, nT, s.P1, s.P2,
+                     s.P1f, s.P2f, pstride, A0, A1, e, n, E2);
 }
 
 template <typename Launch>
@@ -900,6 +930,19 @@ int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double
                      static_cast<T*>(s.S), W, mm, c0, AFF_ROWS_PER_BLK, s.P1, s.P2, s.P1f,  \
                      s.P2f, pstride, A0, A1, prm, thr)
     const float thr = guarded_threshold(epsilon, h->staged_maxabs, d);
+    if (use_sym_fill(h) && (d == 2 || d == 3)) {
+      const int nT = static_cast<int>(ceil_div(mm, AT));
+      dim3 g(static_cast<unsigned>(static_cast<int64_t>(nT) * (nT + 1) / 2));
+      const PointNormalParams none{};
+      const float E2 = guarded_threshold_sq(thr);
+      if (d == 3)
+        launch_sym(k_affinity_sym<3, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
+                   pstride, A0, A1, prm, none, E2);
+      else
+        launch_sym(k_affinity_sym<2, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
+                   pstride, A0, A1, prm, none, E2);
+      return;
+    }
     const bool compact = !h->plain_affinity && (d == 2 || d == 3);
     if (h->storage == CLIPPER_HIP_STORE_F64) {
       if (compact && d == 3) LAUNCH_EUCLID_COMPACT(double, 3);
@@ -932,6 +975,14 @@ int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, doubl
         block(256);
     const int64_t c0 = static_cast<int64_t>(s.slot) * W;
     const float thr = guarded_threshold(epsp, h->staged_maxabs, 3);
+    if (use_sym_fill(h)) {
+      const int nT = static_cast<int>(ceil_div(mm, AT));
+      dim3 g(static_cast<unsigned>(static_cast<int64_t>(nT) * (nT + 1) / 2));
+      const EuclidParams none{};
+      launch_sym(k_affinity_sym<3, true>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
+                 pstride, s.Adev, s.Adev + mm, none, prm, guarded_threshold_sq(thr));
+      return;
+    }
     if (h->plain_affinity) {
       if (h->storage == CLIPPER_HIP_STORE_F64)
         hipLaunchKernelGGL((k_affinity_pointnormal<double>), grid, block, 0, s.stream,

@@ -1629,6 +1629,179 @@ __global__ __launch_bounds__(256) void k_affinity_pointnormal_compact(
 }
 
 // ------------------------------------------------------------------------------------------
+// Symmetric fill (one shard, fp32 storage): M is symmetric and the score of (i, j) is bit-equal
+// to the score of (j, i) (squares and absolute differences only), so only the 128 x 128 tiles
+// of the upper block triangle are evaluated — prefilter and exact scores cost half — and every
+// off-diagonal tile leaves twice: as it stands, and transposed out of an LDS image with an odd
+// row pitch (bank-conflict-free column reads), both as 512-byte row segments.
+// The prefilter needs no square root: |l1 - l2| < E  <=>  t <= 0  or  t^2 < 4 s1 s2 with
+// t = s1 + s2 - E^2 (s = squared lengths, E = the guarded threshold); the right-hand side
+// carries a 2^-18 relative margin for the fp32 roundings of t, t^2 and s1 s2. Survivors get the
+// same exact fp64 evaluation as in the other fill kernels: identical bits.
+// Geometry: 8 waves; wave w owns tile rows [16w, 16w + 16), lane l tile columns 2l, 2l + 1.
+// ------------------------------------------------------------------------------------------
+
+constexpr int AT = 128;           // tile edge
+constexpr int AT_PITCH = AT + 1;  // LDS image row pitch in floats
+#ifndef CLIPPER_AT_WAVES
+#define CLIPPER_AT_WAVES 8
+#endif
+constexpr int AT_WAVES = CLIPPER_AT_WAVES;       // waves per workgroup
+constexpr int AT_ROWS_PER_WAVE = AT / AT_WAVES;  // tile rows a wave owns
+constexpr int AT_QUEUE = 256;     // ring entries per wave: < 64 waiting + one row's 128 candidates
+constexpr int AT_SYM_IMG_BYTES = (AT * AT_PITCH * 4 + 15) / 16 * 16;
+constexpr int AT_SYM_LDS_BYTES = AT_SYM_IMG_BYTES + AT_WAVES * AT_QUEUE * 4;
+
+// linear index t of the upper block triangle (row-major: (0,0) (0,1) ... (1,1) ...) -> (I, J)
+__device__ __forceinline__ void tile_of(int t, int nT, int& I, int& J) {
+  const float b = 2.0f * nT + 1.0f;
+  int i = static_cast<int>((b - sqrtf(b * b - 8.0f * static_cast<float>(t))) * 0.5f);
+  if (i < 0) i = 0;
+  if (i > nT - 1) i = nT - 1;
+  // first(i) = i*nT - i*(i-1)/2 is the index of tile (i, i); fix the float estimate
+  while (i > 0 && i * nT - i * (i - 1) / 2 > t) --i;
+  while (i + 1 < nT && (i + 1) * nT - (i + 1) * i / 2 <= t) ++i;
+  I = i;
+  J = i + (t - (i * nT - i * (i - 1) / 2));
+}
+
+template <int D, bool POINTNORMAL>
+__global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
+    float* __restrict__ S, int64_t ld, int64_t m, int nT, const double* __restrict__ P1,
+    const double* __restrict__ P2, const float* __restrict__ P1f, const float* __restrict__ P2f,
+    int64_t pstride, const int32_t* __restrict__ A0, const int32_t* __restrict__ A1,
+    EuclidParams eprm, PointNormalParams nprm, float E2 /* guarded threshold squared, rounded up */) {
+  // 72.5 KiB of dynamic LDS (two workgroups per CU fit the 160 KiB): the image, then the queues
+  extern __shared__ __attribute__((aligned(16))) char sym_smem[];
+  float* img = reinterpret_cast<float*>(sym_smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* queue = reinterpret_cast<uint32_t*>(sym_smem + AT_SYM_IMG_BYTES) + wave * AT_QUEUE;
+  int I, J;
+  tile_of(blockIdx.x, nT, I, J);
+  const int64_t r0 = static_cast<int64_t>(I) * AT, c0 = static_cast<int64_t>(J) * AT;
+  const double affinityeps = POINTNORMAL ? nprm.affinityeps : eprm.affinityeps;
+
+  // this lane's two columns (fp32 copies for the prefilter)
+  bool validc[2];
+  int32_t a0c[2], a1c[2];
+  float p1c[2][D], p2c[2][D];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int64_t g = c0 + 2 * lane + q;
+    validc[q] = g < m;
+    const int64_t gi = validc[q] ? g : (m - 1);
+    a0c[q] = A0[gi];
+    a1c[q] = A1[gi];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      p1c[q][k] = P1f[k * pstride + gi];
+      p2c[q][k] = P2f[k * pstride + gi];
+    }
+  }
+  // zero this wave's rows of the image
+#pragma unroll 4
+  for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
+    float* row = img + (wave * AT_ROWS_PER_WAVE + rr) * AT_PITCH;
+    row[2 * lane] = 0.f;
+    row[2 * lane + 1] = 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // exact fp64 score of queue entries [head, head + n), scattered into the image
+  auto drain = [&](uint32_t head, uint32_t n) {
+    if (lane < n) {
+      const uint32_t code = queue[(head + lane) & (AT_QUEUE - 1)];
+      const int rl = static_cast<int>(code >> 8);
+      const int cl = static_cast<int>(code & 0xffu);
+      double scr;
+      if (POINTNORMAL) scr = exact_pointnormal_score<float>(P1, P2, pstride, r0 + rl, c0 + cl, nprm);
+      else scr = exact_euclid_score<float, D>(P1, P2, pstride, r0 + rl, c0 + cl, eprm);
+      img[rl * AT_PITCH + cl] = store_score<float>(scr, affinityeps);
+    }
+  };
+
+  // The survivors of the fp32 prefilter go into a per-wave ring; whenever 64 are waiting they are
+  // evaluated by a full wave (the exact score is ~150 fp64-rate instructions: no idle lanes).
+  uint32_t head = 0, tail = 0;  // wave-uniform
+  for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
+    const int rl = wave * AT_ROWS_PER_WAVE + rr;  // tile row
+    const int64_t r = r0 + rl;
+    if (r < m) {  // uniform
+      const int32_t a0r = A0[r], a1r = A1[r];
+      float p1r[D], p2r[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        p1r[k] = P1f[k * pstride + r];
+        p2r[k] = P2f[k * pstride + r];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float t1 = p1r[k] - p1c[q][k];
+          const float t2 = p2r[k] - p2c[q][k];
+          s1 = fmaf(t1, t1, s1);
+          s2 = fmaf(t2, t2, s2);
+        }
+        const float t = (s1 + s2) - E2;
+        const bool close = (t <= 0.f) || (t * t < (4.0f * 1.0000038147f) * (s1 * s2));
+        // clipper.cpp:35-38 distinctness (also removes the diagonal) + conservative c < eps
+        const bool cand = validc[q] && (a0r != a0c[q]) && (a1r != a1c[q]) && close;
+        const uint64_t mask = __ballot(cand);
+        if (mask != 0) {  // uniform
+          if (cand) queue[(tail + lane_prefix(mask)) & (AT_QUEUE - 1)] =
+              (static_cast<uint32_t>(rl) << 8) | static_cast<uint32_t>(2 * lane + q);
+          tail += static_cast<uint32_t>(__popcll(mask));
+        }
+      }
+      if (tail - head >= 64) {  // uniform
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        while (tail - head >= 64) {
+          drain(head, 64);
+          head += 64;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  while (head < tail) {
+    const uint32_t n = (tail - head < 64) ? tail - head : 64;
+    drain(head, n);
+    head += n;
+  }
+  __syncthreads();
+
+  // ---- the tile as it stands: this wave's rows, 512-byte segments -----------------------------
+  if (c0 + 2 * lane < ld) {
+    for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
+      const int rl = wave * AT_ROWS_PER_WAVE + rr;
+      const int64_t r = r0 + rl;
+      if (r < m) {
+        const float* row = img + rl * AT_PITCH + 2 * lane;
+        *reinterpret_cast<float2*>(S + r * ld + c0 + 2 * lane) = make_float2(row[0], row[1]);
+      }
+    }
+  }
+  // ---- and transposed: rows c0 + ... receive the tile's columns ------------------------------
+  if (I != J && r0 + 2 * lane < ld) {
+    for (int cc = 0; cc < AT_ROWS_PER_WAVE; ++cc) {
+      const int cl = wave * AT_ROWS_PER_WAVE + cc;
+      const int64_t c = c0 + cl;
+      if (c < m) {
+        const float v0 = img[(2 * lane) * AT_PITCH + cl];
+        const float v1 = img[(2 * lane + 1) * AT_PITCH + cl];
+        *reinterpret_cast<float2*>(S + c * ld + r0 + 2 * lane) = make_float2(v0, v1);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // matrix upload (setMatrixData / setSparseMatrixData) — clipper.cpp:149-166
 // ------------------------------------------------------------------------------------------
 

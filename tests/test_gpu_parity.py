@@ -445,3 +445,51 @@ def test_window_sharded(monkeypatch, V):
         assert s.nodes.tolist() == s1.nodes.tolist() and s.n_passes == s1.n_passes
         assert s.n_trials == s1.n_trials
         assert abs(s.score - s1.score) <= 1e-12 * abs(s1.score)
+
+
+# ------------------------------------------------------------------------------------------
+# affinity fill variants: the symmetric tile kernel (one shard, fp32: upper block triangle +
+# transposed copies), the compacting strip kernels and the plain kernels must write the same bits
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("m", [1, 2, 63, 127, 128, 129, 255, 257, 1037, 2049])
+def test_fill_kernels_agree_bitwise(monkeypatch, m):
+    rho = 0.8 if m > 20 else 0.0
+    p = synth.make_euclidean_problem(m, rho, seed=100 + m)
+    mats = {}
+    for mode in ("sym", "strip", "plain"):
+        if mode == "sym":
+            monkeypatch.delenv("CLIPPER_HIP_AFFINITY", raising=False)
+        else:
+            monkeypatch.setenv("CLIPPER_HIP_AFFINITY", mode)
+        g = abi.HipClipper(storage=abi.STORE_F32)
+        g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+        mats[mode] = g.get_affinity_matrix()
+        g.close()
+    monkeypatch.delenv("CLIPPER_HIP_AFFINITY", raising=False)
+    assert np.array_equal(mats["sym"], mats["strip"])
+    assert np.array_equal(mats["sym"], mats["plain"])
+    assert np.array_equal(mats["sym"], mats["sym"].T)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    Mr = r.get_affinity_matrix()
+    assert np.array_equal(mats["sym"] != 0, Mr != 0)
+    assert np.max(np.abs(mats["sym"] - Mr.astype(np.float32).astype(np.float64)), initial=0.0) <= 1.2e-7
+
+
+def test_fill_kernels_agree_bitwise_pointnormal(monkeypatch):
+    p = synth.make_pointnormal_problem(1500, 0.85, seed=5)
+    inv = p.meta["invariant"]
+    mats = {}
+    for mode in ("sym", "strip", "plain"):
+        if mode == "sym":
+            monkeypatch.delenv("CLIPPER_HIP_AFFINITY", raising=False)
+        else:
+            monkeypatch.setenv("CLIPPER_HIP_AFFINITY", mode)
+        g = abi.HipClipper(storage=abi.STORE_F32)
+        g.score_pairwise_consistency_pointnormal(p.D1, p.D2, p.A, **inv)
+        mats[mode] = g.get_affinity_matrix()
+        g.close()
+    monkeypatch.delenv("CLIPPER_HIP_AFFINITY", raising=False)
+    assert np.array_equal(mats["sym"], mats["strip"])
+    assert np.array_equal(mats["sym"], mats["plain"])
