@@ -294,7 +294,7 @@ int ensure_problem(Ctx* h, int64_t m) {
     }
     HIPCHK(hipMalloc(&s.cnt, static_cast<size_t>(h->nstrips) * sizeof(int)));
     HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(h->nstrips) * sizeof(int), s.stream));
-    const size_t Q = V * (2 + 2 * V) + 2 * V;
+    const size_t Q = V * (2 + 2 * V) + 2 * V + 2;
     HIPCHK(hipMalloc(&s.scal, static_cast<size_t>(ceil_div(m, TAIL_THREADS)) * Q * sizeof(double)));
     HIPCHK(hipMalloc(&s.ab, NSLOT * nvec));
     HIPCHK(hipMemsetAsync(s.ab, 0, NSLOT * nvec, s.stream));

@@ -61,17 +61,21 @@ namespace clipper_hip {
 // ------------------------------------------------------------------------------------------
 
 constexpr int VS = 8;       // doubles per table row; window sizes V <= VS
-constexpr int nslot(int V) { return V < 2 ? 2 : V; }  // partial-sum slots per row tile: V candidates, or (a, b)
+// partial-sum slots per row tile: slot 0 = a = M_off x_0, slots 1..V-1 = g_v of the other
+// candidates, slot V = b = C_off x_0 (a pair-mode pass fills slots 0 and V only)
+constexpr int nslot(int V) { return V + 1; }
 
 enum Phase : int32_t {
   PH_NORMALIZE = 0,  // no rescale: u = u0/||u0||, no pass consumed       (clipper.cpp:196-198)
   PH_RESCALE = 1,    // pass on x = u0: u = M_off u0 + u0, normalise      (clipper.cpp:193-198)
   PH_INIT = 2,       // pass on x = u: initial d, first gradient          (clipper.cpp:200-220)
   PH_TRIAL = 3,      // pass on a window of trial vectors                 (clipper.cpp:234-262)
-  PH_PENALTY = 4     // pass on x = the inner loop's final u: penalty update (:268-280)
+  PH_PENALTY = 4,    // pass on x = the inner loop's final u: penalty update (:268-280)
+  PH_BUILD = 5       // no pass: the tail forms gradF, F and the first window of an outer
+                     // iteration from (u, a, b) and the new penalty (:219-220, :235-236)
 };
-// PH_TRIAL passes run the mat-vec in window mode (g_v = (M_off + d*C_off) x_v), all others in
-// pair mode (a = M_off x, b = C_off x of candidate 0) — see k_gemv.
+// PH_TRIAL passes run the mat-vec in window mode (candidate 0: a and b apart, the others
+// g_v = (M_off + d*C_off) x_v), all others in pair mode (a, b of candidate 0) — see k_gemv.
 
 enum Stage : int32_t {
   ST_PASS = 0,     // the tables hold the pending vectors of `phase`: run the pass
@@ -139,16 +143,16 @@ struct SolveArgs {
   int64_t mp;   // rows of a candidate table / pitch of a point-slot array (>= m)
   const double* u0;
   double* pt;   // point slots [2][V][2][mp]: u, gradF
-  double* cab;  // [2][mp]: a = M_off x, b = C_off x of the last pair-mode pass
+  double* cab;  // [2][mp]: a = M_off x, b = C_off x of the last pair-mode pass / of candidate 0
   // candidate tables [V+1][mp][VS]. Iteration k READS the pending window from Xin and WRITES
   // the windows of every outcome to Xout; the host swaps the two from iteration to iteration.
   const double* Xin;
   double* Xout;
-  double* ab;     // column-sharded M: gathered RAW sums [P][NSLOT][W], NSLOT = max(V, 2)
+  double* ab;     // column-sharded M: gathered RAW sums [P][NSLOT][W], NSLOT = V + 1
   double* part;   // [ntiles][NSLOT][W] row-tile partials of this shard
   int ntiles;
   int slot;       // this shard's block of `ab`
-  double* scal;   // [nwg][Q] partial scalars of the tail, Q = V*(2+2V) + 2V
+  double* scal;   // [nwg][Q] partial scalars of the tail, Q = V*(2+2V) + 2V + 2
   int nwg;        // tail workgroups per candidate = ceil(m / TAIL_THREADS)
   int* cnt;       // column-sharded M: one arrival counter per column strip
   int nstrips;
@@ -297,12 +301,13 @@ template <int V, int NT>
 __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverState* stash,
                                        PassPlan& plan) {
   constexpr int NR = 2 + 2 * V;
-  constexpr int Q = V * NR + 2 * V;
+  constexpr int PEN = V * NR + 2 * V;  // speculative penalty sums of candidate 0
+  constexpr int Q = PEN + 2;
   constexpr int QPAD = pow2_at_least(Q);
   constexpr int NCH = NT / QPAD;  // interleaved summation chains per quantity
   constexpr int NWV = NT / 64;
   static_assert(QPAD <= NT && V <= VS, "window too large");
-  double* scratch = red + NT;     // block_reduce scratch, NWV * 2V doubles at most
+  double* scratch = red + NT;     // block_reduce scratch, NWV * 2 doubles at most
   const SolverState* st = A.st_cur;
   const int tid = threadIdx.x;
   const int64_t m = A.m;
@@ -314,19 +319,19 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
   int i_ = st->i, j_ = st->j, k_ = st->k, ubp = st->ubp, ubv = st->ubv, sel = st->sel;
   int64_t n_passes = st->n_passes, n_trials = st->n_trials;
   const int64_t n_iters = st->n_iters + 1;
-  int next_phase = PH_TRIAL;
   double nrm[V], sx[V];
 #pragma unroll
   for (int l = 0; l < V; ++l) {
     nrm[l] = 1.0;
     sx[l] = 0.0;
   }
-  bool begin_outer = false, penalty = false, finished = false;
-  bool need_window = false;  // a sweep must build the window from (u, g): after a transition
-  bool need_pair = false;    // a pair-mode pass on u must come first: end of an inner loop
-  bool fast = false;         // the pending window is one of the tables the tail already built
+  // what this iteration does next
+  enum { ACT_PASS, ACT_BUILD, ACT_SLOW, ACT_DONE };
+  int action = ACT_SLOW;
+  int next_phase = PH_TRIAL;
+  bool need_pair = false;  // the pass of this iteration is a pair-mode pass on the accepted x
 
-  if (phase == PH_TRIAL) {
+  if (phase == PH_TRIAL || phase == PH_BUILD) {
     // sums[q] = sum over the tail workgroups w of scal[w][q]: NCH interleaved chains per
     // quantity (w = c, c + NCH, ...), added in chain order
     {
@@ -358,69 +363,99 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
       __syncthreads();
     }
     const double* sums = red;
-    int jstar = -1;
-    double Fnew = 0.0, deltaF = 0.0;
+    if (phase == PH_TRIAL) {
+      // the decisions of clipper.cpp:244-262, candidate by candidate
+      int jstar = -1;
+      double Fnew = 0.0, deltaF = 0.0;
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      if (jstar < 0) {
-        ++n_trials;
-        Fnew = sums[v * NR + 0];
-        deltaF = Fnew - F;  // :244
-        bool accept = true;
-        if (deltaF < -P.eps) {  // :246-248
-          alpha = alpha * P.beta;
-          ++k_;
-          if (k_ < P.maxlsiters) accept = false;  // :234 loop bound; the last trial is kept
+      for (int v = 0; v < V; ++v) {
+        if (jstar < 0) {
+          ++n_trials;
+          Fnew = sums[v * NR + 0];
+          deltaF = Fnew - F;  // :244
+          bool accept = true;
+          if (deltaF < -P.eps) {  // :246-248
+            alpha = alpha * P.beta;
+            ++k_;
+            if (k_ < P.maxlsiters) accept = false;  // :234 loop bound; the last trial is kept
+          }
+          if (accept) jstar = v;
         }
-        if (accept) jstar = v;
       }
-    }
-    if (jstar < 0) {
-      // all V candidates rejected: the v = 0 tail already built the next V step sizes from
-      // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
-      sel = V;
-      fast = true;
-#pragma unroll
-      for (int l = 0; l < V; ++l) {
-        const double z = sums[V * NR + 2 * l];
-        nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
-        sx[l] = sums[V * NR + 2 * l + 1] / nrm[l];
-      }
-    } else {
-      const double deltau = sqrt(sums[jstar * NR + 1]);
-      s = st->sx[jstar];
-      F = Fnew;  // :256-258 — u <- x, gradF <- gradFnew: the point slot the tail filled
-      ubp ^= 1;
-      ubv = jstar;
-      ++j_;
-      if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
-        // the penalty update needs M_off u and C_off u apart (:268, :271): this iteration runs
-        // a pair-mode pass straight on the accepted x (already normalised, in its point slot)
-        need_pair = true;
-        fast = true;
-        next_phase = PH_PENALTY;
-      } else {
-        alpha = 1.0;  // :227
-        k_ = 0;
-        sel = jstar;  // the tail already built max(x + beta^l gradFnew, 0) in table jstar
-        fast = true;
+      if (jstar < 0) {
+        // all V candidates rejected: the v = 0 tail already built the next V step sizes from
+        // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
+        sel = V;
+        action = ACT_PASS;
 #pragma unroll
         for (int l = 0; l < V; ++l) {
-          const double z = sums[jstar * NR + 2 + 2 * l];
+          const double z = sums[V * NR + 2 * l];
+          nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
+          sx[l] = sums[V * NR + 2 * l + 1] / nrm[l];
+        }
+      } else {
+        const double deltau = sqrt(sums[jstar * NR + 1]);
+        s = st->sx[jstar];
+        F = Fnew;  // :256-258 — u <- x, gradF <- gradFnew: the point slot the tail filled
+        ubp ^= 1;
+        ubv = jstar;
+        ++j_;
+        if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
+          // end of the inner loop: the penalty update (:268-280) needs M_off u and C_off u apart
+          if (jstar == 0) {
+            // candidate 0 carries them (cab) and the tail already summed its penalty terms
+            const double cnt = sums[PEN], rs = sums[PEN + 1];
+            if (cnt > 0.0) {
+              d += rs / cnt;  // :276
+              ++i_;           // :218 loop increment
+              action = (i_ >= P.maxoliters) ? ACT_DONE : ACT_BUILD;
+            } else {
+              action = ACT_DONE;  // :278-280 break
+            }
+          } else {
+            // pair-mode pass straight on the accepted x (already normalised, in its point slot)
+            need_pair = true;
+            action = ACT_PASS;
+            next_phase = PH_PENALTY;
+          }
+        } else {
+          alpha = 1.0;  // :227
+          k_ = 0;
+          sel = jstar;  // the tail already built max(x + beta^l gradFnew, 0) in table jstar
+          action = ACT_PASS;
+#pragma unroll
+          for (int l = 0; l < V; ++l) {
+            const double z = sums[jstar * NR + 2 + 2 * l];
+            nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
+            sx[l] = sums[jstar * NR + 3 + 2 * l] / nrm[l];
+          }
+        }
+      }
+    } else {  // PH_BUILD: the tail formed gradF, F and the first window of an outer iteration
+      F = sums[0];  // :220
+      j_ = 0;
+      if (P.maxiniters <= 0) {
+        action = ACT_SLOW;  // empty inner loop: u unchanged, its (a, b) in cab are still valid
+      } else {
+        alpha = 1.0;
+        k_ = 0;
+        sel = 0;
+        action = ACT_PASS;
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          const double z = sums[2 + 2 * l];
           nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
-          sx[l] = sums[jstar * NR + 3 + 2 * l] / nrm[l];
+          sx[l] = sums[3 + 2 * l] / nrm[l];
         }
       }
     }
   }
 
-  if (!fast) {
-    // ---- transition iteration: workgroup (0,0) alone -------------------------------------
+  if (action == ACT_SLOW) {
+    // ---- sweeps over whole vectors: workgroup (0,0) alone -----------------------------------
     if (!writer) return false;
-    const double* ca_ = A.cab;         // a = M_off x of the last pair-mode pass
+    const double* ca_ = A.cab;         // a = M_off x of the last pair-mode pass / of candidate 0
     const double* cb_ = A.cab + A.mp;  // b = C_off x
-    bool to_init = false;
-
     if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
       // clipper.cpp:193-198 — u = M_off*u0 + u0 (or u0), then u /= u.norm()
       double* u = pt_arr(A, V, ubp, ubv, 0);
@@ -451,47 +486,42 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
         }
       }
       sel = 0;
-      next_phase = PH_INIT;
-      to_init = true;
-    } else if (phase == PH_INIT) {
-      // clipper.cpp:200-209 — initial d from the pair-mode pass on u
-      const double* u = pt_arr(A, V, ubp, ubv, 0);
-      double sv[1] = {0.0};
-      VEC_CHUNKS(base) {
-        double uv[VU];
-        VEC_EACH(k, i, base) uv[k] = u[i];
-        VEC_EACH(k, i, base) sv[0] += uv[k];
-      }
-      block_reduce<1, NWV>(sv, scratch);
-      s = sv[0];
-      double ca[2] = {0.0, 0.0};  // count, sum of ratios
-      VEC_CHUNKS(base) {
-        double uv[VU], av[VU], bv[VU];
-        VEC_EACH(k, i, base) {
-          uv[k] = u[i];
-          av[k] = ca_[i];
-          bv[k] = cb_[i];
+      next_phase = PH_INIT;  // action stays ACT_SLOW: "a pass was prepared", see the record below
+    } else {
+      if (phase == PH_INIT) {
+        // clipper.cpp:200-209 — initial d from the pair-mode pass on u
+        const double* u = pt_arr(A, V, ubp, ubv, 0);
+        double sv[1] = {0.0};
+        VEC_CHUNKS(base) {
+          double uv[VU];
+          VEC_EACH(k, i, base) uv[k] = u[i];
+          VEC_EACH(k, i, base) sv[0] += uv[k];
         }
-        VEC_EACH(k, i, base) {
-          const double cbu = s - bv[k] - uv[k];  // :202
-          if (cbu > P.eps && uv[k] > P.eps) {    // :203
-            ca[0] += 1.0;
-            ca[1] += (av[k] + uv[k]) / cbu;  // :205-208
+        block_reduce<1, NWV>(sv, scratch);
+        s = sv[0];
+        double ca[2] = {0.0, 0.0};  // count, sum of ratios
+        VEC_CHUNKS(base) {
+          double uv[VU], av[VU], bv[VU];
+          VEC_EACH(k, i, base) {
+            uv[k] = u[i];
+            av[k] = ca_[i];
+            bv[k] = cb_[i];
+          }
+          VEC_EACH(k, i, base) {
+            const double cbu = s - bv[k] - uv[k];  // :202
+            if (cbu > P.eps && uv[k] > P.eps) {    // :203
+              ca[0] += 1.0;
+              ca[1] += (av[k] + uv[k]) / cbu;  // :205-208
+            }
           }
         }
-      }
-      block_reduce<2, NWV>(ca, scratch);
-      d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
-      i_ = 0;
-      begin_outer = true;
-    } else if (phase == PH_PENALTY) {
-      penalty = true;  // (a, b) of the inner loop's final u have just arrived
-    }
-
-    // penalty update (:268-280) and the gradient at the start of the next outer iteration
-    // (:219-220), from (a, b) of the last pair-mode pass
-    while (!to_init) {
-      if (penalty) {
+        block_reduce<2, NWV>(ca, scratch);
+        d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
+        i_ = 0;
+        action = (i_ >= P.maxoliters) ? ACT_DONE : ACT_BUILD;  // :218 loop bound
+      } else {
+        // PH_PENALTY (the pair-mode pass on the inner loop's final u has run), or an empty
+        // inner loop: penalty update :268-280
         const double* u = pt_arr(A, V, ubp, ubv, 0);
         double ca[2] = {0.0, 0.0};
         VEC_CHUNKS(base) {
@@ -510,87 +540,13 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
           }
         }
         block_reduce<2, NWV>(ca, scratch);
-        penalty = false;
         if (ca[0] > 0.0) {
           d += ca[1] / ca[0];  // :276
           ++i_;                // :218 loop increment
-          begin_outer = true;
+          action = (i_ >= P.maxoliters) ? ACT_DONE : ACT_BUILD;
         } else {
-          finished = true;  // :278-280 break
-          break;
+          action = ACT_DONE;  // :278-280 break
         }
-      }
-      if (begin_outer) {
-        begin_outer = false;
-        if (i_ >= P.maxoliters) {  // :218 loop bound
-          finished = true;
-          break;
-        }
-        const double* u = pt_arr(A, V, ubp, ubv, 0);
-        double* g = pt_arr(A, V, ubp, ubv, 1);
-        double f[1] = {0.0};
-        VEC_CHUNKS(base) {
-          double uv[VU], av[VU], bv[VU];
-          VEC_EACH(k, i, base) {
-            uv[k] = u[i];
-            av[k] = ca_[i];
-            bv[k] = cb_[i];
-          }
-          VEC_EACH(k, i, base) {
-            const double gi = (1 + d) * uv[k] - d * s + av[k] + bv[k] * d;  // :219
-            g[i] = gi;
-            f[0] += uv[k] * gi;  // :220
-          }
-        }
-        block_reduce<1, NWV>(f, scratch);
-        F = f[0];
-        j_ = 0;
-        if (P.maxiniters <= 0) {
-          penalty = true;  // empty inner loop: u is unchanged, its (a, b) are still valid
-          continue;
-        }
-        alpha = 1.0;
-        k_ = 0;
-        need_window = true;
-      }
-      break;
-    }
-
-    if (!finished && need_window) {
-      // :235-236 for alpha = 1, beta, beta^2, ... — gradient step and projection of the whole
-      // window; normalisation is deferred (nrm)
-      const double* u = pt_arr(A, V, ubp, ubv, 0);
-      const double* g = pt_arr(A, V, ubp, ubv, 1);
-      double zs[2 * V];
-#pragma unroll
-      for (int q = 0; q < 2 * V; ++q) zs[q] = 0.0;
-      VEC_CHUNKS(base) {
-        double uv[VU], gv[VU];
-        VEC_EACH(k, i, base) {
-          uv[k] = u[i];
-          gv[k] = g[i];
-        }
-        VEC_EACH(k, i, base) {
-          double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-          double al = alpha;
-#pragma unroll
-          for (int l = 0; l < V; ++l) {
-            double t = uv[k] + al * gv[k];
-            t = (t > 0.0) ? t : 0.0;
-            row[l] = t;
-            zs[2 * l] += t * t;
-            zs[2 * l + 1] += t;
-            al = al * P.beta;
-          }
-          store_row(A.Xout + i * VS, row);
-        }
-      }
-      block_reduce<2 * V, NWV>(zs, scratch);
-      sel = 0;
-#pragma unroll
-      for (int l = 0; l < V; ++l) {
-        nrm[l] = (zs[2 * l] > 0.0) ? sqrt(zs[2 * l]) : 1.0;
-        sx[l] = zs[2 * l + 1] / nrm[l];
       }
     }
   }
@@ -614,20 +570,21 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
       o->sel = sel;
       o->ubp = ubp;
       o->ubv = ubv;
-      o->phase = next_phase;
-      // fast: this iteration streams the pending window, its results are due next time;
-      // transition: the next iteration runs the pass this one prepared
-      o->stage = fast ? ST_RESULTS : ST_PASS;
+      // ACT_PASS : this iteration streams, its results are due next time
+      // ACT_BUILD: no pass; the tail of this iteration forms gradF, F and the first window
+      // ACT_SLOW : (normalisation) the next iteration runs the pass this one prepared
+      o->phase = (action == ACT_BUILD) ? static_cast<int>(PH_BUILD) : next_phase;
+      o->stage = (action == ACT_SLOW) ? ST_PASS : ST_RESULTS;
       o->i = i_;
       o->j = j_;
       o->k = k_;
-      o->n_passes = n_passes + (fast ? 1 : 0);
+      o->n_passes = n_passes + (action == ACT_PASS ? 1 : 0);
       o->n_trials = n_trials;
       o->n_iters = n_iters;
     };
-    if (fast) record(stash);
+    if (action == ACT_PASS) record(stash);
     else record(A.st_next);
-    if (finished) {
+    if (action == ACT_DONE) {
       SolveShared* sh = A.shared;
       sh->F = F;
       sh->d = d;
@@ -640,7 +597,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
     }
     if (A.host != nullptr) {
       HostMirror* hm = A.host;
-      if (finished) {
+      if (action == ACT_DONE) {
         __hip_atomic_store(&hm->F, F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->d, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->n_passes, n_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -651,7 +608,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
         // every store above (and the vectors this workgroup wrote) before the flag
         __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      if (!fast)
+      if (action != ACT_PASS)
         __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -662,7 +619,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
   plan.from_u = __builtin_amdgcn_readfirstlane(need_pair ? ubp * V + ubv : -1);
   plan.d = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(d)),
                             __builtin_amdgcn_readfirstlane(__double2loint(d)));
-  return fast;
+  return action == ACT_PASS;
 }
 #undef VEC_CHUNKS
 #undef VEC_EACH
@@ -731,22 +688,24 @@ __global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, Sol
 template <int V, bool FUSED_REDUCE>
 __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
   constexpr int NR = 2 + 2 * V;
-  constexpr int Q = V * NR + 2 * V;
+  constexpr int PEN = V * NR + 2 * V;
+  constexpr int Q = PEN + 2;
+  constexpr int NRED = NR + 2 * V + 2;  // what a v = 0 workgroup reduces
   constexpr int NSLOT = nslot(V);
-  __shared__ double red[TAIL_WAVES * (NR + 2 * V)];
+  __shared__ double red[TAIL_WAVES * NRED];
   const int v = blockIdx.y;
   const SolverState* st = A.st_next;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
   const bool valid = i < A.m;
 
-  // raw sums of slot v (and of slot 1 for the v = 0 workgroups: the b of a pair-mode pass):
-  // these loads do not depend on the solver state
+  // raw sums of slot v (and of slot V, the b of candidate 0, for the v = 0 workgroups): these
+  // loads do not depend on the solver state
   double p0 = 0.0, p1 = 0.0;
   if (valid) {
+    const int64_t o1 = (v == 0) ? static_cast<int64_t>(V) * A.W : 0;  // slot V relative to slot 0
     if (FUSED_REDUCE) {  // single shard: W >= m; partials in tile order, 8 tiles in flight
       const double* p = A.part + static_cast<int64_t>(v) * A.W + i;
       const int64_t ts = static_cast<int64_t>(NSLOT) * A.W;
-      const int64_t o1 = (v == 0) ? A.W : 0;  // slot 1 sits one pitch after slot 0
       int t = 0;
       for (; t + 8 <= A.ntiles; t += 8) {
         double va[8], vb[8];
@@ -770,15 +729,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
       const int64_t off = i - static_cast<int64_t>(pb) * A.W;
       const double* blk = A.ab + (static_cast<int64_t>(pb) * NSLOT) * A.W;
       p0 = blk[static_cast<int64_t>(v) * A.W + off];
-      p1 = blk[((v == 0) ? A.W : 0) + off];
+      p1 = blk[o1 + off];
     }
   }
   if (A.shared->done) return;
-  if (st->stage != ST_RESULTS) return;  // transition iteration: no pass was run
+  if (st->stage != ST_RESULTS) return;  // a pass was only prepared: nothing to evaluate
   const int phase = st->phase;
   const int ubp = st->ubp, ubv = st->ubv;
 
-  if (phase != PH_TRIAL) {
+  if (phase != PH_TRIAL && phase != PH_BUILD) {
     // pair-mode passes carry one vector (candidate 0, nrm = 1): a = M_off x, b = C_off x
     if (v == 0 && valid) {
       A.cab[i] = p0;
@@ -786,59 +745,100 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
     }
     return;
   }
-  const double nrmv = st->nrm[v], sxv = st->sx[v];
-  const double d = st->d, alpha = st->alpha, beta = A.prm.beta;
-  double r[NR + 2 * V];
+  const double d = st->d, beta = A.prm.beta;
+  double r[NRED];
 #pragma unroll
-  for (int q = 0; q < NR + 2 * V; ++q) r[q] = 0.0;
-  if (valid) {
-    const double xraw = A.Xin[(static_cast<int64_t>(st->sel) * A.mp + i) * VS + v];
-    const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
-    const double xi = xraw / nrmv;  // clipper.cpp:237
-    const double gs = p0 / nrmv;    // (M_off + d*C_off) x
-    const double gn = (1 + d) * xi - d * sxv + gs;  // :238-241
-    pt_arr(A, V, ubp ^ 1, v, 0)[i] = xi;  // becomes (u, gradF) if candidate v is accepted
-    pt_arr(A, V, ubp ^ 1, v, 1)[i] = gn;
-    r[0] = xi * gn;  // :242
-    const double du = xi - ui;
-    r[1] = du * du;  // :253
-    // next window if candidate v is accepted: alpha = 1, beta, beta^2, ... (:227, :235-236)
-    double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    double al = 1.0;
-#pragma unroll
-    for (int l = 0; l < V; ++l) {
-      double t = xi + al * gn;
-      t = (t > 0.0) ? t : 0.0;
-      row[l] = t;
-      r[2 + 2 * l] = t * t;
-      r[3 + 2 * l] = t;
-      al = al * beta;
-    }
-    store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
-    if (v == 0) {
-      // next window if all V candidates are rejected: V more factors of beta (:248)
-      const double gi = pt_arr(A, V, ubp, ubv, 1)[i];
-      double row2[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      al = alpha;
-#pragma unroll
-      for (int l = 0; l < V; ++l) al = al * beta;
+  for (int q = 0; q < NRED; ++q) r[q] = 0.0;
+
+  if (phase == PH_BUILD) {
+    // start of an outer iteration (clipper.cpp:219-220, :235-236): gradF and F at the current u
+    // under the new penalty, and the first window (alpha = 1, beta, ...) — v = 0 workgroups
+    if (v != 0) return;
+    if (valid) {
+      const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
+      const double gi = (1 + d) * ui - d * st->s + A.cab[i] + A.cab[A.mp + i] * d;  // :219
+      pt_arr(A, V, ubp, ubv, 1)[i] = gi;
+      r[0] = ui * gi;  // :220
+      double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      double al = 1.0;
 #pragma unroll
       for (int l = 0; l < V; ++l) {
         double t = ui + al * gi;
         t = (t > 0.0) ? t : 0.0;
-        row2[l] = t;
-        r[NR + 2 * l] = t * t;
-        r[NR + 2 * l + 1] = t;
+        row[l] = t;
+        r[2 + 2 * l] = t * t;
+        r[3 + 2 * l] = t;
         al = al * beta;
       }
-      store_row(A.Xout + (static_cast<int64_t>(V) * A.mp + i) * VS, row2);
+      store_row(A.Xout + i * VS, row);
+    }
+  } else {
+    const double nrmv = st->nrm[v], sxv = st->sx[v];
+    const double alpha = st->alpha;
+    if (valid) {
+      const double xraw = A.Xin[(static_cast<int64_t>(st->sel) * A.mp + i) * VS + v];
+      const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
+      const double xi = xraw / nrmv;  // clipper.cpp:237
+      double gn;
+      if (v == 0) {
+        // candidate 0: a and b apart, exactly the reference's expression (:238-241)
+        const double an = p0 / nrmv, bn = p1 / nrmv;
+        gn = (1 + d) * xi - d * sxv + an + bn * d;
+        A.cab[i] = an;  // (a, b) of the current point if candidate 0 is accepted
+        A.cab[A.mp + i] = bn;
+        // its penalty terms (:268-274), in case the inner loop ends with it
+        const double cbu = sxv - bn - xi;
+        if (cbu > A.prm.eps && xi > A.prm.eps) {
+          r[NR + 2 * V] = 1.0;
+          r[NR + 2 * V + 1] = fabs((an + xi) / cbu);
+        }
+      } else {
+        const double gs = p0 / nrmv;  // (M_off + d*C_off) x
+        gn = (1 + d) * xi - d * sxv + gs;
+      }
+      pt_arr(A, V, ubp ^ 1, v, 0)[i] = xi;  // becomes (u, gradF) if candidate v is accepted
+      pt_arr(A, V, ubp ^ 1, v, 1)[i] = gn;
+      r[0] = xi * gn;  // :242
+      const double du = xi - ui;
+      r[1] = du * du;  // :253
+      // next window if candidate v is accepted: alpha = 1, beta, beta^2, ... (:227, :235-236)
+      double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      double al = 1.0;
+#pragma unroll
+      for (int l = 0; l < V; ++l) {
+        double t = xi + al * gn;
+        t = (t > 0.0) ? t : 0.0;
+        row[l] = t;
+        r[2 + 2 * l] = t * t;
+        r[3 + 2 * l] = t;
+        al = al * beta;
+      }
+      store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
+      if (v == 0) {
+        // next window if all V candidates are rejected: V more factors of beta (:248)
+        const double gi = pt_arr(A, V, ubp, ubv, 1)[i];
+        double row2[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        al = alpha;
+#pragma unroll
+        for (int l = 0; l < V; ++l) al = al * beta;
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          double t = ui + al * gi;
+          t = (t > 0.0) ? t : 0.0;
+          row2[l] = t;
+          r[NR + 2 * l] = t * t;
+          r[NR + 2 * l + 1] = t;
+          al = al * beta;
+        }
+        store_row(A.Xout + (static_cast<int64_t>(V) * A.mp + i) * VS, row2);
+      }
     }
   }
-  const double tot = block_reduce_pick<NR + 2 * V, TAIL_WAVES>(r, red);
+  const double tot = block_reduce_pick<NRED, TAIL_WAVES>(r, red);
   double* out = A.scal + static_cast<int64_t>(blockIdx.x) * Q;
   if (threadIdx.x < NR) out[v * NR + threadIdx.x] = tot;
-  if (v == 0 && threadIdx.x >= NR && threadIdx.x < NR + 2 * V)
-    out[V * NR + (threadIdx.x - NR)] = tot;
+  if (v == 0 && threadIdx.x >= NR && threadIdx.x < NRED)
+    out[V * NR + (threadIdx.x - NR)] = tot;  // "all rejected" window sums, then the penalty sums
 }
 
 // ------------------------------------------------------------------------------------------
@@ -847,10 +847,12 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
 //   window mode (PH_TRIAL): the line search only ever needs a_v + d*b_v (clipper.cpp:238-241:
 //     gradFnew = (1+d)x - d*sum(x) + M_off x + d * C_off x), and d is fixed during a pass. So
 //     every element is turned ONCE into w = M + d*C (one fma with the 0/1 pattern indicator,
-//     or with the explicit C value) and each of the V candidates costs ONE fma per element:
-//         g_v[c] = sum_r w[r][c] * x_v[r]                        4 + V fp64 ops per element
-//     which keeps a window of 6 under the HBM roofline (a separate a/b pair would be 3 + 2V
-//     ops: VALU-bound from V = 5 on — measured, tools/mv_tune.hip).
+//     or with the explicit C value) and a candidate costs ONE fma per element:
+//         g_v[c] = sum_r w[r][c] * x_v[r]
+//     Only candidate 0 keeps a and b apart (two fmas): it is the one accepted when an inner
+//     loop converges, and the penalty update that follows needs them apart. 5 + V fp64 ops per
+//     element, which keeps a window of 6 under the HBM roofline (separate a/b pairs for all
+//     would be 3 + 2V ops: VALU-bound from V = 5 on — measured, tools/mv_tune.hip).
 //   pair mode (initialisation, penalty update; matvec API): a = M_off x and b = C_off x of ONE
 //     vector separately — the products clipper.cpp:194,202,205,268,271 need them apart. Without
 //     an explicit C, b += (M != 0) * x as an fma with the 0/1 indicator, which rounds exactly
@@ -908,23 +910,32 @@ __device__ __forceinline__ void indicator(const typename Vec4<T>::type& mv,
 // workgroup (0,0) issues elsewhere in the kernel.
 typedef const __attribute__((address_space(4))) double* const_f64_ptr;
 
-// window mode: acc[v][e] += (M + d*C)[e] * x_v
+// window mode: candidate 0 keeps a and b apart (acc[0] += M x_0, acc[V] += C x_0 — what a
+// penalty update will need if it is the accepted one), the others acc[v] += (M + d*C) x_v
 template <typename T, bool HASC, int V>
 __device__ __forceinline__ void row_window(const typename Vec4<T>::type& mv,
                                            const typename Vec4<T>::type& cv, double d,
-                                           const_f64_ptr xr, double (&acc)[V][4]) {
+                                           const_f64_ptr xr, double (&acc)[V + 1][4]) {
   const double mm[4] = {static_cast<double>(mv.x), static_cast<double>(mv.y),
                         static_cast<double>(mv.z), static_cast<double>(mv.w)};
   double ii[4];
   indicator<T, HASC>(mv, cv, ii);
-  double w[4];
+  const double x0 = xr[0];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) w[e] = fma(d, ii[e], mm[e]);
+  for (int e = 0; e < 4; ++e) {
+    acc[0][e] = fma(mm[e], x0, acc[0][e]);
+    acc[V][e] = fma(ii[e], x0, acc[V][e]);
+  }
+  if (V > 1) {
+    double w[4];
 #pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const double xv = xr[v];
+    for (int e = 0; e < 4; ++e) w[e] = fma(d, ii[e], mm[e]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[v][e] = fma(w[e], xv, acc[v][e]);
+    for (int v = 1; v < V; ++v) {
+      const double xv = xr[v];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[v][e] = fma(w[e], xv, acc[v][e]);
+    }
   }
 }
 
@@ -945,7 +956,8 @@ __device__ __forceinline__ void row_pair(const typename Vec4<T>::type& mv,
 }
 
 // The streaming part: this workgroup's (strip, row tile) partial sums -> part[tile][slot][ld].
-// X: the pending table, X[row][VS]. NS accumulator sets: V (window mode) or 2 (pair mode).
+// X: the pending table, X[row][VS]. NS accumulator sets: V + 1 (window mode) or 2 (pair mode);
+// the last set (b) always goes to the last slot.
 template <typename T, bool HASC, bool WINDOW, int NS, int NSLOT, int NW, int UNR>
 __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __restrict__ Cs,
                                           int64_t ld, int64_t m, int rows_per_tile, double d,
@@ -979,7 +991,7 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
       }
 #pragma unroll
       for (int q = 0; q < UNR; ++q) {
-        if constexpr (WINDOW) row_window<T, HASC, NS>(mv[q], cv[HASC ? q : 0], d, X + (r + q) * VS, acc);
+        if constexpr (WINDOW) row_window<T, HASC, NS - 1>(mv[q], cv[HASC ? q : 0], d, X + (r + q) * VS, acc);
         else row_pair<T, HASC>(mv[q], cv[HASC ? q : 0], X[(r + q) * xstride], acc);
       }
     }
@@ -989,7 +1001,7 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
       if (rr < r1) {
         const typename Vec4<T>::type mv = load4(p + rr * ld);
         const typename Vec4<T>::type cv = load4(pc + rr * ld);
-        if constexpr (WINDOW) row_window<T, HASC, NS>(mv, cv, d, X + rr * VS, acc);
+        if constexpr (WINDOW) row_window<T, HASC, NS - 1>(mv, cv, d, X + rr * VS, acc);
         else row_pair<T, HASC>(mv, cv, X[rr * xstride], acc);
       }
     }
@@ -1008,7 +1020,8 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
 #pragma unroll
       for (int w = 1; w < NW; ++w) sum += lds[w * 256 + t];
       const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + t;
-      if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * NSLOT + v) * ld + c] = sum;
+      const int slot = (v == NS - 1) ? NSLOT - 1 : v;
+      if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * NSLOT + slot) * ld + c] = sum;
     }
     if (v + 1 < NS) __syncthreads();
   }
@@ -1025,7 +1038,7 @@ __device__ __forceinline__ void gemv_by_plan(const T* __restrict__ S, const T* _
                                              double* __restrict__ part, const PassPlan& plan,
                                              double* lds) {
   if (plan.phase == PH_TRIAL) {
-    gemv_core<T, HASC, true, V, nslot(V), NW, UNR>(
+    gemv_core<T, HASC, true, V + 1, nslot(V), NW, UNR>(
         S, Cs, ld, m, rows_per_tile, plan.d, Xtab + static_cast<int64_t>(plan.sel) * mp * VS, VS,
         part, lds);
   } else if (plan.from_u >= 0) {  // the u array of a point slot, see pt_arr

@@ -4,9 +4,12 @@ slots and decision walk. Test infrastructure: tests/test_window_logic.py checks 
 for every window size V it takes exactly the trials, decisions and result of the oracle's plain
 restatement of findDenseClique (clipper.cpp:172-323); the GPU tests check the kernels.
 
-Pass kinds (k_gemv):   window mode  g_v = (M_off + d*C_off) x_v   for the V candidates of a table
-                       pair mode    a = M_off x, b = C_off x       for candidate 0
-Iteration kinds:       pass iteration (G streams, T = tail) / transition iteration (sweeps)
+Pass kinds (k_gemv):   window mode  candidate 0: a = M_off x_0, b = C_off x_0 apart;
+                                    candidates v >= 1: g_v = (M_off + d*C_off) x_v
+                       pair mode    a = M_off x, b = C_off x of one vector
+Iterations (G, T):     pass iteration        G decides, then streams; T = tail of the pass
+                       build iteration       G decides "no pass"; T forms gradF, F, first window
+                       transition iteration  workgroup (0,0) of G sweeps; T idle
 """
 from __future__ import annotations
 
@@ -14,7 +17,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-PH_NORMALIZE, PH_RESCALE, PH_INIT, PH_TRIAL, PH_PENALTY = range(5)
+PH_NORMALIZE, PH_RESCALE, PH_INIT, PH_TRIAL, PH_PENALTY, PH_BUILD = range(6)
 
 
 @dataclass
@@ -46,11 +49,9 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
     m = len(u0)
     tables = np.zeros((V + 1, m, V))          # candidate tables of the pending set
     nrm, sx = np.ones(V), np.zeros(V)
-    # current point and the V point slots the tail fills
-    u = np.zeros(m)
-    g = np.zeros(m)
+    u, g = np.zeros(m), np.zeros(m)           # the current point slot
     slot_u, slot_g = np.zeros((V, m)), np.zeros((V, m))
-    a = b = None
+    cab = [np.zeros(m), np.zeros(m)]          # (a, b) of the last pair pass / of candidate 0
     d = F = s = 0.0
     alpha = 1.0
     i_ = j_ = k_ = 0
@@ -59,8 +60,9 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
     accepted = []
     phase = PH_RESCALE if P.rescale_u0 else PH_NORMALIZE
     tables[0][:, 0] = u0
-    results_pending = not P.rescale_u0       # PH_NORMALIZE consumes no pass
+    results = not P.rescale_u0                # PH_NORMALIZE consumes no pass: decide at once
     sums = None
+    from_u = False
 
     def build_window(base_u, base_g, alpha0):
         tab = np.zeros((m, V))
@@ -75,13 +77,21 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
             al = al * P.beta
         return tab, n, sxs
 
+    def penalty_sums(uu, a, b, ss):
+        cbu = ss - b - uu
+        idx = (cbu > P.eps) & (uu > P.eps)
+        return float(idx.sum()), float(np.sum(np.abs((a[idx] + uu[idx]) / cbu[idx])))
+
+    def finish():
+        return Result(u, F, d, i_, n_passes, n_trials, n_iters, accepted)
+
     while True:
         n_iters += 1
-        do_pass = True
-        if results_pending:
+        action = "pass"
+        from_u = False
+        if results:
             # ---- the decision at the head of G ------------------------------------------------
-            fast = False
-            begin_outer = penalty = need_window = need_pair = finished = False
+            action = "slow"
             if phase == PH_TRIAL:
                 jstar = -1
                 for v in range(V):
@@ -99,7 +109,7 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
                         break
                 if jstar < 0:
                     sel, nrm, sx = V, sums["none_nrm"], sums["none_sx"]
-                    fast = True
+                    action = "pass"
                 else:
                     accepted.append(jstar)
                     deltau = np.sqrt(sums["du2"][jstar])
@@ -108,89 +118,88 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
                     u, g = slot_u[jstar].copy(), slot_g[jstar].copy()
                     j_ += 1
                     if deltau < P.tol_u or abs(deltaF) < P.tol_F or j_ >= P.maxiniters:
-                        # pair-mode pass straight on the accepted x (its point slot), same iteration
-                        need_pair = fast = True
-                        phase = PH_PENALTY
+                        if jstar == 0:          # (a, b) and the penalty sums came with candidate 0
+                            cnt, rs = sums["pen"]
+                            if cnt > 0:
+                                d += rs / cnt
+                                i_ += 1
+                                if i_ >= P.maxoliters:
+                                    return finish()
+                                action = "build"
+                            else:
+                                return finish()
+                        else:                   # pair pass straight on the accepted x
+                            action, phase, from_u = "pass", PH_PENALTY, True
                     else:
                         alpha, k_ = 1.0, 0
                         sel, nrm, sx = jstar, sums["nrm"][jstar], sums["sx"][jstar]
-                        fast = True
-            if not fast:
-                # ---- transition iteration (workgroup (0,0)) ---------------------------------
-                do_pass = False
-                to_init = False
+                        action = "pass"
+            elif phase == PH_BUILD:
+                F = sums["F"][0]
+                j_ = 0
+                if P.maxiniters > 0:
+                    alpha, k_, sel = 1.0, 0, 0
+                    nrm, sx = sums["nrm"][0], sums["sx"][0]
+                    phase = PH_TRIAL
+                    action = "pass"
+            if action == "slow":
+                # ---- sweeps by workgroup (0,0) ----------------------------------------------
                 if phase in (PH_NORMALIZE, PH_RESCALE):
-                    u = (a + u0) if phase == PH_RESCALE else u0.copy()
+                    u = (cab[0] + u0) if phase == PH_RESCALE else u0.copy()
                     u = u / np.sqrt(float(u @ u))
-                    tab = np.zeros((m, V))
-                    tab[:, 0] = u
-                    new_tables = {0: tab}
+                    tables[0] = 0.0
+                    tables[0][:, 0] = u
                     sel, nrm = 0, np.ones(V)
-                    next_phase, to_init = PH_INIT, True
-                elif phase == PH_INIT:
+                    phase, results = PH_INIT, False      # a pass was prepared
+                    continue
+                if phase == PH_INIT:
                     s = float(u.sum())
-                    cbu = s - b - u
+                    cbu = s - cab[1] - u
                     idx = (cbu > P.eps) & (u > P.eps)
-                    d = float(np.mean((a[idx] + u[idx]) / cbu[idx])) if idx.any() else 0.0
+                    d = float(np.mean((cab[0][idx] + u[idx]) / cbu[idx])) if idx.any() else 0.0
                     i_ = 0
-                    begin_outer = True
-                elif phase == PH_PENALTY:
-                    penalty = True
-                next_phase = PH_TRIAL if not to_init else next_phase
-                new_tables = new_tables if to_init else {}
-                while not to_init:
-                    if penalty:
-                        cbu = s - b - u
-                        idx = (cbu > P.eps) & (u > P.eps)
-                        penalty = False
-                        if idx.any():
-                            d += float(np.mean(np.abs((a[idx] + u[idx]) / cbu[idx])))
-                            i_ += 1
-                            begin_outer = True
-                        else:
-                            finished = True
-                            break
-                    if begin_outer:
-                        begin_outer = False
+                    if i_ >= P.maxoliters:
+                        return finish()
+                    action = "build"
+                else:                                     # PH_PENALTY, or an empty inner loop
+                    cnt, rs = penalty_sums(u, cab[0], cab[1], s)
+                    if cnt > 0:
+                        d += rs / cnt
+                        i_ += 1
                         if i_ >= P.maxoliters:
-                            finished = True
-                            break
-                        g = (1 + d) * u - d * s + a + b * d
-                        F = float(u @ g)
-                        j_ = 0
-                        if P.maxiniters <= 0:
-                            penalty = True
-                            continue
-                        alpha, k_ = 1.0, 0
-                        need_window = True
-                    break
-                if finished:
-                    return Result(u, F, d, i_, n_passes, n_trials, n_iters, accepted)
-                if need_window:
-                    tab, nrm, sx = build_window(u, g, alpha)
-                    new_tables = {0: tab}
-                    sel = 0
-                for k, t in new_tables.items():
-                    tables[k] = t
-                phase = next_phase
-                results_pending = False
-                continue
-        # ---- pass iteration: G streams M against table `sel`, T = tail ----------------------
+                            return finish()
+                        action = "build"
+                    else:
+                        return finish()
+        if action == "build":
+            # ---- build iteration: T forms gradF, F and the first window ----------------------
+            g = (1 + d) * u - d * s + cab[0] + cab[1] * d
+            tab, n0, sx0 = build_window(u, g, 1.0)
+            tables[0] = tab
+            sums = {"F": np.array([float(u @ g)] + [0.0] * (V - 1)), "nrm": {0: n0}, "sx": {0: sx0}}
+            phase, results = PH_BUILD, True
+            continue
+        # ---- pass iteration: G streams M, T = tail ------------------------------------------
         n_passes += 1
         X = tables[sel]
-        if phase != PH_TRIAL:                       # pair mode, candidate 0 (nrm = 1)
-            x = u if phase == PH_PENALTY else X[:, 0]
-            a, b = Moff @ x, Coff @ x
-            results_pending = True
+        if phase != PH_TRIAL:                       # pair mode (nrm = 1)
+            x = u if from_u else X[:, 0]
+            cab = [Moff @ x, Coff @ x]
+            results = True
             continue
-        W = Moff + d * Coff                         # window mode
-        graw = W @ X                                # (m, V)
         sums = {"F": np.zeros(V), "du2": np.zeros(V), "nrm": {}, "sx": {}}
         sx_pass = sx.copy()
         out_tables = {}
+        W = Moff + d * Coff
         for v in range(V):
             xi = X[:, v] / nrm[v]
-            gn = (1 + d) * xi - d * sx[v] + graw[:, v] / nrm[v]
+            if v == 0:                              # a and b apart, the reference's expression
+                an, bn = (Moff @ X[:, 0]) / nrm[0], (Coff @ X[:, 0]) / nrm[0]
+                gn = (1 + d) * xi - d * sx[0] + an + bn * d
+                cab = [an, bn]
+                sums["pen"] = penalty_sums(xi, an, bn, sx[0])
+            else:
+                gn = (1 + d) * xi - d * sx[v] + (W @ X[:, v]) / nrm[v]
             slot_u[v], slot_g[v] = xi, gn
             sums["F"][v] = float(xi @ gn)
             du = xi - u
@@ -202,4 +211,4 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
         out_tables[V], sums["none_nrm"], sums["none_sx"] = build_window(u, g, al)
         for k, t in out_tables.items():
             tables[k] = t
-        results_pending = True
+        results = True
