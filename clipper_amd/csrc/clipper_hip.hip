@@ -82,7 +82,7 @@ constexpr int64_t WINDOW_MIN_M = 6000;
 constexpr int SOLVE_BATCH = 16;  // multi-process: iterations queued between two state snapshots
 constexpr int RUN_AHEAD = 4;     // one process: iterations kept queued ahead of the device
 constexpr int MAX_EVENT_PAIRS = 4096;
-constexpr int PROFILE_EVERY = 4;  // time every 4th mat-vec launch (events perturb the stream)
+constexpr int PROFILE_EVERY = 8;  // time every 8th iteration's mat-vec (an event costs ~5-10 us of stream time)
 
 // ---- RCCL, bound at run time so the single-GPU path never loads librccl -----------------
 struct Rccl {
@@ -467,7 +467,7 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   const int par = h->par;
   h->par ^= 1;
   const bool sharded = !(h->world == 1 && !h->multiproc);
-  // timing events cost ~5 us of stream time each: sample every 4th launch only
+  // timing events cost ~5-10 us of stream time each: sample every 8th launch only
   Shard& s0 = h->sh[0];
   const bool prof = h->profiling && (h->launch_counter % PROFILE_EVERY == 0) &&
                     h->ev_used < MAX_EVENT_PAIRS;
