@@ -236,31 +236,45 @@ int plan_unr(const Ctx* h) {
   return gemv_unr(h->V, static_cast<int>(h->esize()), h->explicitC);
 }
 
+// largest row-tile count plan_tiles considers for this (m, W)
+int64_t max_tiles(const Ctx* h) {
+  const int64_t slots = static_cast<int64_t>(h->cus) * GEMV_WG_PER_CU;
+  int64_t nt = std::max<int64_t>(16, ceil_div(slots, std::max(1, h->nstrips)) + 1);
+  if (const char* e = std::getenv("CLIPPER_HIP_TILES")) nt = std::max<int64_t>(nt, std::atoll(e));
+  return nt;
+}
+
+// Row tiles per column strip. The grid (strips x tiles) runs in waves of `slots` co-resident
+// workgroups (two 8-wave workgroups per CU); a grid a few percent OVER a whole number of waves
+// costs a whole extra wave (measured: m = 30k, 118 strips: 5 tiles = 1.15 waves 742 us,
+// 4 tiles = 0.92 waves 599 us, 13 tiles = 3.0 waves 611 us; m = 10k, 40 strips: 13 tiles =
+// 1.016 waves 78 us, 12 tiles 80 us, 16 tiles = 1.25 waves 95 us). Pick the tile count whose
+// last wave is fullest; more tiles cost partial sums, hence the small per-tile penalty.
 void plan_tiles(Ctx* h) {
   const int unr = plan_unr(h);
   const int64_t chunk = static_cast<int64_t>(GEMV_NW) * unr;
   h->nstrips = static_cast<int>(ceil_div(h->W, 256));
-  // two 8-wave workgroups per CU: measured with tools/gemv_tune.hip / mv_tune.hip, at m = 10k
-  // this geometry sits at the box's pure streaming-read ceiling while needing only ~13 row
-  // tiles, i.e. few partials for the tail
-  const int64_t target = static_cast<int64_t>(h->cus) * GEMV_WG_PER_CU;
-  int64_t nt = std::max<int64_t>(1, ceil_div(target, h->nstrips));
+  const double slots = static_cast<double>(h->cus) * GEMV_WG_PER_CU;
+  const int64_t nt_max = std::min<int64_t>(max_tiles(h), std::max<int64_t>(1, ceil_div(h->m, chunk)));
+  int64_t best = 1;
+  double best_cost = 1e300;
+  for (int64_t nt = 1; nt <= nt_max; ++nt) {
+    const double w = static_cast<double>(h->nstrips) * static_cast<double>(nt) / slots;
+    const double whole = std::floor(w), frac = w - whole;
+    const double waves = whole + ((frac <= 0.03 && whole >= 1.0) ? frac : (frac > 0.0 ? 1.0 : 0.0));
+    const double cost = waves / w + 0.003 * static_cast<double>(nt);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = nt;
+    }
+  }
   if (const char* e = std::getenv("CLIPPER_HIP_TILES")) {  // tuning knob (measurements only)
     const int64_t v = std::atoll(e);
-    if (v > 0) nt = v;
+    if (v > 0) best = std::min<int64_t>(v, std::max<int64_t>(1, ceil_div(h->m, chunk)));
   }
-  nt = std::min<int64_t>(nt, std::max<int64_t>(1, ceil_div(h->m, chunk)));
-  int64_t rpt = round_up(ceil_div(h->m, nt), chunk);
+  int64_t rpt = round_up(ceil_div(h->m, best), chunk);
   h->rows_per_tile = static_cast<int>(rpt);
   h->ntiles = static_cast<int>(ceil_div(h->m, rpt));
-}
-
-int64_t max_tiles(const Ctx* h) {
-  // upper bound of ntiles over every unroll plan_tiles may pick for this (m, W)
-  const int64_t target = static_cast<int64_t>(h->cus) * GEMV_WG_PER_CU;
-  int64_t nt = std::max<int64_t>(1, ceil_div(target, std::max(1, h->nstrips))) + 1;
-  if (const char* e = std::getenv("CLIPPER_HIP_TILES")) nt = std::max<int64_t>(nt, std::atoll(e));
-  return nt;
 }
 
 // (re)allocate everything for an m x m problem
