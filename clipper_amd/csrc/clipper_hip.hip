@@ -483,7 +483,7 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   const bool sharded = !(h->world == 1 && !h->multiproc);
   // timing events cost ~5-10 us of stream time each: sample every 8th launch only
   Shard& s0 = h->sh[0];
-  const bool prof = h->profiling && (h->launch_counter % PROFILE_EVERY == 0) &&
+  const bool prof = h->profiling && (h->launch_counter % PROFILE_EVERY == 3) &&
                     h->ev_used < MAX_EVENT_PAIRS;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));

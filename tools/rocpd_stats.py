@@ -29,6 +29,21 @@ def main():
         out.append(rec)
         print(f"{k[:70]:70s} {rec['calls']:7d} {rec['total_ms']:10.3f} {rec['mean_us']:9.2f} "
               f"{rec['median_us']:9.2f} {rec['min_us']:8.2f} {rec['max_us']:8.2f} {100 * rec['share']:5.1f}%")
+    # the solver's kernels are also launched for transition iterations (one workgroup works)
+    # and, a few times per solve, past convergence (immediate exit): the PASS launches — the
+    # ones bench.py's HIP events time — are those of at least half the median duration
+    print()
+    print("pass launches only (duration >= 0.5 x median):")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        if not ("k_gemv" in k or "k_pass" in k or "k_tail" in k):
+            continue
+        v = sorted(v)
+        med = v[len(v) // 2]
+        w = [x for x in v if x >= 0.5 * med]
+        print(f"{k[:70]:70s} {len(w):7d} launches  mean {sum(w) / len(w) / 1e3:9.2f} us  "
+              f"median {w[len(w) // 2] / 1e3:9.2f} us  min {w[0] / 1e3:8.2f}  max {w[-1] / 1e3:8.2f}")
+        out.append(dict(kernel=k + " [pass launches]", calls=len(w), mean_us=sum(w) / len(w) / 1e3,
+                        median_us=w[len(w) // 2] / 1e3, min_us=w[0] / 1e3, max_us=w[-1] / 1e3))
     if "--json" in sys.argv:
         json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
 
