@@ -18,6 +18,8 @@ from clipper_amd import _abi as abi  # noqa: E402
 from clipper_amd import synth  # noqa: E402
 
 CONFIGS = {
+    # cfg1: 600-point sample of the reference's bunny model, ex4_bunny.ipynb recipe scaled by 0.1
+    "bunny": dict(kind="bunny", m=100, rho=0.90),
     "1k": dict(kind="euclid", m=1000, rho=0.90),
     "10k": dict(kind="euclid", m=10000, rho=0.95),
     "pn5k": dict(kind="pointnormal", m=5000, rho=0.90),
@@ -26,9 +28,24 @@ CONFIGS = {
 }
 
 
+def bunny_problem(m, rho, seed=0):
+    from clipper_amd import registration as reg
+    pts = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "bunny_points.json")))["points"])
+    rng = np.random.default_rng(1000 + seed)
+    T = np.eye(4)
+    T[:3, :3] = reg.random_rotation(rng)
+    T[:3, 3] = rng.uniform(-5, 5, 3)
+    D1, D2, A, Agt = reg.make_registration_dataset(pts, m, m, m // 4, rho, 0.01, T, seed=seed)
+    u0 = np.random.default_rng(seed + 1).random(m)
+    p = synth.Problem(D1=D1, D2=D2, A=A, Agt=Agt, u0=u0, meta=dict(kind="bunny", T=T.tolist()))
+    return p, dict(sigma=0.01, epsilon=0.02, mindist=0.0)
+
+
 def run(name, cfg, reps, storage, with_cpu):
     m, rho = cfg["m"], cfg["rho"]
-    if cfg["kind"] == "euclid":
+    if cfg["kind"] == "bunny":
+        p, inv = bunny_problem(m, rho)
+    elif cfg["kind"] == "euclid":
         p = synth.make_euclidean_problem(m, rho)
         inv = synth.EUCLID_BENCH_PARAMS
     else:
@@ -38,7 +55,7 @@ def run(name, cfg, reps, storage, with_cpu):
     g.stage_inputs(p.D1, p.D2, p.A)
 
     def affinity():
-        if cfg["kind"] == "euclid":
+        if cfg["kind"] in ("euclid", "bunny"):
             g.affinity_euclidean_staged(**inv)
         else:
             g.affinity_pointnormal_staged(**inv)
@@ -71,7 +88,7 @@ def run(name, cfg, reps, storage, with_cpu):
         from oracle import clipper_ref as ref
         r = ref.RefClipper()
         t0 = time.perf_counter()
-        if cfg["kind"] == "euclid":
+        if cfg["kind"] in ("euclid", "bunny"):
             r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **inv)
         else:
             r.score_pairwise_consistency_pointnormal(p.D1, p.D2, p.A, **inv)
