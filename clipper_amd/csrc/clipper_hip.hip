@@ -255,7 +255,10 @@ void plan_tiles(Ctx* h) {
   const int64_t chunk = static_cast<int64_t>(GEMV_NW) * unr;
   h->nstrips = static_cast<int>(ceil_div(h->W, 256));
   const double slots = static_cast<double>(h->cus) * GEMV_WG_PER_CU;
-  const int64_t nt_max = std::min<int64_t>(max_tiles(h), std::max<int64_t>(1, ceil_div(h->m, chunk)));
+  int64_t nt_max = std::min<int64_t>(max_tiles(h), std::max<int64_t>(1, ceil_div(h->m, chunk)));
+  // column shards: the strip's last workgroup adds the tiles serially (k_pass) and the slices are
+  // narrow — bound the tile count instead of chasing a full wave of tiny workgroups
+  if (h->world > 1) nt_max = std::min<int64_t>(nt_max, 32);
   int64_t best = 1;
   double best_cost = 1e300;
   for (int64_t nt = 1; nt <= nt_max; ++nt) {

@@ -1098,12 +1098,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ 
       const double* p = A.part + sl * ld + c;
       double acc = 0.0;
       int tt = 0;
-      for (; tt + 8 <= A.ntiles; tt += 8) {
-        double x[8];
+      for (; tt + 16 <= A.ntiles; tt += 16) {  // 16 tiles in flight: this workgroup is alone now
+        double x[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = p[static_cast<int64_t>(tt + q) * ts];
+        for (int q = 0; q < 16; ++q) x[q] = p[static_cast<int64_t>(tt + q) * ts];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc += x[q];
+        for (int q = 0; q < 16; ++q) acc += x[q];
       }
       for (; tt < A.ntiles; ++tt) acc += p[static_cast<int64_t>(tt) * ts];
       ab_block[sl * ld + c] = acc;
