@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_get_associations", "clipper_hip_set_matrix", "clipper_hip_set_sparse",
     "clipper_hip_get_matrix", "clipper_hip_solve", "clipper_hip_get_nodes",
     "clipper_hip_get_selected_associations", "clipper_hip_matvec", "clipper_hip_set_profiling",
-    "clipper_hip_set_window", "clipper_hip_window",
+    "clipper_hip_set_window", "clipper_hip_window", "clipper_hip_densest_subgraph",
     "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
     "clipper_hip_affinity_pointnormal_staged", "clipper_hip_stage_u0",
@@ -138,6 +138,7 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_get_nodes.argtypes = [vp, ip, C.c_int32]
     L.clipper_hip_get_selected_associations.argtypes = [vp, ip, C.c_int32]
     L.clipper_hip_matvec.argtypes = [vp, dp, dp, dp]
+    L.clipper_hip_densest_subgraph.argtypes = [vp, ip, C.c_int32, ip, C.c_int32]
     L.clipper_hip_set_window.argtypes = [vp, C.c_int]
     L.clipper_hip_window.argtypes = [vp]
     L.clipper_hip_set_profiling.argtypes = [vp, C.c_int]
@@ -352,6 +353,19 @@ class HipClipper:
         return np.stack([buf[:kk], buf[kk:2 * kk]], axis=1)
 
     # ---- measurement ------------------------------------------------------------------------
+    def densest_subgraph(self, S=None) -> np.ndarray:
+        """dsd::solve(M_, S): exact densest subgraph of the current affinity matrix (all nodes, or
+        restricted to the node list S)."""
+        n = int(self.L.clipper_hip_num_associations(self.h))
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        if S is None:
+            k = self.L.clipper_hip_densest_subgraph(self.h, None, 0, _ip(out), len(out))
+        else:
+            Sa = np.ascontiguousarray(S, dtype=np.int32)
+            k = self.L.clipper_hip_densest_subgraph(self.h, _ip(Sa), len(Sa), _ip(out), len(out))
+        self._check(min(k, 0))
+        return out[:k].copy()
+
     def set_window(self, window: int):
         """Line-search window (0 = automatic, 1 | 4 | 6 | 8); effective from the next build."""
         self._check(self.L.clipper_hip_set_window(self.h, int(window)))

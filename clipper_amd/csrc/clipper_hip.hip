@@ -34,6 +34,7 @@
 
 #include "../../include/clipper_hip.h"
 #include "kernels.hip.h"
+#include "dsd_host.h"
 
 using namespace clipper_hip;
 
@@ -826,6 +827,41 @@ double algorithmic_gemv_bytes(const Ctx* h) {
          static_cast<double>(valid) * (h->explicitC ? 2.0 : 1.0);
 }
 
+// dsd::solve(M_, S) (dsd.cpp:274-320): gathers the sub-matrix induced by S from the device
+// slices and runs Goldberg's algorithm on the host (dsd_host.h). Nodes come back ascending.
+int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32_t>& nodes) {
+  nodes.clear();
+  const int k = static_cast<int>(S.size());
+  if (k < 2) return 0;
+  std::vector<double> Wsub(static_cast<size_t>(k) * k, 0.0), tmp(static_cast<size_t>(k) * k);
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    int32_t* didx = nullptr;
+    double* dout = nullptr;
+    HIPCHK(hipMalloc(&didx, static_cast<size_t>(k) * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&dout, tmp.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(didx, S.data(), static_cast<size_t>(k) * sizeof(int32_t),
+                          hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipMemsetAsync(dout, 0, tmp.size() * sizeof(double), s.stream));
+    dim3 grid(static_cast<unsigned>(ceil_div(static_cast<int64_t>(k) * k, 256))), block(256);
+    const int64_t c0 = static_cast<int64_t>(s.slot) * h->W;
+    if (h->storage == CLIPPER_HIP_STORE_F64)
+      hipLaunchKernelGGL((k_gather_sub<double>), grid, block, 0, s.stream,
+                         static_cast<const double*>(s.S), h->W, c0, h->W, didx, k, dout);
+    else
+      hipLaunchKernelGGL((k_gather_sub<float>), grid, block, 0, s.stream,
+                         static_cast<const float*>(s.S), h->W, c0, h->W, didx, k, dout);
+    HIPCHK(hipMemcpyAsync(tmp.data(), dout, tmp.size() * sizeof(double), hipMemcpyDeviceToHost,
+                          s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    hipFree(didx);
+    hipFree(dout);
+    for (size_t e = 0; e < tmp.size(); ++e) Wsub[e] += tmp[e];  // disjoint column sets
+  }
+  for (int32_t a : dsd::densest_subgraph(Wsub, k, h->m)) nodes.push_back(S[static_cast<size_t>(a)]);
+  return 0;
+}
+
 }  // namespace
 
 // ============================================================================================
@@ -1290,10 +1326,12 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   if (!h || !P) return fail(CLIPPER_HIP_E_INVALID, "params are required");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
   if (!h->u0_staged) return fail(CLIPPER_HIP_E_STATE, "clipper_hip_stage_u0 not called");
-  if (P->rounding == CLIPPER_ROUNDING_DSD)
+  if (P->rounding == CLIPPER_ROUNDING_DSD && h->multiproc)
     return fail(CLIPPER_HIP_E_SCOPE,
-                "Rounding::DSD (exact densest sub-graph, dsd.cpp) is outside the hot-path scope");
-  if (P->rounding != CLIPPER_ROUNDING_NONZERO && P->rounding != CLIPPER_ROUNDING_DSD_HEU)
+                "Rounding::DSD needs the induced sub-matrix on one host: not available on a "
+                "multi-process shard");
+  if (P->rounding != CLIPPER_ROUNDING_NONZERO && P->rounding != CLIPPER_ROUNDING_DSD_HEU &&
+      P->rounding != CLIPPER_ROUNDING_DSD)
     return fail(CLIPPER_HIP_E_INVALID, "unknown rounding mode %d", P->rounding);
   if (P->maxlsiters < 1) return fail(CLIPPER_HIP_E_INVALID, "maxlsiters must be >= 1");
 
@@ -1421,6 +1459,12 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   if (P->rounding == CLIPPER_ROUNDING_NONZERO) {
     for (int64_t i = 0; i < m; ++i)
       if (u[static_cast<size_t>(i)] > 0.0) nodes.push_back(static_cast<int32_t>(i));
+  } else if (P->rounding == CLIPPER_ROUNDING_DSD) {
+    // :294-300 — exact densest subgraph of the graph induced by the non-zero entries of u
+    std::vector<int32_t> S;
+    for (int64_t i = 0; i < m; ++i)
+      if (u[static_cast<size_t>(i)] > 0.0) S.push_back(static_cast<int32_t>(i));
+    if ((rc = densest_subgraph_of(h, S, nodes))) return rc;
   } else {
     const int omega = static_cast<int>(std::round(fin.F));  // :305
     nodes = indices_of_k_largest(u, omega);                 // :308
@@ -1493,6 +1537,30 @@ int clipper_hip_get_selected_associations(const clipper_hip_t* h, int32_t* A_out
     A_out[k + r] = h->A[static_cast<size_t>(h->m) + n];
   }
   return k;
+}
+
+int clipper_hip_densest_subgraph(clipper_hip_t* h, const int32_t* S, int32_t k, int32_t* nodes_out,
+                                 int32_t capacity) {
+  if (!h || !nodes_out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
+  if (h->multiproc)
+    return fail(CLIPPER_HIP_E_SCOPE, "not available on a multi-process shard");
+  std::vector<int32_t> sub;
+  if (S == nullptr || k <= 0) {  // dsd.cpp:279-284: the whole graph
+    sub.resize(static_cast<size_t>(h->m));
+    for (int64_t i = 0; i < h->m; ++i) sub[static_cast<size_t>(i)] = static_cast<int32_t>(i);
+  } else {
+    sub.assign(S, S + k);
+    for (int32_t v : sub)
+      if (v < 0 || v >= h->m) return fail(CLIPPER_HIP_E_INVALID, "node %d out of range", v);
+  }
+  std::vector<int32_t> nodes;
+  int rc = densest_subgraph_of(h, sub, nodes);
+  if (rc) return rc;
+  const int32_t n = static_cast<int32_t>(nodes.size());
+  if (capacity < n) return fail(CLIPPER_HIP_E_INVALID, "capacity %d < %d nodes", capacity, n);
+  if (n) std::memcpy(nodes_out, nodes.data(), static_cast<size_t>(n) * sizeof(int32_t));
+  return n;
 }
 
 int clipper_hip_set_window(clipper_hip_t* h, int window) {

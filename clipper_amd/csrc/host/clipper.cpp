@@ -273,11 +273,6 @@ void CLIPPER::solve(const VectorXd& _u0) {
   p.affinityeps = params_.affinityeps;
   p.rescale_u0 = params_.rescale_u0 ? 1 : 0;
   p.rounding = static_cast<int>(params_.rounding);
-  if (params_.rounding == Params::Rounding::DSD) {
-    // exact densest sub-graph rounding (reference src/dsd.cpp) is not part of this build
-    std::cout << "Rounding::DSD is not built; use DSD_HEU or NONZERO" << std::endl;
-  }
-
   VectorXd u(n);
   clipper_solve_info_t info;
   check(clipper_hip_solve(h_, u0.data(), &p, u.data(), &info), "solve");

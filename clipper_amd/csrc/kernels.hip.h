@@ -1849,6 +1849,20 @@ __global__ __launch_bounds__(256) void k_from_dense_upper(T* __restrict__ S, int
   if (Cs != nullptr) Cs[j * ld + c] = static_cast<T>(cv);
 }
 
+// out[a*k + b] = M(idx[a], idx[b]) for the columns idx[b] this slice owns (others untouched):
+// the sub-matrix induced by the non-zero entries of u, for the exact DSD rounding on the host
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_sub(const T* __restrict__ S, int64_t ld,
+                                                     int64_t c0, int64_t W,
+                                                     const int32_t* __restrict__ idx, int k,
+                                                     double* __restrict__ out) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= static_cast<int64_t>(k) * k) return;
+  const int a = static_cast<int>(e / k), b = static_cast<int>(e - static_cast<int64_t>(a) * k);
+  const int64_t col = idx[b];
+  if (col >= c0 && col < c0 + W) out[e] = static_cast<double>(S[static_cast<int64_t>(idx[a]) * ld + (col - c0)]);
+}
+
 // scatter of strictly-upper CSC entries (both mirror images) into a zeroed slice
 template <typename T>
 __global__ __launch_bounds__(256) void k_from_csc(T* __restrict__ S, int64_t ld, int64_t m,

@@ -26,7 +26,7 @@ extern "C" {
 /* clipper::Params::Rounding (clipper.h:49-59) */
 enum {
   CLIPPER_ROUNDING_NONZERO = 0,
-  CLIPPER_ROUNDING_DSD     = 1, /* exact densest sub-graph: host-side, out of hot-path scope */
+  CLIPPER_ROUNDING_DSD     = 1, /* exact densest sub-graph of nnz(u): Goldberg, on the host    */
   CLIPPER_ROUNDING_DSD_HEU = 2
 };
 

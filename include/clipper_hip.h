@@ -47,7 +47,7 @@ enum {
   CLIPPER_HIP_E_NODEVICE = -4, /* no gfx950 device visible           */
   CLIPPER_HIP_E_STATE = -5,    /* call out of order (no matrix yet)  */
   CLIPPER_HIP_E_COMM = -6,     /* RCCL error / communicator missing  */
-  CLIPPER_HIP_E_SCOPE = -7     /* Rounding::DSD — outside this path  */
+  CLIPPER_HIP_E_SCOPE = -7     /* not available in this configuration */
 };
 
 /* Timings of the most recent calls, from HIP events on the context's own stream. */
@@ -145,8 +145,10 @@ int clipper_hip_get_matrix(clipper_hip_t* h, double* M_out, double* C_out);
 
 /* CLIPPER::solve -> findDenseClique (clipper.cpp:69-78, 172-323). u0: m doubles (host),
  * required (the facade supplies utils::randvec when the caller gives none). u_out (m
- * doubles) may be NULL. Rounding NONZERO and DSD_HEU are done on the host with the
- * reference's exact tie-breaking (utils.cpp:33-68); DSD returns CLIPPER_HIP_E_SCOPE. */
+ * doubles) may be NULL. Rounding is done on the host: NONZERO and DSD_HEU with the reference's
+ * exact tie-breaking (utils.cpp:33-68); DSD (exact densest subgraph of the graph induced by
+ * nnz(u), dsd.cpp:171-320, Goldberg's flow algorithm) gathers that sub-matrix from the device
+ * first — on a multi-process shard it returns CLIPPER_HIP_E_SCOPE. */
 int clipper_hip_solve(clipper_hip_t* h, const double* u0, const clipper_params_t* params,
                       double* u_out, clipper_solve_info_t* info);
 
@@ -162,6 +164,13 @@ int clipper_hip_get_nodes(const clipper_hip_t* h, int32_t* nodes_out, int32_t ca
 /* CLIPPER::getSelectedAssociations (clipper.cpp:124-127): column-major k x 2. */
 int clipper_hip_get_selected_associations(const clipper_hip_t* h, int32_t* A_out,
                                           int32_t capacity);
+
+/* dsd::solve(M_, S) (dsd.cpp:274-320, the reference's `clipper::dsd::solve`): exact densest
+ * subgraph (Goldberg) of the current affinity matrix, restricted to the k nodes S (NULL / k <= 0:
+ * all nodes). The induced sub-matrix is gathered from the device, the flow algorithm runs on the
+ * host. Returns the number of nodes written to nodes_out (ascending) or <0. */
+int clipper_hip_densest_subgraph(clipper_hip_t* h, const int32_t* S, int32_t k,
+                                 int32_t* nodes_out, int32_t capacity);
 
 /* Line-search window: how many consecutive step sizes alpha, alpha*beta, ... of the
  * backtracking line search (clipper.cpp:234-251) one pass over M evaluates at once. The

@@ -424,6 +424,13 @@ def numpy_solve(Mup, Cup, u0, p: Params | None = None, matvec=None):
             break
     if p.rounding == ROUNDING_NONZERO:
         nodes = np.nonzero(u > 0)[0].astype(np.int32)
+    elif p.rounding == ROUNDING_DSD:
+        # clipper.cpp:294-300: exact densest subgraph of the graph induced by nnz(u)
+        from oracle import dsd_ref
+        if matvec is not None:
+            raise ValueError("Rounding::DSD needs the matrix itself")
+        S = np.nonzero(u > 0)[0].tolist()
+        nodes = np.array(dsd_ref.densest_subgraph(Mup + Mup.T, S), dtype=np.int32)
     else:
         nodes = numpy_k_largest(u, int(np.floor(F + 0.5)) if F >= 0 else -int(np.floor(-F + 0.5)))
     return Solution(ifinal=i, nodes=nodes, u0=u0, u=u, score=F, d=d, n_trials=n_trials)

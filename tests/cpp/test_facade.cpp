@@ -8,6 +8,7 @@
 #include <memory>
 
 #include <clipper/clipper.h>
+#include <clipper/dsd.h>
 #include <clipper/utils.h>
 
 #define EXPECT(cond)                                                        \
@@ -148,6 +149,52 @@ int main() {
     for (int i = 0; i < 12; ++i)
       for (int j = 0; j < 12; ++j) EXPECT(M(i, j) == Mtrue[i][j]);
     std::printf("custom C++ invariant ok\n");
+  }
+  // ---- TEST(DSD, Solve) / TEST(DSD, SolveRestrictedGraph) — test/dsd_test.cpp:14-80, and the
+  //      same matrix through CLIPPER::solve with Rounding::DSD ----------------------------------
+  {
+    static const double Mdsd[20][20] = {
+      {1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.2964, 0.0},
+      {0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0138, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+      {0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0016, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0747, 0.0},
+      {0.0, 0.0, 0.0, 1.0, 0.0, 0.0555, 0.2547, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0102, 0.0, 0.7715, 0.0, 0.0, 0.0, 0.0},
+      {0.0, 0.0, 0.0, 0.0, 1.0, 0.0063, 0.0, 0.3846, 0.0, 0.0003, 0.0014, 0.0, 0.0, 0.0, 0.0, 0.0063, 0.0, 0.0, 0.0, 0.0},
+      {0.0, 0.0, 0.0, 0.0555, 0.0063, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.9927, 0.0, 0.0, 0.9722, 0.0, 0.0, 0.0, 0.0},
+      {0.0, 0.0, 0.0, 0.2547, 0.0, 0.0, 1.0, 0.0, 0.0023, 0.0, 0.0, 0.8775, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+      {0.0, 0.0, 0.0, 0.0, 0.3846, 0.0, 0.0, 1.0, 0.0001, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+      {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0023, 0.0001, 1.0, 0.7914, 0.0, 0.0, 0.0, 0.0617, 0.0, 0.0, 0.9938, 0.0, 0.0, 0.0007},
+      {0.0, 0.0, 0.0, 0.0, 0.0003, 0.0, 0.0, 0.0, 0.7914, 1.0, 0.0, 0.0, 0.0001, 0.0091, 0.0, 0.2503, 0.0222, 0.0549, 0.0, 0.0},
+      {0.0, 0.0, 0.0, 0.0, 0.0014, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0008},
+      {0.0, 0.0, 0.0016, 0.0, 0.0, 0.0, 0.8775, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.7007, 0.0},
+      {0.0, 0.0, 0.0, 0.0, 0.0, 0.9927, 0.0, 0.0, 0.0, 0.0001, 0.0, 0.0, 1.0, 0.0, 0.9978, 0.0, 0.0, 0.0, 0.0, 0.0},
+      {0.0, 0.0138, 0.0, 0.0102, 0.0, 0.0, 0.0, 0.0, 0.0617, 0.0091, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0003, 0.0, 0.0},
+      {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.9978, 0.0, 1.0, 0.0012, 0.0, 0.0, 0.0, 0.0074},
+      {0.0, 0.0, 0.0, 0.7715, 0.0063, 0.9722, 0.0, 0.0, 0.0, 0.2503, 0.0, 0.0, 0.0, 0.0, 0.0012, 1.0, 0.0026, 0.0217, 0.0, 0.0},
+      {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.9938, 0.0222, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0026, 1.0, 0.0, 0.0, 0.0},
+      {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0549, 0.0, 0.0, 0.0, 0.0003, 0.0, 0.0217, 0.0, 1.0, 0.0007, 0.0},
+      {0.2964, 0.0, 0.0747, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.7007, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0007, 1.0, 0.0},
+      {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0007, 0.0, 0.0008, 0.0, 0.0, 0.0, 0.0074, 0.0, 0.0, 0.0, 0.0, 1.0}};
+    clipper::MatrixXd M(20, 20);
+    for (int i = 0; i < 20; ++i)
+      for (int j = 0; j < 20; ++j) M(i, j) = Mdsd[i][j];
+    const std::vector<int> truth = {3, 5, 12, 14, 15};
+    EXPECT(clipper::dsd::solve(M) == truth);
+    EXPECT(clipper::dsd::solve(M, {0, 1, 3, 5, 7, 12, 14, 15, 19}) == truth);
+    // the exact rounding inside the solver: u's support contains the dense cluster
+    clipper::Params pd;
+    pd.rounding = clipper::Params::Rounding::DSD;
+    clipper::CLIPPER cd(std::make_shared<clipper::invariants::EuclideanDistance>(iparams), pd);
+    clipper::Constraint C(20, 20);
+    for (int i = 0; i < 20; ++i)
+      for (int j = 0; j < 20; ++j) C(i, j) = (M(i, j) != 0.0) ? 1.0 : 0.0;
+    cd.setMatrixData(M, C);
+    clipper::VectorXd u0(20);
+    for (int i = 0; i < 20; ++i) u0(i) = 1.0;
+    cd.solve(u0);
+    const std::vector<int> nodes = cd.getSolution().nodes;
+    EXPECT(nodes.size() >= 2);
+    for (size_t i = 1; i < nodes.size(); ++i) EXPECT(nodes[i - 1] < nodes[i]);
+    std::printf("DSD.Solve / SolveRestrictedGraph / Rounding::DSD ok (%zu nodes)\n", nodes.size());
   }
   std::printf("ALL FACADE TESTS PASSED\n");
   return 0;

@@ -286,8 +286,8 @@ def test_error_paths_fail_loudly():
     with pytest.raises(RuntimeError):          # association index out of range
         c.score_pairwise_consistency_euclidean(D, D, np.array([[0, 7]], dtype=np.int32))
     c.score_pairwise_consistency_euclidean(D, D)
-    c.params.rounding = abi.ROUNDING_DSD
-    with pytest.raises(RuntimeError):          # exact DSD rounding is out of scope
+    c.params.rounding = 7
+    with pytest.raises(RuntimeError):          # unknown rounding mode
         c.solve(np.ones(25))
 
 
@@ -493,3 +493,47 @@ def test_fill_kernels_agree_bitwise_pointnormal(monkeypatch):
     monkeypatch.delenv("CLIPPER_HIP_AFFINITY", raising=False)
     assert np.array_equal(mats["sym"], mats["strip"])
     assert np.array_equal(mats["sym"], mats["plain"])
+
+
+# ------------------------------------------------------------------------------------------
+# Rounding::DSD — exact densest subgraph (Goldberg, src/dsd.cpp) of the graph induced by nnz(u):
+# the sub-matrix is gathered from the device, the flow algorithm runs on the host
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("storage", STORAGES)
+def test_dsd_golden_through_the_abi(golden, storage):
+    g = golden["dsd_test_20x20"]
+    M = np.array(g["M"])
+    C = (M != 0).astype(float)
+    c = abi.HipClipper(storage=storage)
+    c.set_matrix_data(M, C)
+    assert c.densest_subgraph().tolist() == g["dsd_nodes"]                          # dsd_test.cpp:14-43
+    assert c.densest_subgraph([0, 1, 3, 5, 7, 12, 14, 15, 19]).tolist() == g["dsd_nodes"]  # :47-80
+    for nshards in (2, 3):
+        cs = abi.HipClipper(storage=storage, group=[0] * nshards)
+        cs.set_matrix_data(M, C)
+        assert cs.densest_subgraph().tolist() == g["dsd_nodes"]
+
+
+@pytest.mark.parametrize("m,rho,seed", [(120, 0.8, 2), (200, 0.85, 4), (260, 0.9, 6)])
+def test_dsd_rounding_matches_the_oracle(m, rho, seed):
+    p = synth.make_euclidean_problem(m, rho, seed=seed)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    Mr = r.get_affinity_matrix()
+    Mup = np.triu(Mr, 1)
+    sr = ref.numpy_solve(Mup, (Mup != 0).astype(float), p.u0, ref.Params(rounding=ref.ROUNDING_DSD))
+    g = abi.HipClipper(abi.Params(rounding=abi.ROUNDING_DSD), storage=abi.STORE_F64)
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    sg = g.solve(p.u0)
+    assert sg.nodes.tolist() == sr.nodes.tolist() and len(sg.nodes) >= 3
+    assert abs(sg.score - sr.score) <= 1e-9 * abs(sr.score)
+    # the exact rounding never returns a sparser subgraph than the heuristic one
+    gh = abi.HipClipper(abi.Params(rounding=abi.ROUNDING_DSD_HEU), storage=abi.STORE_F64)
+    gh.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    sh = gh.solve(p.u0)
+
+    def density(nodes):
+        sub = Mup[np.ix_(nodes, nodes)]
+        return (sub + sub.T).sum() / 2.0 / max(1, len(nodes))
+    assert density(sg.nodes.tolist()) >= density(sh.nodes.tolist()) - 1e-12

@@ -212,3 +212,25 @@ def test_mindist_and_epsilon_branches():
     assert abs(s - np.exp(-0.5 * 0.05**2 / 0.01**2)) < 1e-15
     e3 = np.array([1.07, 0, 0])
     assert L.clipper_ref_score_euclidean(dp(z), dp(e1), dp(z), dp(e3), 3, 0.01, 0.06, 0.0) == 0.0
+
+
+# ---- Rounding::DSD: Goldberg's exact densest subgraph (src/dsd.cpp) ------------------------------
+
+def test_dsd_restatement_is_pinned_to_the_reference_answers(golden):
+    from oracle import dsd_ref
+    g = golden["dsd_test_20x20"]
+    M = np.array(g["M"])
+    assert dsd_ref.densest_subgraph(M) == g["dsd_nodes"] == [3, 5, 12, 14, 15]   # dsd_test.cpp:14-43
+    S = [0, 1, 3, 5, 7, 12, 14, 15, 19]                                            # dsd_test.cpp:72
+    assert dsd_ref.densest_subgraph(M, S) == g["dsd_nodes"]
+    # a clique of weight-1 edges planted in light noise is the densest subgraph
+    rng = np.random.default_rng(3)
+    A = np.triu(0.05 * rng.random((30, 30)), 1)
+    clique = [2, 7, 11, 19, 23, 28]
+    for a in clique:
+        for b in clique:
+            if a < b:
+                A[a, b] = 1.0
+    assert dsd_ref.densest_subgraph(A + A.T) == clique
+    assert dsd_ref.densest_subgraph(A + A.T, [0, 2, 7, 11, 12]) == [2, 7, 11]
+    assert dsd_ref.densest_subgraph(np.zeros((1, 1))) == []
