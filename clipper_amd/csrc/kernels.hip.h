@@ -16,11 +16,13 @@
 // Reference sites (relative to /root/reference):
 //   k_affinity_*  : src/clipper.cpp:31-56 + src/invariants/euclidean_distance.cpp:13-31,
 //                   src/invariants/pointnormal_distance.cpp:13-35
-//   k_gemv        : every `M_.selfadjointView<Upper>() * v` / `C_...* v` in
-//                   src/clipper.cpp:194,202,205,219,240-241,268,271 (one fused pass gives both)
-//   k_tail (+ the decision of its last workgroup): the O(m) algebra and control flow of findDenseClique,
-//                   src/clipper.cpp:193-209 (init), :219-220 (gradient), :226-262 (step,
-//                   projection, line search), :268-280 (penalty update)
+//   k_gemv / k_pass: every `M_.selfadjointView<Upper>() * v` / `C_...* v` in
+//                   src/clipper.cpp:194,202,205,219,240-241,268,271 (one pass over M serves a
+//                   whole window of line-search candidates), preceded by the decisions of
+//                   findDenseClique's control flow :244-262, :268-280 (decide)
+//   k_tail        : the O(m) algebra of findDenseClique, src/clipper.cpp:219-220 (gradient),
+//                   :235-242, :253 (step, projection, trial objective), :268-274 (penalty terms)
+//   k_affinity_sym: the same scores as k_affinity_*, upper block triangle + mirrored stores
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -13,7 +13,7 @@ for db in sys.argv[1:]:
     agg = defaultdict(list)
     for name, cname, val, dur in rows:
         short = name.split("(")[0].replace("void clipper_hip::", "").replace("clipper_hip::", "")
-        if dur < 3000 and short.startswith(("k_gemv", "k_tail", "k_decide", "k_reduce")):
+        if dur < 3000 and short.startswith(("k_gemv", "k_pass", "k_tail", "k_reduce")):
             continue
         agg[(short, cname)].append(val)
     print(db)

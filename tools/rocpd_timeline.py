@@ -17,7 +17,7 @@ for k in range(1, len(seq)):
     n1, s1, e1 = seq[k]
     if (e1 - s1) < 3000 and n1.startswith("k_gemv"):
         continue  # no-op tail
-    if n1.startswith(("k_gemv", "k_reduce", "k_vec", "k_tail", "k_decide")) and n0.startswith(("k_gemv", "k_reduce", "k_vec", "k_tail", "k_decide")):
+    if n1.startswith(("k_gemv", "k_pass", "k_reduce", "k_tail")) and n0.startswith(("k_gemv", "k_pass", "k_reduce", "k_tail")):
         if (e0 - s0) < 2500 and n0.startswith("k_gemv"):
             continue
         gap[f"{n0[:8]} -> {n1[:8]}"].append(s1 - e0)
