@@ -873,6 +873,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
 // operands would need a cross-lane transpose first).
 // ------------------------------------------------------------------------------------------
 
+#ifndef CLIPPER_GEMV_SLR
+#define CLIPPER_GEMV_SLR 3
+#endif
+constexpr int GEMV_SLR = CLIPPER_GEMV_SLR;  // accumulator sets combined per LDS round (48 KiB at 3)
+
 template <typename T>
 struct Vec4;
 template <>
@@ -1009,27 +1014,37 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
     }
   }
 
-  // cross-wave combine in wave order (fixed summation tree), one slot at a time
+  // cross-wave combine in wave order (fixed summation tree), GEMV_SLR slots per LDS round
   __syncthreads();  // the decision at the head of the launch used the same LDS
 #pragma unroll
-  for (int v = 0; v < NS; ++v) {
-    double* mine = lds + wave * 256 + lane * 4;
+  for (int v0 = 0; v0 < NS; v0 += GEMV_SLR) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) mine[e] = acc[v][e];
-    __syncthreads();
-    for (int t = threadIdx.x; t < 256; t += NW * 64) {
-      double sum = lds[t];
+    for (int j = 0; j < GEMV_SLR; ++j) {
+      if (v0 + j < NS) {
+        double* mine = lds + (wave * GEMV_SLR + j) * 256 + lane * 4;
 #pragma unroll
-      for (int w = 1; w < NW; ++w) sum += lds[w * 256 + t];
-      const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + t;
-      const int slot = (v == NS - 1) ? NSLOT - 1 : v;
-      if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * NSLOT + slot) * ld + c] = sum;
+        for (int e = 0; e < 4; ++e) mine[e] = acc[v0 + j][e];
+      }
     }
-    if (v + 1 < NS) __syncthreads();
+    __syncthreads();
+    constexpr int NOUT = GEMV_SLR * 256;
+    for (int t = threadIdx.x; t < NOUT; t += NW * 64) {
+      const int j = t >> 8, cl = t & 255;
+      if (v0 + j < NS) {
+        double sum = lds[j * 256 + cl];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sum += lds[(w * GEMV_SLR + j) * 256 + cl];
+        const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + cl;
+        const int v = v0 + j;
+        const int slot = (v == NS - 1) ? NSLOT - 1 : v;
+        if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * NSLOT + slot) * ld + c] = sum;
+      }
+    }
+    if (v0 + GEMV_SLR < NS) __syncthreads();
   }
 }
 
-constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * 256 + 2; }  // + the arrival flag
+constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * GEMV_SLR * 256 + 2; }  // + the arrival flag
 
 // window or pair mode by the plan of this iteration
 template <typename T, bool HASC, int V, int NW, int UNR>
