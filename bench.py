@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--m", type=int, default=10000, help="putative associations")
     ap.add_argument("--rho", type=float, default=None, help="outlier ratio (default 0.95; 0.90 at m<=1000)")
-    ap.add_argument("--storage", choices=["f32", "f64"], default="f32",
+    ap.add_argument("--storage", choices=["f32", "f64", "csc"], default="f32",
                     help="element type of the dense M in HBM (vectors/accumulators are always f64)")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,7 +112,7 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    storage = abi.STORE_F32 if args.storage == "f32" else abi.STORE_F64
+    storage = {"f32": abi.STORE_F32, "f64": abi.STORE_F64, "csc": abi.STORE_F32_CSC}[args.storage]
     problem = synth.make_euclidean_problem(args.m, rho, seed=args.seed)  # identical on every rank
     if N > 1:
         g = abi.HipClipper(device=local_rank, storage=storage, rank=rank, world=N)

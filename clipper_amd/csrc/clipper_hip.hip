@@ -145,6 +145,15 @@ struct Shard {
   size_t capP = 0, capA = 0, capD1 = 0, capD2 = 0;
   hipEvent_t ev_reduced = nullptr, ev_copied = nullptr;
   size_t bytes_S = 0;
+  size_t part_tiles = 0;  // row tiles `part` has room for
+  // column-compressed copy of M (CLIPPER_HIP_STORE_F32_CSC), see kernels.hip.h
+  uint32_t* cLc = nullptr;
+  uint64_t* cPre = nullptr;
+  float* cvals = nullptr;
+  uint8_t* crows = nullptr;
+  int* ctb = nullptr;
+  CscBuildCtl* cctl = nullptr;
+  size_t ccap_units = 0, ccap_groups = 0, ccap_tb = 0;
 };
 
 }  // namespace
@@ -161,6 +170,14 @@ struct clipper_hip_ctx {
   int64_t alloc_m = 0, alloc_W = 0;
   bool has_matrix = false;
   bool explicitC = false;
+  bool compressed = false;   // CLIPPER_HIP_STORE_F32_CSC was asked for
+  bool csc_valid = false;    // ... and the compressed copy of the current matrix exists
+  int csc_nblocks = 0, csc_ntmax = 0;
+  uint64_t csc_units = 0;    // sum of the padded list lengths (units of 256 entries)
+  uint32_t* csc_hLc = nullptr;     // pinned host copy of Lc
+  CscBuildCtl* csc_hctl = nullptr; // pinned host copy of the build's counters
+  int* csc_htb = nullptr;          // pinned staging of the tile boundaries
+  size_t csc_hcap_groups = 0, csc_hcap_tb = 0;
   int staged_d = 0;          // dimension of the staged point tables (0 = nothing staged)
   double staged_maxabs = 0;  // max |coordinate| of D1, D2: bounds the fp32 prefilter's error
   bool plain_affinity = false;  // CLIPPER_HIP_AFFINITY=plain: non-compacting fill kernels
@@ -220,6 +237,14 @@ int free_shard_buffers(Shard& s) {
   fr(s.scal);
   fr(s.st);
   fr(s.shared);
+  fr(s.cLc);
+  fr(s.cPre);
+  fr(s.cvals);
+  fr(s.crows);
+  fr(s.ctb);
+  fr(s.cctl);
+  s.ccap_units = s.ccap_groups = s.ccap_tb = 0;
+  s.part_tiles = 0;
   fr(s.P1);
   fr(s.P2);
   fr(s.P1f);
@@ -316,7 +341,8 @@ int ensure_problem(Ctx* h, int64_t m) {
     HIPCHK(hipMalloc(&s.scal, static_cast<size_t>(ceil_div(m, TAIL_THREADS)) * Q * sizeof(double)));
     HIPCHK(hipMalloc(&s.ab, NSLOT * nvec));
     HIPCHK(hipMemsetAsync(s.ab, 0, NSLOT * nvec, s.stream));
-    HIPCHK(hipMalloc(&s.part, static_cast<size_t>(max_tiles(h)) * NSLOT * W * sizeof(double)));
+    s.part_tiles = static_cast<size_t>(max_tiles(h));
+    HIPCHK(hipMalloc(&s.part, s.part_tiles * NSLOT * W * sizeof(double)));
     HIPCHK(hipMalloc(&s.st, 2 * sizeof(SolverState)));
     HIPCHK(hipMemsetAsync(s.st, 0, 2 * sizeof(SolverState), s.stream));
     HIPCHK(hipMalloc(&s.shared, sizeof(SolveShared)));
@@ -325,6 +351,7 @@ int ensure_problem(Ctx* h, int64_t m) {
   h->alloc_m = m;
   h->alloc_W = W;
   h->has_matrix = false;
+  h->csc_valid = false;
   h->explicitC = false;
   plan_tiles(h);
   h->u0_staged = false;
@@ -381,6 +408,21 @@ void launch_plain(Ctx* h, Shard& s, const double* X) {
   dispatch_storage(h, [&](auto t, auto c) {
     launch_plain_t<decltype(t), decltype(c)::value>(h, s, X);
   });
+}
+
+// G on the compressed copy of M (one shard, C == pattern(M), fp32)
+template <int V>
+void launch_pass_csc(Ctx* h, Shard& s, const SolveArgs& a) {
+  CscView M;
+  M.vals = s.cvals;
+  M.rows = s.crows;
+  M.Lc = s.cLc;
+  M.Pre = s.cPre;
+  M.tb = s.ctb;
+  M.nblocks = h->csc_nblocks;
+  M.ntmax = h->csc_ntmax;
+  dim3 grid(h->nstrips, h->csc_ntmax), block(GEMV_NW * 64);
+  hipLaunchKernelGGL((k_gemv_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
 }
 
 // calls f(integral_constant<V>) for the context's window size
@@ -467,7 +509,7 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.Xout = s.X[par ^ 1];
   a.ab = s.ab;
   a.part = s.part;
-  a.ntiles = h->ntiles;
+  a.ntiles = h->csc_valid ? h->csc_ntmax : h->ntiles;
   a.slot = s.slot;
   a.scal = s.scal;
   a.nwg = static_cast<int>(ceil_div(h->m, TAIL_THREADS));
@@ -494,6 +536,7 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
     const SolveArgs a = solve_args(h, s, prm, par);
     if (prof && &s == &s0) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
     if (sharded) launch_pass<V, true>(h, s, a);
+    else if (h->csc_valid) launch_pass_csc<V>(h, s, a);
     else launch_pass<V, false>(h, s, a);
     if (prof && &s == &s0) {
       HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used + 1], s.stream));
@@ -579,12 +622,14 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     fail(CLIPPER_HIP_E_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
     return nullptr;
   }
-  if (storage != CLIPPER_HIP_STORE_F32 && storage != CLIPPER_HIP_STORE_F64) {
-    fail(CLIPPER_HIP_E_INVALID, "storage must be CLIPPER_HIP_STORE_F32 or _F64");
+  if (storage != CLIPPER_HIP_STORE_F32 && storage != CLIPPER_HIP_STORE_F64 &&
+      storage != CLIPPER_HIP_STORE_F32_CSC) {
+    fail(CLIPPER_HIP_E_INVALID, "storage must be CLIPPER_HIP_STORE_F32, _F64 or _F32_CSC");
     return nullptr;
   }
   Ctx* h = new Ctx();
-  h->storage = storage;
+  h->compressed = (storage == CLIPPER_HIP_STORE_F32_CSC);
+  h->storage = h->compressed ? CLIPPER_HIP_STORE_F32 : storage;
   h->world = world;
   h->multiproc = multiproc;
   h->sh.resize(static_cast<size_t>(nlocal));
@@ -779,6 +824,154 @@ void launch_sym(K kernel, dim3 grid, hipStream_t stream, float* S, int64_t W, in
                      s.P1f, s.P2f, pstride, A0, A1, e, n, E2);
 }
 
+// ---- the column-compressed copy (CLIPPER_HIP_STORE_F32_CSC) ---------------------------------
+bool csc_applies(const Ctx* h) {
+  return h->compressed && h->world == 1 && !h->multiproc && !h->explicitC &&
+         h->storage == CLIPPER_HIP_STORE_F32;
+}
+
+// enqueue the build from the dense store (stream order: after the fill) and the copies of its
+// counters to pinned host memory; csc_finish() after the stream was synchronised
+int csc_enqueue(Ctx* h) {
+  h->csc_valid = false;
+  if (!csc_applies(h)) return 0;
+  Shard& s = h->sh[0];
+  HIPCHK(hipSetDevice(s.device));
+  const int nblocks = static_cast<int>(ceil_div(h->m, CSC_RB));
+  const size_t G = static_cast<size_t>(h->nstrips) * static_cast<size_t>(nblocks);
+  h->csc_nblocks = nblocks;
+  if (G > s.ccap_groups) {
+    if (s.cLc) hipFree(s.cLc);
+    if (s.cPre) hipFree(s.cPre);
+    s.cLc = nullptr;
+    s.cPre = nullptr;
+    HIPCHK(hipMalloc(&s.cLc, G * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&s.cPre, G * sizeof(uint64_t)));
+    s.ccap_groups = G;
+  }
+  if (!s.cctl) HIPCHK(hipMalloc(&s.cctl, sizeof(CscBuildCtl)));
+  if (G > h->csc_hcap_groups) {
+    if (h->csc_hLc) hipHostFree(h->csc_hLc);
+    h->csc_hLc = nullptr;
+    HIPCHK(hipHostMalloc(&h->csc_hLc, G * sizeof(uint32_t), hipHostMallocDefault));
+    h->csc_hcap_groups = G;
+  }
+  if (!h->csc_hctl) HIPCHK(hipHostMalloc(&h->csc_hctl, sizeof(CscBuildCtl), hipHostMallocDefault));
+  h->csc_hctl->cursor = 0;
+  h->csc_hctl->capacity = s.ccap_units;
+  h->csc_hctl->overflow = 0;
+  HIPCHK(hipMemcpyAsync(s.cctl, h->csc_hctl, sizeof(CscBuildCtl), hipMemcpyHostToDevice, s.stream));
+  dim3 grid(h->nstrips, nblocks), block(256);
+  hipLaunchKernelGGL(k_csc_build, grid, block, 0, s.stream, static_cast<const float*>(s.S), h->W,
+                     h->m, nblocks, s.cLc, s.cPre, s.cvals, s.crows, s.cctl);
+  HIPCHK(hipMemcpyAsync(h->csc_hctl, s.cctl, sizeof(CscBuildCtl), hipMemcpyDeviceToHost, s.stream));
+  HIPCHK(hipMemcpyAsync(h->csc_hLc, s.cLc, G * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+  return 0;
+}
+
+// Row tiles of equal cost per strip (cost of a block: its padded list length + a constant for
+// the staging of its x rows). The number of workgroups aims at whole waves of co-resident ones
+// (three 8-wave workgroups per CU), at most ~32 blocks each.
+int csc_plan(Ctx* h) {
+  Shard& s = h->sh[0];
+  const int nstrips = h->nstrips, nblocks = h->csc_nblocks;
+  const uint32_t* L = h->csc_hLc;
+  const double slots = static_cast<double>(h->cus) * 3.0;
+  const double G = static_cast<double>(nstrips) * nblocks;
+  double target = slots * std::max(1.0, std::ceil(G / (slots * 32.0)));
+  if (const char* e = std::getenv("CLIPPER_HIP_CSC_WGS")) target = std::max(1.0, std::atof(e));
+  std::vector<double> tot(static_cast<size_t>(nstrips), 0.0);
+  double total = 0.0;
+  for (int st = 0; st < nstrips; ++st) {
+    double t = 0.0;
+    for (int b = 0; b < nblocks; ++b) t += static_cast<double>(L[static_cast<size_t>(st) * nblocks + b]) + 2.0;
+    tot[static_cast<size_t>(st)] = t;
+    total += t;
+  }
+  const double Q = total / target;
+  std::vector<int> nts(static_cast<size_t>(nstrips));
+  int ntmax = 1;
+  for (int st = 0; st < nstrips; ++st) {
+    int n = static_cast<int>(std::max(1.0, std::floor(tot[static_cast<size_t>(st)] / Q + 0.5)));
+    n = std::min(n, nblocks);
+    nts[static_cast<size_t>(st)] = n;
+    ntmax = std::max(ntmax, n);
+  }
+  const size_t ntb = static_cast<size_t>(nstrips) * static_cast<size_t>(ntmax + 1);
+  if (ntb > h->csc_hcap_tb) {
+    if (h->csc_htb) hipHostFree(h->csc_htb);
+    h->csc_htb = nullptr;
+    HIPCHK(hipHostMalloc(&h->csc_htb, ntb * sizeof(int), hipHostMallocDefault));
+    h->csc_hcap_tb = ntb;
+  }
+  for (int st = 0; st < nstrips; ++st) {
+    int* t = h->csc_htb + static_cast<size_t>(st) * (ntmax + 1);
+    const int n = nts[static_cast<size_t>(st)];
+    const double T = tot[static_cast<size_t>(st)];
+    double run = 0.0;
+    int k = 1;
+    t[0] = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      run += static_cast<double>(L[static_cast<size_t>(st) * nblocks + b]) + 2.0;
+      while (k < n && run >= T * k / n) t[k++] = b + 1;
+    }
+    for (; k <= ntmax; ++k) t[k] = nblocks;
+  }
+  HIPCHK(hipSetDevice(s.device));
+  if (ntb > s.ccap_tb) {
+    if (s.ctb) hipFree(s.ctb);
+    s.ctb = nullptr;
+    HIPCHK(hipMalloc(&s.ctb, ntb * sizeof(int)));
+    s.ccap_tb = ntb;
+  }
+  HIPCHK(hipMemcpyAsync(s.ctb, h->csc_htb, ntb * sizeof(int), hipMemcpyHostToDevice, s.stream));
+  const size_t NSLOT = static_cast<size_t>(nslot(h->V));
+  if (static_cast<size_t>(ntmax) > s.part_tiles) {
+    HIPCHK(hipFree(s.part));
+    s.part = nullptr;
+    s.part_tiles = static_cast<size_t>(ntmax) + 8;
+    HIPCHK(hipMalloc(&s.part, s.part_tiles * NSLOT * static_cast<size_t>(h->W) * sizeof(double)));
+  }
+  h->csc_ntmax = ntmax;
+  return 0;
+}
+
+// after the stream was synchronised: grow the buffers and build again if the lists did not fit
+// (always the case for the first matrix of a size), then plan the tiles
+int csc_finish(Ctx* h) {
+  if (!csc_applies(h)) return 0;
+  Shard& s = h->sh[0];
+  HIPCHK(hipSetDevice(s.device));
+  if (h->csc_hctl->overflow || h->csc_hctl->cursor > s.ccap_units) {
+    const size_t need = static_cast<size_t>(h->csc_hctl->cursor);
+    if (s.cvals) hipFree(s.cvals);
+    if (s.crows) hipFree(s.crows);
+    s.cvals = nullptr;
+    s.crows = nullptr;
+    s.ccap_units = need + need / 8 + 64;
+    HIPCHK(hipMalloc(&s.cvals, s.ccap_units * 256 * sizeof(float)));
+    HIPCHK(hipMalloc(&s.crows, s.ccap_units * 256));
+    int rc = csc_enqueue(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(s.stream));
+    if (h->csc_hctl->overflow) return fail(CLIPPER_HIP_E_HIP, "compressed copy: build overflowed twice");
+  }
+  h->csc_units = h->csc_hctl->cursor;
+  int rc = csc_plan(h);
+  if (rc) return rc;
+  h->csc_valid = true;
+  return 0;
+}
+
+// build + wait + plan (the setMatrixData paths)
+int csc_rebuild(Ctx* h) {
+  int rc = csc_enqueue(h);
+  if (rc) return rc;
+  rc = sync_all(h);
+  if (rc) return rc;
+  return csc_finish(h);
+}
+
 template <typename Launch>
 int run_affinity(Ctx* h, Launch launch) {
   // explicit constraint storage is not needed on this path: C == pattern(M)
@@ -801,9 +994,13 @@ int run_affinity(Ctx* h, Launch launch) {
     HIPCHK(hipSetDevice(s.device));
     launch(s);
   }
+  int rc = csc_enqueue(h);  // counted as part of the affinity build
+  if (rc) return rc;
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipEventRecord(e1, s0.stream));
-  int rc = sync_all(h);
+  rc = sync_all(h);
+  if (rc) return rc;
+  rc = csc_finish(h);
   if (rc) return rc;
   float ms = 0.f;
   HIPCHK(hipSetDevice(s0.device));
@@ -821,6 +1018,9 @@ constexpr int AFF_ROWS_PER_BLK = 32;
 // (= s*m^2 on one GPU; the zero padding up to the 64-column pitch is not counted), doubled
 // when an explicit constraint matrix is read as well.
 double algorithmic_gemv_bytes(const Ctx* h) {
+  if (h->csc_valid)  // the compressed copy: 5 bytes per (padded) entry + the group directory
+    return static_cast<double>(h->csc_units) * 256.0 * 5.0 +
+           static_cast<double>(h->nstrips) * h->csc_nblocks * 12.0;
   const int64_t c0 = static_cast<int64_t>(h->sh[0].slot) * h->W;
   const int64_t valid = std::max<int64_t>(0, std::min<int64_t>(h->W, h->m - c0));
   return static_cast<double>(h->esize()) * static_cast<double>(h->m) *
@@ -950,6 +1150,9 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   if (h->mirror) hipHostFree(h->mirror);
   if (h->kind) hipHostFree(h->kind);
   if (h->u_pinned) hipHostFree(h->u_pinned);
+  if (h->csc_hLc) hipHostFree(h->csc_hLc);
+  if (h->csc_hctl) hipHostFree(h->csc_hctl);
+  if (h->csc_htb) hipHostFree(h->csc_htb);
   delete h;
 }
 
@@ -1181,6 +1384,8 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
     hipFree(dflag[k]);
   }
   if (rc) return rc;
+  rc = csc_rebuild(h);
+  if (rc) return rc;
   h->has_matrix = true;
   return 0;
 }
@@ -1248,6 +1453,8 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
       if (rc) return rc;
     }
   }
+  rc = csc_rebuild(h);
+  if (rc) return rc;
   h->has_matrix = true;
   return 0;
 }

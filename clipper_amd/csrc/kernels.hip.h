@@ -1140,6 +1140,293 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_plain(const T* __restr
   gemv_core<T, HASC, false, 2, 2, NW, UNR>(S, Cs, ld, m, rows_per_tile, 0.0, X, VS, part, lds);
 }
 
+// ------------------------------------------------------------------------------------------
+// column-compressed copy of M for the solver's passes (CLIPPER_HIP_STORE_F32_CSC)
+// ------------------------------------------------------------------------------------------
+// M at the headline configuration is ~11 % dense; the dense pass spends its time multiplying
+// zeros (it is VALU-bound before it is HBM-bound once a window of candidates shares one pass).
+// The compressed copy stores, per GROUP = (256-column strip s, block b of CSC_RB rows), every
+// column's nonzeros as (row-in-block u8, value fp32). All 256 columns of a group are padded to
+// the group's longest list, rounded up to 4 (padding: value 0, row 0 — adds exact zeros), and laid
+// out [column-of-lane e = 0..3][quad kq][lane][4 entries]: lane l owns columns 4l..4l+3 of the
+// strip as in the dense pass, and a wave reads 1 KiB of values + 256 B of rows per instruction.
+// A lane multiplies only ITS columns' nonzeros; the x rows a block needs (64 table rows) are
+// staged by the wave in LDS and gathered from there by row index.
+//   Lc[g]   padded list length of group g = s * nblocks + b (multiple of 4)
+//   Pre[g]  where the group's data starts, in units of 256 entries (vals: floats, rows: bytes)
+//   tb      row-tile boundaries per strip [nstrips][ntmax + 1] in blocks: tiles of EQUAL COST
+//           (sum of Lc), so that the dense inlier block at the end of the matrix does not land
+//           in one workgroup; strips with fewer tiles have empty ones (they write zeros)
+// The values are the fp32 M the dense store holds, the products are the same fp64 products, the
+// zeros the dense pass adds are exact — only the summation order over the rows differs.
+constexpr int CSC_RB = 64;
+constexpr int CSC_MAXQ = 6;  // quads of one column phase in flight per lane
+
+struct CscView {
+  const float* vals;
+  const uint8_t* rows;
+  const uint32_t* Lc;
+  const uint64_t* Pre;
+  const int* tb;
+  int nblocks;
+  int ntmax;
+};
+
+// k_csc_build — one group per workgroup, one column per thread: the 64 rows of the block are
+// loaded at once (independent loads), counted, the group's space is claimed with one atomic
+// (the ORDER of the groups in memory therefore varies from build to build; the content of a
+// group, and with it every sum, does not), and the lists are written as quads.
+// A build that does not fit `capacity` (always: the first one of a problem size, capacity 0)
+// writes nothing but Lc and the total; the host grows the buffers and builds again.
+struct CscBuildCtl {
+  unsigned long long cursor;    // units of 256 entries claimed so far
+  unsigned long long capacity;  // units available
+  int overflow;
+};
+
+__global__ __launch_bounds__(256) void k_csc_build(const float* __restrict__ S, int64_t ld,
+                                                    int64_t m, int nblocks,
+                                                    uint32_t* __restrict__ Lc,
+                                                    uint64_t* __restrict__ Pre,
+                                                    float* __restrict__ vals,
+                                                    uint8_t* __restrict__ rows,
+                                                    CscBuildCtl* __restrict__ ctl) {
+  __shared__ int red[4];
+  __shared__ unsigned long long base_s;
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int64_t g = static_cast<int64_t>(s) * nblocks + b;
+  const int t = threadIdx.x;
+  const int64_t c = static_cast<int64_t>(s) * 256 + t;
+  const int64_t r0 = static_cast<int64_t>(b) * CSC_RB;
+  float v[CSC_RB];
+#pragma unroll
+  for (int q = 0; q < CSC_RB; ++q) {
+    const int64_t r = r0 + q;
+    v[q] = (c < ld && r < m) ? S[r * ld + c] : 0.f;
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < CSC_RB; ++q) cnt += (v[q] != 0.f) ? 1 : 0;
+  int mx = cnt;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int other = __shfl_xor(mx, o);
+    mx = mx > other ? mx : other;
+  }
+  if ((t & 63) == 0) red[t >> 6] = mx;
+  __syncthreads();
+  if (t == 0) {
+    int w = red[0];
+    for (int k = 1; k < 4; ++k) w = w > red[k] ? w : red[k];
+    const unsigned L = static_cast<unsigned>((w + 3) & ~3);
+    Lc[g] = L;
+    unsigned long long base = atomicAdd(&ctl->cursor, static_cast<unsigned long long>(L));
+    if (base + L > ctl->capacity) {
+      ctl->overflow = 1;
+      base = ~0ull;
+    }
+    Pre[g] = base;
+    base_s = base;
+    red[0] = static_cast<int>(L);
+  }
+  __syncthreads();
+  const unsigned long long base = base_s;
+  if (base == ~0ull) return;
+  const int LQ = red[0] >> 2;
+  const int lane = t >> 2, e = t & 3;
+  float4* vq = reinterpret_cast<float4*>(vals + base * 256) + static_cast<int64_t>(e) * LQ * 64 + lane;
+  uint32_t* rq = reinterpret_cast<uint32_t*>(rows + base * 256) + static_cast<int64_t>(e) * LQ * 64 + lane;
+  float v4[4] = {0.f, 0.f, 0.f, 0.f};
+  uint32_t r4 = 0;
+  int k = 0;
+#pragma unroll
+  for (int q = 0; q < CSC_RB; ++q) {
+    if (v[q] != 0.f) {
+      const int j = k & 3;
+      v4[0] = j == 0 ? v[q] : v4[0];
+      v4[1] = j == 1 ? v[q] : v4[1];
+      v4[2] = j == 2 ? v[q] : v4[2];
+      v4[3] = j == 3 ? v[q] : v4[3];
+      r4 |= static_cast<uint32_t>(q) << (8 * j);
+      ++k;
+      if (j == 3) {
+        const int kq = (k >> 2) - 1;
+        vq[kq * 64] = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        rq[kq * 64] = r4;
+        v4[0] = v4[1] = v4[2] = v4[3] = 0.f;
+        r4 = 0;
+      }
+    }
+  }
+  for (int kq = k >> 2; kq < LQ; ++kq) {  // the open quad and the padding quads
+    vq[kq * 64] = make_float4(v4[0], v4[1], v4[2], v4[3]);
+    rq[kq * 64] = r4;
+    v4[0] = v4[1] = v4[2] = v4[3] = 0.f;
+    r4 = 0;
+  }
+}
+
+constexpr int csc_xpitch(int V) { return V <= 1 ? 2 : (V <= 6 ? 6 : 10); }  // doubles per staged row
+constexpr int csc_lds_doubles(int V, int NW) {
+  const int a = NW * CSC_RB * csc_xpitch(V), b = NW * (V + 1) * 64;
+  return (a > b ? a : b) + 2;
+}
+
+// The streaming part on the compressed copy: this workgroup's (strip, tile) partial sums ->
+// part[tile][slot][ld], the slots of gemv_core. Wave (e, h) of the workgroup: column e of every
+// lane's four, blocks b0 + h, b0 + h + NW/4, ... of the tile — the four column phases of a block
+// cost the same by construction. WINDOW / pair mode as in gemv_core.
+template <bool WINDOW, int V, int NSLOT, int NW>
+__device__ __forceinline__ void csc_core(const CscView& M, int64_t ld, int64_t m, double d,
+                                         const double* __restrict__ X, int xstride,
+                                         double* __restrict__ part, double* lds) {
+  constexpr int NS = WINDOW ? V + 1 : 2;
+  constexpr int XP = WINDOW ? csc_xpitch(V) : 1;
+  constexpr int NH = NW / 4;
+  constexpr int XT = CSC_RB * XP;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int e = wave & 3, h = wave >> 2;
+  const int s = blockIdx.x;
+  const int b0 = M.tb[s * (M.ntmax + 1) + blockIdx.y];
+  const int b1 = M.tb[s * (M.ntmax + 1) + blockIdx.y + 1];
+  double* xs = lds + wave * XT;
+
+  double acc[NS];
+#pragma unroll
+  for (int v = 0; v < NS; ++v) acc[v] = 0.0;
+
+  __syncthreads();  // the decision at the head of the launch used the same LDS
+  for (int b = b0 + h; b < b1; b += NH) {
+    const int64_t g = static_cast<int64_t>(s) * M.nblocks + b;
+    const int LQ = __builtin_amdgcn_readfirstlane(static_cast<int>(M.Lc[g] >> 2));
+    const int64_t base = static_cast<int64_t>(M.Pre[g]) * 256;
+    const float4* vq =
+        reinterpret_cast<const float4*>(M.vals + base) + static_cast<int64_t>(e) * LQ * 64 + lane;
+    const uint32_t* rq =
+        reinterpret_cast<const uint32_t*>(M.rows + base) + static_cast<int64_t>(e) * LQ * 64 + lane;
+    float4 mv[CSC_MAXQ];
+    uint32_t rw[CSC_MAXQ];
+#pragma unroll
+    for (int q = 0; q < CSC_MAXQ; ++q) {
+      if (q < LQ) {
+        mv[q] = vq[q * 64];
+        rw[q] = rq[q * 64];
+      }
+    }
+    // stage the block's x rows (the wave's own tile: LDS operations of one wave stay in order)
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int64_t r = static_cast<int64_t>(b) * CSC_RB + lane;
+      if constexpr (WINDOW) {
+        double xr[VS];
+#pragma unroll
+        for (int v = 0; v < VS; ++v) xr[v] = 0.0;
+        if (r < m) {
+          const double2* xp = reinterpret_cast<const double2*>(X + r * VS);
+#pragma unroll
+          for (int v = 0; v < ((V + 1) & ~1); v += 2) {
+            const double2 t2 = xp[v >> 1];
+            xr[v] = t2.x;
+            xr[v + 1] = t2.y;
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < ((V + 1) & ~1); v += 2)
+          *reinterpret_cast<double2*>(xs + lane * XP + v) = make_double2(xr[v], xr[v + 1]);
+      } else {
+        xs[lane] = (r < m) ? X[r * xstride] : 0.0;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k0 = 0; k0 < LQ; k0 += CSC_MAXQ) {
+      if (k0 > 0) {
+#pragma unroll
+        for (int q = 0; q < CSC_MAXQ; ++q) {
+          if (k0 + q < LQ) {
+            mv[q] = vq[(k0 + q) * 64];
+            rw[q] = rq[(k0 + q) * 64];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CSC_MAXQ; ++q) {
+        if (k0 + q < LQ) {
+          const float mf[4] = {mv[q].x, mv[q].y, mv[q].z, mv[q].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double mm = static_cast<double>(mf[j]);
+            const double ii = mf[j] != 0.f ? 1.0 : 0.0;
+            const uint32_t row = (rw[q] >> (8 * j)) & 255u;
+            if constexpr (WINDOW) {
+              const double* xr = xs + row * XP;
+              double xv[(V + 1) & ~1];
+#pragma unroll
+              for (int v = 0; v < ((V + 1) & ~1); v += 2) {
+                const double2 t2 = *reinterpret_cast<const double2*>(xr + v);
+                xv[v] = t2.x;
+                xv[v + 1] = t2.y;
+              }
+              acc[0] = fma(mm, xv[0], acc[0]);
+              acc[V] = fma(ii, xv[0], acc[V]);
+              if (V > 1) {
+                const double w = fma(d, ii, mm);
+#pragma unroll
+                for (int v = 1; v < V; ++v) acc[v] = fma(w, xv[v], acc[v]);
+              }
+            } else {
+              const double xv = xs[row];
+              acc[0] = fma(mm, xv, acc[0]);
+              acc[1] = fma(ii, xv, acc[1]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // cross-wave combine: the NH waves of a column phase, in wave order
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < NS; ++v) lds[(wave * NS + v) * 64 + lane] = acc[v];
+  __syncthreads();
+  for (int t = threadIdx.x; t < NS * 256; t += NW * 64) {
+    const int v = t >> 8, cl = t & 255;
+    const int ee = cl & 3, ln = cl >> 2;
+    double sum = lds[(ee * NS + v) * 64 + ln];
+#pragma unroll
+    for (int hh = 1; hh < NH; ++hh) sum += lds[((hh * 4 + ee) * NS + v) * 64 + ln];
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + cl;
+    const int slot = (v == NS - 1) ? NSLOT - 1 : v;
+    if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * NSLOT + slot) * ld + c] = sum;
+  }
+}
+
+// G of a solver iteration on the compressed copy (one shard): decision, then the pass
+template <int V, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_csc(CscView M, SolveArgs A) {
+  static_assert(csc_lds_doubles(V, NW) >= NW * 64 + NW * 2 * V,
+                "LDS of the mat-vec must hold the decision's scratch");
+  __shared__ double lds[csc_lds_doubles(V, NW)];
+  __shared__ SolverState stash;
+  PassPlan plan;
+  if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
+  if (plan.phase == PH_TRIAL) {
+    csc_core<true, V, nslot(V), NW>(M, A.W, A.m, plan.d,
+                                    A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS, VS, A.part,
+                                    lds);
+  } else if (plan.from_u >= 0) {
+    csc_core<false, V, nslot(V), NW>(M, A.W, A.m, 0.0,
+                                     A.pt + static_cast<int64_t>(plan.from_u) * 2 * A.mp, 1,
+                                     A.part, lds);
+  } else {
+    csc_core<false, V, nslot(V), NW>(M, A.W, A.m, 0.0,
+                                     A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS, VS,
+                                     A.part, lds);
+  }
+  flush_state(A, &stash);
+}
+
 // k_reduce — adds the row-tile partials in tile order and writes this shard's block of the
 // gathered layout (matvec API only: the solver folds this into k_pass / k_tail). One thread per
 // output element e = slot*ld + c; the loads of 8 tiles are issued before they are summed (the

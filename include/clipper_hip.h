@@ -25,6 +25,12 @@
  *   On the scorePairwiseConsistency path C == pattern(M) (clipper.cpp:63-64) and is not
  *   stored: the mat-vec kernel derives C_off*x from the same pass over M. setMatrixData
  *   with any other C stores a second dense matrix.
+ *   CLIPPER_HIP_STORE_F32_CSC keeps, next to the dense fp32 store, a column-compressed copy
+ *   of it (nonzeros only: fp32 value + row byte, blocked and padded for 64-wide waves) that
+ *   the SOLVER's passes read instead of the dense store — the same fp32 values, the same fp64
+ *   products, only the zeros are skipped. It applies to one shard with C == pattern(M);
+ *   otherwise the context behaves as CLIPPER_HIP_STORE_F32. gemv_bytes then reports the
+ *   bytes of the compressed copy one pass streams.
  */
 #ifndef CLIPPER_HIP_H
 #define CLIPPER_HIP_H
@@ -37,7 +43,7 @@ extern "C" {
 
 typedef struct clipper_hip_ctx clipper_hip_t;
 
-enum { CLIPPER_HIP_STORE_F32 = 0, CLIPPER_HIP_STORE_F64 = 1 };
+enum { CLIPPER_HIP_STORE_F32 = 0, CLIPPER_HIP_STORE_F64 = 1, CLIPPER_HIP_STORE_F32_CSC = 2 };
 
 enum {
   CLIPPER_HIP_OK = 0,

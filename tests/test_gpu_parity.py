@@ -19,7 +19,7 @@ from oracle import clipper_ref as ref
 
 pytestmark = pytest.mark.gpu
 
-STORAGES = [abi.STORE_F32, abi.STORE_F64]
+STORAGES = [abi.STORE_F32, abi.STORE_F64, abi.STORE_F32_CSC]
 REL_SCORE = 1e-6
 
 
@@ -32,7 +32,7 @@ def _check_affinity(g, r, storage, f64_rel=4 * 2.3e-16):
     assert Mg.shape == Mr.shape
     assert np.array_equal(Mg != 0, Mr != 0), "non-zero pattern differs"
     assert np.array_equal(Mg, Mg.T)
-    if storage == abi.STORE_F32:
+    if storage != abi.STORE_F64:
         assert np.array_equal(Mg.astype(np.float32), Mr.astype(np.float32)) or \
             np.max(np.abs(Mg - Mr.astype(np.float32).astype(np.float64))) <= 1.2e-7
     else:
@@ -162,7 +162,7 @@ def test_euclidean_parity(storage, m, rho, seed):
     # one mat-vec pass in isolation
     x = np.random.default_rng(seed + 5).random(m)
     (aM, aC), (rM, rC) = c.matvec(x), r.matvec(x)
-    tol = 1e-6 if storage == abi.STORE_F32 else 1e-12
+    tol = 1e-6 if storage != abi.STORE_F64 else 1e-12
     assert np.allclose(aM, rM, rtol=tol, atol=tol)
     assert np.allclose(aC, rC, rtol=1e-12, atol=1e-12)
     sg, sr = c.solve(p.u0), r.solve(p.u0)
@@ -407,8 +407,10 @@ def test_window_sizes_agree(monkeypatch, m, rho, seed):
                 s = sols[(V, storage, rep)]
                 assert s.nodes.tolist() == base.nodes.tolist(), (V, storage, rep)
                 assert s.ifinal == base.ifinal and s.n_trials == base.n_trials, (V, storage, rep)
-                assert abs(s.score - base.score) <= 1e-12 * abs(base.score)
-                assert np.allclose(s.u, base.u, rtol=0, atol=1e-12)
+                # windows > 1 form g_v = (M + d*C) x_v in one product, window 1 adds a + d*b:
+                # rounding-level differences only
+                assert abs(s.score - base.score) <= 1e-11 * abs(base.score)
+                assert np.allclose(s.u, base.u, rtol=0, atol=1e-11)
                 assert s.n_passes <= base.n_passes
                 assert np.array_equal(s.u, sols[(V, storage, 0)].u)   # run-to-run bit-identical
 

@@ -76,7 +76,7 @@ def run(name, cfg, reps, storage, with_cpu):
         gemv.append(g.timings().gemv_avg_us)
     tm = g.timings()
     row = dict(config=name, kind=cfg["kind"], m=m, rho=rho,
-               storage="f32" if storage == abi.STORE_F32 else "f64",
+               storage={abi.STORE_F32: "f32", abi.STORE_F64: "f64", abi.STORE_F32_CSC: "csc"}[storage],
                gpu_affinity_ms=round(float(np.median(ta)), 4), gpu_solve_ms=round(float(np.median(ts)), 4),
                passes=int(sol.n_passes), gemv_us=round(float(np.median(gemv)), 2),
                gemv_GBps=round(tm.gemv_bytes / (float(np.median(gemv)) * 1e-6) / 1e9, 1),
@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--storage", default="f32")
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
-    storage = abi.STORE_F32 if a.storage == "f32" else abi.STORE_F64
+    storage = {"f32": abi.STORE_F32, "f64": abi.STORE_F64, "csc": abi.STORE_F32_CSC}[a.storage]
     for name in a.configs.split(","):
         run(name, CONFIGS[name], a.reps, storage, not a.no_cpu)
 
