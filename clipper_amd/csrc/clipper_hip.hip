@@ -172,8 +172,10 @@ struct clipper_hip_ctx {
   bool explicitC = false;
   bool compressed = false;   // CLIPPER_HIP_STORE_F32_CSC was asked for
   bool csc_valid = false;    // ... and the compressed copy of the current matrix exists
-  int csc_nblocks = 0, csc_ntmax = 0;
-  uint64_t csc_units = 0;    // sum of the padded list lengths (units of 256 entries)
+  bool csc_emitted = false;  // the fill kernel of this build wrote the groups itself
+  CscOut csc_out{};          // what that kernel was given
+  int csc_nblocks = 0, csc_ntmax = 0, csc_nstrips = 0;
+  uint64_t csc_units = 0;    // sum of the padded list lengths (units of 128 entries)
   uint32_t* csc_hLc = nullptr;     // pinned host copy of Lc
   CscBuildCtl* csc_hctl = nullptr; // pinned host copy of the build's counters
   int* csc_htb = nullptr;          // pinned staging of the tile boundaries
@@ -421,7 +423,7 @@ void launch_pass_csc(Ctx* h, Shard& s, const SolveArgs& a) {
   M.tb = s.ctb;
   M.nblocks = h->csc_nblocks;
   M.ntmax = h->csc_ntmax;
-  dim3 grid(h->nstrips, h->csc_ntmax), block(GEMV_NW * 64);
+  dim3 grid(h->csc_nstrips, h->csc_ntmax), block(GEMV_NW * 64);
   hipLaunchKernelGGL((k_gemv_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
 }
 
@@ -813,7 +815,7 @@ bool use_sym_fill(const Ctx* h) {
 template <typename K>
 void launch_sym(K kernel, dim3 grid, hipStream_t stream, float* S, int64_t W, int64_t mm, int nT,
                 const Shard& s, int64_t pstride, const int32_t* A0, const int32_t* A1,
-                const EuclidParams& e, const PointNormalParams& n, float E2) {
+                const EuclidParams& e, const PointNormalParams& n, float E2, const CscOut& O) {
   static std::vector<const void*> raised;  // once per kernel instantiation and device
   const void* fn = reinterpret_cast<const void*>(kernel);
   if (std::find(raised.begin(), raised.end(), fn) == raised.end()) {
@@ -821,7 +823,7 @@ void launch_sym(K kernel, dim3 grid, hipStream_t stream, float* S, int64_t W, in
     raised.push_back(fn);
   }
   hipLaunchKernelGGL(kernel, grid, dim3(AT_WAVES * 64), AT_SYM_LDS_BYTES, stream, S, W, mm, nT, s.P1, s.P2,
-                     s.P1f, s.P2f, pstride, A0, A1, e, n, E2);
+                     s.P1f, s.P2f, pstride, A0, A1, e, n, E2, O);
 }
 
 // ---- the column-compressed copy (CLIPPER_HIP_STORE_F32_CSC) ---------------------------------
@@ -830,15 +832,18 @@ bool csc_applies(const Ctx* h) {
          h->storage == CLIPPER_HIP_STORE_F32;
 }
 
-// enqueue the build from the dense store (stream order: after the fill) and the copies of its
-// counters to pinned host memory; csc_finish() after the stream was synchronised
-int csc_enqueue(Ctx* h) {
+// Before the fill: buffers of the group directory, the arenas' cursors reset. Returns what a
+// kernel that emits groups needs (k_affinity_sym, k_csc_build); out.Lc == null: not in use.
+int csc_prepare(Ctx* h, CscOut& out) {
+  out = CscOut{};
   h->csc_valid = false;
+  h->csc_emitted = false;
   if (!csc_applies(h)) return 0;
   Shard& s = h->sh[0];
   HIPCHK(hipSetDevice(s.device));
   const int nblocks = static_cast<int>(ceil_div(h->m, CSC_RB));
-  const size_t G = static_cast<size_t>(h->nstrips) * static_cast<size_t>(nblocks);
+  h->csc_nstrips = static_cast<int>(ceil_div(h->W, CSC_CW));
+  const size_t G = static_cast<size_t>(h->csc_nstrips) * static_cast<size_t>(nblocks);
   h->csc_nblocks = nblocks;
   if (G > s.ccap_groups) {
     if (s.cLc) hipFree(s.cLc);
@@ -849,34 +854,62 @@ int csc_enqueue(Ctx* h) {
     HIPCHK(hipMalloc(&s.cPre, G * sizeof(uint64_t)));
     s.ccap_groups = G;
   }
-  if (!s.cctl) HIPCHK(hipMalloc(&s.cctl, sizeof(CscBuildCtl)));
+  if (!s.cctl) HIPCHK(hipMalloc(&s.cctl, CSC_ARENAS * sizeof(CscBuildCtl)));
   if (G > h->csc_hcap_groups) {
     if (h->csc_hLc) hipHostFree(h->csc_hLc);
     h->csc_hLc = nullptr;
     HIPCHK(hipHostMalloc(&h->csc_hLc, G * sizeof(uint32_t), hipHostMallocDefault));
     h->csc_hcap_groups = G;
   }
-  if (!h->csc_hctl) HIPCHK(hipHostMalloc(&h->csc_hctl, sizeof(CscBuildCtl), hipHostMallocDefault));
-  h->csc_hctl->cursor = 0;
-  h->csc_hctl->capacity = s.ccap_units;
-  h->csc_hctl->overflow = 0;
-  HIPCHK(hipMemcpyAsync(s.cctl, h->csc_hctl, sizeof(CscBuildCtl), hipMemcpyHostToDevice, s.stream));
-  dim3 grid(h->nstrips, nblocks), block(256);
-  hipLaunchKernelGGL(k_csc_build, grid, block, 0, s.stream, static_cast<const float*>(s.S), h->W,
-                     h->m, nblocks, s.cLc, s.cPre, s.cvals, s.crows, s.cctl);
-  HIPCHK(hipMemcpyAsync(h->csc_hctl, s.cctl, sizeof(CscBuildCtl), hipMemcpyDeviceToHost, s.stream));
+  if (!h->csc_hctl) {
+    HIPCHK(hipHostMalloc(&h->csc_hctl, 2 * CSC_ARENAS * sizeof(CscBuildCtl), hipHostMallocDefault));
+  }
+  CscBuildCtl* init = h->csc_hctl + CSC_ARENAS;  // second half: what the device starts from
+  for (int k = 0; k < CSC_ARENAS; ++k) {
+    init[k].cursor = 0;
+    init[k].capacity = s.ccap_units / CSC_ARENAS;
+    init[k].origin = static_cast<unsigned long long>(k) * (s.ccap_units / CSC_ARENAS);
+    init[k].overflow = 0;
+  }
+  HIPCHK(hipMemcpyAsync(s.cctl, init, CSC_ARENAS * sizeof(CscBuildCtl), hipMemcpyHostToDevice,
+                        s.stream));
+  out.Lc = s.cLc;
+  out.Pre = s.cPre;
+  out.vals = s.cvals;
+  out.rows = s.crows;
+  out.ctl = s.cctl;
+  out.nblocks = nblocks;
+  return 0;
+}
+
+// After the fill: the build from the dense store unless the fill kernel emitted the groups
+// itself, then the copies of the counters to pinned host memory (csc_finish() reads them once
+// the stream was synchronised).
+int csc_enqueue(Ctx* h, const CscOut& O) {
+  if (O.Lc == nullptr) return 0;
+  Shard& s = h->sh[0];
+  HIPCHK(hipSetDevice(s.device));
+  if (!h->csc_emitted) {
+    dim3 grid(h->csc_nstrips, static_cast<unsigned>(ceil_div(h->csc_nblocks, 2))), block(256);
+    hipLaunchKernelGGL(k_csc_build, grid, block, 0, s.stream, static_cast<const float*>(s.S), h->W,
+                       h->m, O);
+  }
+  const size_t G = static_cast<size_t>(h->csc_nstrips) * static_cast<size_t>(h->csc_nblocks);
+  HIPCHK(hipMemcpyAsync(h->csc_hctl, s.cctl, CSC_ARENAS * sizeof(CscBuildCtl),
+                        hipMemcpyDeviceToHost, s.stream));
   HIPCHK(hipMemcpyAsync(h->csc_hLc, s.cLc, G * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
   return 0;
 }
 
 // Row tiles of equal cost per strip (cost of a block: its padded list length + a constant for
 // the staging of its x rows). The number of workgroups aims at whole waves of co-resident ones
-// (three 8-wave workgroups per CU), at most ~32 blocks each.
+// (two 8-wave workgroups per CU measured best: every workgroup repeats the decision), at most
+// ~32 blocks each.
 int csc_plan(Ctx* h) {
   Shard& s = h->sh[0];
-  const int nstrips = h->nstrips, nblocks = h->csc_nblocks;
+  const int nstrips = h->csc_nstrips, nblocks = h->csc_nblocks;
   const uint32_t* L = h->csc_hLc;
-  const double slots = static_cast<double>(h->cus) * 3.0;
+  const double slots = static_cast<double>(h->cus) * 2.0;
   const double G = static_cast<double>(nstrips) * nblocks;
   double target = slots * std::max(1.0, std::ceil(G / (slots * 32.0)));
   if (const char* e = std::getenv("CLIPPER_HIP_CSC_WGS")) target = std::max(1.0, std::atof(e));
@@ -942,21 +975,39 @@ int csc_finish(Ctx* h) {
   if (!csc_applies(h)) return 0;
   Shard& s = h->sh[0];
   HIPCHK(hipSetDevice(s.device));
-  if (h->csc_hctl->overflow || h->csc_hctl->cursor > s.ccap_units) {
-    const size_t need = static_cast<size_t>(h->csc_hctl->cursor);
+  auto totals = [&](bool& over, size_t& worst, uint64_t& sum) {
+    over = false;
+    worst = 0;
+    sum = 0;
+    for (int k = 0; k < CSC_ARENAS; ++k) {
+      over = over || h->csc_hctl[k].overflow != 0;
+      worst = std::max(worst, static_cast<size_t>(h->csc_hctl[k].cursor));
+      sum += h->csc_hctl[k].cursor;
+    }
+  };
+  bool over;
+  size_t worst;
+  uint64_t sum;
+  totals(over, worst, sum);
+  if (over) {
+    const size_t need = worst * CSC_ARENAS;  // every arena as large as the fullest one
     if (s.cvals) hipFree(s.cvals);
     if (s.crows) hipFree(s.crows);
     s.cvals = nullptr;
     s.crows = nullptr;
-    s.ccap_units = need + need / 8 + 64;
-    HIPCHK(hipMalloc(&s.cvals, s.ccap_units * 256 * sizeof(float)));
-    HIPCHK(hipMalloc(&s.crows, s.ccap_units * 256));
-    int rc = csc_enqueue(h);
+    s.ccap_units = (need + need / 8 + 64 * CSC_ARENAS) / CSC_ARENAS * CSC_ARENAS;
+    HIPCHK(hipMalloc(&s.cvals, s.ccap_units * 128 * sizeof(float)));
+    HIPCHK(hipMalloc(&s.crows, s.ccap_units * 128));
+    CscOut O;
+    int rc = csc_prepare(h, O);  // again, now from the dense store
+    if (rc) return rc;
+    rc = csc_enqueue(h, O);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s.stream));
-    if (h->csc_hctl->overflow) return fail(CLIPPER_HIP_E_HIP, "compressed copy: build overflowed twice");
+    totals(over, worst, sum);
+    if (over) return fail(CLIPPER_HIP_E_HIP, "compressed copy: build overflowed twice");
   }
-  h->csc_units = h->csc_hctl->cursor;
+  h->csc_units = sum;
   int rc = csc_plan(h);
   if (rc) return rc;
   h->csc_valid = true;
@@ -965,7 +1016,10 @@ int csc_finish(Ctx* h) {
 
 // build + wait + plan (the setMatrixData paths)
 int csc_rebuild(Ctx* h) {
-  int rc = csc_enqueue(h);
+  CscOut O;
+  int rc = csc_prepare(h, O);
+  if (rc) return rc;
+  rc = csc_enqueue(h, O);
   if (rc) return rc;
   rc = sync_all(h);
   if (rc) return rc;
@@ -989,12 +1043,16 @@ int run_affinity(Ctx* h, Launch launch) {
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
+  CscOut O;
+  int rc = csc_prepare(h, O);
+  if (rc) return rc;
+  h->csc_out = O;
   HIPCHK(hipEventRecord(e0, s0.stream));
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    launch(s);
+    launch(s);  // k_affinity_sym emits the compressed copy itself and sets csc_emitted
   }
-  int rc = csc_enqueue(h);  // counted as part of the affinity build
+  rc = csc_enqueue(h, O);  // counted as part of the affinity build
   if (rc) return rc;
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipEventRecord(e1, s0.stream));
@@ -1019,8 +1077,8 @@ constexpr int AFF_ROWS_PER_BLK = 32;
 // when an explicit constraint matrix is read as well.
 double algorithmic_gemv_bytes(const Ctx* h) {
   if (h->csc_valid)  // the compressed copy: 5 bytes per (padded) entry + the group directory
-    return static_cast<double>(h->csc_units) * 256.0 * 5.0 +
-           static_cast<double>(h->nstrips) * h->csc_nblocks * 12.0;
+    return static_cast<double>(h->csc_units) * 128.0 * 5.0 +
+           static_cast<double>(h->csc_nstrips) * h->csc_nblocks * 12.0;
   const int64_t c0 = static_cast<int64_t>(h->sh[0].slot) * h->W;
   const int64_t valid = std::max<int64_t>(0, std::min<int64_t>(h->W, h->m - c0));
   return static_cast<double>(h->esize()) * static_cast<double>(h->m) *
@@ -1193,10 +1251,11 @@ int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double
       const float E2 = guarded_threshold_sq(thr);
       if (d == 3)
         launch_sym(k_affinity_sym<3, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
-                   pstride, A0, A1, prm, none, E2);
+                   pstride, A0, A1, prm, none, E2, h->csc_out);
       else
         launch_sym(k_affinity_sym<2, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
-                   pstride, A0, A1, prm, none, E2);
+                   pstride, A0, A1, prm, none, E2, h->csc_out);
+      h->csc_emitted = (h->csc_out.Lc != nullptr);
       return;
     }
     const bool compact = !h->plain_affinity && (d == 2 || d == 3);
@@ -1236,7 +1295,8 @@ int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, doubl
       dim3 g(static_cast<unsigned>(static_cast<int64_t>(nT) * (nT + 1) / 2));
       const EuclidParams none{};
       launch_sym(k_affinity_sym<3, true>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
-                 pstride, s.Adev, s.Adev + mm, none, prm, guarded_threshold_sq(thr));
+                 pstride, s.Adev, s.Adev + mm, none, prm, guarded_threshold_sq(thr), h->csc_out);
+      h->csc_emitted = (h->csc_out.Lc != nullptr);
       return;
     }
     if (h->plain_affinity) {

@@ -1145,21 +1145,25 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_plain(const T* __restr
 // ------------------------------------------------------------------------------------------
 // M at the headline configuration is ~11 % dense; the dense pass spends its time multiplying
 // zeros (it is VALU-bound before it is HBM-bound once a window of candidates shares one pass).
-// The compressed copy stores, per GROUP = (256-column strip s, block b of CSC_RB rows), every
-// column's nonzeros as (row-in-block u8, value fp32). All 256 columns of a group are padded to
+// The compressed copy stores, per GROUP = (128-column strip s, block b of 64 rows), every
+// column's nonzeros as (row-in-block u8, value fp32). All 128 columns of a group are padded to
 // the group's longest list, rounded up to 4 (padding: value 0, row 0 — adds exact zeros), and laid
-// out [column-of-lane e = 0..3][quad kq][lane][4 entries]: lane l owns columns 4l..4l+3 of the
-// strip as in the dense pass, and a wave reads 1 KiB of values + 256 B of rows per instruction.
-// A lane multiplies only ITS columns' nonzeros; the x rows a block needs (64 table rows) are
-// staged by the wave in LDS and gathered from there by row index.
+// out [column-of-lane e = 0..1][quad kq][lane][4 entries]: lane l owns columns 2l, 2l+1 of the
+// strip, and a wave reads 1 KiB of values + 256 B of rows per instruction. A lane multiplies
+// only ITS columns' nonzeros; the x rows a block needs (64 table rows) are staged by the wave
+// in LDS and gathered from there by row index.
 //   Lc[g]   padded list length of group g = s * nblocks + b (multiple of 4)
-//   Pre[g]  where the group's data starts, in units of 256 entries (vals: floats, rows: bytes)
+//   Pre[g]  where the group's data starts, in units of 128 entries (vals: floats, rows: bytes)
 //   tb      row-tile boundaries per strip [nstrips][ntmax + 1] in blocks: tiles of EQUAL COST
 //           (sum of Lc), so that the dense inlier block at the end of the matrix does not land
 //           in one workgroup; strips with fewer tiles have empty ones (they write zeros)
 // The values are the fp32 M the dense store holds, the products are the same fp64 products, the
 // zeros the dense pass adds are exact — only the summation order over the rows differs.
-constexpr int CSC_RB = 64;
+// A group is as wide as a tile of k_affinity_sym, which therefore emits the groups of the tiles
+// it computes (and of their mirror images) straight from its LDS image; k_csc_build does the
+// same from a dense store (the other fill kernels, setMatrixData).
+constexpr int CSC_RB = 64;   // rows per block
+constexpr int CSC_CW = 128;  // columns per strip
 constexpr int CSC_MAXQ = 6;  // quads of one column phase in flight per lane
 
 struct CscView {
@@ -1172,38 +1176,37 @@ struct CscView {
   int ntmax;
 };
 
-// k_csc_build — one group per workgroup, one column per thread: the 64 rows of the block are
-// loaded at once (independent loads), counted, the group's space is claimed with one atomic
-// (the ORDER of the groups in memory therefore varies from build to build; the content of a
-// group, and with it every sum, does not), and the lists are written as quads.
-// A build that does not fit `capacity` (always: the first one of a problem size, capacity 0)
-// writes nothing but Lc and the total; the host grows the buffers and builds again.
-struct CscBuildCtl {
-  unsigned long long cursor;    // units of 256 entries claimed so far
-  unsigned long long capacity;  // units available
+// The space of a group is claimed with one atomic on the cursor of one of CSC_ARENAS arenas
+// (same-address atomics serialise at ~25-50 ns each — thousands of groups on ONE cursor cost more
+// than the build itself): the ORDER of the groups in memory varies from build to build; the
+// content of a group, and with it every sum, does not. A build that does not fit an arena
+// (always: the first one of a problem size, capacity 0) writes nothing but Lc and the totals;
+// the host grows the buffers and builds again.
+constexpr int CSC_ARENAS = 64;
+struct alignas(128) CscArena {
+  unsigned long long cursor;    // units of 128 entries claimed so far in this arena
+  unsigned long long capacity;  // units available to it
+  unsigned long long origin;    // where the arena starts, same units
   int overflow;
 };
+typedef CscArena CscBuildCtl;  // [CSC_ARENAS]
 
-__global__ __launch_bounds__(256) void k_csc_build(const float* __restrict__ S, int64_t ld,
-                                                    int64_t m, int nblocks,
-                                                    uint32_t* __restrict__ Lc,
-                                                    uint64_t* __restrict__ Pre,
-                                                    float* __restrict__ vals,
-                                                    uint8_t* __restrict__ rows,
-                                                    CscBuildCtl* __restrict__ ctl) {
-  __shared__ int red[4];
-  __shared__ unsigned long long base_s;
-  const int s = blockIdx.x, b = blockIdx.y;
-  const int64_t g = static_cast<int64_t>(s) * nblocks + b;
-  const int t = threadIdx.x;
-  const int64_t c = static_cast<int64_t>(s) * 256 + t;
-  const int64_t r0 = static_cast<int64_t>(b) * CSC_RB;
-  float v[CSC_RB];
-#pragma unroll
-  for (int q = 0; q < CSC_RB; ++q) {
-    const int64_t r = r0 + q;
-    v[q] = (c < ld && r < m) ? S[r * ld + c] : 0.f;
-  }
+struct CscOut {
+  uint32_t* Lc;
+  uint64_t* Pre;
+  float* vals;
+  uint8_t* rows;
+  CscBuildCtl* ctl;
+  int nblocks;
+};
+
+// Emission of NG groups by one workgroup of NG*128 threads: thread t holds the 64 values of
+// column (t & 127) of group (t >> 7); g = its group id or -1 (nothing to emit: the whole group,
+// uniformly). `red` [2*NG] ints and `base_s` [NG] are LDS scratch. Contains barriers.
+template <int NG>
+__device__ __forceinline__ void csc_emit(const float (&v)[CSC_RB], int64_t g, const CscOut& O,
+                                         int* red, unsigned long long* base_s) {
+  const int t = threadIdx.x, gi = t >> 7, cl = t & 127;
   int cnt = 0;
 #pragma unroll
   for (int q = 0; q < CSC_RB; ++q) cnt += (v[q] != 0.f) ? 1 : 0;
@@ -1215,27 +1218,30 @@ __global__ __launch_bounds__(256) void k_csc_build(const float* __restrict__ S, 
   }
   if ((t & 63) == 0) red[t >> 6] = mx;
   __syncthreads();
-  if (t == 0) {
-    int w = red[0];
-    for (int k = 1; k < 4; ++k) w = w > red[k] ? w : red[k];
+  if (cl == 0 && g >= 0) {
+    const int w = red[2 * gi] > red[2 * gi + 1] ? red[2 * gi] : red[2 * gi + 1];
     const unsigned L = static_cast<unsigned>((w + 3) & ~3);
-    Lc[g] = L;
-    unsigned long long base = atomicAdd(&ctl->cursor, static_cast<unsigned long long>(L));
-    if (base + L > ctl->capacity) {
-      ctl->overflow = 1;
+    O.Lc[g] = L;
+    CscArena* ar = O.ctl + static_cast<int>((g * 11 + (g >> 6)) & (CSC_ARENAS - 1));
+    unsigned long long base = atomicAdd(&ar->cursor, static_cast<unsigned long long>(L));
+    if (base + L > ar->capacity) {
+      ar->overflow = 1;
       base = ~0ull;
+    } else {
+      base += ar->origin;
     }
-    Pre[g] = base;
-    base_s = base;
-    red[0] = static_cast<int>(L);
+    O.Pre[g] = base;
+    base_s[gi] = base;
   }
   __syncthreads();
-  const unsigned long long base = base_s;
+  if (g < 0) return;
+  const unsigned long long base = base_s[gi];
   if (base == ~0ull) return;
-  const int LQ = red[0] >> 2;
-  const int lane = t >> 2, e = t & 3;
-  float4* vq = reinterpret_cast<float4*>(vals + base * 256) + static_cast<int64_t>(e) * LQ * 64 + lane;
-  uint32_t* rq = reinterpret_cast<uint32_t*>(rows + base * 256) + static_cast<int64_t>(e) * LQ * 64 + lane;
+  const int w = red[2 * gi] > red[2 * gi + 1] ? red[2 * gi] : red[2 * gi + 1];
+  const int LQ = ((w + 3) & ~3) >> 2;
+  const int lane = cl >> 1, e = cl & 1;
+  float4* vq = reinterpret_cast<float4*>(O.vals + base * 128) + static_cast<int64_t>(e) * LQ * 64 + lane;
+  uint32_t* rq = reinterpret_cast<uint32_t*>(O.rows + base * 128) + static_cast<int64_t>(e) * LQ * 64 + lane;
   float v4[4] = {0.f, 0.f, 0.f, 0.f};
   uint32_t r4 = 0;
   int k = 0;
@@ -1266,6 +1272,26 @@ __global__ __launch_bounds__(256) void k_csc_build(const float* __restrict__ S, 
   }
 }
 
+// k_csc_build — from a dense fp32 store: two groups (row blocks 2y, 2y+1 of strip x) per
+// workgroup, one column per thread, the 64 rows of the block loaded at once.
+__global__ __launch_bounds__(256) void k_csc_build(const float* __restrict__ S, int64_t ld,
+                                                    int64_t m, CscOut O) {
+  __shared__ int red[4];
+  __shared__ unsigned long long base_s[2];
+  const int s = blockIdx.x, t = threadIdx.x;
+  const int b = 2 * blockIdx.y + (t >> 7);
+  const int64_t c = static_cast<int64_t>(s) * CSC_CW + (t & 127);
+  const int64_t r0 = static_cast<int64_t>(b) * CSC_RB;
+  float v[CSC_RB];
+#pragma unroll
+  for (int q = 0; q < CSC_RB; ++q) {
+    const int64_t r = r0 + q;
+    v[q] = (c < ld && r < m) ? S[r * ld + c] : 0.f;
+  }
+  const int64_t g = (b < O.nblocks) ? static_cast<int64_t>(s) * O.nblocks + b : -1;
+  csc_emit<2>(v, g, O, red, base_s);
+}
+
 constexpr int csc_xpitch(int V) { return V <= 1 ? 2 : (V <= 6 ? 6 : 10); }  // doubles per staged row
 constexpr int csc_lds_doubles(int V, int NW) {
   const int a = NW * CSC_RB * csc_xpitch(V), b = NW * (V + 1) * 64;
@@ -1274,19 +1300,19 @@ constexpr int csc_lds_doubles(int V, int NW) {
 
 // The streaming part on the compressed copy: this workgroup's (strip, tile) partial sums ->
 // part[tile][slot][ld], the slots of gemv_core. Wave (e, h) of the workgroup: column e of every
-// lane's four, blocks b0 + h, b0 + h + NW/4, ... of the tile — the four column phases of a block
-// cost the same by construction. WINDOW / pair mode as in gemv_core.
+// lane's two, blocks b0 + h, b0 + h + NW/2, ... of the tile — the column phases of a block cost
+// the same by construction. WINDOW / pair mode as in gemv_core.
 template <bool WINDOW, int V, int NSLOT, int NW>
 __device__ __forceinline__ void csc_core(const CscView& M, int64_t ld, int64_t m, double d,
                                          const double* __restrict__ X, int xstride,
                                          double* __restrict__ part, double* lds) {
   constexpr int NS = WINDOW ? V + 1 : 2;
   constexpr int XP = WINDOW ? csc_xpitch(V) : 1;
-  constexpr int NH = NW / 4;
+  constexpr int NH = NW / 2;
   constexpr int XT = CSC_RB * XP;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int e = wave & 3, h = wave >> 2;
+  const int e = wave & 1, h = wave >> 1;
   const int s = blockIdx.x;
   const int b0 = M.tb[s * (M.ntmax + 1) + blockIdx.y];
   const int b1 = M.tb[s * (M.ntmax + 1) + blockIdx.y + 1];
@@ -1300,7 +1326,7 @@ __device__ __forceinline__ void csc_core(const CscView& M, int64_t ld, int64_t m
   for (int b = b0 + h; b < b1; b += NH) {
     const int64_t g = static_cast<int64_t>(s) * M.nblocks + b;
     const int LQ = __builtin_amdgcn_readfirstlane(static_cast<int>(M.Lc[g] >> 2));
-    const int64_t base = static_cast<int64_t>(M.Pre[g]) * 256;
+    const int64_t base = static_cast<int64_t>(M.Pre[g]) * 128;
     const float4* vq =
         reinterpret_cast<const float4*>(M.vals + base) + static_cast<int64_t>(e) * LQ * 64 + lane;
     const uint32_t* rq =
@@ -1390,13 +1416,13 @@ __device__ __forceinline__ void csc_core(const CscView& M, int64_t ld, int64_t m
 #pragma unroll
   for (int v = 0; v < NS; ++v) lds[(wave * NS + v) * 64 + lane] = acc[v];
   __syncthreads();
-  for (int t = threadIdx.x; t < NS * 256; t += NW * 64) {
-    const int v = t >> 8, cl = t & 255;
-    const int ee = cl & 3, ln = cl >> 2;
+  for (int t = threadIdx.x; t < NS * CSC_CW; t += NW * 64) {
+    const int v = t >> 7, cl = t & 127;
+    const int ee = cl & 1, ln = cl >> 1;
     double sum = lds[(ee * NS + v) * 64 + ln];
 #pragma unroll
-    for (int hh = 1; hh < NH; ++hh) sum += lds[((hh * 4 + ee) * NS + v) * 64 + ln];
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + cl;
+    for (int hh = 1; hh < NH; ++hh) sum += lds[((hh * 2 + ee) * NS + v) * 64 + ln];
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * CSC_CW + cl;
     const int slot = (v == NS - 1) ? NSLOT - 1 : v;
     if (c < ld) part[(static_cast<int64_t>(blockIdx.y) * NSLOT + slot) * ld + c] = sum;
   }
@@ -1987,7 +2013,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
     float* __restrict__ S, int64_t ld, int64_t m, int nT, const double* __restrict__ P1,
     const double* __restrict__ P2, const float* __restrict__ P1f, const float* __restrict__ P2f,
     int64_t pstride, const int32_t* __restrict__ A0, const int32_t* __restrict__ A1,
-    EuclidParams eprm, PointNormalParams nprm, float E2 /* guarded threshold squared, rounded up */) {
+    EuclidParams eprm, PointNormalParams nprm, float E2 /* guarded threshold squared, rounded up */,
+    CscOut O /* O.Lc != null: also emit the tile's groups of the compressed copy */) {
   // 72.5 KiB of dynamic LDS (two workgroups per CU fit the 160 KiB): the image, then the queues
   extern __shared__ __attribute__((aligned(16))) char sym_smem[];
   float* img = reinterpret_cast<float*>(sym_smem);
@@ -2093,8 +2120,32 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
   }
   __syncthreads();
 
+  // ---- the compressed copy: row blocks 2I, 2I+1 of strip J, and of the mirror image row blocks
+  // 2J, 2J+1 of strip I, one column per thread straight from the image (csc_emit) ---------------
+  if (O.Lc != nullptr) {
+    static_assert(AT_WAVES == 8 && AT == CSC_CW && AT == 2 * CSC_RB, "four groups per tile");
+    int* red = reinterpret_cast<int*>(sym_smem + AT_SYM_IMG_BYTES);  // the queues are drained
+    unsigned long long* base_s = reinterpret_cast<unsigned long long*>(red + 8);
+    const int t = threadIdx.x, gi = t >> 7, cl = t & 127;
+    const int rb = gi & 1;
+    const bool mirror = gi >= 2;
+    float v[CSC_RB];
+    if (!mirror) {
+#pragma unroll
+      for (int q = 0; q < CSC_RB; ++q) v[q] = img[(rb * CSC_RB + q) * AT_PITCH + cl];
+    } else {
+#pragma unroll
+      for (int q = 0; q < CSC_RB; ++q) v[q] = img[cl * AT_PITCH + rb * CSC_RB + q];
+    }
+    const int strip = mirror ? I : J;
+    const int b = 2 * (mirror ? J : I) + rb;
+    const int64_t g = (b < O.nblocks && !(mirror && I == J))
+                          ? static_cast<int64_t>(strip) * O.nblocks + b : -1;
+    csc_emit<4>(v, g, O, red, base_s);
+  }
+
   // ---- the tile as it stands: this wave's rows, 512-byte segments -----------------------------
-  if (c0 + 2 * lane < ld) {
+  if (S != nullptr && c0 + 2 * lane < ld) {
     for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
       const int rl = wave * AT_ROWS_PER_WAVE + rr;
       const int64_t r = r0 + rl;
@@ -2105,7 +2156,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
     }
   }
   // ---- and transposed: rows c0 + ... receive the tile's columns ------------------------------
-  if (I != J && r0 + 2 * lane < ld) {
+  if (S != nullptr && I != J && r0 + 2 * lane < ld) {
     for (int cc = 0; cc < AT_ROWS_PER_WAVE; ++cc) {
       const int cl = wave * AT_ROWS_PER_WAVE + cc;
       const int64_t c = c0 + cl;
