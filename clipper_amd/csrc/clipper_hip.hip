@@ -260,6 +260,11 @@ int free_shard_buffers(Shard& s) {
   return 0;
 }
 
+// CLIPPER_HIP_STORE_F32_CSC on one unsharded device (C == pattern(M) is checked per matrix)
+bool csc_possible(const Ctx* h) {
+  return h->compressed && h->world == 1 && !h->multiproc && h->storage == CLIPPER_HIP_STORE_F32;
+}
+
 int plan_unr(const Ctx* h) {
   return gemv_unr(h->V, static_cast<int>(h->esize()), h->explicitC);
 }
@@ -325,8 +330,10 @@ int ensure_problem(Ctx* h, int64_t m) {
     free_shard_buffers(s);
     HIPCHK(hipSetDevice(s.device));
     const size_t bytesS = static_cast<size_t>(m) * static_cast<size_t>(W) * h->esize();
-    HIPCHK(hipMalloc(&s.S, bytesS));
     s.bytes_S = bytesS;
+    // CLIPPER_HIP_STORE_F32_CSC keeps M compressed: the dense store exists only while a path
+    // that needs it is in use (ensure_dense)
+    if (!csc_possible(h)) HIPCHK(hipMalloc(&s.S, bytesS));
     const size_t nvec = static_cast<size_t>(P * W) * sizeof(double);
     const size_t V = static_cast<size_t>(h->V);
     HIPCHK(hipMalloc(&s.u0, nvec));
@@ -413,16 +420,11 @@ void launch_plain(Ctx* h, Shard& s, const double* X) {
 }
 
 // G on the compressed copy of M (one shard, C == pattern(M), fp32)
+CscView csc_view(const Ctx* h, const Shard& s);
+
 template <int V>
 void launch_pass_csc(Ctx* h, Shard& s, const SolveArgs& a) {
-  CscView M;
-  M.vals = s.cvals;
-  M.rows = s.crows;
-  M.Lc = s.cLc;
-  M.Pre = s.cPre;
-  M.tb = s.ctb;
-  M.nblocks = h->csc_nblocks;
-  M.ntmax = h->csc_ntmax;
+  const CscView M = csc_view(h, s);
   dim3 grid(h->csc_nstrips, h->csc_ntmax), block(GEMV_NW * 64);
   hipLaunchKernelGGL((k_gemv_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
 }
@@ -827,9 +829,48 @@ void launch_sym(K kernel, dim3 grid, hipStream_t stream, float* S, int64_t W, in
 }
 
 // ---- the column-compressed copy (CLIPPER_HIP_STORE_F32_CSC) ---------------------------------
-bool csc_applies(const Ctx* h) {
-  return h->compressed && h->world == 1 && !h->multiproc && !h->explicitC &&
-         h->storage == CLIPPER_HIP_STORE_F32;
+bool csc_applies(const Ctx* h) { return csc_possible(h) && !h->explicitC; }
+
+CscView csc_view(const Ctx* h, const Shard& s) {
+  CscView M;
+  M.vals = s.cvals;
+  M.rows = s.crows;
+  M.Lc = s.cLc;
+  M.Pre = s.cPre;
+  M.tb = s.ctb;
+  M.nblocks = h->csc_nblocks;
+  M.ntmax = h->csc_ntmax;
+  return M;
+}
+
+// The dense store of every local shard, allocated if it is not; with `from_csc` its content is
+// materialised from the compressed copy when that is all there is.
+int ensure_dense(Ctx* h, bool from_csc) {
+  for (auto& s : h->sh) {
+    if (s.S) continue;
+    HIPCHK(hipSetDevice(s.device));
+    if (hipMalloc(&s.S, s.bytes_S) != hipSuccess) {
+      s.S = nullptr;
+      return fail(CLIPPER_HIP_E_NOMEM, "dense store of %zu bytes (this call needs one) does not fit",
+                  s.bytes_S);
+    }
+    if (from_csc && h->csc_valid) {
+      dim3 grid(h->csc_nstrips, static_cast<unsigned>(ceil_div(h->csc_nblocks, 2))), block(256);
+      hipLaunchKernelGGL(k_csc_expand, grid, block, 0, s.stream, csc_view(h, s),
+                         static_cast<float*>(s.S), h->W, h->m);
+      HIPCHK(hipStreamSynchronize(s.stream));
+    }
+  }
+  return 0;
+}
+
+void drop_dense(Ctx* h) {
+  for (auto& s : h->sh) {
+    if (!s.S) continue;
+    hipSetDevice(s.device);
+    hipFree(s.S);
+    s.S = nullptr;
+  }
 }
 
 // Before the fill: buffers of the group directory, the arenas' cursors reset. Returns what a
@@ -969,26 +1010,22 @@ int csc_plan(Ctx* h) {
   return 0;
 }
 
-// after the stream was synchronised: grow the buffers and build again if the lists did not fit
-// (always the case for the first matrix of a size), then plan the tiles
-int csc_finish(Ctx* h) {
+// After the stream was synchronised: did the lists fit? If not (always the case for the first
+// matrix of a size) the buffers are grown and `again` is set — the caller repeats the step that
+// produces the groups; otherwise the tiles are planned and the copy is valid.
+int csc_check(Ctx* h, bool& again) {
+  again = false;
   if (!csc_applies(h)) return 0;
   Shard& s = h->sh[0];
   HIPCHK(hipSetDevice(s.device));
-  auto totals = [&](bool& over, size_t& worst, uint64_t& sum) {
-    over = false;
-    worst = 0;
-    sum = 0;
-    for (int k = 0; k < CSC_ARENAS; ++k) {
-      over = over || h->csc_hctl[k].overflow != 0;
-      worst = std::max(worst, static_cast<size_t>(h->csc_hctl[k].cursor));
-      sum += h->csc_hctl[k].cursor;
-    }
-  };
-  bool over;
-  size_t worst;
-  uint64_t sum;
-  totals(over, worst, sum);
+  bool over = false;
+  size_t worst = 0;
+  uint64_t sum = 0;
+  for (int k = 0; k < CSC_ARENAS; ++k) {
+    over = over || h->csc_hctl[k].overflow != 0;
+    worst = std::max(worst, static_cast<size_t>(h->csc_hctl[k].cursor));
+    sum += h->csc_hctl[k].cursor;
+  }
   if (over) {
     const size_t need = worst * CSC_ARENAS;  // every arena as large as the fullest one
     if (s.cvals) hipFree(s.cvals);
@@ -998,14 +1035,8 @@ int csc_finish(Ctx* h) {
     s.ccap_units = (need + need / 8 + 64 * CSC_ARENAS) / CSC_ARENAS * CSC_ARENAS;
     HIPCHK(hipMalloc(&s.cvals, s.ccap_units * 128 * sizeof(float)));
     HIPCHK(hipMalloc(&s.crows, s.ccap_units * 128));
-    CscOut O;
-    int rc = csc_prepare(h, O);  // again, now from the dense store
-    if (rc) return rc;
-    rc = csc_enqueue(h, O);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(s.stream));
-    totals(over, worst, sum);
-    if (over) return fail(CLIPPER_HIP_E_HIP, "compressed copy: build overflowed twice");
+    again = true;
+    return 0;
   }
   h->csc_units = sum;
   int rc = csc_plan(h);
@@ -1014,20 +1045,28 @@ int csc_finish(Ctx* h) {
   return 0;
 }
 
-// build + wait + plan (the setMatrixData paths)
+// build from the dense store + wait + plan (the setMatrixData paths)
 int csc_rebuild(Ctx* h) {
-  CscOut O;
-  int rc = csc_prepare(h, O);
-  if (rc) return rc;
-  rc = csc_enqueue(h, O);
-  if (rc) return rc;
-  rc = sync_all(h);
-  if (rc) return rc;
-  return csc_finish(h);
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    CscOut O;
+    int rc = csc_prepare(h, O);
+    if (rc) return rc;
+    rc = csc_enqueue(h, O);
+    if (rc) return rc;
+    rc = sync_all(h);
+    if (rc) return rc;
+    bool again = false;
+    rc = csc_check(h, again);
+    if (rc) return rc;
+    if (!again) return 0;
+  }
+  return fail(CLIPPER_HIP_E_HIP, "compressed copy: the build keeps overflowing");
 }
 
+// `emits`: the fill kernel `launch` starts writes the compressed copy itself when asked to
+// (k_affinity_sym) — then no dense store is needed at all
 template <typename Launch>
-int run_affinity(Ctx* h, Launch launch) {
+int run_affinity(Ctx* h, bool emits, Launch launch) {
   // explicit constraint storage is not needed on this path: C == pattern(M)
   for (auto& s : h->sh) {
     if (s.Cs) {
@@ -1038,28 +1077,37 @@ int run_affinity(Ctx* h, Launch launch) {
   }
   h->explicitC = false;
   plan_tiles(h);
+  int rc = 0;
+  if (csc_applies(h) && emits) drop_dense(h);  // a materialised copy would be stale
+  else if ((rc = ensure_dense(h, false))) return rc;
   hipEvent_t e0, e1;
   Shard& s0 = h->sh[0];
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  CscOut O;
-  int rc = csc_prepare(h, O);
-  if (rc) return rc;
-  h->csc_out = O;
-  HIPCHK(hipEventRecord(e0, s0.stream));
-  for (auto& s : h->sh) {
-    HIPCHK(hipSetDevice(s.device));
-    launch(s);  // k_affinity_sym emits the compressed copy itself and sets csc_emitted
+  for (int attempt = 0;; ++attempt) {
+    CscOut O;
+    rc = csc_prepare(h, O);
+    if (rc) return rc;
+    h->csc_out = O;
+    HIPCHK(hipSetDevice(s0.device));
+    HIPCHK(hipEventRecord(e0, s0.stream));
+    for (auto& s : h->sh) {
+      HIPCHK(hipSetDevice(s.device));
+      launch(s);  // k_affinity_sym emits the compressed copy itself and sets csc_emitted
+    }
+    rc = csc_enqueue(h, O);  // counted as part of the affinity build
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(s0.device));
+    HIPCHK(hipEventRecord(e1, s0.stream));
+    rc = sync_all(h);
+    if (rc) return rc;
+    bool again = false;
+    rc = csc_check(h, again);
+    if (rc) return rc;
+    if (!again) break;
+    if (attempt >= 2) return fail(CLIPPER_HIP_E_HIP, "compressed copy: the build keeps overflowing");
   }
-  rc = csc_enqueue(h, O);  // counted as part of the affinity build
-  if (rc) return rc;
-  HIPCHK(hipSetDevice(s0.device));
-  HIPCHK(hipEventRecord(e1, s0.stream));
-  rc = sync_all(h);
-  if (rc) return rc;
-  rc = csc_finish(h);
-  if (rc) return rc;
   float ms = 0.f;
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
@@ -1075,8 +1123,8 @@ constexpr int AFF_ROWS_PER_BLK = 32;
 // ALGORITHMIC bytes one mat-vec launch of shard 0 must move: s * m * (valid owned columns)
 // (= s*m^2 on one GPU; the zero padding up to the 64-column pitch is not counted), doubled
 // when an explicit constraint matrix is read as well.
-double algorithmic_gemv_bytes(const Ctx* h) {
-  if (h->csc_valid)  // the compressed copy: 5 bytes per (padded) entry + the group directory
+double algorithmic_gemv_bytes(const Ctx* h, bool dense = false) {
+  if (h->csc_valid && !dense)  // the compressed copy: 5 bytes per (padded) entry + the group directory
     return static_cast<double>(h->csc_units) * 128.0 * 5.0 +
            static_cast<double>(h->csc_nstrips) * h->csc_nblocks * 12.0;
   const int64_t c0 = static_cast<int64_t>(h->sh[0].slot) * h->W;
@@ -1092,6 +1140,7 @@ int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32
   const int k = static_cast<int>(S.size());
   if (k < 2) return 0;
   std::vector<double> Wsub(static_cast<size_t>(k) * k, 0.0), tmp(static_cast<size_t>(k) * k);
+  if (int rc = ensure_dense(h, true)) return rc;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     int32_t* didx = nullptr;
@@ -1228,7 +1277,7 @@ int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double
   const EuclidParams prm{sigma, epsilon, mindist, affinityeps};
   const int64_t mm = h->m, W = h->W, pstride = h->staged_pstride;
   const int d = h->staged_d;
-  return run_affinity(h, [&](Shard& s) {
+  return run_affinity(h, use_sym_fill(h) && (d == 2 || d == 3), [&](Shard& s) {
     dim3 grid(static_cast<unsigned>(ceil_div(W, 1024)),
               static_cast<unsigned>(ceil_div(mm, AFF_ROWS_PER_BLK))),
         block(256);
@@ -1284,7 +1333,7 @@ int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, doubl
     return fail(CLIPPER_HIP_E_STATE, "PointNormalDistance needs staged inputs with d == 6");
   const PointNormalParams prm{sigp, epsp, sign, epsn, affinityeps};
   const int64_t mm = h->m, W = h->W, pstride = h->staged_pstride;
-  return run_affinity(h, [&](Shard& s) {
+  return run_affinity(h, use_sym_fill(h), [&](Shard& s) {
     dim3 grid(static_cast<unsigned>(ceil_div(W, 1024)),
               static_cast<unsigned>(ceil_div(mm, AFF_ROWS_PER_BLK))),
         block(256);
@@ -1370,6 +1419,8 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
   h->nodes.clear();
   int rc = ensure_problem(h, m);
   if (rc) return rc;
+  h->csc_valid = false;
+  if ((rc = ensure_dense(h, false))) return rc;
   const size_t bytes = static_cast<size_t>(m) * m * sizeof(double);
   const int64_t W = h->W;
   // pass 1: fill S and detect whether C is anything other than pattern(M)
@@ -1461,6 +1512,8 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
   h->nodes.clear();
   int rc = ensure_problem(h, m);
   if (rc) return rc;
+  h->csc_valid = false;
+  if ((rc = ensure_dense(h, false))) return rc;
   // C == pattern(M)?  (same structure, every stored C equal to 1, every stored M non-zero)
   bool pattern = (nnzM == nnzC) && std::equal(Mcolptr, Mcolptr + m + 1, Ccolptr) &&
                  std::equal(Mrow, Mrow + nnzM, Crow);
@@ -1526,6 +1579,7 @@ int clipper_hip_get_matrix(clipper_hip_t* h, double* M_out, double* C_out) {
     return fail(CLIPPER_HIP_E_STATE, "get_matrix is not available on a multi-process shard");
   const int64_t m = h->m, W = h->W;
   const bool f64 = (h->storage == CLIPPER_HIP_STORE_F64);
+  if (int rc = ensure_dense(h, true)) return rc;
   std::vector<unsigned char> buf;
   auto fetch = [&](Shard& s, const void* src, double* out, bool as_pattern) -> int {
     buf.resize(s.bytes_S);
@@ -1853,8 +1907,9 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
                        s.stream, s.u0, m, s.X[0]);
   }
   h->u0_staged = false;
-  int rc = enqueue_gemv_plain(h);
+  int rc = ensure_dense(h, true);
   if (rc) return rc;
+  if ((rc = enqueue_gemv_plain(h))) return rc;
   if ((rc = enqueue_reduce_exchange(h))) return rc;
   if ((rc = sync_all(h))) return rc;
   std::vector<double> ab(static_cast<size_t>(h->world) * 2 * W);
@@ -1886,6 +1941,7 @@ int clipper_hip_get_timings(const clipper_hip_t* h, clipper_hip_timings_t* out) 
 int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   if (!h || reps < 1 || !avg_us) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
+  if (int rc = ensure_dense(h, true)) return rc;
   Shard& s = h->sh[0];
   HIPCHK(hipSetDevice(s.device));
   hipEvent_t e0, e1;
@@ -1901,7 +1957,7 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   *avg_us = static_cast<double>(ms) * 1e3 / reps;
-  h->tm.gemv_bytes = algorithmic_gemv_bytes(h);
+  h->tm.gemv_bytes = algorithmic_gemv_bytes(h, /*dense=*/true);
   return 0;
 }
 

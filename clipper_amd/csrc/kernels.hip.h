@@ -1292,6 +1292,35 @@ __global__ __launch_bounds__(256) void k_csc_build(const float* __restrict__ S, 
   csc_emit<2>(v, g, O, red, base_s);
 }
 
+// k_csc_expand — the dense fp32 store back from the compressed copy (getters, the exact DSD
+// rounding's gather and the matvec API read a dense store; it is materialised on demand): one
+// group per workgroup half, one column per thread — zeros first, then the column's entries.
+__global__ __launch_bounds__(256) void k_csc_expand(CscView M, float* __restrict__ S, int64_t ld,
+                                                     int64_t m) {
+  const int s = blockIdx.x, t = threadIdx.x;
+  const int b = 2 * blockIdx.y + (t >> 7);
+  const int cl = t & 127;
+  const int64_t c = static_cast<int64_t>(s) * CSC_CW + cl;
+  if (b >= M.nblocks || c >= ld) return;
+  const int64_t r0 = static_cast<int64_t>(b) * CSC_RB;
+  for (int q = 0; q < CSC_RB; ++q)
+    if (r0 + q < m) S[(r0 + q) * ld + c] = 0.f;
+  const int64_t g = static_cast<int64_t>(s) * M.nblocks + b;
+  const int LQ = static_cast<int>(M.Lc[g] >> 2);
+  const int64_t base = static_cast<int64_t>(M.Pre[g]) * 128;
+  const int lane = cl >> 1, e = cl & 1;
+  const float4* vq = reinterpret_cast<const float4*>(M.vals + base) + static_cast<int64_t>(e) * LQ * 64 + lane;
+  const uint32_t* rq = reinterpret_cast<const uint32_t*>(M.rows + base) + static_cast<int64_t>(e) * LQ * 64 + lane;
+  for (int kq = 0; kq < LQ; ++kq) {
+    const float4 v = vq[kq * 64];
+    const uint32_t r = rq[kq * 64];
+    const float vf[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (vf[j] != 0.f) S[(r0 + ((r >> (8 * j)) & 255u)) * ld + c] = vf[j];
+  }
+}
+
 constexpr int csc_xpitch(int V) { return V <= 1 ? 2 : (V <= 6 ? 6 : 10); }  // doubles per staged row
 constexpr int csc_lds_doubles(int V, int NW) {
   const int a = NW * CSC_RB * csc_xpitch(V), b = NW * (V + 1) * 64;
