@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_get_matrix", "clipper_hip_solve", "clipper_hip_get_nodes",
     "clipper_hip_get_selected_associations", "clipper_hip_matvec", "clipper_hip_set_profiling",
     "clipper_hip_set_window", "clipper_hip_window", "clipper_hip_densest_subgraph",
+    "clipper_hip_storage_in_use",
     "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
     "clipper_hip_affinity_pointnormal_staged", "clipper_hip_stage_u0",
@@ -141,6 +142,7 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_densest_subgraph.argtypes = [vp, ip, C.c_int32, ip, C.c_int32]
     L.clipper_hip_set_window.argtypes = [vp, C.c_int]
     L.clipper_hip_window.argtypes = [vp]
+    L.clipper_hip_storage_in_use.argtypes = [vp]
     L.clipper_hip_set_profiling.argtypes = [vp, C.c_int]
     L.clipper_hip_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.clipper_hip_bench_matvec.argtypes = [vp, C.c_int, dp]
@@ -373,6 +375,10 @@ class HipClipper:
     @property
     def window(self) -> int:
         return int(self.L.clipper_hip_window(self.h))
+
+    @property
+    def storage_in_use(self) -> int:
+        return int(self.L.clipper_hip_storage_in_use(self.h))
 
     def set_profiling(self, on: bool):
         self._check(self.L.clipper_hip_set_profiling(self.h, int(on)))

@@ -1894,6 +1894,11 @@ int clipper_hip_set_window(clipper_hip_t* h, int window) {
 
 int clipper_hip_window(const clipper_hip_t* h) { return h ? h->V : 0; }
 
+int clipper_hip_storage_in_use(const clipper_hip_t* h) {
+  if (!h) return -1;
+  return h->csc_valid ? CLIPPER_HIP_STORE_F32_CSC : h->storage;
+}
+
 int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC) {
   if (!h || !x) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");

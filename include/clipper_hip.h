@@ -187,6 +187,10 @@ int clipper_hip_densest_subgraph(clipper_hip_t* h, const int32_t* S, int32_t k,
 int clipper_hip_set_window(clipper_hip_t* h, int window);
 int clipper_hip_window(const clipper_hip_t* h);
 
+/* How the current matrix is stored: CLIPPER_HIP_STORE_F32_CSC only while the compressed copy is
+ * in use (one shard, C == pattern(M)); a context created with it otherwise reports _F32. */
+int clipper_hip_storage_in_use(const clipper_hip_t* h);
+
 /* One pass of the mat-vec kernel: yM = M_off*x, yC = C_off*x (the products at
  * clipper.cpp:194,202,205,219,240-241,268,271). x, yM, yC: m doubles on the host. */
 int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC);
