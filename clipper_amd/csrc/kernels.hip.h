@@ -1200,16 +1200,16 @@ struct CscOut {
   int nblocks;
 };
 
-// Emission of NG groups by one workgroup of NG*128 threads: thread t holds the 64 values of
-// column (t & 127) of group (t >> 7); g = its group id or -1 (nothing to emit: the whole group,
-// uniformly). `red` [2*NG] ints and `base_s` [NG] are LDS scratch. Contains barriers.
+// Emission of NG groups by one workgroup of NG*128 threads: thread t owns column (t & 127) of
+// group (t >> 7); g = its group id or -1 (nothing to emit: the whole group, uniformly).
+// csc_claim: the group's padded length from the columns' counts, its space claimed with one
+// atomic. `red` [2*NG] ints and `base_s` [NG] are LDS scratch. Contains barriers. Returns false
+// for a thread that has nothing to write.
 template <int NG>
-__device__ __forceinline__ void csc_emit(const float (&v)[CSC_RB], int64_t g, const CscOut& O,
-                                         int* red, unsigned long long* base_s) {
+__device__ __forceinline__ bool csc_claim(int cnt, int64_t g, const CscOut& O, int* red,
+                                          unsigned long long* base_s, int& LQ,
+                                          unsigned long long& base) {
   const int t = threadIdx.x, gi = t >> 7, cl = t & 127;
-  int cnt = 0;
-#pragma unroll
-  for (int q = 0; q < CSC_RB; ++q) cnt += (v[q] != 0.f) ? 1 : 0;
   int mx = cnt;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1218,58 +1218,112 @@ __device__ __forceinline__ void csc_emit(const float (&v)[CSC_RB], int64_t g, co
   }
   if ((t & 63) == 0) red[t >> 6] = mx;
   __syncthreads();
+  const int w = red[2 * gi] > red[2 * gi + 1] ? red[2 * gi] : red[2 * gi + 1];
   if (cl == 0 && g >= 0) {
-    const int w = red[2 * gi] > red[2 * gi + 1] ? red[2 * gi] : red[2 * gi + 1];
     const unsigned L = static_cast<unsigned>((w + 3) & ~3);
     O.Lc[g] = L;
     CscArena* ar = O.ctl + static_cast<int>((g * 11 + (g >> 6)) & (CSC_ARENAS - 1));
-    unsigned long long base = atomicAdd(&ar->cursor, static_cast<unsigned long long>(L));
-    if (base + L > ar->capacity) {
+    unsigned long long bb = atomicAdd(&ar->cursor, static_cast<unsigned long long>(L));
+    if (bb + L > ar->capacity) {
       ar->overflow = 1;
-      base = ~0ull;
+      bb = ~0ull;
     } else {
-      base += ar->origin;
+      bb += ar->origin;
     }
-    O.Pre[g] = base;
-    base_s[gi] = base;
+    O.Pre[g] = bb;
+    base_s[gi] = bb;
   }
   __syncthreads();
-  if (g < 0) return;
-  const unsigned long long base = base_s[gi];
-  if (base == ~0ull) return;
-  const int w = red[2 * gi] > red[2 * gi + 1] ? red[2 * gi] : red[2 * gi + 1];
-  const int LQ = ((w + 3) & ~3) >> 2;
-  const int lane = cl >> 1, e = cl & 1;
-  float4* vq = reinterpret_cast<float4*>(O.vals + base * 128) + static_cast<int64_t>(e) * LQ * 64 + lane;
-  uint32_t* rq = reinterpret_cast<uint32_t*>(O.rows + base * 128) + static_cast<int64_t>(e) * LQ * 64 + lane;
-  float v4[4] = {0.f, 0.f, 0.f, 0.f};
-  uint32_t r4 = 0;
-  int k = 0;
-#pragma unroll
-  for (int q = 0; q < CSC_RB; ++q) {
-    if (v[q] != 0.f) {
-      const int j = k & 3;
-      v4[0] = j == 0 ? v[q] : v4[0];
-      v4[1] = j == 1 ? v[q] : v4[1];
-      v4[2] = j == 2 ? v[q] : v4[2];
-      v4[3] = j == 3 ? v[q] : v4[3];
-      r4 |= static_cast<uint32_t>(q) << (8 * j);
-      ++k;
-      if (j == 3) {
-        const int kq = (k >> 2) - 1;
-        vq[kq * 64] = make_float4(v4[0], v4[1], v4[2], v4[3]);
-        rq[kq * 64] = r4;
-        v4[0] = v4[1] = v4[2] = v4[3] = 0.f;
-        r4 = 0;
-      }
-    }
+  if (g < 0) return false;
+  base = base_s[gi];
+  LQ = ((w + 3) & ~3) >> 2;
+  return base != ~0ull;
+}
+
+// the list of one column, written quad by quad
+struct CscColumnWriter {
+  float4* vq;
+  uint32_t* rq;
+  float v4[4];
+  uint32_t r4;
+  int k;
+  __device__ __forceinline__ void open(const CscOut& O, unsigned long long base, int LQ) {
+    const int cl = threadIdx.x & 127;
+    const int lane = cl >> 1, e = cl & 1;
+    vq = reinterpret_cast<float4*>(O.vals + base * 128) + static_cast<int64_t>(e) * LQ * 64 + lane;
+    rq = reinterpret_cast<uint32_t*>(O.rows + base * 128) + static_cast<int64_t>(e) * LQ * 64 + lane;
+    v4[0] = v4[1] = v4[2] = v4[3] = 0.f;
+    r4 = 0;
+    k = 0;
   }
-  for (int kq = k >> 2; kq < LQ; ++kq) {  // the open quad and the padding quads
+  __device__ __forceinline__ void flush(int kq) {
     vq[kq * 64] = make_float4(v4[0], v4[1], v4[2], v4[3]);
     rq[kq * 64] = r4;
     v4[0] = v4[1] = v4[2] = v4[3] = 0.f;
     r4 = 0;
   }
+  __device__ __forceinline__ void push(float v, uint32_t row) {
+    const int j = k & 3;
+    v4[0] = j == 0 ? v : v4[0];
+    v4[1] = j == 1 ? v : v4[1];
+    v4[2] = j == 2 ? v : v4[2];
+    v4[3] = j == 3 ? v : v4[3];
+    r4 |= row << (8 * j);
+    ++k;
+    if (j == 3) flush((k >> 2) - 1);
+  }
+  __device__ __forceinline__ void close(int LQ) {  // the open quad and the padding quads
+    for (int kq = k >> 2; kq < LQ; ++kq) flush(kq);
+  }
+};
+
+// from 64 values held in registers (k_csc_build)
+template <int NG>
+__device__ __forceinline__ void csc_emit(const float (&v)[CSC_RB], int64_t g, const CscOut& O,
+                                         int* red, unsigned long long* base_s) {
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < CSC_RB; ++q) cnt += (v[q] != 0.f) ? 1 : 0;
+  int LQ;
+  unsigned long long base;
+  if (!csc_claim<NG>(cnt, g, O, red, base_s, LQ, base)) return;
+  CscColumnWriter w;
+  w.open(O, base, LQ);
+#pragma unroll
+  for (int q = 0; q < CSC_RB; ++q)
+    if (v[q] != 0.f) w.push(v[q], static_cast<uint32_t>(q));
+  w.close(LQ);
+}
+
+// from a column of an LDS image (k_affinity_sym): col[q * stride], q = 0..63. A first sweep
+// builds the bit mask of the nonzeros; only those are visited again (an ~11 % dense column: ~7
+// of 64), the trip count of a wave being its longest column.
+template <int NG>
+__device__ __forceinline__ void csc_emit_lds(const float* col, int stride, int64_t g,
+                                             const CscOut& O, int* red,
+                                             unsigned long long* base_s) {
+  uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) mlo |= (col[q * stride] != 0.f ? 1u : 0u) << q;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) mhi |= (col[(q + 32) * stride] != 0.f ? 1u : 0u) << q;
+  const int cnt = __popc(mlo) + __popc(mhi);
+  int LQ;
+  unsigned long long base;
+  if (!csc_claim<NG>(cnt, g, O, red, base_s, LQ, base)) return;
+  CscColumnWriter w;
+  w.open(O, base, LQ);
+  while (mlo) {
+    const int q = __ffs(mlo) - 1;
+    mlo &= mlo - 1;
+    w.push(col[q * stride], static_cast<uint32_t>(q));
+  }
+  while (mhi) {
+    const int q = __ffs(mhi) - 1 + 32;
+    mhi &= mhi - 1;
+    w.push(col[q * stride], static_cast<uint32_t>(q));
+  }
+  w.close(LQ);
 }
 
 // k_csc_build — from a dense fp32 store: two groups (row blocks 2y, 2y+1 of strip x) per
@@ -2158,19 +2212,13 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
     const int t = threadIdx.x, gi = t >> 7, cl = t & 127;
     const int rb = gi & 1;
     const bool mirror = gi >= 2;
-    float v[CSC_RB];
-    if (!mirror) {
-#pragma unroll
-      for (int q = 0; q < CSC_RB; ++q) v[q] = img[(rb * CSC_RB + q) * AT_PITCH + cl];
-    } else {
-#pragma unroll
-      for (int q = 0; q < CSC_RB; ++q) v[q] = img[cl * AT_PITCH + rb * CSC_RB + q];
-    }
+    // element q of the thread's column: tile (rb*64 + q, cl), or (cl, rb*64 + q) of the mirror
+    const float* col = mirror ? img + cl * AT_PITCH + rb * CSC_RB : img + rb * CSC_RB * AT_PITCH + cl;
     const int strip = mirror ? I : J;
     const int b = 2 * (mirror ? J : I) + rb;
     const int64_t g = (b < O.nblocks && !(mirror && I == J))
                           ? static_cast<int64_t>(strip) * O.nblocks + b : -1;
-    csc_emit<4>(v, g, O, red, base_s);
+    csc_emit_lds<4>(col, mirror ? 1 : AT_PITCH, g, O, red, base_s);
   }
 
   // ---- the tile as it stands: this wave's rows, 512-byte segments -----------------------------

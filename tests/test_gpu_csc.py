@@ -1,0 +1,146 @@
+"""GPU tests of the compressed storage (CLIPPER_HIP_STORE_F32_CSC): M kept as blocked column
+lists, written by k_affinity_sym / k_csc_build, read by k_gemv_csc, expanded on demand by
+k_csc_expand. Everything the parity suite runs per storage mode (tests/test_gpu_parity.py,
+STORAGES) covers it too; here are the cases specific to the format: block / strip edges, empty
+and fully dense groups, growth of the buffers, the fall-back to the dense store."""
+import numpy as np
+import pytest
+
+from clipper_amd import _abi as abi
+from clipper_amd import synth
+from oracle import clipper_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+INV = synth.EUCLID_BENCH_PARAMS
+
+
+def _affinity(storage, p, **inv):
+    g = abi.HipClipper(storage=storage)
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **(inv or INV))
+    return g
+
+
+# groups are 64 rows x 128 columns: sizes on and around their edges, and a ragged last tile
+@pytest.mark.parametrize("m", [2, 63, 64, 65, 127, 128, 129, 191, 193, 257, 640, 1000, 2049])
+def test_matrix_round_trip_bitwise(m):
+    p = synth.make_euclidean_problem(m, 0.7, seed=m)
+    gd, gc = _affinity(abi.STORE_F32, p), _affinity(abi.STORE_F32_CSC, p)
+    assert gc.storage_in_use == abi.STORE_F32_CSC and gd.storage_in_use == abi.STORE_F32
+    Md, Mc = gd.get_affinity_matrix(), gc.get_affinity_matrix()   # k_csc_expand behind the second
+    assert np.array_equal(Md, Mc)
+    assert np.array_equal(gd.get_constraint_matrix(), gc.get_constraint_matrix())
+    x = np.random.default_rng(m).random(m)
+    yd, yc = gd.matvec(x), gc.matvec(x)
+    assert np.array_equal(yd[0], yc[0]) and np.array_equal(yd[1], yc[1])
+    # the solver (compressed passes) after the dense store was materialised for the getters
+    sd, sc = gd.solve(p.u0), gc.solve(p.u0)
+    assert sorted(sd.nodes.tolist()) == sorted(sc.nodes.tolist())
+    assert abs(sd.score - sc.score) <= 1e-9 * max(1.0, abs(sd.score))
+
+
+@pytest.mark.parametrize("rho,eps", [(0.0, 0.05), (0.95, 1e-9), (0.5, 10.0)])
+def test_dense_and_empty_groups(rho, eps):
+    """rho = 0: every association is an inlier — every group is full (64 entries per column);
+    epsilon -> 0: no consistent pair at all — every list is empty; epsilon huge: everything
+    consistent."""
+    m = 700
+    p = synth.make_euclidean_problem(m, rho, seed=3)
+    inv = dict(sigma=0.015, epsilon=eps, mindist=0.0)
+    g = _affinity(abi.STORE_F32_CSC, p, **inv)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **inv)
+    Mg, Mr = g.get_affinity_matrix(), r.get_affinity_matrix()
+    assert np.array_equal(Mg != 0, Mr != 0)
+    sg, sr = g.solve(p.u0), r.solve(p.u0)
+    assert sorted(sg.nodes.tolist()) == sorted(sr.nodes.tolist())
+    assert abs(sg.score - sr.score) <= 1e-6 * max(1.0, abs(sr.score))
+    assert sg.ifinal == sr.ifinal
+
+
+def test_buffers_grow_and_are_reused():
+    """one context, problems of changing size and density: the lists are re-allocated when they
+    do not fit and reused when they do; results equal those of fresh contexts."""
+    g = abi.HipClipper(storage=abi.STORE_F32_CSC)
+    for m, rho, seed in [(500, 0.9, 1), (2000, 0.9, 2), (2000, 0.2, 3), (500, 0.9, 1), (2000, 0.95, 4)]:
+        p = synth.make_euclidean_problem(m, rho, seed=seed)
+        g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+        s = g.solve(p.u0)
+        f = _affinity(abi.STORE_F32_CSC, p)
+        sf = f.solve(p.u0)
+        assert s.nodes.tolist() == sf.nodes.tolist() and s.score == sf.score   # bit-identical
+        assert np.array_equal(s.u, sf.u)
+        r = ref.RefClipper()
+        r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+        sr = r.solve(p.u0)
+        assert sorted(s.nodes.tolist()) == sorted(sr.nodes.tolist())
+        f.close()
+    g.close()
+
+
+def _random_symmetric(m, density, seed):
+    rng = np.random.default_rng(seed)
+    U = np.triu((rng.random((m, m)) < density) * rng.uniform(0.1, 1.0, (m, m)), 1)
+    M = U + U.T + np.eye(m)
+    return M, (M != 0).astype(np.float64)
+
+
+@pytest.mark.parametrize("m", [130, 777])
+def test_set_matrix_paths(m):
+    """setMatrixData with C == pattern(M): k_csc_build from the uploaded dense store; with any
+    other C the context falls back to the dense store (and says so)."""
+    M, C = _random_symmetric(m, 0.08, seed=m)
+    u0 = np.random.default_rng(1).random(m)
+    gd, gc = abi.HipClipper(storage=abi.STORE_F32), abi.HipClipper(storage=abi.STORE_F32_CSC)
+    gd.set_matrix_data(M, C)
+    gc.set_matrix_data(M, C)
+    assert gc.storage_in_use == abi.STORE_F32_CSC
+    assert np.array_equal(gd.get_affinity_matrix(), gc.get_affinity_matrix())
+    sd, sc = gd.solve(u0), gc.solve(u0)
+    assert sorted(sd.nodes.tolist()) == sorted(sc.nodes.tolist())
+    assert abs(sd.score - sc.score) <= 1e-9 * max(1.0, abs(sd.score))
+    # a constraint matrix that is NOT the pattern of M: dense fall-back
+    C2 = C.copy()
+    i, j = np.argwhere(np.triu(M, 1) != 0)[0]
+    C2[i, j] = C2[j, i] = 0.0
+    gc.set_matrix_data(M, C2)
+    gd.set_matrix_data(M, C2)
+    assert gc.storage_in_use == abi.STORE_F32
+    sd, sc = gd.solve(u0), gc.solve(u0)
+    assert sd.nodes.tolist() == sc.nodes.tolist() and sd.score == sc.score
+    # and back to the compressed copy with the next affinity build
+    p = synth.make_euclidean_problem(m, 0.8, seed=5)
+    gc.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    assert gc.storage_in_use == abi.STORE_F32_CSC
+
+
+def test_pointnormal_and_other_fill_kernels(monkeypatch):
+    """PointNormalDistance through k_affinity_sym<3, true>; the strip / plain fill kernels
+    through k_csc_build (CLIPPER_HIP_AFFINITY)."""
+    p = synth.make_pointnormal_problem(900, 0.8, seed=9)
+    inv = p.meta["invariant"]
+    mats = {}
+    for mode in ("", "strip", "plain"):
+        if mode:
+            monkeypatch.setenv("CLIPPER_HIP_AFFINITY", mode)
+        g = abi.HipClipper(storage=abi.STORE_F32_CSC)
+        g.score_pairwise_consistency_pointnormal(p.D1, p.D2, p.A, **inv)
+        assert g.storage_in_use == abi.STORE_F32_CSC
+        mats[mode] = (g.get_affinity_matrix(), g.solve(p.u0))
+        g.close()
+        if mode:
+            monkeypatch.delenv("CLIPPER_HIP_AFFINITY")
+    for mode in ("strip", "plain"):
+        assert np.array_equal(mats[""][0], mats[mode][0])
+        assert mats[""][1].nodes.tolist() == mats[mode][1].nodes.tolist()
+        assert mats[""][1].score == mats[mode][1].score
+
+
+def test_dsd_rounding_on_compressed_storage():
+    p = synth.make_euclidean_problem(400, 0.8, seed=21)
+    out = {}
+    for st in (abi.STORE_F32, abi.STORE_F32_CSC):
+        g = abi.HipClipper(abi.Params(rounding=abi.ROUNDING_DSD), storage=st)
+        g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+        out[st] = g.solve(p.u0)
+    assert sorted(out[abi.STORE_F32].nodes.tolist()) == sorted(out[abi.STORE_F32_CSC].nodes.tolist())

@@ -28,6 +28,11 @@ constexpr int VS = 8;
 #define CSC_RB 64
 #endif
 constexpr int RB = CSC_RB;  // rows per block
+#ifndef CSC_CW
+#define CSC_CW 128
+#endif
+constexpr int CW = CSC_CW;     // columns per strip
+constexpr int CPL = CW / 64;   // columns per lane
 
 __global__ void k_rand(float* S, int64_t ld, int64_t m, float density) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,12 +52,12 @@ __global__ void k_rand(float* S, int64_t ld, int64_t m, float density) {
 }
 
 // ---- build ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_csc_count(const float* __restrict__ S, int64_t ld,
+__global__ __launch_bounds__(CW) void k_csc_count(const float* __restrict__ S, int64_t ld,
                                                     int64_t m, int nblocks,
                                                     uint32_t* __restrict__ Lc) {
   __shared__ int red[4];
   const int s = blockIdx.x, b = blockIdx.y;
-  const int64_t c = (int64_t)s * 256 + threadIdx.x;
+  const int64_t c = (int64_t)s * CW + threadIdx.x;
   const int64_t r0 = (int64_t)b * RB;
   int cnt = 0;
   if (c < ld) {
@@ -71,12 +76,12 @@ __global__ __launch_bounds__(256) void k_csc_count(const float* __restrict__ S, 
   __syncthreads();
   if (threadIdx.x == 0) {
     int mx = red[0];
-    for (int w = 1; w < 4; ++w) mx = mx > red[w] ? mx : red[w];
+    for (int w = 1; w < CW / 64; ++w) mx = mx > red[w] ? mx : red[w];
     Lc[(int64_t)s * nblocks + b] = (uint32_t)((mx + 3) & ~3);
   }
 }
 
-__global__ __launch_bounds__(256) void k_csc_fill(const float* __restrict__ S, int64_t ld,
+__global__ __launch_bounds__(CW) void k_csc_fill(const float* __restrict__ S, int64_t ld,
                                                    int64_t m, int nblocks,
                                                    const uint32_t* __restrict__ Lc,
                                                    const uint64_t* __restrict__ Pre,
@@ -86,9 +91,9 @@ __global__ __launch_bounds__(256) void k_csc_fill(const float* __restrict__ S, i
   const int64_t g = (int64_t)s * nblocks + b;
   const int L = (int)Lc[g];
   const int LQ = L >> 2;
-  const int64_t base = (int64_t)Pre[g] * 256;  // entries before this group
-  const int t = threadIdx.x, lane = t >> 2, e = t & 3;
-  const int64_t c = (int64_t)s * 256 + t;
+  const int64_t base = (int64_t)Pre[g] * CW;  // entries before this group
+  const int t = threadIdx.x, lane = t / CPL, e = t % CPL;
+  const int64_t c = (int64_t)s * CW + t;
   const int64_t r0 = (int64_t)b * RB;
   float4* vq = reinterpret_cast<float4*>(vals + base);
   uint32_t* rq = reinterpret_cast<uint32_t*>(rows + base);
@@ -140,13 +145,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_csc(
     const double* __restrict__ X, double* __restrict__ part) {
   constexpr int XP = xpitch(V);
   constexpr int NS = V + 1;
-  constexpr int NH = NW / 4;
+  constexpr int NH = NW / CPL;
   constexpr int XT = RB * XP;
   constexpr int LDSD = (NW * XT > NW * NS * 64) ? NW * XT : NW * NS * 64;
   __shared__ double lds[LDSD];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int e = wave & 3, h = wave >> 2;
+  const int e = wave % CPL, h = wave / CPL;
   const int s = blockIdx.x;
   const int b0 = tb[s * (ntmax + 1) + blockIdx.y];
   const int b1 = tb[s * (ntmax + 1) + blockIdx.y + 1];
@@ -156,10 +161,60 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_csc(
 #pragma unroll
   for (int v = 0; v < NS; ++v) acc[v] = 0.0;
 
+#ifdef CSC_PREFETCH
+  // cross-block software pipeline: the directory, the first quads and the x rows of the NEXT block
+  // are in flight while the current one is multiplied
+  int LQ = 0;
+  const float4* vq = nullptr;
+  const uint32_t* rq = nullptr;
+  float4 mv[MAXQ];
+  uint32_t rw[MAXQ];
+  double xr[VS];
+  auto fetch = [&](int bb, int& LQ_, const float4*& vq_, const uint32_t*& rq_, float4 (&mv_)[MAXQ],
+                   uint32_t (&rw_)[MAXQ], double (&xr_)[VS]) {
+    const int64_t g = (int64_t)s * nblocks + bb;
+    LQ_ = __builtin_amdgcn_readfirstlane((int)(Lc[g] >> 2));
+    const int64_t base = (int64_t)Pre[g] * CW;
+    vq_ = reinterpret_cast<const float4*>(vals + base) + (int64_t)e * LQ_ * 64 + lane;
+    rq_ = reinterpret_cast<const uint32_t*>(rows + base) + (int64_t)e * LQ_ * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      if (q < LQ_) {
+        mv_[q] = vq_[q * 64];
+        rw_[q] = rq_[q * 64];
+      }
+    }
+    const int64_t r = (int64_t)bb * RB + lane;
+#pragma unroll
+    for (int v = 0; v < VS; ++v) xr_[v] = 0.0;
+    if (r < m) {
+      const double2* xp = reinterpret_cast<const double2*>(X + r * VS);
+#pragma unroll
+      for (int v = 0; v < ((V + 1) & ~1); v += 2) {
+        const double2 t2 = xp[v >> 1];
+        xr_[v] = t2.x;
+        xr_[v + 1] = t2.y;
+      }
+    }
+  };
+  if (b0 + h < b1) fetch(b0 + h, LQ, vq, rq, mv, rw, xr);
+  for (int b = b0 + h; b < b1; b += NH) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int v = 0; v < ((V + 1) & ~1); v += 2)
+      *reinterpret_cast<double2*>(xs + lane * XP + v) = make_double2(xr[v], xr[v + 1]);
+    __builtin_amdgcn_wave_barrier();
+    int LQn = 0;
+    const float4* vqn = nullptr;
+    const uint32_t* rqn = nullptr;
+    float4 mvn[MAXQ];
+    uint32_t rwn[MAXQ];
+    if (b + NH < b1) fetch(b + NH, LQn, vqn, rqn, mvn, rwn, xr);
+#else
   for (int b = b0 + h; b < b1; b += NH) {
     const int64_t g = (int64_t)s * nblocks + b;
     const int LQ = __builtin_amdgcn_readfirstlane((int)(Lc[g] >> 2));
-    const int64_t base = (int64_t)Pre[g] * 256;
+    const int64_t base = (int64_t)Pre[g] * CW;
     const float4* vq = reinterpret_cast<const float4*>(vals + base) + (int64_t)e * LQ * 64 + lane;
     const uint32_t* rq = reinterpret_cast<const uint32_t*>(rows + base) + (int64_t)e * LQ * 64 + lane;
     float4 mv[MAXQ];
@@ -193,6 +248,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_csc(
         *reinterpret_cast<double2*>(xs + (rr + lane) * XP + v) = make_double2(xr[v], xr[v + 1]);
     }
     __builtin_amdgcn_wave_barrier();
+#endif
     for (int k0 = 0; k0 < LQ; k0 += MAXQ) {
       if (k0 > 0) {
 #pragma unroll
@@ -231,19 +287,29 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_csc(
         }
       }
     }
+  #ifdef CSC_PREFETCH
+    LQ = LQn;
+    vq = vqn;
+    rq = rqn;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      mv[q] = mvn[q];
+      rw[q] = rwn[q];
+    }
+#endif
   }
 
   __syncthreads();
 #pragma unroll
   for (int v = 0; v < NS; ++v) lds[(wave * NS + v) * 64 + lane] = acc[v];
   __syncthreads();
-  for (int t = threadIdx.x; t < NS * 256; t += NW * 64) {
-    const int v = t >> 8, cl = t & 255;
-    const int ee = cl & 3, ln = cl >> 2;
+  for (int t = threadIdx.x; t < NS * CW; t += NW * 64) {
+    const int v = t / CW, cl = t % CW;
+    const int ee = cl % CPL, ln = cl / CPL;
     double sum = lds[(ee * NS + v) * 64 + ln];
 #pragma unroll
-    for (int hh = 1; hh < NH; ++hh) sum += lds[((hh * 4 + ee) * NS + v) * 64 + ln];
-    const int64_t c = (int64_t)blockIdx.x * 256 + cl;
+    for (int hh = 1; hh < NH; ++hh) sum += lds[((hh * CPL + ee) * NS + v) * 64 + ln];
+    const int64_t c = (int64_t)blockIdx.x * CW + cl;
     if (c < ld) part[((int64_t)blockIdx.y * NS + v) * ld + c] = sum;
   }
 }
@@ -272,7 +338,7 @@ static void run(const char* tag, int64_t ld, int64_t m, const float* vals, const
                 const uint32_t* Lc, const uint64_t* Pre, const std::vector<uint32_t>& hL,
                 int nblocks, int target_wgs, const double* X, const std::vector<double>& ref,
                 double bytes) {
-  const int nstrips = (int)(ld / 256);
+  const int nstrips = (int)(ld / CW);
   // cost-balanced tiles: cost of a block = Lc + 2
   std::vector<double> tot(nstrips, 0.0);
   double total = 0;
@@ -368,7 +434,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&X, hx.size() * 8));
   CK(hipMemcpy(X, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
 
-  const int nstrips = (int)(ld / 256), nblocks = (int)((m + RB - 1) / RB);
+  const int nstrips = (int)(ld / CW), nblocks = (int)((m + RB - 1) / RB);
   const int64_t G = (int64_t)nstrips * nblocks;
   uint32_t* Lc;
   uint64_t* Pre;
@@ -378,10 +444,10 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   CK(hipEventCreate(&e2));
-  k_csc_count<<<dim3(nstrips, nblocks), 256>>>(S, ld, m, nblocks, Lc);  // warm
+  k_csc_count<<<dim3(nstrips, nblocks), CW>>>(S, ld, m, nblocks, Lc);  // warm
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  k_csc_count<<<dim3(nstrips, nblocks), 256>>>(S, ld, m, nblocks, Lc);
+  k_csc_count<<<dim3(nstrips, nblocks), CW>>>(S, ld, m, nblocks, Lc);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   std::vector<uint32_t> hL(G);
@@ -397,19 +463,19 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(Pre, hP.data(), G * 8, hipMemcpyHostToDevice));
   float* vals;
   uint8_t* rows;
-  CK(hipMalloc(&vals, tot * 256 * 4));
-  CK(hipMalloc(&rows, tot * 256));
-  k_csc_fill<<<dim3(nstrips, nblocks), 256>>>(S, ld, m, nblocks, Lc, Pre, vals, rows);  // warm
+  CK(hipMalloc(&vals, tot * CW * 4));
+  CK(hipMalloc(&rows, tot * CW));
+  k_csc_fill<<<dim3(nstrips, nblocks), CW>>>(S, ld, m, nblocks, Lc, Pre, vals, rows);  // warm
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e1));
-  k_csc_fill<<<dim3(nstrips, nblocks), 256>>>(S, ld, m, nblocks, Lc, Pre, vals, rows);
+  k_csc_fill<<<dim3(nstrips, nblocks), CW>>>(S, ld, m, nblocks, Lc, Pre, vals, rows);
   CK(hipEventRecord(e2));
   CK(hipDeviceSynchronize());
   float msf;
   CK(hipEventElapsedTime(&msf, e1, e2));
   // nnz for the padding ratio
   std::vector<float> hs;
-  double bytes = (double)tot * 256 * 5;
+  double bytes = (double)tot * CW * 5;
   printf("m=%lld groups=%lld  sum(Lc)=%llu  mean Lc=%.2f  max Lc=%u  compressed %.1f MB (dense %.1f MB)  fill %.1f us\n",
          (long long)m, (long long)G, (unsigned long long)tot, (double)tot / G, mx, bytes * 1e-6,
          4.0 * m * ld * 1e-6, msf * 1e3);

@@ -17,6 +17,6 @@ print("col nnz min/mean/max", cnt.min(), cnt.mean(), cnt.max())
 Mx.tofile("/tmp/S.f32")
 PY
 cat $OUT/dump.log
-for rb in 64 128; do timeout 300 tools/_bin/csc_tune$rb $M /tmp/S.f32 2>&1 | tee -a $OUT/real.log; done
-timeout 300 tools/_bin/csc_tune64 $M 0.1125 2>&1 | tee $OUT/rand.log
+for v in pf0 pf1; do timeout 300 tools/_bin/csc_tune_$v $M /tmp/S.f32 2>&1 | tee -a $OUT/real.log; done
+
 
