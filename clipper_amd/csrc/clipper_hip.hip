@@ -347,7 +347,8 @@ int ensure_problem(Ctx* h, int64_t m) {
     HIPCHK(hipMalloc(&s.cnt, static_cast<size_t>(h->nstrips) * sizeof(int)));
     HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(h->nstrips) * sizeof(int), s.stream));
     const size_t Q = V * (2 + 2 * V) + 2 * V + 2;
-    HIPCHK(hipMalloc(&s.scal, static_cast<size_t>(ceil_div(m, TAIL_THREADS)) * Q * sizeof(double)));
+    const size_t nwg = static_cast<size_t>(ceil_div(m, TAIL_THREADS));
+    HIPCHK(hipMalloc(&s.scal, (nwg + ceil_div(nwg, SCAL_FOLD) + 1) * Q * sizeof(double)));
     HIPCHK(hipMalloc(&s.ab, NSLOT * nvec));
     HIPCHK(hipMemsetAsync(s.ab, 0, NSLOT * nvec, s.stream));
     s.part_tiles = static_cast<size_t>(max_tiles(h));
@@ -517,6 +518,12 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.slot = s.slot;
   a.scal = s.scal;
   a.nwg = static_cast<int>(ceil_div(h->m, TAIL_THREADS));
+  a.scal_in = s.scal;
+  a.nwg_in = a.nwg;
+  if (a.nwg > SCAL_FOLD_MIN) {  // folded copy behind the partials themselves
+    a.scal_in = s.scal + static_cast<int64_t>(a.nwg) * (h->V * (2 + 2 * h->V) + 2 * h->V + 2);
+    a.nwg_in = static_cast<int>(ceil_div(a.nwg, SCAL_FOLD));
+  }
   a.cnt = s.cnt;
   a.nstrips = h->nstrips;
   a.kind = (h->profiling && &s == &h->sh[0]) ? h->kind_dev : nullptr;
@@ -559,6 +566,10 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
     dim3 grid(static_cast<unsigned>(a.nwg), V), block(TAIL_THREADS);
     if (sharded) hipLaunchKernelGGL((k_tail<V, false>), grid, block, 0, s.stream, a);
     else hipLaunchKernelGGL((k_tail<V, true>), grid, block, 0, s.stream, a);
+    if (a.nwg_in != a.nwg)
+      hipLaunchKernelGGL(k_scal_fold, dim3(static_cast<unsigned>(a.nwg_in)), dim3(128), 0, s.stream,
+                         a.scal, a.nwg, V * (2 + 2 * V) + 2 * V + 2,
+                         const_cast<double*>(a.scal_in), a.shared);
   }
   return 0;
 }

@@ -156,6 +156,10 @@ struct SolveArgs {
   int slot;       // this shard's block of `ab`
   double* scal;   // [nwg][Q] partial scalars of the tail, Q = V*(2+2V) + 2V + 2
   int nwg;        // tail workgroups per candidate = ceil(m / TAIL_THREADS)
+  // what the decision sums: scal itself, or (large m: every workgroup of G repeats the decision,
+  // nwg*Q doubles each) the SCAL_FOLD-fold pre-reduction k_scal_fold makes of it
+  const double* scal_in;
+  int nwg_in;
   int* cnt;       // column-sharded M: one arrival counter per column strip
   int nstrips;
   uint8_t* kind;  // pinned host memory [KIND_CAP], profiling only: iteration n_iters ran a pass
@@ -341,16 +345,16 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
       double acc = 0.0;
       if (q < Q) {
         constexpr int U = 10;  // loads in flight per chain
-        const double* p = A.scal + q;
+        const double* p = A.scal_in + q;
         int w = c;
-        for (; w + NCH * (U - 1) < A.nwg; w += NCH * U) {
+        for (; w + NCH * (U - 1) < A.nwg_in; w += NCH * U) {
           double x[U];
 #pragma unroll
           for (int k = 0; k < U; ++k) x[k] = p[static_cast<int64_t>(w + NCH * k) * Q];
 #pragma unroll
           for (int k = 0; k < U; ++k) acc += x[k];
         }
-        for (; w < A.nwg; w += NCH) acc += p[static_cast<int64_t>(w) * Q];
+        for (; w < A.nwg_in; w += NCH) acc += p[static_cast<int64_t>(w) * Q];
       }
       red[tid] = acc;
       __syncthreads();
@@ -687,6 +691,24 @@ __global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, Sol
 //                 gathered raw sums of all shards).
 // Reads the state G decided on (st_next); communicates with nobody.
 // ------------------------------------------------------------------------------------------
+// k_scal_fold — out[b][q] = sum of scal[w][q] over the SCAL_FOLD tail workgroups w of block b, in
+// order. Launched after the tail when nwg > SCAL_FOLD_MIN (m > 16k): the decision at the head of
+// every workgroup of the next pass then reads nwg/SCAL_FOLD rows instead of nwg.
+constexpr int SCAL_FOLD = 32;
+constexpr int SCAL_FOLD_MIN = 64;
+__global__ __launch_bounds__(128) void k_scal_fold(const double* __restrict__ scal, int nwg, int Q,
+                                                    double* __restrict__ out,
+                                                    const SolveShared* __restrict__ shared) {
+  if (shared->done) return;
+  const int w0 = blockIdx.x * SCAL_FOLD;
+  const int w1 = (w0 + SCAL_FOLD < nwg) ? w0 + SCAL_FOLD : nwg;
+  for (int q = threadIdx.x; q < Q; q += 128) {
+    double acc = 0.0;
+    for (int w = w0; w < w1; ++w) acc += scal[static_cast<int64_t>(w) * Q + q];
+    out[static_cast<int64_t>(blockIdx.x) * Q + q] = acc;
+  }
+}
+
 template <int V, bool FUSED_REDUCE>
 __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
   constexpr int NR = 2 + 2 * V;
