@@ -7,7 +7,7 @@
  *
  * Differences a maintainer should know (all additive):
  *   - the built-in invariants expose params() (the GPU dispatcher needs them);
- *   - setDevice()/setStorage() choose the GPU and the storage type of M (fp32 | fp64);
+ *   - setDevice()/setStorage() choose the GPU and the storage type of M (fp32 compressed | fp32 dense | fp64 dense);
  *   - failures of the GPU path throw std::runtime_error (the reference has no error path;
  *     there is deliberately NO silent CPU fallback for the built-in invariants);
  *   - solveAsMaximumClique / solveAsMSRCSDR / Rounding::DSD are outside this build and
@@ -83,7 +83,7 @@ struct Solution {
 class CLIPPER {
  public:
   /// Element type of the dense M kept in HBM (vectors and accumulators are always fp64).
-  enum class Storage { F32 = 0, F64 = 1 };
+  enum class Storage { F32 = 0, F64 = 1, F32_CSC = 2 };  ///< see clipper_hip.h (CLIPPER_HIP_STORE_*)
 
   CLIPPER(const invariants::PairwiseInvariantPtr& invariant, const Params& params);
   ~CLIPPER();
@@ -114,7 +114,7 @@ class CLIPPER {
 
   // ---- additions of this build -----------------------------------------------------------
   void setDevice(int device);        ///< HIP device ordinal (default 0); before the first call
-  void setStorage(Storage storage);  ///< default F32; before the first call
+  void setStorage(Storage storage);  ///< default F32_CSC (compressed; dense fp32 where it does not apply); before the first call
   struct PathStats {
     long long n_passes = 0, n_trials = 0;
     double affinity_kernel_ms = 0, d = 0;
@@ -129,7 +129,7 @@ class CLIPPER {
   Solution soln_;
   PathStats stats_;
   int device_ = 0;
-  Storage storage_ = Storage::F32;
+  Storage storage_ = Storage::F32_CSC;
   clipper_hip_ctx* h_ = nullptr;
 
   clipper_hip_ctx* handle();
