@@ -199,7 +199,8 @@ struct clipper_hip_ctx {
   HostMirror* mirror_dev = nullptr;  // its device address
   uint8_t* kind = nullptr;           // pinned + coherent: per-iteration pass / transition marks
   uint8_t* kind_dev = nullptr;       // (profiling only), written by the device
-  double* u_pinned = nullptr;        // pinned staging of the final u
+  double* u_pinned = nullptr;        // pinned staging of the final u (the device writes it)
+  double* u_pinned_dev = nullptr;    // its device address
   size_t u_pinned_cap = 0;
   int V = 6;               // line-search window: candidate vectors per pass
   int V_forced = 0;        // CLIPPER_HIP_WINDOW
@@ -527,6 +528,7 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.cnt = s.cnt;
   a.nstrips = h->nstrips;
   a.kind = (h->profiling && &s == &h->sh[0]) ? h->kind_dev : nullptr;
+  a.host_u = (!h->multiproc && &s == &h->sh[0]) ? h->u_pinned_dev : nullptr;
   return a;
 }
 
@@ -1698,6 +1700,17 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   // with rescaling the first iteration runs the pair pass on u0; without, it only normalises
   init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
   init.stage = P->rescale_u0 ? ST_PASS : ST_RESULTS;
+  if (h->u_pinned_cap < vbytes) {
+    if (h->u_pinned) hipHostFree(h->u_pinned);
+    h->u_pinned = nullptr;
+    h->u_pinned_dev = nullptr;
+    h->u_pinned_cap = 0;
+    HIPCHK(hipSetDevice(h->sh[0].device));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->u_pinned), vbytes,
+                         hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->u_pinned_dev), h->u_pinned, 0));
+    h->u_pinned_cap = vbytes;
+  }
   // prologue, one launch per shard: pending vector = u0 (T pair 0, nrm = 1), state, counters
   h->par = 0;
   std::memset(h->mirror, 0, sizeof(HostMirror));
@@ -1770,20 +1783,19 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     HIPCHK(hipMemcpy(&fin, s0.shared, sizeof(fin), hipMemcpyDeviceToHost));
   }
 
-  // final u: one D2H copy into pinned staging (also drains the few no-op launches queued
-  // past convergence)
-  if (h->u_pinned_cap < vbytes) {
-    if (h->u_pinned) hipHostFree(h->u_pinned);
-    h->u_pinned = nullptr;
-    h->u_pinned_cap = 0;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->u_pinned), vbytes, hipHostMallocDefault));
-    h->u_pinned_cap = vbytes;
-  }
+  // final u
   HIPCHK(hipSetDevice(s0.device));
-  const double* u_dev =
-      s0.pt + ((static_cast<int64_t>(fin.ubp & 1) * h->V + fin.ubv) * 2 + 0) * h->mp;
-  HIPCHK(hipMemcpyAsync(h->u_pinned, u_dev, vbytes, hipMemcpyDeviceToHost, s0.stream));
-  if ((rc = sync_all(h))) return rc;
+  if (h->multiproc) {
+    const double* u_dev =
+        s0.pt + ((static_cast<int64_t>(fin.ubp & 1) * h->V + fin.ubv) * 2 + 0) * h->mp;
+    HIPCHK(hipMemcpyAsync(h->u_pinned, u_dev, vbytes, hipMemcpyDeviceToHost, s0.stream));
+    if ((rc = sync_all(h))) return rc;
+  } else {
+    // one process: the deciding workgroup wrote u into the pinned buffer before it raised `done`;
+    // the few no-op launches still queued drain behind the caller's back (stream order keeps
+    // every later call behind them)
+    HIPCHK(hipGetLastError());
+  }
   std::vector<double> u(h->u_pinned, h->u_pinned + m);
 
   // rounding — clipper.cpp:287-310 with utils.cpp:33-68, on the host

@@ -163,6 +163,7 @@ struct SolveArgs {
   int* cnt;       // column-sharded M: one arrival counter per column strip
   int nstrips;
   uint8_t* kind;  // pinned host memory [KIND_CAP], profiling only: iteration n_iters ran a pass
+  double* host_u; // pinned host memory [m] (may be null): the final u, written before `done`
 };
 constexpr int KIND_CAP = 1 << 16;
 
@@ -555,6 +556,16 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
         }
       }
     }
+  }
+
+  // ---- the end: the deciding workgroup hands the final u to the host itself (pinned memory), so
+  // that the host needs neither a copy nor a wait on the stream once it sees `done`
+  if (writer && action == ACT_DONE && A.host_u != nullptr) {
+    const double* u = pt_arr(A, V, ubp, ubv, 0);
+    for (int64_t i = tid; i < m; i += NT)
+      __hip_atomic_store(A.host_u + i, u[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
   }
 
   // ---- record the decided state (workgroup (0,0), one thread) ------------------------------
