@@ -144,3 +144,46 @@ def test_dsd_rounding_on_compressed_storage():
         g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
         out[st] = g.solve(p.u0)
     assert sorted(out[abi.STORE_F32].nodes.tolist()) == sorted(out[abi.STORE_F32_CSC].nodes.tolist())
+
+
+def test_sharded_contexts_fall_back_to_the_dense_store(monkeypatch):
+    """what bench.py --gpus N > 1 does with its default storage: a multi-process rank (here a
+    1-rank RCCL world) and an in-process group keep dense column shards."""
+    p = synth.make_euclidean_problem(1200, 0.9, seed=3)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    sr = r.solve(p.u0)
+    monkeypatch.setenv("CLIPPER_HIP_FORCE_RCCL", "1")
+    g = abi.HipClipper(storage=abi.STORE_F32_CSC, rank=0, world=1)
+    g.comm_init(g.unique_id())
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    assert g.storage_in_use == abi.STORE_F32
+    sg = g.solve(p.u0)
+    assert sg.nodes.tolist() == sr.nodes.tolist()
+    monkeypatch.delenv("CLIPPER_HIP_FORCE_RCCL")
+    grp = abi.HipClipper(storage=abi.STORE_F32_CSC, group=[0, 0, 0])
+    grp.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    assert grp.storage_in_use == abi.STORE_F32
+    s3 = grp.solve(p.u0)
+    assert s3.nodes.tolist() == sr.nodes.tolist() and s3.score == sg.score
+
+
+def test_full_size_10k_compressed_parity():
+    """BASELINE.json's headline problem in the storage bench.py runs: oracle comparison."""
+    m = 10000
+    p = synth.make_euclidean_problem(m, 0.95, seed=12345)
+    g = abi.HipClipper(storage=abi.STORE_F32_CSC)
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    sg = g.solve(p.u0)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    sr = r.solve(p.u0)
+    assert sg.nodes.tolist() == sr.nodes.tolist()
+    assert abs(sg.score - sr.score) <= 1e-6 * abs(sr.score)
+    assert sg.ifinal == sr.ifinal
+    # the pass as a linear map (compressed) against the dense store's pass of a second context
+    d = abi.HipClipper(storage=abi.STORE_F32)
+    d.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    sd = d.solve(p.u0)
+    assert sorted(sd.nodes.tolist()) == sorted(sg.nodes.tolist())
+    assert abs(sd.score - sg.score) <= 1e-9 * abs(sd.score)
