@@ -1,0 +1,688 @@
+// k_affinity.hip.h — affinity fill: k_gather_points, k_affinity_* (plain, compacting strips, symmetric tiles)
+// Part of kernels.hip.h (include that one): hand-written gfx950 device code of the CLIPPER hot path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "k_csc.hip.h"
+
+namespace clipper_hip {
+
+// ------------------------------------------------------------------------------------------
+// affinity fill
+// ------------------------------------------------------------------------------------------
+
+// P[k * pstride + i] = D[k + d * idx[i]] : per-association point table, structure of arrays,
+// so that column data loads in the fill kernels are contiguous across lanes. Pf is the same
+// table rounded to fp32 (input of the conservative prefilter of the compacting fill kernels).
+__global__ __launch_bounds__(256) void k_gather_points(const double* __restrict__ D, int d,
+                                                        const int32_t* __restrict__ idx,
+                                                        int64_t m, int64_t pstride,
+                                                        double* __restrict__ P,
+                                                        float* __restrict__ Pf) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= pstride) return;
+  const int64_t src = (i < m) ? idx[i] : 0;
+  for (int k = 0; k < d; ++k) {
+    const double v = (i < m) ? D[k + d * src] : 0.0;
+    P[k * pstride + i] = v;
+    Pf[k * pstride + i] = static_cast<float>(v);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T store_score(double scr, double affinityeps) {
+  // clipper.cpp:53-55 — keep the score only when it exceeds affinityeps.
+  if (!(scr > affinityeps)) return T(0);
+  T v = static_cast<T>(scr);
+  // an fp32 underflow must not erase an entry from the pattern (C == pattern(M))
+  if (v == T(0)) v = static_cast<T>(1.17549435e-38);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, T a, T b, T c, T d);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4<double>(double* p, double a, double b, double c,
+                                               double d) {
+  *reinterpret_cast<double4*>(p) = make_double4(a, b, c, d);
+}
+
+struct EuclidParams {
+  double sigma, epsilon, mindist, affinityeps;
+};
+
+// One thread = 4 adjacent columns of S, looping down `rows_per_blk` rows; the 4 columns'
+// points and association indices stay in registers for the whole loop, the row's point is
+// wave-uniform (scalar loads). Each lane stores 4 consecutive elements, a wave 256: whole
+// 1 KiB (fp32) row segments per store instruction.
+// D > 0: compile-time dimension (2 or 3); D == 0: run-time dimension `d` (slow path).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_affinity_euclid(
+    T* __restrict__ S, int64_t ld, int64_t m, int64_t c0, int rows_per_blk, int d,
+    const double* __restrict__ P1, const double* __restrict__ P2, int64_t pstride,
+    const int32_t* __restrict__ A0, const int32_t* __restrict__ A1, EuclidParams prm) {
+  const int64_t c = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  if (c >= ld) return;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_blk;
+  const int64_t r1 = (r0 + rows_per_blk < m) ? r0 + rows_per_blk : m;
+  constexpr int DD = (D > 0) ? D : 1;
+
+  int64_t gi[4];
+  bool valid[4];
+  int32_t a0c[4], a1c[4];
+  double p1c[4][DD], p2c[4][DD];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t g = c0 + c + q;
+    valid[q] = g < m;
+    gi[q] = valid[q] ? g : (m - 1);
+    a0c[q] = A0[gi[q]];
+    a1c[q] = A1[gi[q]];
+    if (D > 0) {
+#pragma unroll
+      for (int k = 0; k < DD; ++k) {
+        p1c[q][k] = P1[k * pstride + gi[q]];
+        p2c[q][k] = P2[k * pstride + gi[q]];
+      }
+    }
+  }
+
+  for (int64_t r = r0; r < r1; ++r) {
+    const int32_t a0r = A0[r], a1r = A1[r];
+    double p1r[DD], p2r[DD];
+    if (D > 0) {
+#pragma unroll
+      for (int k = 0; k < DD; ++k) {
+        p1r[k] = P1[k * pstride + r];
+        p2r[k] = P2[k * pstride + r];
+      }
+    }
+    T out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double s1 = 0.0, s2 = 0.0;  // euclidean_distance.cpp:18-19, sequential fma chain
+      if (D > 0) {
+#pragma unroll
+        for (int k = 0; k < DD; ++k) {
+          const double t1 = p1r[k] - p1c[q][k];
+          const double t2 = p2r[k] - p2c[q][k];
+          s1 = fma(t1, t1, s1);
+          s2 = fma(t2, t2, s2);
+        }
+      } else {
+        for (int k = 0; k < d; ++k) {
+          const double t1 = P1[k * pstride + r] - P1[k * pstride + gi[q]];
+          const double t2 = P2[k * pstride + r] - P2[k * pstride + gi[q]];
+          s1 = fma(t1, t1, s1);
+          s2 = fma(t2, t2, s2);
+        }
+      }
+      const double l1 = sqrt(s1), l2 = sqrt(s2);
+      // clipper.cpp:35-38 distinctness; the diagonal (r == column) fails it by construction
+      bool ok = valid[q] && (a0r != a0c[q]) && (a1r != a1c[q]);
+      // euclidean_distance.cpp:23-25
+      if (prm.mindist > 0 && (l1 < prm.mindist || l2 < prm.mindist)) ok = false;
+      const double cc = fabs(l1 - l2);  // :28
+      double scr = 0.0;
+      if (ok && cc < prm.epsilon) scr = exp(-0.5 * cc * cc / (prm.sigma * prm.sigma));  // :30
+      out[q] = store_score<T>(scr, prm.affinityeps);
+    }
+    store4<T>(S + r * ld + c, out[0], out[1], out[2], out[3]);
+  }
+}
+
+struct PointNormalParams {
+  double sigp, epsp, sign, epsn, affinityeps;
+};
+
+// PointNormalDistance: datum = [x y z nx ny nz] (pointnormal_distance.cpp:13-35).
+template <typename T>
+__global__ __launch_bounds__(256) void k_affinity_pointnormal(
+    T* __restrict__ S, int64_t ld, int64_t m, int64_t c0, int rows_per_blk,
+    const double* __restrict__ P1, const double* __restrict__ P2, int64_t pstride,
+    const int32_t* __restrict__ A0, const int32_t* __restrict__ A1, PointNormalParams prm) {
+  const int64_t c = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  if (c >= ld) return;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_blk;
+  const int64_t r1 = (r0 + rows_per_blk < m) ? r0 + rows_per_blk : m;
+
+  bool valid[4];
+  int32_t a0c[4], a1c[4];
+  double p1c[4][6], p2c[4][6];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t g = c0 + c + q;
+    valid[q] = g < m;
+    const int64_t gi = valid[q] ? g : (m - 1);
+    a0c[q] = A0[gi];
+    a1c[q] = A1[gi];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      p1c[q][k] = P1[k * pstride + gi];
+      p2c[q][k] = P2[k * pstride + gi];
+    }
+  }
+
+  for (int64_t r = r0; r < r1; ++r) {
+    const int32_t a0r = A0[r], a1r = A1[r];
+    double p1r[6], p2r[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      p1r[k] = P1[k * pstride + r];
+      p2r[k] = P2[k * pstride + r];
+    }
+    T out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double t1 = p1r[k] - p1c[q][k];
+        const double t2 = p2r[k] - p2c[q][k];
+        s1 = fma(t1, t1, s1);
+        s2 = fma(t2, t2, s2);
+      }
+      const double l1 = sqrt(s1), l2 = sqrt(s2);  // :17-18
+      const double dot1 = fma(p1r[5], p1c[q][5], fma(p1r[4], p1c[q][4], p1r[3] * p1c[q][3]));
+      const double dot2 = fma(p2r[5], p2c[q][5], fma(p2r[4], p2c[q][4], p2r[3] * p2c[q][3]));
+      const bool ok = valid[q] && (a0r != a0c[q]) && (a1r != a1c[q]);
+      double scr = 0.0;
+      if (ok) {
+        const double alpha1 = acos(dot1);  // :21 (NaN when |dot| > 1, as in the reference)
+        const double alpha2 = acos(dot2);  // :22
+        const double dp = fabs(l1 - l2);          // :25
+        const double dn = fabs(alpha1 - alpha2);  // :26
+        if (dp < prm.epsp && dn < prm.epsn) {     // :28
+          const double sp = exp(-0.5 * dp * dp / (prm.sigp * prm.sigp));  // :29
+          const double sn = exp(-0.5 * dn * dn / (prm.sign * prm.sign));  // :30
+          scr = sp * sn;                                                  // :31
+        }
+      }
+      out[q] = store_score<T>(scr, prm.affinityeps);
+    }
+    store4<T>(S + r * ld + c, out[0], out[1], out[2], out[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Compacting fill kernels.
+//
+// The exact score costs ~150 fp64-rate instructions per pair (two correctly rounded sqrt, one
+// division, exp / acos), yet on registration data only ~10 % of the pairs pass `c < epsilon`
+// — and with 64-lane waves a plain branch saves nothing. So every pair first goes through a
+// CONSERVATIVE fp32 prefilter (|l1f - l2f| >= epsilon + guard  =>  certainly c >= epsilon; the
+// guard bounds the fp32 error from the data's magnitude, incl. the 1-ulp raw v_sqrt_f32), survivors are compacted into a
+// per-wave LDS queue with ballot/mbcnt (no atomics, no workgroup barrier), and only they are
+// evaluated exactly in fp64 — with the same instruction sequence as the plain kernels, so the
+// results are bit-identical to them. Scores are scattered into an LDS staging tile and leave
+// as whole 1 KiB row segments, so the HBM store pattern is unchanged.
+// Geometry: 4 waves per workgroup, wave w owns 256 columns (4 per lane); rows are processed in
+// groups of AFF_RG = 8: queue 8 KiB + staging 8 (fp32) / 16 (fp64) KiB per wave.
+// ------------------------------------------------------------------------------------------
+
+constexpr int AFF_RG = 8;
+
+__device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+template <typename T, int D>
+__device__ __forceinline__ double exact_euclid_score(const double* __restrict__ P1,
+                                                     const double* __restrict__ P2,
+                                                     int64_t pstride, int64_t r, int64_t g,
+                                                     const EuclidParams& prm) {
+  double s1 = 0.0, s2 = 0.0;  // euclidean_distance.cpp:18-19, sequential fma chain
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double t1 = P1[k * pstride + r] - P1[k * pstride + g];
+    const double t2 = P2[k * pstride + r] - P2[k * pstride + g];
+    s1 = fma(t1, t1, s1);
+    s2 = fma(t2, t2, s2);
+  }
+  const double l1 = sqrt(s1), l2 = sqrt(s2);
+  if (prm.mindist > 0 && (l1 < prm.mindist || l2 < prm.mindist)) return 0.0;  // :23-25
+  const double cc = fabs(l1 - l2);                                            // :28
+  return (cc < prm.epsilon) ? exp(-0.5 * cc * cc / (prm.sigma * prm.sigma)) : 0.0;  // :30
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_affinity_euclid_compact(
+    T* __restrict__ S, int64_t ld, int64_t m, int64_t c0, int rows_per_blk,
+    const double* __restrict__ P1, const double* __restrict__ P2,
+    const float* __restrict__ P1f, const float* __restrict__ P2f, int64_t pstride,
+    const int32_t* __restrict__ A0, const int32_t* __restrict__ A1, EuclidParams prm,
+    float eps_guarded) {
+  __shared__ uint32_t queue[4][AFF_RG * 256];
+  __shared__ T stage[4][AFF_RG][256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t cw = static_cast<int64_t>(blockIdx.x) * 1024 + wave * 256;  // wave's first column
+  const int64_t c = cw + lane * 4;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_blk;
+  const int64_t r1 = (r0 + rows_per_blk < m) ? r0 + rows_per_blk : m;
+  if (cw >= ld) return;  // whole wave outside the slice (wave-uniform)
+
+  // column data (fp32) in registers for the prefilter
+  bool valid[4];
+  int32_t a0c[4], a1c[4];
+  float p1c[4][D], p2c[4][D];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t g = c0 + c + q;
+    valid[q] = (g < m) && (c + q < ld);
+    const int64_t gi = (g < m) ? g : (m - 1);
+    a0c[q] = A0[gi];
+    a1c[q] = A1[gi];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      p1c[q][k] = P1f[k * pstride + gi];
+      p2c[q][k] = P2f[k * pstride + gi];
+    }
+  }
+#pragma unroll
+  for (int r8 = 0; r8 < AFF_RG; ++r8)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage[wave][r8][lane * 4 + q] = T(0);
+
+  for (int64_t base = r0; base < r1; base += AFF_RG) {
+    // ---- phase A: fp32 prefilter + compaction of the surviving (row, column) pairs --------
+    uint32_t count = 0;  // wave-uniform
+#pragma unroll
+    for (int r8 = 0; r8 < AFF_RG; ++r8) {
+      const int64_t r = base + r8;
+      if (r < r1) {  // uniform
+        const int32_t a0r = A0[r], a1r = A1[r];
+        float p1r[D], p2r[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          p1r[k] = P1f[k * pstride + r];
+          p2r[k] = P2f[k * pstride + r];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const float t1 = p1r[k] - p1c[q][k];
+            const float t2 = p2r[k] - p2c[q][k];
+            s1 = fmaf(t1, t1, s1);
+            s2 = fmaf(t2, t2, s2);
+          }
+          const float cf = fabsf(__builtin_amdgcn_sqrtf(s1) - __builtin_amdgcn_sqrtf(s2));
+          // clipper.cpp:35-38 distinctness (also removes the diagonal) + conservative c < eps
+          const bool cand = valid[q] && (a0r != a0c[q]) && (a1r != a1c[q]) && (cf < eps_guarded);
+          const uint64_t mask = __ballot(cand);
+          if (mask != 0) {  // uniform
+            if (cand) queue[wave][count + lane_prefix(mask)] =
+                (static_cast<uint32_t>(r8) << 16) | static_cast<uint32_t>(lane * 4 + q);
+            count += static_cast<uint32_t>(__popcll(mask));
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase B: exact fp64 score of the survivors, scattered into the staging tile -------
+    for (uint32_t e = lane; e < count; e += 64) {
+      const uint32_t code = queue[wave][e];
+      const int r8 = static_cast<int>(code >> 16);
+      const int cl = static_cast<int>(code & 0xffffu);
+      const double scr = exact_euclid_score<T, D>(P1, P2, pstride, base + r8, c0 + cw + cl, prm);
+      stage[wave][r8][cl] = store_score<T>(scr, prm.affinityeps);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase C: whole row segments leave for HBM; the staging tile is re-zeroed ----------
+    if (c < ld) {
+#pragma unroll
+      for (int r8 = 0; r8 < AFF_RG; ++r8) {
+        const int64_t r = base + r8;
+        if (r < r1) {
+          T* sp = &stage[wave][r8][lane * 4];
+          store4<T>(S + r * ld + c, sp[0], sp[1], sp[2], sp[3]);
+          sp[0] = sp[1] = sp[2] = sp[3] = T(0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ double exact_pointnormal_score(const double* __restrict__ P1,
+                                                          const double* __restrict__ P2,
+                                                          int64_t pstride, int64_t r, int64_t g,
+                                                          const PointNormalParams& prm) {
+  double p1r[6], p1g[6], p2r[6], p2g[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    p1r[k] = P1[k * pstride + r];
+    p1g[k] = P1[k * pstride + g];
+    p2r[k] = P2[k * pstride + r];
+    p2g[k] = P2[k * pstride + g];
+  }
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double t1 = p1r[k] - p1g[k];
+    const double t2 = p2r[k] - p2g[k];
+    s1 = fma(t1, t1, s1);
+    s2 = fma(t2, t2, s2);
+  }
+  const double l1 = sqrt(s1), l2 = sqrt(s2);  // :17-18
+  const double dot1 = fma(p1r[5], p1g[5], fma(p1r[4], p1g[4], p1r[3] * p1g[3]));
+  const double dot2 = fma(p2r[5], p2g[5], fma(p2r[4], p2g[4], p2r[3] * p2g[3]));
+  const double alpha1 = acos(dot1);  // :21
+  const double alpha2 = acos(dot2);  // :22
+  const double dp = fabs(l1 - l2);          // :25
+  const double dn = fabs(alpha1 - alpha2);  // :26
+  if (dp < prm.epsp && dn < prm.epsn) {     // :28
+    const double sp = exp(-0.5 * dp * dp / (prm.sigp * prm.sigp));  // :29
+    const double sn = exp(-0.5 * dn * dn / (prm.sign * prm.sign));  // :30
+    return sp * sn;                                                 // :31
+  }
+  return 0.0;
+}
+
+// PointNormalDistance: the prefilter tests only the point-distance residual dp (the normal
+// residual needs acos); survivors get the full exact evaluation.
+template <typename T>
+__global__ __launch_bounds__(256) void k_affinity_pointnormal_compact(
+    T* __restrict__ S, int64_t ld, int64_t m, int64_t c0, int rows_per_blk,
+    const double* __restrict__ P1, const double* __restrict__ P2,
+    const float* __restrict__ P1f, const float* __restrict__ P2f, int64_t pstride,
+    const int32_t* __restrict__ A0, const int32_t* __restrict__ A1, PointNormalParams prm,
+    float eps_guarded) {
+  __shared__ uint32_t queue[4][AFF_RG * 256];
+  __shared__ T stage[4][AFF_RG][256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t cw = static_cast<int64_t>(blockIdx.x) * 1024 + wave * 256;
+  const int64_t c = cw + lane * 4;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_blk;
+  const int64_t r1 = (r0 + rows_per_blk < m) ? r0 + rows_per_blk : m;
+  if (cw >= ld) return;
+
+  bool valid[4];
+  int32_t a0c[4], a1c[4];
+  float p1c[4][3], p2c[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t g = c0 + c + q;
+    valid[q] = (g < m) && (c + q < ld);
+    const int64_t gi = (g < m) ? g : (m - 1);
+    a0c[q] = A0[gi];
+    a1c[q] = A1[gi];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p1c[q][k] = P1f[k * pstride + gi];
+      p2c[q][k] = P2f[k * pstride + gi];
+    }
+  }
+#pragma unroll
+  for (int r8 = 0; r8 < AFF_RG; ++r8)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage[wave][r8][lane * 4 + q] = T(0);
+
+  for (int64_t base = r0; base < r1; base += AFF_RG) {
+    uint32_t count = 0;
+#pragma unroll
+    for (int r8 = 0; r8 < AFF_RG; ++r8) {
+      const int64_t r = base + r8;
+      if (r < r1) {
+        const int32_t a0r = A0[r], a1r = A1[r];
+        float p1r[3], p2r[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          p1r[k] = P1f[k * pstride + r];
+          p2r[k] = P2f[k * pstride + r];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float t1 = p1r[k] - p1c[q][k];
+            const float t2 = p2r[k] - p2c[q][k];
+            s1 = fmaf(t1, t1, s1);
+            s2 = fmaf(t2, t2, s2);
+          }
+          const float dpf = fabsf(__builtin_amdgcn_sqrtf(s1) - __builtin_amdgcn_sqrtf(s2));
+          const bool cand = valid[q] && (a0r != a0c[q]) && (a1r != a1c[q]) && (dpf < eps_guarded);
+          const uint64_t mask = __ballot(cand);
+          if (mask != 0) {
+            if (cand) queue[wave][count + lane_prefix(mask)] =
+                (static_cast<uint32_t>(r8) << 16) | static_cast<uint32_t>(lane * 4 + q);
+            count += static_cast<uint32_t>(__popcll(mask));
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = lane; e < count; e += 64) {
+      const uint32_t code = queue[wave][e];
+      const int r8 = static_cast<int>(code >> 16);
+      const int cl = static_cast<int>(code & 0xffffu);
+      const double scr = exact_pointnormal_score<T>(P1, P2, pstride, base + r8, c0 + cw + cl, prm);
+      stage[wave][r8][cl] = store_score<T>(scr, prm.affinityeps);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (c < ld) {
+#pragma unroll
+      for (int r8 = 0; r8 < AFF_RG; ++r8) {
+        const int64_t r = base + r8;
+        if (r < r1) {
+          T* sp = &stage[wave][r8][lane * 4];
+          store4<T>(S + r * ld + c, sp[0], sp[1], sp[2], sp[3]);
+          sp[0] = sp[1] = sp[2] = sp[3] = T(0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Symmetric fill (one shard, fp32 storage): M is symmetric and the score of (i, j) is bit-equal
+// to the score of (j, i) (squares and absolute differences only), so only the 128 x 128 tiles
+// of the upper block triangle are evaluated — prefilter and exact scores cost half — and every
+// off-diagonal tile leaves twice: as it stands, and transposed out of an LDS image with an odd
+// row pitch (bank-conflict-free column reads), both as 512-byte row segments.
+// The prefilter needs no square root: |l1 - l2| < E  <=>  t <= 0  or  t^2 < 4 s1 s2 with
+// t = s1 + s2 - E^2 (s = squared lengths, E = the guarded threshold); the right-hand side
+// carries a 2^-18 relative margin for the fp32 roundings of t, t^2 and s1 s2. Survivors get the
+// same exact fp64 evaluation as in the other fill kernels: identical bits.
+// Geometry: 8 waves; wave w owns tile rows [16w, 16w + 16), lane l tile columns 2l, 2l + 1.
+// ------------------------------------------------------------------------------------------
+
+constexpr int AT = 128;           // tile edge
+constexpr int AT_PITCH = AT + 1;  // LDS image row pitch in floats
+#ifndef CLIPPER_AT_WAVES
+#define CLIPPER_AT_WAVES 8
+#endif
+constexpr int AT_WAVES = CLIPPER_AT_WAVES;       // waves per workgroup
+constexpr int AT_ROWS_PER_WAVE = AT / AT_WAVES;  // tile rows a wave owns
+constexpr int AT_QUEUE = 256;     // ring entries per wave: < 64 waiting + one row's 128 candidates
+constexpr int AT_SYM_IMG_BYTES = (AT * AT_PITCH * 4 + 15) / 16 * 16;
+constexpr int AT_SYM_LDS_BYTES = AT_SYM_IMG_BYTES + AT_WAVES * AT_QUEUE * 4;
+
+// linear index t of the upper block triangle (row-major: (0,0) (0,1) ... (1,1) ...) -> (I, J)
+__device__ __forceinline__ void tile_of(int t, int nT, int& I, int& J) {
+  const float b = 2.0f * nT + 1.0f;
+  int i = static_cast<int>((b - sqrtf(b * b - 8.0f * static_cast<float>(t))) * 0.5f);
+  if (i < 0) i = 0;
+  if (i > nT - 1) i = nT - 1;
+  // first(i) = i*nT - i*(i-1)/2 is the index of tile (i, i); fix the float estimate
+  while (i > 0 && i * nT - i * (i - 1) / 2 > t) --i;
+  while (i + 1 < nT && (i + 1) * nT - (i + 1) * i / 2 <= t) ++i;
+  I = i;
+  J = i + (t - (i * nT - i * (i - 1) / 2));
+}
+
+template <int D, bool POINTNORMAL>
+__global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
+    float* __restrict__ S, int64_t ld, int64_t m, int nT, const double* __restrict__ P1,
+    const double* __restrict__ P2, const float* __restrict__ P1f, const float* __restrict__ P2f,
+    int64_t pstride, const int32_t* __restrict__ A0, const int32_t* __restrict__ A1,
+    EuclidParams eprm, PointNormalParams nprm, float E2 /* guarded threshold squared, rounded up */,
+    CscOut O /* O.Lc != null: also emit the tile's groups of the compressed copy */) {
+  // 72.5 KiB of dynamic LDS (two workgroups per CU fit the 160 KiB): the image, then the queues
+  extern __shared__ __attribute__((aligned(16))) char sym_smem[];
+  float* img = reinterpret_cast<float*>(sym_smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* queue = reinterpret_cast<uint32_t*>(sym_smem + AT_SYM_IMG_BYTES) + wave * AT_QUEUE;
+  int I, J;
+  tile_of(blockIdx.x, nT, I, J);
+  const int64_t r0 = static_cast<int64_t>(I) * AT, c0 = static_cast<int64_t>(J) * AT;
+  const double affinityeps = POINTNORMAL ? nprm.affinityeps : eprm.affinityeps;
+
+  // this lane's two columns (fp32 copies for the prefilter)
+  bool validc[2];
+  int32_t a0c[2], a1c[2];
+  float p1c[2][D], p2c[2][D];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int64_t g = c0 + 2 * lane + q;
+    validc[q] = g < m;
+    const int64_t gi = validc[q] ? g : (m - 1);
+    a0c[q] = A0[gi];
+    a1c[q] = A1[gi];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      p1c[q][k] = P1f[k * pstride + gi];
+      p2c[q][k] = P2f[k * pstride + gi];
+    }
+  }
+  // zero this wave's rows of the image
+#pragma unroll 4
+  for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
+    float* row = img + (wave * AT_ROWS_PER_WAVE + rr) * AT_PITCH;
+    row[2 * lane] = 0.f;
+    row[2 * lane + 1] = 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // exact fp64 score of queue entries [head, head + n), scattered into the image
+  auto drain = [&](uint32_t head, uint32_t n) {
+    if (lane < n) {
+      const uint32_t code = queue[(head + lane) & (AT_QUEUE - 1)];
+      const int rl = static_cast<int>(code >> 8);
+      const int cl = static_cast<int>(code & 0xffu);
+      double scr;
+      if (POINTNORMAL) scr = exact_pointnormal_score<float>(P1, P2, pstride, r0 + rl, c0 + cl, nprm);
+      else scr = exact_euclid_score<float, D>(P1, P2, pstride, r0 + rl, c0 + cl, eprm);
+      img[rl * AT_PITCH + cl] = store_score<float>(scr, affinityeps);
+    }
+  };
+
+  // The survivors of the fp32 prefilter go into a per-wave ring; whenever 64 are waiting they are
+  // evaluated by a full wave (the exact score is ~150 fp64-rate instructions: no idle lanes).
+  uint32_t head = 0, tail = 0;  // wave-uniform
+  for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
+    const int rl = wave * AT_ROWS_PER_WAVE + rr;  // tile row
+    const int64_t r = r0 + rl;
+    if (r < m) {  // uniform
+      const int32_t a0r = A0[r], a1r = A1[r];
+      float p1r[D], p2r[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        p1r[k] = P1f[k * pstride + r];
+        p2r[k] = P2f[k * pstride + r];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float t1 = p1r[k] - p1c[q][k];
+          const float t2 = p2r[k] - p2c[q][k];
+          s1 = fmaf(t1, t1, s1);
+          s2 = fmaf(t2, t2, s2);
+        }
+        const float t = (s1 + s2) - E2;
+        const bool close = (t <= 0.f) || (t * t < (4.0f * 1.0000038147f) * (s1 * s2));
+        // clipper.cpp:35-38 distinctness (also removes the diagonal) + conservative c < eps
+        const bool cand = validc[q] && (a0r != a0c[q]) && (a1r != a1c[q]) && close;
+        const uint64_t mask = __ballot(cand);
+        if (mask != 0) {  // uniform
+          if (cand) queue[(tail + lane_prefix(mask)) & (AT_QUEUE - 1)] =
+              (static_cast<uint32_t>(rl) << 8) | static_cast<uint32_t>(2 * lane + q);
+          tail += static_cast<uint32_t>(__popcll(mask));
+        }
+      }
+      if (tail - head >= 64) {  // uniform
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        while (tail - head >= 64) {
+          drain(head, 64);
+          head += 64;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  while (head < tail) {
+    const uint32_t n = (tail - head < 64) ? tail - head : 64;
+    drain(head, n);
+    head += n;
+  }
+  __syncthreads();
+
+  // ---- the compressed copy: row blocks 2I, 2I+1 of strip J, and of the mirror image row blocks
+  // 2J, 2J+1 of strip I, one column per thread straight from the image (csc_emit) ---------------
+  if (O.Lc != nullptr) {
+    static_assert(AT_WAVES == 8 && AT == CSC_CW && AT == 2 * CSC_RB, "four groups per tile");
+    int* red = reinterpret_cast<int*>(sym_smem + AT_SYM_IMG_BYTES);  // the queues are drained
+    unsigned long long* base_s = reinterpret_cast<unsigned long long*>(red + 8);
+    const int t = threadIdx.x, gi = t >> 7, cl = t & 127;
+    const int rb = gi & 1;
+    const bool mirror = gi >= 2;
+    // element q of the thread's column: tile (rb*64 + q, cl), or (cl, rb*64 + q) of the mirror
+    const float* col = mirror ? img + cl * AT_PITCH + rb * CSC_RB : img + rb * CSC_RB * AT_PITCH + cl;
+    const int strip = mirror ? I : J;
+    const int b = 2 * (mirror ? J : I) + rb;
+    const int64_t g = (b < O.nblocks && !(mirror && I == J))
+                          ? static_cast<int64_t>(strip) * O.nblocks + b : -1;
+    csc_emit_lds<4>(col, mirror ? 1 : AT_PITCH, g, O, red, base_s);
+  }
+
+  // ---- the tile as it stands: this wave's rows, 512-byte segments -----------------------------
+  if (S != nullptr && c0 + 2 * lane < ld) {
+    for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
+      const int rl = wave * AT_ROWS_PER_WAVE + rr;
+      const int64_t r = r0 + rl;
+      if (r < m) {
+        const float* row = img + rl * AT_PITCH + 2 * lane;
+        *reinterpret_cast<float2*>(S + r * ld + c0 + 2 * lane) = make_float2(row[0], row[1]);
+      }
+    }
+  }
+  // ---- and transposed: rows c0 + ... receive the tile's columns ------------------------------
+  if (S != nullptr && I != J && r0 + 2 * lane < ld) {
+    for (int cc = 0; cc < AT_ROWS_PER_WAVE; ++cc) {
+      const int cl = wave * AT_ROWS_PER_WAVE + cc;
+      const int64_t c = c0 + cl;
+      if (c < m) {
+        const float v0 = img[(2 * lane) * AT_PITCH + cl];
+        const float v1 = img[(2 * lane + 1) * AT_PITCH + cl];
+        *reinterpret_cast<float2*>(S + c * ld + r0 + 2 * lane) = make_float2(v0, v1);
+      }
+    }
+  }
+}
+
+}  // namespace clipper_hip

@@ -1,0 +1,857 @@
+// k_solver.hip.h — solver state, the decision at the head of a pass (decide), k_init, k_tail, k_scal_fold
+// Part of kernels.hip.h (include that one): hand-written gfx950 device code of the CLIPPER hot path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+
+namespace clipper_hip {
+
+// ------------------------------------------------------------------------------------------
+// The line-search WINDOW (what makes this solver an MI355X design rather than a port)
+//
+// One pass over M costs s*m^2 bytes of HBM traffic and, for a single vector, ~20 % of the
+// fp64 VALU time that fits under it. The reference's backtracking line search
+// (clipper.cpp:234-251) tries alpha = 1, beta, beta^2, ... one mat-vec pair at a time — at
+// m = 10k half of all passes are rejected trials. Every one of those candidates
+//     c_l = max(u + alpha*beta^l * gradF, 0)                         (clipper.cpp:235-236)
+// is known BEFORE the first of them is evaluated, so a pass here multiplies M by a window of
+// V consecutive candidates at once (V accumulator sets per lane, one read of M): the decision
+// then walks the window in the reference's order and takes the first candidate the reference
+// would have accepted. Same trials, same arithmetic per trial, same result — in 1/2 to 1/3 of
+// the passes. Candidates live interleaved in "tables" X[row][VS] (64-byte rows) so that the
+// V wave-uniform multipliers of a row arrive with one scalar load.
+//
+// One solver ITERATION is two launches, and no workgroup ever waits for another:
+//   G  k_gemv   every workgroup first DECIDES, redundantly and identically, what the results
+//               of the previous iteration mean (a few KB of partial scalars from L2 — the
+//               loads overlap the first rows of M) and then streams its tile of M against the
+//               pending window. Workgroup (0,0) also records the state it decided on.
+//   T  k_tail   once per candidate v (grid = blocks x V): gradFnew_v, the partial sums of
+//               Fnew_v and ||x_v - u||^2, (x_v, gradFnew_v) into point slot (ubp^1, v), and —
+//               speculatively — the NEXT window for the outcome "candidate v was accepted"
+//               (table v of Xout: max(x_v + beta^l gradFnew_v, 0), l < V) with the partial sums
+//               of its norms; the v = 0 workgroups also build the outcome "all V rejected"
+//               (table V: the next V step sizes from the unchanged (u, gradF)).
+// The rare steps that sweep whole vectors (initialisation clipper.cpp:193-220, penalty update
+// :268-280, a new outer iteration :219-220) take an iteration of their own: every workgroup of
+// G sees that the decision needs one, workgroup (0,0) alone performs it, the others exit, and T
+// finds nothing to do.
+// ------------------------------------------------------------------------------------------
+
+constexpr int VS = 8;       // doubles per table row; window sizes V <= VS
+// partial-sum slots per row tile: slot 0 = a = M_off x_0, slots 1..V-1 = g_v of the other
+// candidates, slot V = b = C_off x_0 (a pair-mode pass fills slots 0 and V only)
+constexpr int nslot(int V) { return V + 1; }
+
+enum Phase : int32_t {
+  PH_NORMALIZE = 0,  // no rescale: u = u0/||u0||, no pass consumed       (clipper.cpp:196-198)
+  PH_RESCALE = 1,    // pass on x = u0: u = M_off u0 + u0, normalise      (clipper.cpp:193-198)
+  PH_INIT = 2,       // pass on x = u: initial d, first gradient          (clipper.cpp:200-220)
+  PH_TRIAL = 3,      // pass on a window of trial vectors                 (clipper.cpp:234-262)
+  PH_PENALTY = 4,    // pass on x = the inner loop's final u: penalty update (:268-280)
+  PH_BUILD = 5       // no pass: the tail forms gradF, F and the first window of an outer
+                     // iteration from (u, a, b) and the new penalty (:219-220, :235-236)
+};
+// PH_TRIAL passes run the mat-vec in window mode (candidate 0: a and b apart, the others
+// g_v = (M_off + d*C_off) x_v), all others in pair mode (a, b of candidate 0) — see k_gemv.
+
+enum Stage : int32_t {
+  ST_PASS = 0,     // the tables hold the pending vectors of `phase`: run the pass
+  ST_RESULTS = 1   // the pass of `phase` and its tail have run: decide what they mean first
+};
+
+// Candidates are kept UN-normalised: x_l = Xin[sel][.][l] / nrm[l]. The mat-vec multiplies M
+// by the raw table; the tail divides the sums by nrm[l].
+// Two copies ST[2] alternate: iteration k reads ST[k & 1], its workgroup (0,0) writes the state
+// it decided on to ST[(k+1) & 1], which the tail of iteration k and iteration k+1 read.
+struct SolverState {
+  double d;        // penalty
+  double F;        // objective at u
+  double alpha;    // step size of candidate 0 of the pending window
+  double s;        // sum(u)
+  double nrm[VS];  // ||candidate l|| of the pending window (1 for an already normalised vector)
+  double sx[VS];   // sum(x_l)
+  int32_t sel;     // which table of Xin holds the pending window
+  int32_t ubp, ubv;  // point slot that holds the current (u, gradF)
+  int32_t phase;
+  int32_t stage;
+  int32_t i, j, k;  // outer / inner / line-search counters (clipper.cpp:217)
+  int64_t n_passes;
+  int64_t n_trials;  // trials the reference would have evaluated (window slots past the
+                     // accepted candidate do not count)
+  int64_t n_iters;   // iterations (G, T) the device has started
+};
+
+// What outlives the alternating state: the end of the solve. Kernels launched after
+// convergence see `done` and return immediately.
+struct SolveShared {
+  double F, d;
+  int64_t n_passes, n_trials;
+  int32_t ifinal, ubp, ubv;
+  int32_t done;
+};
+
+// Host-visible progress record in pinned, coherent host memory. Workgroup (0,0) of G writes it
+// with system-scope stores; the host spins on `iters` / `done` instead of issuing memcpy +
+// event round trips, and keeps only a few iterations queued ahead of the device.
+struct HostMirror {
+  double F, d;
+  int64_t n_passes, n_trials;
+  int64_t iters;
+  int32_t ifinal, ubp, ubv;
+  int32_t done;
+};
+
+struct SolverParams {
+  double tol_u, tol_F, beta, eps;
+  int32_t maxiniters, maxoliters, maxlsiters;
+};
+
+constexpr int TAIL_THREADS = 256;
+constexpr int TAIL_WAVES = TAIL_THREADS / 64;
+
+struct SolveArgs {
+  const SolverState* st_cur;  // ST[k & 1]: what iteration k starts from
+  SolverState* st_next;       // ST[(k+1) & 1]: what it decided on (read by its tail)
+  SolveShared* shared;
+  HostMirror* host;  // device address of the pinned progress record (may be null)
+  SolverParams prm;
+  int64_t m;    // problem size
+  int64_t W;    // shard pitch: element i lives in block p = i / W of `ab`
+  int64_t mp;   // rows of a candidate table / pitch of a point-slot array (>= m)
+  const double* u0;
+  double* pt;   // point slots [2][V][2][mp]: u, gradF
+  double* cab;  // [2][mp]: a = M_off x, b = C_off x of the last pair-mode pass / of candidate 0
+  // candidate tables [V+1][mp][VS]. Iteration k READS the pending window from Xin and WRITES
+  // the windows of every outcome to Xout; the host swaps the two from iteration to iteration.
+  const double* Xin;
+  double* Xout;
+  double* ab;     // column-sharded M: gathered RAW sums [P][NSLOT][W], NSLOT = V + 1
+  double* part;   // [ntiles][NSLOT][W] row-tile partials of this shard
+  int ntiles;
+  int slot;       // this shard's block of `ab`
+  double* scal;   // [nwg][Q] partial scalars of the tail, Q = V*(2+2V) + 2V + 2
+  int nwg;        // tail workgroups per candidate = ceil(m / TAIL_THREADS)
+  // what the decision sums: scal itself, or (large m: every workgroup of G repeats the decision,
+  // nwg*Q doubles each) the SCAL_FOLD-fold pre-reduction k_scal_fold makes of it
+  const double* scal_in;
+  int nwg_in;
+  int* cnt;       // column-sharded M: one arrival counter per column strip
+  int nstrips;
+  uint8_t* kind;  // pinned host memory [KIND_CAP], profiling only: iteration n_iters ran a pass
+  double* host_u; // pinned host memory [m] (may be null): the final u, written before `done`
+};
+constexpr int KIND_CAP = 1 << 16;
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+
+// array k (0 = u, 1 = gradF) of point slot (p, v)
+__device__ __forceinline__ double* pt_arr(const SolveArgs& A, int V, int p, int v, int k) {
+  return A.pt + ((static_cast<int64_t>(p) * V + v) * 2 + k) * A.mp;
+}
+
+// Last-arriver hand-off inside one launch (CDNA guide, section 6 guideline 16, counter form;
+// the split-K recipe) — used only by k_pass (column-sharded M): every workgroup publishes what
+// it stored — each wave drains its own stores, one lane issues the agent-scope release and
+// draws a ticket — and the workgroup that draws the last ticket acquires at agent scope and
+// continues with plain loads. Correct for any placement of the workgroups over the 8 XCDs
+// (their L2s are not coherent with each other). The counter is zeroed before the first launch
+// of a solve (k_init) and re-armed by the last arriver. Returns true in every thread of the
+// last workgroup. `flag` is one int of LDS.
+__device__ __forceinline__ bool arrive_last(int* counter, int expected, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop the fence's own wait
+    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == expected - 1) ? 1 : 0;
+    if (last) {
+      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  const bool last = (*flag != 0);
+  __syncthreads();  // the flag word is free again
+  return last;
+}
+
+// Wave-level sum with DPP moves (VALU speed, no LDS crossbar): after the six steps lane 63
+// holds the total of the 64 lanes; the order of the additions is fixed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v += dpp_f64<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_f64<0x140, 0xf>(v);  // row_mirror: every lane holds the sum of its row of 16
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast15 into rows 1, 3
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast31 into rows 2, 3: lane 63 holds the wave total
+  return v;
+}
+
+// Sum over the NWAVES waves of the workgroup; every thread must call it, every thread gets the
+// totals. Fixed tree: bit-reproducible.
+template <int N, int NWAVES>
+__device__ __forceinline__ void block_reduce(double (&v)[N], double* lds /* [NWAVES*N] */) {
+#pragma unroll
+  for (int q = 0; q < N; ++q) v[q] = wave_sum_to_lane63(v[q]);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) lds[wave * N + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    double acc = lds[q];
+#pragma unroll
+    for (int w = 1; w < NWAVES; ++w) acc += lds[w * N + q];
+    v[q] = acc;
+  }
+}
+
+// The same sums, left in LDS: thread t < N returns total t (its own registers are never indexed
+// at run time, which would push the array to scratch), other threads return 0.
+template <int N, int NWAVES>
+__device__ __forceinline__ double block_reduce_pick(double (&v)[N], double* lds) {
+#pragma unroll
+  for (int q = 0; q < N; ++q) v[q] = wave_sum_to_lane63(v[q]);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) lds[wave * N + q] = v[q];
+  }
+  __syncthreads();
+  double acc = 0.0;
+  if (threadIdx.x < N) {
+    acc = lds[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < NWAVES; ++w) acc += lds[w * N + threadIdx.x];
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void store_row(double* row, const double (&c)[VS]) {
+  double4* q = reinterpret_cast<double4*>(row);
+  q[0] = make_double4(c[0], c[1], c[2], c[3]);
+  q[1] = make_double4(c[4], c[5], c[6], c[7]);
+}
+
+constexpr int pow2_at_least(int x) {
+  int p = 1;
+  while (p < x) p *= 2;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// decide — the head of every G launch (NT threads per workgroup). Returns true when this
+// iteration performs a pass (plan = what to stream against), false when the workgroup has
+// nothing more to do (transition iteration or end of the solve).
+//
+// Common case (a window pass and its tail have run): EVERY workgroup adds the tail's partial
+// scalars in the same fixed order and walks the window exactly like the reference's line
+// search (clipper.cpp:244-251, 261) — all workgroups reach the same decision on their own, no
+// communication. Workgroup (0,0) records the decided state in st_next.
+// Transitions (everything that sweeps whole vectors): workgroup (0,0) alone, the others leave.
+// ------------------------------------------------------------------------------------------
+
+struct PassPlan {
+  int phase;
+  int sel;     // table of Xin that holds the pending window, or
+  int from_u;  // -1, or (p*V + v): pair-mode pass straight on the u array of point slot (p, v)
+  double d;
+};
+
+constexpr int VU = 4;  // elements per thread per sweep step (all NT threads of the workgroup sweep)
+#define VEC_CHUNKS(base) for (int64_t base = tid; base < m; base += NT * VU)
+#define VEC_EACH(k, i, base)            \
+  _Pragma("unroll") for (int k = 0; k < VU; ++k) \
+    if (const int64_t i = base + static_cast<int64_t>(k) * NT; i < m)
+
+template <int V, int NT>
+__device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverState* stash,
+                                       PassPlan& plan) {
+  constexpr int NR = 2 + 2 * V;
+  constexpr int PEN = V * NR + 2 * V;  // speculative penalty sums of candidate 0
+  constexpr int Q = PEN + 2;
+  constexpr int QPAD = pow2_at_least(Q);
+  constexpr int NCH = NT / QPAD;  // interleaved summation chains per quantity
+  constexpr int NWV = NT / 64;
+  static_assert(QPAD <= NT && V <= VS, "window too large");
+  double* scratch = red + NT;     // block_reduce scratch, NWV * 2 doubles at most
+  const SolverState* st = A.st_cur;
+  const int tid = threadIdx.x;
+  const int64_t m = A.m;
+  const SolverParams P = A.prm;
+  const bool writer = (blockIdx.x == 0 && blockIdx.y == 0);
+
+  const int phase = st->phase;
+  double d = st->d, F = st->F, alpha = st->alpha, s = st->s;
+  int i_ = st->i, j_ = st->j, k_ = st->k, ubp = st->ubp, ubv = st->ubv, sel = st->sel;
+  int64_t n_passes = st->n_passes, n_trials = st->n_trials;
+  const int64_t n_iters = st->n_iters + 1;
+  double nrm[V], sx[V];
+#pragma unroll
+  for (int l = 0; l < V; ++l) {
+    nrm[l] = 1.0;
+    sx[l] = 0.0;
+  }
+  // what this iteration does next
+  enum { ACT_PASS, ACT_BUILD, ACT_SLOW, ACT_DONE };
+  int action = ACT_SLOW;
+  int next_phase = PH_TRIAL;
+  bool need_pair = false;  // the pass of this iteration is a pair-mode pass on the accepted x
+
+  if (phase == PH_TRIAL || phase == PH_BUILD) {
+    // sums[q] = sum over the tail workgroups w of scal[w][q]: NCH interleaved chains per
+    // quantity (w = c, c + NCH, ...), added in chain order
+    {
+      const int q = tid & (QPAD - 1), c = tid / QPAD;
+      double acc = 0.0;
+      if (q < Q) {
+        constexpr int U = 10;  // loads in flight per chain
+        const double* p = A.scal_in + q;
+        int w = c;
+        for (; w + NCH * (U - 1) < A.nwg_in; w += NCH * U) {
+          double x[U];
+#pragma unroll
+          for (int k = 0; k < U; ++k) x[k] = p[static_cast<int64_t>(w + NCH * k) * Q];
+#pragma unroll
+          for (int k = 0; k < U; ++k) acc += x[k];
+        }
+        for (; w < A.nwg_in; w += NCH) acc += p[static_cast<int64_t>(w) * Q];
+      }
+      red[tid] = acc;
+      __syncthreads();
+      double tot = 0.0;
+      if (tid < QPAD) {
+        tot = red[tid];
+#pragma unroll
+        for (int c2 = 1; c2 < NCH; ++c2) tot += red[c2 * QPAD + tid];
+      }
+      __syncthreads();
+      if (tid < QPAD) red[tid] = tot;
+      __syncthreads();
+    }
+    const double* sums = red;
+    if (phase == PH_TRIAL) {
+      // the decisions of clipper.cpp:244-262, candidate by candidate
+      int jstar = -1;
+      double Fnew = 0.0, deltaF = 0.0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        if (jstar < 0) {
+          ++n_trials;
+          Fnew = sums[v * NR + 0];
+          deltaF = Fnew - F;  // :244
+          bool accept = true;
+          if (deltaF < -P.eps) {  // :246-248
+            alpha = alpha * P.beta;
+            ++k_;
+            if (k_ < P.maxlsiters) accept = false;  // :234 loop bound; the last trial is kept
+          }
+          if (accept) jstar = v;
+        }
+      }
+      if (jstar < 0) {
+        // all V candidates rejected: the v = 0 tail already built the next V step sizes from
+        // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
+        sel = V;
+        action = ACT_PASS;
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          const double z = sums[V * NR + 2 * l];
+          nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
+          sx[l] = sums[V * NR + 2 * l + 1] / nrm[l];
+        }
+      } else {
+        const double deltau = sqrt(sums[jstar * NR + 1]);
+        s = st->sx[jstar];
+        F = Fnew;  // :256-258 — u <- x, gradF <- gradFnew: the point slot the tail filled
+        ubp ^= 1;
+        ubv = jstar;
+        ++j_;
+        if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
+          // end of the inner loop: the penalty update (:268-280) needs M_off u and C_off u apart
+          if (jstar == 0) {
+            // candidate 0 carries them (cab) and the tail already summed its penalty terms
+            const double cnt = sums[PEN], rs = sums[PEN + 1];
+            if (cnt > 0.0) {
+              d += rs / cnt;  // :276
+              ++i_;           // :218 loop increment
+              action = (i_ >= P.maxoliters) ? ACT_DONE : ACT_BUILD;
+            } else {
+              action = ACT_DONE;  // :278-280 break
+            }
+          } else {
+            // pair-mode pass straight on the accepted x (already normalised, in its point slot)
+            need_pair = true;
+            action = ACT_PASS;
+            next_phase = PH_PENALTY;
+          }
+        } else {
+          alpha = 1.0;  // :227
+          k_ = 0;
+          sel = jstar;  // the tail already built max(x + beta^l gradFnew, 0) in table jstar
+          action = ACT_PASS;
+#pragma unroll
+          for (int l = 0; l < V; ++l) {
+            const double z = sums[jstar * NR + 2 + 2 * l];
+            nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
+            sx[l] = sums[jstar * NR + 3 + 2 * l] / nrm[l];
+          }
+        }
+      }
+    } else {  // PH_BUILD: the tail formed gradF, F and the first window of an outer iteration
+      F = sums[0];  // :220
+      j_ = 0;
+      if (P.maxiniters <= 0) {
+        action = ACT_SLOW;  // empty inner loop: u unchanged, its (a, b) in cab are still valid
+      } else {
+        alpha = 1.0;
+        k_ = 0;
+        sel = 0;
+        action = ACT_PASS;
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          const double z = sums[2 + 2 * l];
+          nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
+          sx[l] = sums[3 + 2 * l] / nrm[l];
+        }
+      }
+    }
+  }
+
+  if (action == ACT_SLOW) {
+    // ---- sweeps over whole vectors: workgroup (0,0) alone -----------------------------------
+    if (!writer) return false;
+    const double* ca_ = A.cab;         // a = M_off x of the last pair-mode pass / of candidate 0
+    const double* cb_ = A.cab + A.mp;  // b = C_off x
+    if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
+      // clipper.cpp:193-198 — u = M_off*u0 + u0 (or u0), then u /= u.norm()
+      double* u = pt_arr(A, V, ubp, ubv, 0);
+      double z[1] = {0.0};
+      VEC_CHUNKS(base) {
+        double uv[VU], av[VU];
+        VEC_EACH(k, i, base) {
+          uv[k] = A.u0[i];
+          if (phase == PH_RESCALE) av[k] = ca_[i];
+        }
+        VEC_EACH(k, i, base) {
+          const double ui = (phase == PH_RESCALE) ? av[k] + uv[k] : uv[k];
+          u[i] = ui;
+          z[0] += ui * ui;
+        }
+      }
+      block_reduce<1, NWV>(z, scratch);
+      const double n0 = sqrt(z[0]);
+      VEC_CHUNKS(base) {
+        double uv[VU];
+        VEC_EACH(k, i, base) uv[k] = u[i];
+        VEC_EACH(k, i, base) {
+          const double ui = uv[k] / n0;
+          u[i] = ui;
+          // next pass (pair mode) runs on x = u, already normalised: candidate 0 of table 0
+          const double row[VS] = {ui, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          store_row(A.Xout + i * VS, row);
+        }
+      }
+      sel = 0;
+      next_phase = PH_INIT;  // action stays ACT_SLOW: "a pass was prepared", see the record below
+    } else {
+      if (phase == PH_INIT) {
+        // clipper.cpp:200-209 — initial d from the pair-mode pass on u
+        const double* u = pt_arr(A, V, ubp, ubv, 0);
+        double sv[1] = {0.0};
+        VEC_CHUNKS(base) {
+          double uv[VU];
+          VEC_EACH(k, i, base) uv[k] = u[i];
+          VEC_EACH(k, i, base) sv[0] += uv[k];
+        }
+        block_reduce<1, NWV>(sv, scratch);
+        s = sv[0];
+        double ca[2] = {0.0, 0.0};  // count, sum of ratios
+        VEC_CHUNKS(base) {
+          double uv[VU], av[VU], bv[VU];
+          VEC_EACH(k, i, base) {
+            uv[k] = u[i];
+            av[k] = ca_[i];
+            bv[k] = cb_[i];
+          }
+          VEC_EACH(k, i, base) {
+            const double cbu = s - bv[k] - uv[k];  // :202
+            if (cbu > P.eps && uv[k] > P.eps) {    // :203
+              ca[0] += 1.0;
+              ca[1] += (av[k] + uv[k]) / cbu;  // :205-208
+            }
+          }
+        }
+        block_reduce<2, NWV>(ca, scratch);
+        d = (ca[0] > 0.0) ? ca[1] / ca[0] : 0.0;
+        i_ = 0;
+        action = (i_ >= P.maxoliters) ? ACT_DONE : ACT_BUILD;  // :218 loop bound
+      } else {
+        // PH_PENALTY (the pair-mode pass on the inner loop's final u has run), or an empty
+        // inner loop: penalty update :268-280
+        const double* u = pt_arr(A, V, ubp, ubv, 0);
+        double ca[2] = {0.0, 0.0};
+        VEC_CHUNKS(base) {
+          double uv[VU], av[VU], bv[VU];
+          VEC_EACH(k, i, base) {
+            uv[k] = u[i];
+            av[k] = ca_[i];
+            bv[k] = cb_[i];
+          }
+          VEC_EACH(k, i, base) {
+            const double cbu = s - bv[k] - uv[k];  // :268
+            if (cbu > P.eps && uv[k] > P.eps) {    // :269
+              ca[0] += 1.0;
+              ca[1] += fabs((av[k] + uv[k]) / cbu);  // :271-274
+            }
+          }
+        }
+        block_reduce<2, NWV>(ca, scratch);
+        if (ca[0] > 0.0) {
+          d += ca[1] / ca[0];  // :276
+          ++i_;                // :218 loop increment
+          action = (i_ >= P.maxoliters) ? ACT_DONE : ACT_BUILD;
+        } else {
+          action = ACT_DONE;  // :278-280 break
+        }
+      }
+    }
+  }
+
+  // ---- the end: the deciding workgroup hands the final u to the host itself (pinned memory), so
+  // that the host needs neither a copy nor a wait on the stream once it sees `done`
+  if (writer && action == ACT_DONE && A.host_u != nullptr) {
+    const double* u = pt_arr(A, V, ubp, ubv, 0);
+    for (int64_t i = tid; i < m; i += NT)
+      __hip_atomic_store(A.host_u + i, u[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+  }
+
+  // ---- record the decided state (workgroup (0,0), one thread) ------------------------------
+  // A pass iteration parks it in LDS and writes it out AFTER the streaming loop (flush_state):
+  // a global store ahead of the loop would make the compiler treat the table rows as possibly
+  // clobbered and turn their scalar loads into per-lane vector loads.
+  if (writer && tid == 0) {
+    // (two call sites so that each store keeps its address space: LDS or global, never flat)
+    auto record = [&](SolverState* o) {
+      o->d = d;
+      o->F = F;
+      o->alpha = alpha;
+      o->s = s;
+#pragma unroll
+      for (int l = 0; l < V; ++l) {
+        o->nrm[l] = nrm[l];
+        o->sx[l] = sx[l];
+      }
+      o->sel = sel;
+      o->ubp = ubp;
+      o->ubv = ubv;
+      // ACT_PASS : this iteration streams, its results are due next time
+      // ACT_BUILD: no pass; the tail of this iteration forms gradF, F and the first window
+      // ACT_SLOW : (normalisation) the next iteration runs the pass this one prepared
+      o->phase = (action == ACT_BUILD) ? static_cast<int>(PH_BUILD) : next_phase;
+      o->stage = (action == ACT_SLOW) ? ST_PASS : ST_RESULTS;
+      o->i = i_;
+      o->j = j_;
+      o->k = k_;
+      o->n_passes = n_passes + (action == ACT_PASS ? 1 : 0);
+      o->n_trials = n_trials;
+      o->n_iters = n_iters;
+    };
+    if (action == ACT_PASS) record(stash);
+    else record(A.st_next);
+    if (action == ACT_DONE) {
+      SolveShared* sh = A.shared;
+      sh->F = F;
+      sh->d = d;
+      sh->n_passes = n_passes;
+      sh->n_trials = n_trials;
+      sh->ifinal = i_;
+      sh->ubp = ubp;
+      sh->ubv = ubv;
+      sh->done = 1;
+    }
+    if (A.host != nullptr) {
+      HostMirror* hm = A.host;
+      if (action == ACT_DONE) {
+        __hip_atomic_store(&hm->F, F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->d, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->n_passes, n_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->n_trials, n_trials, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->ifinal, i_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->ubp, ubp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->ubv, ubv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // every store above (and the vectors this workgroup wrote) before the flag
+        __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (action != ACT_PASS)
+        __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // the decision came out of LDS reads: tell the compiler it is wave-uniform, so that the
+  // multipliers of the streaming loop stay scalar loads
+  plan.phase = __builtin_amdgcn_readfirstlane(next_phase);
+  plan.sel = __builtin_amdgcn_readfirstlane(sel);
+  plan.from_u = __builtin_amdgcn_readfirstlane(need_pair ? ubp * V + ubv : -1);
+  plan.d = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(d)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(d)));
+  return action == ACT_PASS;
+}
+#undef VEC_CHUNKS
+#undef VEC_EACH
+
+// What every G launch starts with. Returns false when this workgroup has nothing to stream.
+// `stash`: LDS copy of the state a pass iteration decided on, see flush_state.
+template <int V, int NT>
+__device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
+                                               SolverState* stash, PassPlan& plan) {
+  if (A.shared->done) return false;
+  const SolverState* st = A.st_cur;
+  if (st->stage == ST_RESULTS) return decide<V, NT>(A, lds, stash, plan);
+  // the pass was prepared by a transition iteration (or by k_init): run it as it stands
+  plan.phase = st->phase;
+  plan.sel = st->sel;
+  plan.from_u = -1;
+  plan.d = st->d;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    *stash = *st;
+    stash->stage = ST_RESULTS;
+    stash->n_passes = st->n_passes + 1;
+    stash->n_iters = st->n_iters + 1;
+  }
+  return true;
+}
+
+// End of a pass iteration: workgroup (0,0) writes the state it decided on where the tail and
+// the next iteration read it, marks the iteration as a pass and reports progress to the host.
+__device__ __forceinline__ void flush_state(const SolveArgs& A, const SolverState* stash) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    *A.st_next = *stash;
+    const int64_t n_iters = stash->n_iters;
+    if (A.kind != nullptr && n_iters <= KIND_CAP)
+      __hip_atomic_store(A.kind + (n_iters - 1), static_cast<uint8_t>(1), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if (A.host != nullptr)
+      __hip_atomic_store(&A.host->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Solve prologue, one launch: pending vector = u0 (candidate 0 of table 0, un-normalised,
+// nrm = 1), initial state in ST[0], arrival counters zeroed.
+__global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, SolverState* st0,
+                                               double* X0) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < A.m) {
+    const double row[VS] = {A.u0[i], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    store_row(X0 + i * VS, row);
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < A.nstrips; c += 256) A.cnt[c] = 0;
+    if (threadIdx.x == 0) {
+      *st0 = init;
+      A.shared->done = 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// tail — grid (ceil(m/256), V): workgroup (blk, v) handles candidate v of 256 elements
+// (one element per thread: more elements per thread only lengthens the latency chain — measured).
+//   FUSED_REDUCE: sum the row-tile partials of the single shard here (else `ab` holds the
+//                 gathered raw sums of all shards).
+// Reads the state G decided on (st_next); communicates with nobody.
+// ------------------------------------------------------------------------------------------
+// k_scal_fold — out[b][q] = sum of scal[w][q] over the SCAL_FOLD tail workgroups w of block b, in
+// order. Launched after the tail when nwg > SCAL_FOLD_MIN (m > 16k): the decision at the head of
+// every workgroup of the next pass then reads nwg/SCAL_FOLD rows instead of nwg.
+constexpr int SCAL_FOLD = 32;
+constexpr int SCAL_FOLD_MIN = 64;
+__global__ __launch_bounds__(128) void k_scal_fold(const double* __restrict__ scal, int nwg, int Q,
+                                                    double* __restrict__ out,
+                                                    const SolveShared* __restrict__ shared) {
+  if (shared->done) return;
+  const int w0 = blockIdx.x * SCAL_FOLD;
+  const int w1 = (w0 + SCAL_FOLD < nwg) ? w0 + SCAL_FOLD : nwg;
+  for (int q = threadIdx.x; q < Q; q += 128) {
+    double acc = 0.0;
+    for (int w = w0; w < w1; ++w) acc += scal[static_cast<int64_t>(w) * Q + q];
+    out[static_cast<int64_t>(blockIdx.x) * Q + q] = acc;
+  }
+}
+
+template <int V, bool FUSED_REDUCE>
+__global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
+  constexpr int NR = 2 + 2 * V;
+  constexpr int PEN = V * NR + 2 * V;
+  constexpr int Q = PEN + 2;
+  constexpr int NRED = NR + 2 * V + 2;  // what a v = 0 workgroup reduces
+  constexpr int NSLOT = nslot(V);
+  __shared__ double red[TAIL_WAVES * NRED];
+  const int v = blockIdx.y;
+  const SolverState* st = A.st_next;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
+  const bool valid = i < A.m;
+
+  // raw sums of slot v (and of slot V, the b of candidate 0, for the v = 0 workgroups): these
+  // loads do not depend on the solver state
+  double p0 = 0.0, p1 = 0.0;
+  if (valid) {
+    const int64_t o1 = (v == 0) ? static_cast<int64_t>(V) * A.W : 0;  // slot V relative to slot 0
+    if (FUSED_REDUCE) {  // single shard: W >= m; partials in tile order, 8 tiles in flight
+      const double* p = A.part + static_cast<int64_t>(v) * A.W + i;
+      const int64_t ts = static_cast<int64_t>(NSLOT) * A.W;
+      int t = 0;
+      for (; t + 8 <= A.ntiles; t += 8) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          va[q] = p[static_cast<int64_t>(t + q) * ts];
+          vb[q] = p[static_cast<int64_t>(t + q) * ts + o1];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          p0 += va[q];
+          p1 += vb[q];
+        }
+      }
+      for (; t < A.ntiles; ++t) {
+        p0 += p[static_cast<int64_t>(t) * ts];
+        p1 += p[static_cast<int64_t>(t) * ts + o1];
+      }
+    } else {  // block pb = i / W of the gathered [P][NSLOT][W] layout (32-bit division)
+      const uint32_t pb = static_cast<uint32_t>(i) / static_cast<uint32_t>(A.W);
+      const int64_t off = i - static_cast<int64_t>(pb) * A.W;
+      const double* blk = A.ab + (static_cast<int64_t>(pb) * NSLOT) * A.W;
+      p0 = blk[static_cast<int64_t>(v) * A.W + off];
+      p1 = blk[o1 + off];
+    }
+  }
+  if (A.shared->done) return;
+  if (st->stage != ST_RESULTS) return;  // a pass was only prepared: nothing to evaluate
+  const int phase = st->phase;
+  const int ubp = st->ubp, ubv = st->ubv;
+
+  if (phase != PH_TRIAL && phase != PH_BUILD) {
+    // pair-mode passes carry one vector (candidate 0, nrm = 1): a = M_off x, b = C_off x
+    if (v == 0 && valid) {
+      A.cab[i] = p0;
+      A.cab[A.mp + i] = p1;
+    }
+    return;
+  }
+  const double d = st->d, beta = A.prm.beta;
+  double r[NRED];
+#pragma unroll
+  for (int q = 0; q < NRED; ++q) r[q] = 0.0;
+
+  if (phase == PH_BUILD) {
+    // start of an outer iteration (clipper.cpp:219-220, :235-236): gradF and F at the current u
+    // under the new penalty, and the first window (alpha = 1, beta, ...) — v = 0 workgroups
+    if (v != 0) return;
+    if (valid) {
+      const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
+      const double gi = (1 + d) * ui - d * st->s + A.cab[i] + A.cab[A.mp + i] * d;  // :219
+      pt_arr(A, V, ubp, ubv, 1)[i] = gi;
+      r[0] = ui * gi;  // :220
+      double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      double al = 1.0;
+#pragma unroll
+      for (int l = 0; l < V; ++l) {
+        double t = ui + al * gi;
+        t = (t > 0.0) ? t : 0.0;
+        row[l] = t;
+        r[2 + 2 * l] = t * t;
+        r[3 + 2 * l] = t;
+        al = al * beta;
+      }
+      store_row(A.Xout + i * VS, row);
+    }
+  } else {
+    const double nrmv = st->nrm[v], sxv = st->sx[v];
+    const double alpha = st->alpha;
+    if (valid) {
+      const double xraw = A.Xin[(static_cast<int64_t>(st->sel) * A.mp + i) * VS + v];
+      const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
+      const double xi = xraw / nrmv;  // clipper.cpp:237
+      double gn;
+      if (v == 0) {
+        // candidate 0: a and b apart, exactly the reference's expression (:238-241)
+        const double an = p0 / nrmv, bn = p1 / nrmv;
+        gn = (1 + d) * xi - d * sxv + an + bn * d;
+        A.cab[i] = an;  // (a, b) of the current point if candidate 0 is accepted
+        A.cab[A.mp + i] = bn;
+        // its penalty terms (:268-274), in case the inner loop ends with it
+        const double cbu = sxv - bn - xi;
+        if (cbu > A.prm.eps && xi > A.prm.eps) {
+          r[NR + 2 * V] = 1.0;
+          r[NR + 2 * V + 1] = fabs((an + xi) / cbu);
+        }
+      } else {
+        const double gs = p0 / nrmv;  // (M_off + d*C_off) x
+        gn = (1 + d) * xi - d * sxv + gs;
+      }
+      pt_arr(A, V, ubp ^ 1, v, 0)[i] = xi;  // becomes (u, gradF) if candidate v is accepted
+      pt_arr(A, V, ubp ^ 1, v, 1)[i] = gn;
+      r[0] = xi * gn;  // :242
+      const double du = xi - ui;
+      r[1] = du * du;  // :253
+      // next window if candidate v is accepted: alpha = 1, beta, beta^2, ... (:227, :235-236)
+      double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      double al = 1.0;
+#pragma unroll
+      for (int l = 0; l < V; ++l) {
+        double t = xi + al * gn;
+        t = (t > 0.0) ? t : 0.0;
+        row[l] = t;
+        r[2 + 2 * l] = t * t;
+        r[3 + 2 * l] = t;
+        al = al * beta;
+      }
+      store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
+      if (v == 0) {
+        // next window if all V candidates are rejected: V more factors of beta (:248)
+        const double gi = pt_arr(A, V, ubp, ubv, 1)[i];
+        double row2[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        al = alpha;
+#pragma unroll
+        for (int l = 0; l < V; ++l) al = al * beta;
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          double t = ui + al * gi;
+          t = (t > 0.0) ? t : 0.0;
+          row2[l] = t;
+          r[NR + 2 * l] = t * t;
+          r[NR + 2 * l + 1] = t;
+          al = al * beta;
+        }
+        store_row(A.Xout + (static_cast<int64_t>(V) * A.mp + i) * VS, row2);
+      }
+    }
+  }
+  const double tot = block_reduce_pick<NRED, TAIL_WAVES>(r, red);
+  double* out = A.scal + static_cast<int64_t>(blockIdx.x) * Q;
+  if (threadIdx.x < NR) out[v * NR + threadIdx.x] = tot;
+  if (v == 0 && threadIdx.x >= NR && threadIdx.x < NRED)
+    out[V * NR + (threadIdx.x - NR)] = tot;  // "all rejected" window sums, then the penalty sums
+}
+
+}  // namespace clipper_hip
