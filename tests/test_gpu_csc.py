@@ -165,7 +165,8 @@ def test_sharded_contexts_fall_back_to_the_dense_store(monkeypatch):
     grp.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
     assert grp.storage_in_use == abi.STORE_F32
     s3 = grp.solve(p.u0)
-    assert s3.nodes.tolist() == sr.nodes.tolist() and s3.score == sg.score
+    assert s3.nodes.tolist() == sr.nodes.tolist()
+    assert abs(s3.score - sg.score) <= 1e-12 * abs(sg.score)   # 3 shards vs 1: another summation order
 
 
 def test_full_size_10k_compressed_parity():
