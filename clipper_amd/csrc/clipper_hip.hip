@@ -154,6 +154,8 @@ struct Shard {
   int* ctb = nullptr;
   CscBuildCtl* cctl = nullptr;
   size_t ccap_units = 0, ccap_groups = 0, ccap_tb = 0;
+  int c_ntmax = 0;        // row tiles per strip of this shard's plan
+  uint64_t c_units = 0;   // sum of the padded list lengths (units of 128 entries)
 };
 
 }  // namespace
@@ -174,8 +176,7 @@ struct clipper_hip_ctx {
   bool csc_valid = false;    // ... and the compressed copy of the current matrix exists
   bool csc_emitted = false;  // the fill kernel of this build wrote the groups itself
   CscOut csc_out{};          // what that kernel was given
-  int csc_nblocks = 0, csc_ntmax = 0, csc_nstrips = 0;
-  uint64_t csc_units = 0;    // sum of the padded list lengths (units of 128 entries)
+  int csc_nblocks = 0, csc_nstrips = 0;
   uint32_t* csc_hLc = nullptr;     // pinned host copy of Lc
   CscBuildCtl* csc_hctl = nullptr; // pinned host copy of the build's counters
   int* csc_htb = nullptr;          // pinned staging of the tile boundaries
@@ -261,10 +262,11 @@ int free_shard_buffers(Shard& s) {
   return 0;
 }
 
-// CLIPPER_HIP_STORE_F32_CSC on one unsharded device (C == pattern(M) is checked per matrix)
-bool csc_possible(const Ctx* h) {
-  return h->compressed && h->world == 1 && !h->multiproc && h->storage == CLIPPER_HIP_STORE_F32;
-}
+// CLIPPER_HIP_STORE_F32_CSC (C == pattern(M) is checked per matrix). On one unsharded device
+// M exists ONLY compressed (csc_single: the fill kernel emits the groups, no dense store); column
+// shards keep their dense slice and build a compressed copy of it for the solver's passes.
+bool csc_possible(const Ctx* h) { return h->compressed && h->storage == CLIPPER_HIP_STORE_F32; }
+bool csc_single(const Ctx* h) { return csc_possible(h) && h->world == 1 && !h->multiproc; }
 
 int plan_unr(const Ctx* h) {
   return gemv_unr(h->V, static_cast<int>(h->esize()), h->explicitC);
@@ -334,7 +336,7 @@ int ensure_problem(Ctx* h, int64_t m) {
     s.bytes_S = bytesS;
     // CLIPPER_HIP_STORE_F32_CSC keeps M compressed: the dense store exists only while a path
     // that needs it is in use (ensure_dense)
-    if (!csc_possible(h)) HIPCHK(hipMalloc(&s.S, bytesS));
+    if (!csc_single(h)) HIPCHK(hipMalloc(&s.S, bytesS));
     const size_t nvec = static_cast<size_t>(P * W) * sizeof(double);
     const size_t V = static_cast<size_t>(h->V);
     HIPCHK(hipMalloc(&s.u0, nvec));
@@ -345,8 +347,9 @@ int ensure_problem(Ctx* h, int64_t m) {
       HIPCHK(hipMalloc(&s.X[k], (V + 1) * VS * nvec));
       HIPCHK(hipMemsetAsync(s.X[k], 0, (V + 1) * VS * nvec, s.stream));
     }
-    HIPCHK(hipMalloc(&s.cnt, static_cast<size_t>(h->nstrips) * sizeof(int)));
-    HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(h->nstrips) * sizeof(int), s.stream));
+    // arrival counters per column strip (256 wide: k_pass, 128 wide: k_pass_csc)
+    HIPCHK(hipMalloc(&s.cnt, static_cast<size_t>(2 * h->nstrips + 2) * sizeof(int)));
+    HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(2 * h->nstrips + 2) * sizeof(int), s.stream));
     const size_t Q = V * (2 + 2 * V) + 2 * V + 2;
     const size_t nwg = static_cast<size_t>(ceil_div(m, TAIL_THREADS));
     HIPCHK(hipMalloc(&s.scal, (nwg + ceil_div(nwg, SCAL_FOLD) + 1) * Q * sizeof(double)));
@@ -424,11 +427,12 @@ void launch_plain(Ctx* h, Shard& s, const double* X) {
 // G on the compressed copy of M (one shard, C == pattern(M), fp32)
 CscView csc_view(const Ctx* h, const Shard& s);
 
-template <int V>
+template <int V, bool SHARDED>
 void launch_pass_csc(Ctx* h, Shard& s, const SolveArgs& a) {
   const CscView M = csc_view(h, s);
-  dim3 grid(h->csc_nstrips, h->csc_ntmax), block(GEMV_NW * 64);
-  hipLaunchKernelGGL((k_gemv_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
+  dim3 grid(h->csc_nstrips, s.c_ntmax), block(GEMV_NW * 64);
+  if (SHARDED) hipLaunchKernelGGL((k_pass_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
+  else hipLaunchKernelGGL((k_gemv_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
 }
 
 // calls f(integral_constant<V>) for the context's window size
@@ -515,7 +519,7 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.Xout = s.X[par ^ 1];
   a.ab = s.ab;
   a.part = s.part;
-  a.ntiles = h->csc_valid ? h->csc_ntmax : h->ntiles;
+  a.ntiles = h->csc_valid ? s.c_ntmax : h->ntiles;
   a.slot = s.slot;
   a.scal = s.scal;
   a.nwg = static_cast<int>(ceil_div(h->m, TAIL_THREADS));
@@ -548,9 +552,14 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, par);
     if (prof && &s == &s0) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
-    if (sharded) launch_pass<V, true>(h, s, a);
-    else if (h->csc_valid) launch_pass_csc<V>(h, s, a);
-    else launch_pass<V, false>(h, s, a);
+    if (h->csc_valid) {
+      if (sharded) launch_pass_csc<V, true>(h, s, a);
+      else launch_pass_csc<V, false>(h, s, a);
+    } else if (sharded) {
+      launch_pass<V, true>(h, s, a);
+    } else {
+      launch_pass<V, false>(h, s, a);
+    }
     if (prof && &s == &s0) {
       HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used + 1], s.stream));
       h->ev_launch_index[h->ev_used] = h->launch_counter;
@@ -852,7 +861,7 @@ CscView csc_view(const Ctx* h, const Shard& s) {
   M.Pre = s.cPre;
   M.tb = s.ctb;
   M.nblocks = h->csc_nblocks;
-  M.ntmax = h->csc_ntmax;
+  M.ntmax = s.c_ntmax;
   return M;
 }
 
@@ -888,12 +897,11 @@ void drop_dense(Ctx* h) {
 
 // Before the fill: buffers of the group directory, the arenas' cursors reset. Returns what a
 // kernel that emits groups needs (k_affinity_sym, k_csc_build); out.Lc == null: not in use.
-int csc_prepare(Ctx* h, CscOut& out) {
+int csc_prepare(Ctx* h, Shard& s, CscOut& out) {
   out = CscOut{};
   h->csc_valid = false;
   h->csc_emitted = false;
   if (!csc_applies(h)) return 0;
-  Shard& s = h->sh[0];
   HIPCHK(hipSetDevice(s.device));
   const int nblocks = static_cast<int>(ceil_div(h->m, CSC_RB));
   h->csc_nstrips = static_cast<int>(ceil_div(h->W, CSC_CW));
@@ -939,9 +947,8 @@ int csc_prepare(Ctx* h, CscOut& out) {
 // After the fill: the build from the dense store unless the fill kernel emitted the groups
 // itself, then the copies of the counters to pinned host memory (csc_finish() reads them once
 // the stream was synchronised).
-int csc_enqueue(Ctx* h, const CscOut& O) {
+int csc_enqueue(Ctx* h, Shard& s, const CscOut& O) {
   if (O.Lc == nullptr) return 0;
-  Shard& s = h->sh[0];
   HIPCHK(hipSetDevice(s.device));
   if (!h->csc_emitted) {
     dim3 grid(h->csc_nstrips, static_cast<unsigned>(ceil_div(h->csc_nblocks, 2))), block(256);
@@ -959,8 +966,7 @@ int csc_enqueue(Ctx* h, const CscOut& O) {
 // the staging of its x rows). The number of workgroups aims at whole waves of co-resident ones
 // (two 8-wave workgroups per CU measured best: every workgroup repeats the decision), at most
 // ~32 blocks each.
-int csc_plan(Ctx* h) {
-  Shard& s = h->sh[0];
+int csc_plan(Ctx* h, Shard& s) {
   const int nstrips = h->csc_nstrips, nblocks = h->csc_nblocks;
   const uint32_t* L = h->csc_hLc;
   const double slots = static_cast<double>(h->cus) * 2.0;
@@ -1019,17 +1025,16 @@ int csc_plan(Ctx* h) {
     s.part_tiles = static_cast<size_t>(ntmax) + 8;
     HIPCHK(hipMalloc(&s.part, s.part_tiles * NSLOT * static_cast<size_t>(h->W) * sizeof(double)));
   }
-  h->csc_ntmax = ntmax;
+  s.c_ntmax = ntmax;
   return 0;
 }
 
 // After the stream was synchronised: did the lists fit? If not (always the case for the first
 // matrix of a size) the buffers are grown and `again` is set — the caller repeats the step that
 // produces the groups; otherwise the tiles are planned and the copy is valid.
-int csc_check(Ctx* h, bool& again) {
+int csc_check(Ctx* h, Shard& s, bool& again) {
   again = false;
   if (!csc_applies(h)) return 0;
-  Shard& s = h->sh[0];
   HIPCHK(hipSetDevice(s.device));
   bool over = false;
   size_t worst = 0;
@@ -1051,29 +1056,31 @@ int csc_check(Ctx* h, bool& again) {
     again = true;
     return 0;
   }
-  h->csc_units = sum;
-  int rc = csc_plan(h);
-  if (rc) return rc;
-  h->csc_valid = true;
-  return 0;
+  s.c_units = sum;
+  return csc_plan(h, s);  // the caller declares the copy valid once every shard has one
 }
 
-// build from the dense store + wait + plan (the setMatrixData paths)
+// build from the dense store(s) + wait + plan: the setMatrixData paths, and every fill of
+// column shards. Shard by shard (the pinned staging of the counters is shared).
 int csc_rebuild(Ctx* h) {
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    CscOut O;
-    int rc = csc_prepare(h, O);
-    if (rc) return rc;
-    rc = csc_enqueue(h, O);
-    if (rc) return rc;
-    rc = sync_all(h);
-    if (rc) return rc;
-    bool again = false;
-    rc = csc_check(h, again);
-    if (rc) return rc;
-    if (!again) return 0;
+  h->csc_valid = false;
+  if (!csc_applies(h)) return 0;
+  for (auto& s : h->sh) {
+    bool again = true;
+    for (int attempt = 0; again; ++attempt) {
+      if (attempt >= 3) return fail(CLIPPER_HIP_E_HIP, "compressed copy: the build keeps overflowing");
+      CscOut O;
+      int rc = csc_prepare(h, s, O);
+      if (rc) return rc;
+      rc = csc_enqueue(h, s, O);
+      if (rc) return rc;
+      HIPCHK(hipStreamSynchronize(s.stream));
+      rc = csc_check(h, s, again);
+      if (rc) return rc;
+    }
   }
-  return fail(CLIPPER_HIP_E_HIP, "compressed copy: the build keeps overflowing");
+  h->csc_valid = true;
+  return 0;
 }
 
 // `emits`: the fill kernel `launch` starts writes the compressed copy itself when asked to
@@ -1091,17 +1098,24 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
   h->explicitC = false;
   plan_tiles(h);
   int rc = 0;
-  if (csc_applies(h) && emits) drop_dense(h);  // a materialised copy would be stale
+  const bool emit = csc_applies(h) && csc_single(h) && emits;
+  if (emit) drop_dense(h);  // a materialised copy would be stale
   else if ((rc = ensure_dense(h, false))) return rc;
   hipEvent_t e0, e1;
   Shard& s0 = h->sh[0];
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
+  double build_ms = 0.0;
   for (int attempt = 0;; ++attempt) {
-    CscOut O;
-    rc = csc_prepare(h, O);
-    if (rc) return rc;
+    CscOut O{};
+    if (emit) {
+      rc = csc_prepare(h, s0, O);
+      if (rc) return rc;
+    } else {
+      h->csc_valid = false;
+      h->csc_emitted = false;
+    }
     h->csc_out = O;
     HIPCHK(hipSetDevice(s0.device));
     HIPCHK(hipEventRecord(e0, s0.stream));
@@ -1109,22 +1123,36 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
       HIPCHK(hipSetDevice(s.device));
       launch(s);  // k_affinity_sym emits the compressed copy itself and sets csc_emitted
     }
-    rc = csc_enqueue(h, O);  // counted as part of the affinity build
-    if (rc) return rc;
+    if (emit) {
+      rc = csc_enqueue(h, s0, O);  // counted as part of the affinity build
+      if (rc) return rc;
+    }
     HIPCHK(hipSetDevice(s0.device));
     HIPCHK(hipEventRecord(e1, s0.stream));
     rc = sync_all(h);
     if (rc) return rc;
+    if (!emit) {
+      // dense slices (column shards, the other fill kernels): the compressed copies from them
+      const auto t0 = std::chrono::high_resolution_clock::now();
+      rc = csc_rebuild(h);
+      if (rc) return rc;
+      build_ms = std::chrono::duration<double, std::milli>(
+                     std::chrono::high_resolution_clock::now() - t0).count();
+      break;
+    }
     bool again = false;
-    rc = csc_check(h, again);
+    rc = csc_check(h, s0, again);
     if (rc) return rc;
-    if (!again) break;
+    if (!again) {
+      h->csc_valid = true;
+      break;
+    }
     if (attempt >= 2) return fail(CLIPPER_HIP_E_HIP, "compressed copy: the build keeps overflowing");
   }
   float ms = 0.f;
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  h->tm.affinity_kernel_ms = ms;
+  h->tm.affinity_kernel_ms = ms + (h->csc_valid ? build_ms : 0.0);
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   h->has_matrix = true;
@@ -1138,7 +1166,7 @@ constexpr int AFF_ROWS_PER_BLK = 32;
 // when an explicit constraint matrix is read as well.
 double algorithmic_gemv_bytes(const Ctx* h, bool dense = false) {
   if (h->csc_valid && !dense)  // the compressed copy: 5 bytes per (padded) entry + the group directory
-    return static_cast<double>(h->csc_units) * 128.0 * 5.0 +
+    return static_cast<double>(h->sh[0].c_units) * 128.0 * 5.0 +
            static_cast<double>(h->csc_nstrips) * h->csc_nblocks * 12.0;
   const int64_t c0 = static_cast<int64_t>(h->sh[0].slot) * h->W;
   const int64_t valid = std::max<int64_t>(0, std::min<int64_t>(h->W, h->m - c0));

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "k_solver.hip.h"
+#include "k_gemv.hip.h"
 
 namespace clipper_hip {
 
@@ -380,15 +381,10 @@ __device__ __forceinline__ void csc_core(const CscView& M, int64_t ld, int64_t m
   }
 }
 
-// G of a solver iteration on the compressed copy (one shard): decision, then the pass
+// window or pair mode by the plan of this iteration
 template <int V, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_csc(CscView M, SolveArgs A) {
-  static_assert(csc_lds_doubles(V, NW) >= NW * 64 + NW * 2 * V,
-                "LDS of the mat-vec must hold the decision's scratch");
-  __shared__ double lds[csc_lds_doubles(V, NW)];
-  __shared__ SolverState stash;
-  PassPlan plan;
-  if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
+__device__ __forceinline__ void csc_by_plan(const CscView& M, const SolveArgs& A,
+                                            const PassPlan& plan, double* lds) {
   if (plan.phase == PH_TRIAL) {
     csc_core<true, V, nslot(V), NW>(M, A.W, A.m, plan.d,
                                     A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS, VS, A.part,
@@ -402,7 +398,34 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_csc(CscView M, SolveAr
                                      A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS, VS,
                                      A.part, lds);
   }
+}
+
+// G of a solver iteration on the compressed copy (one shard): decision, then the pass
+template <int V, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_csc(CscView M, SolveArgs A) {
+  static_assert(csc_lds_doubles(V, NW) >= NW * 64 + NW * 2 * V,
+                "LDS of the mat-vec must hold the decision's scratch");
+  __shared__ double lds[csc_lds_doubles(V, NW)];
+  __shared__ SolverState stash;
+  PassPlan plan;
+  if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
+  csc_by_plan<V, NW>(M, A, plan, lds);
   flush_state(A, &stash);
+}
+
+// the same for a column shard (k_pass of the dense store): the last-arriving workgroup of a
+// strip adds the strip's tile partials into this shard's block of the gathered layout
+template <int V, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_pass_csc(CscView M, SolveArgs A) {
+  __shared__ double lds[csc_lds_doubles(V, NW)];
+  __shared__ SolverState stash;
+  PassPlan plan;
+  if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
+  csc_by_plan<V, NW>(M, A, plan, lds);
+  flush_state(A, &stash);
+  int* flag = reinterpret_cast<int*>(lds + csc_lds_doubles(V, NW) - 1);
+  if (!arrive_last(A.cnt + blockIdx.x, gridDim.y, flag)) return;
+  strip_reduce<nslot(V), CSC_CW, NW * 64>(A);
 }
 
 }  // namespace clipper_hip

@@ -251,6 +251,33 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv(const T* __restrict__ 
   flush_state(A, &stash);
 }
 
+// The last workgroup of a column strip (CW columns wide) adds the strip's row-tile partials in
+// tile order into this shard's block of the gathered layout ab[P][NSLOT][W].
+template <int NSLOT, int CW, int NT>
+__device__ __forceinline__ void strip_reduce(const SolveArgs& A) {
+  const int64_t ld = A.W;
+  double* ab_block = A.ab + static_cast<int64_t>(A.slot) * NSLOT * ld;
+  const int64_t ts = static_cast<int64_t>(NSLOT) * ld;
+  for (int t = threadIdx.x; t < NSLOT * CW; t += NT) {
+    const int sl = t / CW;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * CW + (t % CW);
+    if (c < ld) {
+      const double* p = A.part + sl * ld + c;
+      double acc = 0.0;
+      int tt = 0;
+      for (; tt + 16 <= A.ntiles; tt += 16) {  // 16 tiles in flight: this workgroup is alone now
+        double x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = p[static_cast<int64_t>(tt + q) * ts];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += x[q];
+      }
+      for (; tt < A.ntiles; ++tt) acc += p[static_cast<int64_t>(tt) * ts];
+      ab_block[sl * ld + c] = acc;
+    }
+  }
+}
+
 // k_pass — the same for a column-sharded M, with the reduction of the row-tile partials folded
 // into the epilogue: the LAST row-tile workgroup of a column strip (arrival counter per strip)
 // adds the strip's partials in tile order into this shard's block of the gathered layout
@@ -271,27 +298,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ 
   flush_state(A, &stash);
   int* flag = reinterpret_cast<int*>(lds + GEMV_LDS_DOUBLES(NW) - 1);
   if (!arrive_last(A.cnt + blockIdx.x, gridDim.y, flag)) return;
-  // ---- last workgroup of this column strip ------------------------------------------------
-  double* ab_block = A.ab + static_cast<int64_t>(A.slot) * NSLOT * ld;
-  const int64_t ts = static_cast<int64_t>(NSLOT) * ld;
-  for (int t = threadIdx.x; t < NSLOT * 256; t += NW * 64) {
-    const int sl = t >> 8;
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + (t & 255);
-    if (c < ld) {
-      const double* p = A.part + sl * ld + c;
-      double acc = 0.0;
-      int tt = 0;
-      for (; tt + 16 <= A.ntiles; tt += 16) {  // 16 tiles in flight: this workgroup is alone now
-        double x[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) x[q] = p[static_cast<int64_t>(tt + q) * ts];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc += x[q];
-      }
-      for (; tt < A.ntiles; ++tt) acc += p[static_cast<int64_t>(tt) * ts];
-      ab_block[sl * ld + c] = acc;
-    }
-  }
+  strip_reduce<NSLOT, 256, NW * 64>(A);
 }
 
 // the pair-mode pass alone, on table 0 (matvec API, micro-benchmark): no solver state

@@ -146,9 +146,10 @@ def test_dsd_rounding_on_compressed_storage():
     assert sorted(out[abi.STORE_F32].nodes.tolist()) == sorted(out[abi.STORE_F32_CSC].nodes.tolist())
 
 
-def test_sharded_contexts_fall_back_to_the_dense_store(monkeypatch):
-    """what bench.py --gpus N > 1 does with its default storage: a multi-process rank (here a
-    1-rank RCCL world) and an in-process group keep dense column shards."""
+def test_column_shards_keep_a_compressed_copy_each(monkeypatch):
+    """what bench.py --gpus N > 1 does with its default storage: every column shard (here a
+    1-rank RCCL world, and in-process groups of 2, 3 and 5 shards on the one GPU) builds a
+    compressed copy of its dense slice (k_csc_build) and streams it with k_pass_csc."""
     p = synth.make_euclidean_problem(1200, 0.9, seed=3)
     r = ref.RefClipper()
     r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
@@ -157,16 +158,40 @@ def test_sharded_contexts_fall_back_to_the_dense_store(monkeypatch):
     g = abi.HipClipper(storage=abi.STORE_F32_CSC, rank=0, world=1)
     g.comm_init(g.unique_id())
     g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
-    assert g.storage_in_use == abi.STORE_F32
+    assert g.storage_in_use == abi.STORE_F32_CSC
     sg = g.solve(p.u0)
     assert sg.nodes.tolist() == sr.nodes.tolist()
+    assert abs(sg.score - sr.score) <= 1e-6 * abs(sr.score)
     monkeypatch.delenv("CLIPPER_HIP_FORCE_RCCL")
-    grp = abi.HipClipper(storage=abi.STORE_F32_CSC, group=[0, 0, 0])
+    Md = abi.HipClipper(storage=abi.STORE_F32)
+    Md.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    Mref = Md.get_affinity_matrix()
+    for nshards in (2, 3, 5):
+        grp = abi.HipClipper(storage=abi.STORE_F32_CSC, group=[0] * nshards)
+        grp.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+        assert grp.storage_in_use == abi.STORE_F32_CSC
+        assert np.array_equal(grp.get_affinity_matrix(), Mref)
+        s3 = grp.solve(p.u0)
+        assert s3.nodes.tolist() == sr.nodes.tolist()
+        assert abs(s3.score - sg.score) <= 1e-12 * abs(sg.score)   # another summation order
+        s3b = grp.solve(p.u0)
+        assert np.array_equal(s3.u, s3b.u)                           # run-to-run bit-identical
+        grp.close()
+
+
+@pytest.mark.parametrize("m,rho,seed", [(6500, 0.95, 2)])
+def test_column_shards_window_mode(m, rho, seed):
+    """m >= 6000: the automatic window of 6 candidates per pass on sharded compressed copies."""
+    p = synth.make_euclidean_problem(m, rho, seed=seed)
+    one = abi.HipClipper(storage=abi.STORE_F32_CSC)
+    one.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    s1 = one.solve(p.u0)
+    grp = abi.HipClipper(storage=abi.STORE_F32_CSC, group=[0] * 4)
     grp.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
-    assert grp.storage_in_use == abi.STORE_F32
-    s3 = grp.solve(p.u0)
-    assert s3.nodes.tolist() == sr.nodes.tolist()
-    assert abs(s3.score - sg.score) <= 1e-12 * abs(sg.score)   # 3 shards vs 1: another summation order
+    assert grp.window == 6 and grp.storage_in_use == abi.STORE_F32_CSC
+    s4 = grp.solve(p.u0)
+    assert sorted(s4.nodes.tolist()) == sorted(s1.nodes.tolist())
+    assert abs(s4.score - s1.score) <= 1e-9 * abs(s1.score)
 
 
 def test_full_size_10k_compressed_parity():
