@@ -25,9 +25,9 @@
  *   On the scorePairwiseConsistency path C == pattern(M) (clipper.cpp:63-64) and is not
  *   stored: the mat-vec kernel derives C_off*x from the same pass over M. setMatrixData
  *   with any other C stores a second dense matrix.
- *   CLIPPER_HIP_STORE_F32_CSC keeps M column-compressed (nonzeros only: fp32 value + row byte, blocked and padded for 64-wide waves) that
- *   the SOLVER's passes read instead of the dense store — the same fp32 values, the same fp64
- *   products, only the zeros are skipped. It applies whenever C == pattern(M); otherwise the
+ *   CLIPPER_HIP_STORE_F32_CSC keeps M column-compressed (nonzeros only: fp32 value + row
+ *   byte, blocked and padded for 64-wide waves); the SOLVER's passes read that instead of a
+ *   dense store — the same fp32 values, the same fp64 products, only the zeros are skipped. It applies whenever C == pattern(M); otherwise the
  *   context behaves as CLIPPER_HIP_STORE_F32. One unsharded device holds M ONLY in this form
  *   (a dense store is materialised when a getter / the matvec API needs one); column shards
  *   keep their dense slice and add a compressed copy of it. gemv_bytes then reports the bytes
