@@ -77,9 +77,11 @@ constexpr int gemv_unr(int V, int esize, bool hasc) {
   if (hasc) u /= 2;
   return u < 1 ? 1 : u;
 }
-// line-search candidates per pass: 6 from this size on, else 1 (below, a pass is latency-bound and
-// the V-fold tail costs more than the saved passes); CLIPPER_HIP_WINDOW = 1|4|6|8 overrides
+// line-search candidates per pass: 6 from m = 6000 on, 4 from m = 2000 on, else 1 (an iteration
+// is latency-bound there: at m = 100 and 1k the 10 % fewer passes of a window of 4 cost 10 %
+// more per iteration; at m = 5k it is 20 % fewer for 15 %); CLIPPER_HIP_WINDOW = 1|4|6|8 overrides
 constexpr int64_t WINDOW_MIN_M = 6000;
+constexpr int64_t WINDOW4_MIN_M = 2000;
 constexpr int SOLVE_BATCH = 16;  // multi-process: iterations queued between two state snapshots
 constexpr int RUN_AHEAD = 4;     // one process: iterations kept queued ahead of the device
 constexpr int MAX_EVENT_PAIRS = 4096;
@@ -324,7 +326,7 @@ int ensure_problem(Ctx* h, int64_t m) {
   h->m = m;
   h->W = W;
   h->mp = P * W;
-  const int V = h->V_forced ? h->V_forced : (m >= WINDOW_MIN_M ? 6 : 1);
+  const int V = h->V_forced ? h->V_forced : (m >= WINDOW_MIN_M ? 6 : (m >= WINDOW4_MIN_M ? 4 : 1));
   const bool same = (h->alloc_m == m && h->alloc_W == W && h->V == V);
   h->V = V;
   plan_tiles(h);
