@@ -133,7 +133,6 @@ struct Shard {
   double* pt = nullptr;    // point slots [2][V][2][mp]
   double* cab = nullptr;   // (a, b) of the last pair-mode pass [2][mp]
   double* X[2] = {nullptr, nullptr};  // candidate tables [V+1][mp][VS], see SolveArgs
-  int* cnt = nullptr;      // arrival counters [nstrips + 1]
   double* ab = nullptr;    // [P][NSLOT][W]
   double* scal = nullptr;  // [nwg][Q] partial scalars of k_tail
   SolverState* st = nullptr;      // ST[2], see SolverState
@@ -238,7 +237,6 @@ int free_shard_buffers(Shard& s) {
   fr(s.cab);
   fr(s.X[0]);
   fr(s.X[1]);
-  fr(s.cnt);
   fr(s.ab);
   fr(s.scal);
   fr(s.st);
@@ -294,8 +292,8 @@ void plan_tiles(Ctx* h) {
   h->nstrips = static_cast<int>(ceil_div(h->W, 256));
   const double slots = static_cast<double>(h->cus) * GEMV_WG_PER_CU;
   int64_t nt_max = std::min<int64_t>(max_tiles(h), std::max<int64_t>(1, ceil_div(h->m, chunk)));
-  // column shards: the strip's last workgroup adds the tiles serially (k_pass) and the slices are
-  // narrow — bound the tile count instead of chasing a full wave of tiny workgroups
+  // column shards: the slices are narrow — bound the tile count (k_reduce_pass adds them per
+  // element) instead of chasing a full wave of tiny workgroups
   if (h->world > 1) nt_max = std::min<int64_t>(nt_max, 32);
   int64_t best = 1;
   double best_cost = 1e300;
@@ -349,9 +347,6 @@ int ensure_problem(Ctx* h, int64_t m) {
       HIPCHK(hipMalloc(&s.X[k], (V + 1) * VS * nvec));
       HIPCHK(hipMemsetAsync(s.X[k], 0, (V + 1) * VS * nvec, s.stream));
     }
-    // arrival counters per column strip (256 wide: k_pass, 128 wide: k_pass_csc)
-    HIPCHK(hipMalloc(&s.cnt, static_cast<size_t>(2 * h->nstrips + 2) * sizeof(int)));
-    HIPCHK(hipMemsetAsync(s.cnt, 0, static_cast<size_t>(2 * h->nstrips + 2) * sizeof(int), s.stream));
     const size_t Q = V * (2 + 2 * V) + 2 * V + 2;
     const size_t nwg = static_cast<size_t>(ceil_div(m, TAIL_THREADS));
     HIPCHK(hipMalloc(&s.scal, (nwg + ceil_div(nwg, SCAL_FOLD) + 1) * Q * sizeof(double)));
@@ -376,18 +371,12 @@ int ensure_problem(Ctx* h, int64_t m) {
 }
 
 // ---- kernel dispatch over (storage type, explicit C, window size) -------------------------
-template <typename T, bool HASC, int V, bool SHARDED>
+template <typename T, bool HASC, int V>
 void launch_pass_tv(Ctx* h, Shard& s, const SolveArgs& a) {
   constexpr int UNR = gemv_unr(V, sizeof(T), HASC);
   dim3 grid(h->nstrips, h->ntiles), block(GEMV_NW * 64);
-  if (SHARDED)
-    hipLaunchKernelGGL((k_pass<T, HASC, V, GEMV_NW, UNR>), grid, block, 0, s.stream,
-                       static_cast<const T*>(s.S), static_cast<const T*>(s.Cs),
-                       h->rows_per_tile, a);
-  else
-    hipLaunchKernelGGL((k_gemv<T, HASC, V, GEMV_NW, UNR>), grid, block, 0, s.stream,
-                       static_cast<const T*>(s.S), static_cast<const T*>(s.Cs),
-                       h->rows_per_tile, a);
+  hipLaunchKernelGGL((k_gemv<T, HASC, V, GEMV_NW, UNR>), grid, block, 0, s.stream,
+                     static_cast<const T*>(s.S), static_cast<const T*>(s.Cs), h->rows_per_tile, a);
 }
 
 template <typename T, bool HASC>
@@ -411,11 +400,11 @@ void dispatch_storage(Ctx* h, F&& f) {
   }
 }
 
-// G of one solver iteration: decision + mat-vec of the pending window (sharded: + reduction)
-template <int V, bool SHARDED>
+// G of one solver iteration: decision + mat-vec of the pending window
+template <int V>
 void launch_pass(Ctx* h, Shard& s, const SolveArgs& a) {
   dispatch_storage(h, [&](auto t, auto c) {
-    launch_pass_tv<decltype(t), decltype(c)::value, V, SHARDED>(h, s, a);
+    launch_pass_tv<decltype(t), decltype(c)::value, V>(h, s, a);
   });
 }
 
@@ -429,12 +418,11 @@ void launch_plain(Ctx* h, Shard& s, const double* X) {
 // G on the compressed copy of M (one shard, C == pattern(M), fp32)
 CscView csc_view(const Ctx* h, const Shard& s);
 
-template <int V, bool SHARDED>
+template <int V>
 void launch_pass_csc(Ctx* h, Shard& s, const SolveArgs& a) {
   const CscView M = csc_view(h, s);
   dim3 grid(h->csc_nstrips, s.c_ntmax), block(GEMV_NW * 64);
-  if (SHARDED) hipLaunchKernelGGL((k_pass_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
-  else hipLaunchKernelGGL((k_gemv_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
+  hipLaunchKernelGGL((k_gemv_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
 }
 
 // calls f(integral_constant<V>) for the context's window size
@@ -531,21 +519,22 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
     a.scal_in = s.scal + static_cast<int64_t>(a.nwg) * (h->V * (2 + 2 * h->V) + 2 * h->V + 2);
     a.nwg_in = static_cast<int>(ceil_div(a.nwg, SCAL_FOLD));
   }
-  a.cnt = s.cnt;
-  a.nstrips = h->nstrips;
   a.kind = (h->profiling && &s == &h->sh[0]) ? h->kind_dev : nullptr;
   a.host_u = (!h->multiproc && &s == &h->sh[0]) ? h->u_pinned_dev : nullptr;
   return a;
 }
 
 // One full solver iteration:
-//   one shard : k_gemv (decision + pass) -> k_tail<V, true>
-//   sharded   : k_pass (decision + pass + reduction) -> exchange -> k_tail<V, false>
+//   one shard : k_gemv[_csc] (decision + pass) -> k_tail<V, true> (adds the tile partials itself)
+//   sharded   : k_gemv[_csc] -> k_reduce_pass (tile partials -> own block) -> exchange -> k_tail<V, false>
 template <int V>
 int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   const int par = h->par;
   h->par ^= 1;
-  const bool sharded = !(h->world == 1 && !h->multiproc);
+  // CLIPPER_HIP_FORCE_SHARDED: test / measurement knob — the column-shard protocol (reduce launch,
+  // exchange, k_tail<V, false>) on a single unsharded device
+  static const bool force_sharded = std::getenv("CLIPPER_HIP_FORCE_SHARDED") != nullptr;
+  const bool sharded = !(h->world == 1 && !h->multiproc) || force_sharded;
   // timing events cost ~5-10 us of stream time each: sample every 8th launch only
   Shard& s0 = h->sh[0];
   const bool prof = h->profiling && (h->launch_counter % PROFILE_EVERY == 3) &&
@@ -554,14 +543,8 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, par);
     if (prof && &s == &s0) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
-    if (h->csc_valid) {
-      if (sharded) launch_pass_csc<V, true>(h, s, a);
-      else launch_pass_csc<V, false>(h, s, a);
-    } else if (sharded) {
-      launch_pass<V, true>(h, s, a);
-    } else {
-      launch_pass<V, false>(h, s, a);
-    }
+    if (h->csc_valid) launch_pass_csc<V>(h, s, a);
+    else launch_pass<V>(h, s, a);
     if (prof && &s == &s0) {
       HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used + 1], s.stream));
       h->ev_launch_index[h->ev_used] = h->launch_counter;
@@ -570,6 +553,13 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   }
   ++h->launch_counter;
   if (sharded) {
+    for (auto& s : h->sh) {  // the tile partials of the pass -> this shard's block of `ab`
+      HIPCHK(hipSetDevice(s.device));
+      const SolveArgs a = solve_args(h, s, prm, par);
+      const int64_t n = static_cast<int64_t>(nslot(V)) * h->W;
+      hipLaunchKernelGGL(k_reduce_pass, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0,
+                         s.stream, a, nslot(V));
+    }
     int rc = exchange(h, nslot(V));
     if (rc) return rc;
   }

@@ -6,7 +6,6 @@
 #include <stdint.h>
 
 #include "k_solver.hip.h"
-#include "k_gemv.hip.h"
 
 namespace clipper_hip {
 
@@ -411,21 +410,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_csc(CscView M, SolveAr
   if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
   csc_by_plan<V, NW>(M, A, plan, lds);
   flush_state(A, &stash);
-}
-
-// the same for a column shard (k_pass of the dense store): the last-arriving workgroup of a
-// strip adds the strip's tile partials into this shard's block of the gathered layout
-template <int V, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 2) void k_pass_csc(CscView M, SolveArgs A) {
-  __shared__ double lds[csc_lds_doubles(V, NW)];
-  __shared__ SolverState stash;
-  PassPlan plan;
-  if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
-  csc_by_plan<V, NW>(M, A, plan, lds);
-  flush_state(A, &stash);
-  int* flag = reinterpret_cast<int*>(lds + csc_lds_doubles(V, NW) - 1);
-  if (!arrive_last(A.cnt + blockIdx.x, gridDim.y, flag)) return;
-  strip_reduce<nslot(V), CSC_CW, NW * 64>(A);
 }
 
 }  // namespace clipper_hip

@@ -1,4 +1,4 @@
-// k_gemv.hip.h — the dense pass over M: k_gemv, k_pass (column shards), k_gemv_plain, k_reduce, k_spread
+// k_gemv.hip.h — the dense pass over M: k_gemv, k_gemv_plain, k_reduce_pass (column shards), k_reduce, k_spread
 // Part of kernels.hip.h (include that one): hand-written gfx950 device code of the CLIPPER hot path.
 #pragma once
 
@@ -210,7 +210,7 @@ __device__ __forceinline__ void gemv_core(const T* __restrict__ S, const T* __re
   }
 }
 
-constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * GEMV_SLR * 256 + 2; }  // + the arrival flag
+constexpr int GEMV_LDS_DOUBLES(int NW) { return NW * GEMV_SLR * 256 + 2; }
 
 // window or pair mode by the plan of this iteration
 template <typename T, bool HASC, int V, int NW, int UNR>
@@ -251,56 +251,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv(const T* __restrict__ 
   flush_state(A, &stash);
 }
 
-// The last workgroup of a column strip (CW columns wide) adds the strip's row-tile partials in
-// tile order into this shard's block of the gathered layout ab[P][NSLOT][W].
-template <int NSLOT, int CW, int NT>
-__device__ __forceinline__ void strip_reduce(const SolveArgs& A) {
-  const int64_t ld = A.W;
-  double* ab_block = A.ab + static_cast<int64_t>(A.slot) * NSLOT * ld;
-  const int64_t ts = static_cast<int64_t>(NSLOT) * ld;
-  for (int t = threadIdx.x; t < NSLOT * CW; t += NT) {
-    const int sl = t / CW;
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * CW + (t % CW);
-    if (c < ld) {
-      const double* p = A.part + sl * ld + c;
-      double acc = 0.0;
-      int tt = 0;
-      for (; tt + 16 <= A.ntiles; tt += 16) {  // 16 tiles in flight: this workgroup is alone now
-        double x[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) x[q] = p[static_cast<int64_t>(tt + q) * ts];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc += x[q];
-      }
-      for (; tt < A.ntiles; ++tt) acc += p[static_cast<int64_t>(tt) * ts];
-      ab_block[sl * ld + c] = acc;
-    }
-  }
-}
-
-// k_pass — the same for a column-sharded M, with the reduction of the row-tile partials folded
-// into the epilogue: the LAST row-tile workgroup of a column strip (arrival counter per strip)
-// adds the strip's partials in tile order into this shard's block of the gathered layout
-// ab[P][NSLOT][W] — what k_reduce would do in a launch of its own. The exchange and
-// k_tail<V, false> follow. Every rank takes the same decision from the same bits.
-template <typename T, bool HASC, int V, int NW, int UNR>
-__global__ __launch_bounds__(NW * 64, NW / 2) void k_pass(const T* __restrict__ S,
-                                                           const T* __restrict__ Cs,
-                                                           int rows_per_tile, SolveArgs A) {
-  constexpr int NSLOT = nslot(V);
-  __shared__ double lds[GEMV_LDS_DOUBLES(NW)];
-  __shared__ SolverState stash;
-  PassPlan plan;
-  if (!iteration_head<V, NW * 64>(A, lds, &stash, plan)) return;
-  const int64_t ld = A.W;
-  gemv_by_plan<T, HASC, V, NW, UNR>(S, Cs, ld, A.m, rows_per_tile, A.Xin, A.pt, A.mp, A.part,
-                                    plan, lds);
-  flush_state(A, &stash);
-  int* flag = reinterpret_cast<int*>(lds + GEMV_LDS_DOUBLES(NW) - 1);
-  if (!arrive_last(A.cnt + blockIdx.x, gridDim.y, flag)) return;
-  strip_reduce<NSLOT, 256, NW * 64>(A);
-}
-
 // the pair-mode pass alone, on table 0 (matvec API, micro-benchmark): no solver state
 template <typename T, bool HASC, int NW, int UNR>
 __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_plain(const T* __restrict__ S,
@@ -314,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_gemv_plain(const T* __restr
 }
 
 // k_reduce — adds the row-tile partials in tile order and writes this shard's block of the
-// gathered layout (matvec API only: the solver folds this into k_pass / k_tail). One thread per
+// gathered layout (matvec API only: the solver uses k_reduce_pass or folds it into k_tail). One thread per
 // output element e = slot*ld + c; the loads of 8 tiles are issued before they are summed (the
 // partials sit in L2 / MALL).
 __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ part, int ntiles,
@@ -335,6 +285,32 @@ __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ part,
   }
   for (; t < ntiles; ++t) acc += p[static_cast<int64_t>(t) * tstride];
   ab_block[e] = acc;
+}
+
+// k_reduce_pass — column shards, between the pass and the exchange: the row-tile partials of the
+// pass THIS iteration ran (none: nothing to do) added in tile order into this shard's block of
+// the gathered layout ab[P][NSLOT][W]. A launch of its own: folding it into the pass (the last
+// workgroup of a strip, found with an arrival counter and agent-scope release/acquire fences)
+// cost 16 us per pass — every workgroup's release writes the L2 back.
+__global__ __launch_bounds__(256) void k_reduce_pass(SolveArgs A, int nslots) {
+  if (A.shared->done) return;
+  if (A.st_next->n_passes == A.st_cur->n_passes) return;  // no pass in this iteration
+  const int64_t ld = A.W;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t tstride = static_cast<int64_t>(nslots) * ld;
+  if (e >= tstride) return;
+  const double* p = A.part + e;
+  double acc = 0.0;
+  int t = 0;
+  for (; t + 8 <= A.ntiles; t += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p[static_cast<int64_t>(t + q) * tstride];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc += v[q];
+  }
+  for (; t < A.ntiles; ++t) acc += p[static_cast<int64_t>(t) * tstride];
+  A.ab[static_cast<int64_t>(A.slot) * tstride + e] = acc;
 }
 
 // x[i] -> candidate 0 of a table row (matvec API)

@@ -138,8 +138,6 @@ struct SolveArgs {
   // nwg*Q doubles each) the SCAL_FOLD-fold pre-reduction k_scal_fold makes of it
   const double* scal_in;
   int nwg_in;
-  int* cnt;       // column-sharded M: one arrival counter per column strip
-  int nstrips;
   uint8_t* kind;  // pinned host memory [KIND_CAP], profiling only: iteration n_iters ran a pass
   double* host_u; // pinned host memory [m] (may be null): the final u, written before `done`
 };
@@ -152,34 +150,6 @@ constexpr int KIND_CAP = 1 << 16;
 // array k (0 = u, 1 = gradF) of point slot (p, v)
 __device__ __forceinline__ double* pt_arr(const SolveArgs& A, int V, int p, int v, int k) {
   return A.pt + ((static_cast<int64_t>(p) * V + v) * 2 + k) * A.mp;
-}
-
-// Last-arriver hand-off inside one launch (CDNA guide, section 6 guideline 16, counter form;
-// the split-K recipe) — used only by k_pass (column-sharded M): every workgroup publishes what
-// it stored — each wave drains its own stores, one lane issues the agent-scope release and
-// draws a ticket — and the workgroup that draws the last ticket acquires at agent scope and
-// continues with plain loads. Correct for any placement of the workgroups over the 8 XCDs
-// (their L2s are not coherent with each other). The counter is zeroed before the first launch
-// of a solve (k_init) and re-armed by the last arriver. Returns true in every thread of the
-// last workgroup. `flag` is one int of LDS.
-__device__ __forceinline__ bool arrive_last(int* counter, int expected, int* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop the fence's own wait
-    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == expected - 1) ? 1 : 0;
-    if (last) {
-      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    *flag = last;
-  }
-  __syncthreads();
-  const bool last = (*flag != 0);
-  __syncthreads();  // the flag word is free again
-  return last;
 }
 
 // Wave-level sum with DPP moves (VALU speed, no LDS crossbar): after the six steps lane 63
@@ -656,7 +626,7 @@ __device__ __forceinline__ void flush_state(const SolveArgs& A, const SolverStat
 }
 
 // Solve prologue, one launch: pending vector = u0 (candidate 0 of table 0, un-normalised,
-// nrm = 1), initial state in ST[0], arrival counters zeroed.
+// nrm = 1), initial state in ST[0].
 __global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, SolverState* st0,
                                                double* X0) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -665,7 +635,6 @@ __global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, Sol
     store_row(X0 + i * VS, row);
   }
   if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < A.nstrips; c += 256) A.cnt[c] = 0;
     if (threadIdx.x == 0) {
       *st0 = init;
       A.shared->done = 0;

@@ -16,7 +16,7 @@
 // Reference sites (relative to /root/reference):
 //   k_affinity_*  : src/clipper.cpp:31-56 + src/invariants/euclidean_distance.cpp:13-31,
 //                   src/invariants/pointnormal_distance.cpp:13-35
-//   k_gemv / k_pass: every `M_.selfadjointView<Upper>() * v` / `C_...* v` in
+//   k_gemv[_csc]   : every `M_.selfadjointView<Upper>() * v` / `C_...* v` in
 //                   src/clipper.cpp:194,202,205,219,240-241,268,271 (one pass over M serves a
 //                   whole window of line-search candidates), preceded by the decisions of
 //                   findDenseClique's control flow :244-262, :268-280 (decide)
@@ -26,7 +26,7 @@
 //
 // Files (all in namespace clipper_hip):
 //   k_solver.hip.h    solver state, decide (the head of every pass launch), k_init, k_tail, k_scal_fold
-//   k_gemv.hip.h      the dense pass: k_gemv, k_pass (column shards), k_gemv_plain, k_reduce, k_spread
+//   k_gemv.hip.h      the dense pass: k_gemv, k_gemv_plain, k_reduce_pass (column shards), k_reduce, k_spread
 //   k_csc.hip.h       the compressed storage: layout, emission, k_csc_build, k_csc_expand, k_gemv_csc
 //   k_affinity.hip.h  k_gather_points, k_affinity_* (plain, compacting strips, symmetric tiles + emission)
 //   k_matrix.hip.h    k_from_dense_upper, k_from_csc, k_gather_sub

@@ -4,7 +4,7 @@ with torch.distributed.run. torch.distributed is used only for bootstrap and boo
 per-pass exchange of the solver is an RCCL all-gather issued by libclipper_hip.so itself on
 its own stream (clipper_hip_comm_init / ncclAllGather in csrc/clipper_hip.hip).
 
-Layout contract shared with the kernels (kernels.hip.h, k_pass / k_tail): shard p of P owns
+Layout contract shared with the kernels (kernels.hip.h, k_reduce_pass / k_tail): shard p of P owns
 global columns [p*W, p*W + W), W = round_up(ceil(m / P), 64); the gathered sums are
 ab[P][NSLOT][W] — block p holds, slot after slot, this shard's columns of every product of the
 pass (slot 0 = M_off x_0, slots 1..V-1 = (M_off + d C_off) x_v, slot V = C_off x_0). The helpers

@@ -149,7 +149,8 @@ def test_dsd_rounding_on_compressed_storage():
 def test_column_shards_keep_a_compressed_copy_each(monkeypatch):
     """what bench.py --gpus N > 1 does with its default storage: every column shard (here a
     1-rank RCCL world, and in-process groups of 2, 3 and 5 shards on the one GPU) builds a
-    compressed copy of its dense slice (k_csc_build) and streams it with k_pass_csc."""
+    compressed copy of its dense slice (k_csc_build) and streams it with k_gemv_csc +
+    k_reduce_pass."""
     p = synth.make_euclidean_problem(1200, 0.9, seed=3)
     r = ref.RefClipper()
     r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)

@@ -434,7 +434,7 @@ def test_window_with_line_search_limits(monkeypatch, V):
 
 @pytest.mark.parametrize("V", [1, 4, 6, 8])
 def test_window_sharded(monkeypatch, V):
-    # column-sharded M: k_pass (reduction folded in), exchange of [V][2][W] blocks, k_tail
+    # column-sharded M: k_gemv + k_reduce_pass, exchange of the [V+1][W] blocks, k_tail
     monkeypatch.setenv("CLIPPER_HIP_WINDOW", str(V))
     p = synth.make_euclidean_problem(1500, 0.9, seed=77)
     g1 = abi.HipClipper(storage=abi.STORE_F32)

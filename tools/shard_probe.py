@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-shard cost of the column-sharded iteration on ONE GPU: P logical shards driven by one thread
 (clipper_hip_create_group with a repeated device). Prints the solve time and the mean duration of
-shard 0's k_pass (decision + pass over its W columns + folded reduction).
+shard 0's pass kernel (decision + pass over its W columns).
   python tools/shard_probe.py [m] [P ...]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
