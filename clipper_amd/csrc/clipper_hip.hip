@@ -82,7 +82,10 @@ constexpr int gemv_unr(int V, int esize, bool hasc) {
 // more per iteration; at m = 5k it is 20 % fewer for 15 %); CLIPPER_HIP_WINDOW = 1|4|6|8 overrides
 constexpr int64_t WINDOW_MIN_M = 6000;
 constexpr int64_t WINDOW4_MIN_M = 2000;
-constexpr int SOLVE_BATCH = 16;  // multi-process: iterations queued between two state snapshots
+// multi-process: iterations queued between two state snapshots. Up to two batches of no-op
+// iterations (each still holds its all-gather) run past convergence: keep them short. 16 -> 4
+// changes nothing on a 1-rank world (tools/rank1_probe.py).
+constexpr int SOLVE_BATCH = 4;
 constexpr int RUN_AHEAD = 4;     // one process: iterations kept queued ahead of the device
 constexpr int MAX_EVENT_PAIRS = 4096;
 constexpr int PROFILE_EVERY = 8;  // time every 8th iteration's mat-vec (an event costs ~5-10 us of stream time)
@@ -1783,8 +1786,10 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     int slot = 0;
     bool have_prev = false;
     bool done = false;
+    int batch = SOLVE_BATCH;
+    if (const char* e = std::getenv("CLIPPER_HIP_SOLVE_BATCH")) batch = std::max(1, std::atoi(e));  // tuning knob, same on every rank
     while (!done) {
-      for (int it = 0; it < SOLVE_BATCH; ++it) {
+      for (int it = 0; it < batch; ++it) {
         if ((rc = enqueue_iteration(h, prm))) return rc;
       }
       HIPCHK(hipSetDevice(s0.device));
