@@ -16,7 +16,7 @@ per GPU, per-pass RCCL all-gather of the (M_off x, C_off x) slices): strong scal
 Prints ONE JSON line on rank 0 (see the contract in the task statement), extended with
   "roofline"     achieved HBM GB/s of the dominant kernel (the mat-vec: one pass over M for a
                  whole line-search window), from HIP events recorded on the solver stream
-                 around every 8th launch in the timed region. Default storage "csc" (one GPU):
+                 around every 20th launch in the timed region (an event pair costs ~30 us of stream time). Default storage "csc" (one GPU):
                  k_gemv_csc streams the compressed copy of M — bytes per launch = what that
                  copy holds (5 B per padded entry + the group directory), NOT s*m^2; the
                  dense-equivalent rate is reported beside it and is not a roofline figure.

@@ -87,8 +87,10 @@ constexpr int64_t WINDOW4_MIN_M = 2000;
 // changes nothing on a 1-rank world (tools/rank1_probe.py).
 constexpr int SOLVE_BATCH = 4;
 constexpr int RUN_AHEAD = 4;     // one process: iterations kept queued ahead of the device
-constexpr int MAX_EVENT_PAIRS = 4096;
-constexpr int PROFILE_EVERY = 8;  // time every 8th iteration's mat-vec (an event costs ~5-10 us of stream time)
+constexpr int MAX_EVENT_PAIRS = 256;  // per solve; created when profiling is switched on
+// time every 20th iteration's mat-vec: an event pair costs ~30 us of stream time (the launches
+// around it no longer pipeline) — every 8th was 0.13 ms of a 2.0 ms step at m = 10k
+constexpr int PROFILE_EVERY = 20;
 
 // ---- RCCL, bound at run time so the single-GPU path never loads librccl -----------------
 struct Rccl {
@@ -139,6 +141,7 @@ struct Shard {
   double* ab = nullptr;    // [P][NSLOT][W]
   double* scal = nullptr;  // [nwg][Q] partial scalars of k_tail
   SolverState* st = nullptr;      // ST[2], see SolverState
+  uint8_t* marks = nullptr;       // [KIND_CAP] per-iteration pass marks (profiling), see SolveArgs
   SolveShared* shared = nullptr;
   // affinity inputs (staged once, reused while the sizes fit)
   double *P1 = nullptr, *P2 = nullptr;  // gathered point tables [d][pstride]
@@ -213,7 +216,7 @@ struct clipper_hip_ctx {
   int par = 0;             // which table set the next launch reads
 
   bool profiling = false;
-  std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created lazily
+  std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created by clipper_hip_set_profiling
   std::vector<int64_t> ev_launch_index;  // which mat-vec launch of the solve each pair timed
   int ev_used = 0;
   int64_t launch_counter = 0;
@@ -244,6 +247,7 @@ int free_shard_buffers(Shard& s) {
   fr(s.scal);
   fr(s.st);
   fr(s.shared);
+  fr(s.marks);
   fr(s.cLc);
   fr(s.cPre);
   fr(s.cvals);
@@ -360,6 +364,8 @@ int ensure_problem(Ctx* h, int64_t m) {
     HIPCHK(hipMalloc(&s.st, 2 * sizeof(SolverState)));
     HIPCHK(hipMemsetAsync(s.st, 0, 2 * sizeof(SolverState), s.stream));
     HIPCHK(hipMalloc(&s.shared, sizeof(SolveShared)));
+    HIPCHK(hipMalloc(&s.marks, KIND_CAP));
+    HIPCHK(hipMemsetAsync(s.marks, 0, KIND_CAP, s.stream));
     HIPCHK(hipMemsetAsync(s.shared, 0, sizeof(SolveShared), s.stream));
   }
   h->alloc_m = m;
@@ -522,7 +528,8 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
     a.scal_in = s.scal + static_cast<int64_t>(a.nwg) * (h->V * (2 + 2 * h->V) + 2 * h->V + 2);
     a.nwg_in = static_cast<int>(ceil_div(a.nwg, SCAL_FOLD));
   }
-  a.kind = (h->profiling && &s == &h->sh[0]) ? h->kind_dev : nullptr;
+  a.marks = (h->profiling && &s == &h->sh[0]) ? s.marks : nullptr;
+  a.kind = (a.marks && !h->multiproc) ? h->kind_dev : nullptr;
   a.host_u = (!h->multiproc && &s == &h->sh[0]) ? h->u_pinned_dev : nullptr;
   return a;
 }
@@ -540,7 +547,8 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   const bool sharded = !(h->world == 1 && !h->multiproc) || force_sharded;
   // timing events cost ~5-10 us of stream time each: sample every 8th launch only
   Shard& s0 = h->sh[0];
-  const bool prof = h->profiling && (h->launch_counter % PROFILE_EVERY == 3) &&
+  static const int every = std::getenv("CLIPPER_HIP_PROFILE_EVERY") ? std::max(4, std::atoi(std::getenv("CLIPPER_HIP_PROFILE_EVERY"))) : PROFILE_EVERY;
+  const bool prof = h->profiling && (h->launch_counter % every == 3) &&
                     h->ev_used < MAX_EVENT_PAIRS;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
@@ -1696,15 +1704,14 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   const int64_t m = h->m;
   const size_t vbytes = static_cast<size_t>(m) * sizeof(double);
 
-  if (h->profiling && h->ev_pairs.empty()) {
-    HIPCHK(hipSetDevice(h->sh[0].device));
-    h->ev_pairs.resize(2 * MAX_EVENT_PAIRS);
-    h->ev_launch_index.assign(MAX_EVENT_PAIRS, 0);
-    for (auto& e : h->ev_pairs) HIPCHK(hipEventCreate(&e));
-  }
   h->ev_used = 0;
   if (h->profiling)  // marks of the previous solve
-    std::memset(h->kind, 0, static_cast<size_t>(std::min<int64_t>(h->launch_counter + 1, KIND_CAP)));
+  {
+    const size_t n = static_cast<size_t>(std::min<int64_t>(h->launch_counter + 1, KIND_CAP));
+    std::memset(h->kind, 0, n);
+    HIPCHK(hipSetDevice(h->sh[0].device));
+    HIPCHK(hipMemsetAsync(h->sh[0].marks, 0, n, h->sh[0].stream));
+  }
   h->launch_counter = 0;
 
   SolverParams prm;
@@ -1814,6 +1821,10 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     const double* u_dev =
         s0.pt + ((static_cast<int64_t>(fin.ubp & 1) * h->V + fin.ubv) * 2 + 0) * h->mp;
     HIPCHK(hipMemcpyAsync(h->u_pinned, u_dev, vbytes, hipMemcpyDeviceToHost, s0.stream));
+    if (h->profiling)
+      HIPCHK(hipMemcpyAsync(h->kind, s0.marks,
+                            static_cast<size_t>(std::min<int64_t>(h->launch_counter, KIND_CAP)),
+                            hipMemcpyDeviceToHost, s0.stream));
     if ((rc = sync_all(h))) return rc;
   } else {
     // one process: the deciding workgroup wrote u into the pinned buffer before it raised `done`;
@@ -1982,6 +1993,12 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
 int clipper_hip_set_profiling(clipper_hip_t* h, int on) {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   h->profiling = (on != 0);
+  if (h->profiling && h->ev_pairs.empty()) {  // here, not inside the first profiled solve (~1 ms)
+    HIPCHK(hipSetDevice(h->sh[0].device));
+    h->ev_pairs.resize(2 * MAX_EVENT_PAIRS);
+    h->ev_launch_index.assign(MAX_EVENT_PAIRS, 0);
+    for (auto& e : h->ev_pairs) HIPCHK(hipEventCreate(&e));
+  }
   return 0;
 }
 

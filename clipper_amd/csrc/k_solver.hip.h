@@ -138,7 +138,11 @@ struct SolveArgs {
   // nwg*Q doubles each) the SCAL_FOLD-fold pre-reduction k_scal_fold makes of it
   const double* scal_in;
   int nwg_in;
-  uint8_t* kind;  // pinned host memory [KIND_CAP], profiling only: iteration n_iters ran a pass
+  // profiling only: iteration n_iters ran a pass. `marks` [KIND_CAP] is device memory (a store to
+  // pinned host memory at the end of EVERY pass launch cost ~2 us each); the deciding workgroup
+  // copies the marks to `kind` (pinned host memory) once, when the solve ends
+  uint8_t* marks;
+  uint8_t* kind;
   double* host_u; // pinned host memory [m] (may be null): the final u, written before `done`
 };
 constexpr int KIND_CAP = 1 << 16;
@@ -512,6 +516,11 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
     const double* u = pt_arr(A, V, ubp, ubv, 0);
     for (int64_t i = tid; i < m; i += NT)
       __hip_atomic_store(A.host_u + i, u[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (A.kind != nullptr && A.marks != nullptr) {
+      const int64_t n = (n_iters < KIND_CAP) ? n_iters : KIND_CAP;
+      for (int64_t i = tid; i < n; i += NT)
+        __hip_atomic_store(A.kind + i, A.marks[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __threadfence_system();
     __syncthreads();
   }
@@ -617,9 +626,7 @@ __device__ __forceinline__ void flush_state(const SolveArgs& A, const SolverStat
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     *A.st_next = *stash;
     const int64_t n_iters = stash->n_iters;
-    if (A.kind != nullptr && n_iters <= KIND_CAP)
-      __hip_atomic_store(A.kind + (n_iters - 1), static_cast<uint8_t>(1), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if (A.marks != nullptr && n_iters <= KIND_CAP) A.marks[n_iters - 1] = 1;
     if (A.host != nullptr)
       __hip_atomic_store(&A.host->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
