@@ -603,9 +603,10 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
 template <int V, int NT>
 __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
                                                SolverState* stash, PassPlan& plan) {
-  if (A.shared->done) return false;
   const SolverState* st = A.st_cur;
-  if (st->stage == ST_RESULTS) return decide<V, NT>(A, lds, stash, plan);
+  const int done = A.shared->done, stage = st->stage;  // one round trip, not two
+  if (done) return false;
+  if (stage == ST_RESULTS) return decide<V, NT>(A, lds, stash, plan);
   // the pass was prepared by a transition iteration (or by k_init): run it as it stands
   plan.phase = st->phase;
   plan.sel = st->sel;
@@ -686,6 +687,13 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
   const SolverState* st = A.st_next;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
   const bool valid = i < A.m;
+  // everything this launch needs of the solver state, requested up front: one round trip in the
+  // shadow of the partial sums instead of a chain of dependent scalar loads after them
+  const int done = A.shared->done;
+  const int stage = st->stage, phase = st->phase;
+  const int ubp = st->ubp, ubv = st->ubv, sel = st->sel;
+  const double d = st->d, alpha = st->alpha, s_cur = st->s;
+  const double nrmv = st->nrm[v], sxv = st->sx[v];
 
   // raw sums of slot v (and of slot V, the b of candidate 0, for the v = 0 workgroups): these
   // loads do not depend on the solver state
@@ -721,10 +729,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
       p1 = blk[o1 + off];
     }
   }
-  if (A.shared->done) return;
-  if (st->stage != ST_RESULTS) return;  // a pass was only prepared: nothing to evaluate
-  const int phase = st->phase;
-  const int ubp = st->ubp, ubv = st->ubv;
+  if (done) return;
+  if (stage != ST_RESULTS) return;  // a pass was only prepared: nothing to evaluate
 
   if (phase != PH_TRIAL && phase != PH_BUILD) {
     // pair-mode passes carry one vector (candidate 0, nrm = 1): a = M_off x, b = C_off x
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
     }
     return;
   }
-  const double d = st->d, beta = A.prm.beta;
+  const double beta = A.prm.beta;
   double r[NRED];
 #pragma unroll
   for (int q = 0; q < NRED; ++q) r[q] = 0.0;
@@ -745,7 +751,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
     if (v != 0) return;
     if (valid) {
       const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
-      const double gi = (1 + d) * ui - d * st->s + A.cab[i] + A.cab[A.mp + i] * d;  // :219
+      const double gi = (1 + d) * ui - d * s_cur + A.cab[i] + A.cab[A.mp + i] * d;  // :219
       pt_arr(A, V, ubp, ubv, 1)[i] = gi;
       r[0] = ui * gi;  // :220
       double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -762,10 +768,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
       store_row(A.Xout + i * VS, row);
     }
   } else {
-    const double nrmv = st->nrm[v], sxv = st->sx[v];
-    const double alpha = st->alpha;
     if (valid) {
-      const double xraw = A.Xin[(static_cast<int64_t>(st->sel) * A.mp + i) * VS + v];
+      const double xraw = A.Xin[(static_cast<int64_t>(sel) * A.mp + i) * VS + v];
       const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
       const double xi = xraw / nrmv;  // clipper.cpp:237
       double gn;
