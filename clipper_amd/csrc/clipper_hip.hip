@@ -548,7 +548,9 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   // timing events cost ~5-10 us of stream time each: sample every 8th launch only
   Shard& s0 = h->sh[0];
   static const int every = std::getenv("CLIPPER_HIP_PROFILE_EVERY") ? std::max(4, std::atoi(std::getenv("CLIPPER_HIP_PROFILE_EVERY"))) : PROFILE_EVERY;
-  const bool prof = h->profiling && (h->launch_counter % every == 3) &&
+  // iterations 4, 11, then every `every`-th: short solves (20 iterations) still get samples, and
+  // one of them is a pass (3 and 9 both hit transitions at cfg4)
+  const bool prof = h->profiling && (h->launch_counter % every == 4 || h->launch_counter == 11) &&
                     h->ev_used < MAX_EVENT_PAIRS;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));

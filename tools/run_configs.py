@@ -79,8 +79,8 @@ def run(name, cfg, reps, storage, with_cpu):
                storage={abi.STORE_F32: "f32", abi.STORE_F64: "f64", abi.STORE_F32_CSC: "csc"}[storage],
                gpu_affinity_ms=round(float(np.median(ta)), 4), gpu_solve_ms=round(float(np.median(ts)), 4),
                passes=int(sol.n_passes), gemv_us=round(float(np.median(gemv)), 2),
-               gemv_GBps=round(tm.gemv_bytes / (float(np.median(gemv)) * 1e-6) / 1e9, 1),
-               frac_of_8TBps=round(tm.gemv_bytes / (float(np.median(gemv)) * 1e-6) / 8e12, 4),
+               gemv_GBps=round(tm.gemv_bytes / max(float(np.median(gemv)), 1e-9) * 1e-3, 1),
+               frac_of_8TBps=round(tm.gemv_bytes / max(float(np.median(gemv)), 1e-9) / 8e6, 4),
                score=sol.score, nodes=int(len(sol.nodes)), ifinal=int(sol.ifinal))
     prec, rec = synth.precision_recall(g.get_selected_associations(), p.Agt)
     row.update(precision=round(prec, 4), recall=round(rec, 4))
