@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_get_matrix", "clipper_hip_solve", "clipper_hip_get_nodes",
     "clipper_hip_get_selected_associations", "clipper_hip_matvec", "clipper_hip_set_profiling",
     "clipper_hip_set_window", "clipper_hip_window", "clipper_hip_densest_subgraph",
-    "clipper_hip_storage_in_use",
+    "clipper_hip_storage_in_use", "clipper_hip_knn", "clipper_hip_distance_based_correspondences",
     "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
     "clipper_hip_affinity_pointnormal_staged", "clipper_hip_stage_u0",
@@ -143,6 +143,10 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_set_window.argtypes = [vp, C.c_int]
     L.clipper_hip_window.argtypes = [vp]
     L.clipper_hip_storage_in_use.argtypes = [vp]
+    L.clipper_hip_knn.argtypes = [C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_int, C.c_int, ip, dp]
+    L.clipper_hip_distance_based_correspondences.argtypes = [
+        C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, ip, C.c_int64]
+    L.clipper_hip_distance_based_correspondences.restype = C.c_int64
     L.clipper_hip_set_profiling.argtypes = [vp, C.c_int]
     L.clipper_hip_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.clipper_hip_bench_matvec.argtypes = [vp, C.c_int, dp]
@@ -402,3 +406,42 @@ class HipClipper:
 
 def device_count() -> int:
     return int(load_library().clipper_hip_device_count())
+
+
+def _last_error() -> str:
+    L = load_library()
+    return (L.clipper_hip_last_error() or b"").decode()
+
+
+def knn(P0, P1, knn: int, device: int = 0):
+    """k nearest neighbours in P1 (d x n1) of every point of P0 (d x n0), columns = points as
+    `clipper::Data`. Returns (idx n0 x knn int32, sqd n0 x knn)."""
+    L = load_library()
+    P0c, P1c = _f64_colmajor(P0), _f64_colmajor(P1)
+    d, n0 = P0c.shape
+    n1 = P1c.shape[1]
+    idx = np.zeros((n0, knn), dtype=np.int32)
+    sqd = np.zeros((n0, knn), dtype=np.float64)
+    rc = L.clipper_hip_knn(device, _dp(P0c), n0, _dp(P1c), n1, d, knn, _ip(idx), _dp(sqd))
+    if rc != 0:
+        raise RuntimeError(f"clipper_hip error {rc}: {_last_error()}")
+    return idx, sqd
+
+
+def distance_based_correspondences(P0, P1, knn: int, radius: float, enforce_1to1: bool,
+                                   device: int = 0) -> np.ndarray:
+    """utils::distance_based_correspondences of the reference benchmark (bm_utils.cpp:147-232) on
+    the device. P0: d x n0, P1: d x n1 (columns = points). Returns the associations n x 2."""
+    L = load_library()
+    P0c, P1c = _f64_colmajor(P0), _f64_colmajor(P1)
+    d, n0 = P0c.shape
+    n1 = P1c.shape[1]
+    cap = n0 * knn
+    buf = np.zeros(2 * max(cap, 1), dtype=np.int32)
+    n = L.clipper_hip_distance_based_correspondences(device, _dp(P0c), n0, _dp(P1c), n1, d, knn,
+                                                     float(radius), int(bool(enforce_1to1)),
+                                                     _ip(buf), cap)
+    if n < 0:
+        raise RuntimeError(f"clipper_hip error {n}: {_last_error()}")
+    n = int(n)
+    return np.stack([buf[:n], buf[n:2 * n]], axis=1).astype(np.int32)

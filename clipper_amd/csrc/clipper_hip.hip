@@ -30,6 +30,7 @@
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <map>
 #include <vector>
 
 #include "../../include/clipper_hip.h"
@@ -1218,6 +1219,21 @@ int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32
 }  // namespace
 
 // ============================================================================================
+// brute-force nearest neighbours: launch of the two kernels for one (K, D)
+namespace {
+
+template <int K, int D>
+int knn_run(const double* dP0, int64_t n0, const double* dP1, int64_t n1, int S, int64_t chunk,
+            double* pd, int32_t* pi, double* od, int32_t* oi, hipStream_t st) {
+  dim3 g(static_cast<unsigned>(ceil_div(n0, 256)), static_cast<unsigned>(S));
+  hipLaunchKernelGGL((k_knn_partial<K, D>), g, dim3(256), 0, st, dP0, n0, dP1, n1, chunk, pd, pi);
+  hipLaunchKernelGGL((k_knn_merge<K>), dim3(static_cast<unsigned>(ceil_div(n0, 256))), dim3(256), 0,
+                     st, pd, pi, n0, S, od, oi);
+  return 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* clipper_hip_last_error(void) { return g_err.c_str(); }
@@ -1942,6 +1958,118 @@ int clipper_hip_densest_subgraph(clipper_hip_t* h, const int32_t* S, int32_t k, 
   const int32_t n = static_cast<int32_t>(nodes.size());
   if (capacity < n) return fail(CLIPPER_HIP_E_INVALID, "capacity %d < %d nodes", capacity, n);
   if (n) std::memcpy(nodes_out, nodes.data(), static_cast<size_t>(n) * sizeof(int32_t));
+  return n;
+}
+
+// ---- putative associations (before the path): brute-force nearest neighbours -------------------
+
+int clipper_hip_knn(int device, const double* P0, int64_t n0, const double* P1, int64_t n1, int d,
+                    int knn, int32_t* idx_out, double* sqd_out) {
+  if (!P0 || !P1 || !idx_out || n0 < 1 || n1 < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (d != 2 && d != 3) return fail(CLIPPER_HIP_E_INVALID, "points must have 2 or 3 coordinates");
+  if (knn < 1 || knn > 16) return fail(CLIPPER_HIP_E_INVALID, "knn must be in 1..16");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(CLIPPER_HIP_E_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(CLIPPER_HIP_E_INVALID, "device %d out of range", device);
+  HIPCHK(hipSetDevice(device));
+  const int K = knn <= 1 ? 1 : (knn <= 2 ? 2 : (knn <= 4 ? 4 : (knn <= 8 ? 8 : 16)));
+  // enough workgroups to fill the chip: split pcd1 into S chunks of whole tiles
+  const int64_t qblocks = ceil_div(n0, 256);
+  const int64_t tiles = ceil_div(n1, KNN_TILE);
+  const int S = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(512, qblocks))));
+  const int64_t chunk = ceil_div(tiles, S) * KNN_TILE;
+  double *dP0 = nullptr, *dP1 = nullptr, *pd = nullptr, *od = nullptr;
+  int32_t *pi = nullptr, *oi = nullptr;
+  auto cleanup = [&]() {
+    hipFree(dP0); hipFree(dP1); hipFree(pd); hipFree(od); hipFree(pi); hipFree(oi);
+  };
+  const size_t b0 = static_cast<size_t>(n0) * d * sizeof(double), b1 = static_cast<size_t>(n1) * d * sizeof(double);
+  const size_t np = static_cast<size_t>(S) * n0 * K, no = static_cast<size_t>(n0) * K;
+  if (hipMalloc(&dP0, b0) != hipSuccess || hipMalloc(&dP1, b1) != hipSuccess ||
+      hipMalloc(&pd, np * sizeof(double)) != hipSuccess || hipMalloc(&pi, np * sizeof(int32_t)) != hipSuccess ||
+      hipMalloc(&od, no * sizeof(double)) != hipSuccess || hipMalloc(&oi, no * sizeof(int32_t)) != hipSuccess) {
+    cleanup();
+    return fail(CLIPPER_HIP_E_NOMEM, "device allocation failed");
+  }
+  hipStream_t st = nullptr;  // the default stream: a stand-alone call
+  bool ok = hipMemcpyAsync(dP0, P0, b0, hipMemcpyHostToDevice, st) == hipSuccess &&
+            hipMemcpyAsync(dP1, P1, b1, hipMemcpyHostToDevice, st) == hipSuccess;
+  if (ok) {
+#define KNN_CASE(KK)                                                                        \
+  case KK:                                                                                  \
+    if (d == 3) knn_run<KK, 3>(dP0, n0, dP1, n1, S, chunk, pd, pi, od, oi, st);             \
+    else knn_run<KK, 2>(dP0, n0, dP1, n1, S, chunk, pd, pi, od, oi, st);                    \
+    break
+    switch (K) {
+      KNN_CASE(1);
+      KNN_CASE(2);
+      KNN_CASE(4);
+      KNN_CASE(8);
+      default:
+        if (d == 3) knn_run<16, 3>(dP0, n0, dP1, n1, S, chunk, pd, pi, od, oi, st);
+        else knn_run<16, 2>(dP0, n0, dP1, n1, S, chunk, pd, pi, od, oi, st);
+        break;
+    }
+#undef KNN_CASE
+    std::vector<double> hd(no);
+    std::vector<int32_t> hi(no);
+    ok = hipMemcpy(hd.data(), od, no * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(hi.data(), oi, no * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipGetLastError() == hipSuccess;
+    if (ok) {
+      for (int64_t i = 0; i < n0; ++i)
+        for (int k = 0; k < knn; ++k) {
+          idx_out[i * knn + k] = hi[static_cast<size_t>(i) * K + k];
+          if (sqd_out) sqd_out[i * knn + k] = hd[static_cast<size_t>(i) * K + k];
+        }
+    }
+  }
+  cleanup();
+  if (!ok) return fail(CLIPPER_HIP_E_HIP, "nearest-neighbour search failed: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
+int64_t clipper_hip_distance_based_correspondences(int device, const double* P0, int64_t n0,
+                                                   const double* P1, int64_t n1, int d, int knn,
+                                                   double radius, int enforce_1to1, int32_t* A_out,
+                                                   int64_t capacity) {
+  if (!A_out && capacity > 0) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  std::vector<int32_t> idx(static_cast<size_t>(std::max<int64_t>(n0, 0)) * std::max(knn, 0));
+  std::vector<double> sqd(idx.size());
+  int rc = clipper_hip_knn(device, P0, n0, P1, n1, d, knn, idx.data(), sqd.data());
+  if (rc) return rc;
+  // bm_utils.cpp:187-229: rows (i, nn_j(i)) for i ascending, neighbours by distance, kept if within
+  // the radius; one-to-one: per point of pcd1 (ascending) the FIRST closest of its claimants
+  const double r2 = radius * radius;
+  std::vector<std::pair<int32_t, int32_t>> rows;
+  std::map<int32_t, std::vector<std::pair<int32_t, double>>> claim;
+  for (int64_t i = 0; i < n0; ++i)
+    for (int k = 0; k < knn; ++k) {
+      const int32_t c1 = idx[static_cast<size_t>(i) * knn + k];
+      const double sd = sqd[static_cast<size_t>(i) * knn + k];
+      if (c1 < 0) continue;  // fewer than knn points in pcd1
+      if (sd <= r2) {
+        rows.emplace_back(static_cast<int32_t>(i), c1);
+        if (enforce_1to1) claim[c1].emplace_back(static_cast<int32_t>(i), sd);
+      }
+    }
+  if (enforce_1to1) {
+    rows.clear();
+    for (const auto& it : claim) {
+      size_t best = 0;
+      for (size_t q = 1; q < it.second.size(); ++q)
+        if (it.second[q].second < it.second[best].second) best = q;  // std::min_element: first minimum
+      rows.emplace_back(it.second[best].first, it.first);
+    }
+  }
+  const int64_t n = static_cast<int64_t>(rows.size());
+  if (n > capacity) return fail(CLIPPER_HIP_E_INVALID, "capacity %lld < %lld associations",
+                                static_cast<long long>(capacity), static_cast<long long>(n));
+  for (int64_t r = 0; r < n; ++r) {  // column-major n x 2, as clipper::Association
+    A_out[r] = rows[static_cast<size_t>(r)].first;
+    A_out[n + r] = rows[static_cast<size_t>(r)].second;
+  }
   return n;
 }
 

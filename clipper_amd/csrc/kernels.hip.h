@@ -30,6 +30,7 @@
 //   k_csc.hip.h       the compressed storage: layout, emission, k_csc_build, k_csc_expand, k_gemv_csc
 //   k_affinity.hip.h  k_gather_points, k_affinity_* (plain, compacting strips, symmetric tiles + emission)
 //   k_matrix.hip.h    k_from_dense_upper, k_from_csc, k_gather_sub
+//   k_knn.hip.h       brute-force k-nearest neighbours (putative associations)
 #pragma once
 
 #include "k_solver.hip.h"
@@ -37,3 +38,4 @@
 #include "k_csc.hip.h"
 #include "k_affinity.hip.h"
 #include "k_matrix.hip.h"
+#include "k_knn.hip.h"

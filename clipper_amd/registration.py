@@ -160,3 +160,61 @@ def precision_recall(Ain: np.ndarray, Agt: np.ndarray):
     gt = {tuple(r) for r in np.asarray(Agt).tolist()}
     hit = len(sel & gt)
     return (hit / len(sel) if sel else 0.0), (hit / len(gt) if gt else 0.0)
+
+
+# ---- the reference benchmark's putative-association recipe (benchmarks/main.cpp:156-166) --------
+
+def scale_to_cube(pts: np.ndarray, s: float = 1.0) -> np.ndarray:
+    """bm_utils.cpp:110-115: uniform scale so that the longest bounding-box edge is `s`."""
+    d = pts.max(axis=0) - pts.min(axis=0)
+    return pts * (s / d.max())
+
+
+def bounded_normal_noise(rng: np.random.Generator, n: int, sigma: float, beta: float) -> np.ndarray:
+    """bm_utils.cpp:117-143: N(0, sigma^2 I) conditioned on ||v|| <= beta (batched rejection)."""
+    eta = rng.normal(0.0, sigma, (n, 3))
+    bad = np.linalg.norm(eta, axis=1) > beta
+    while bad.any():
+        eta[bad] = rng.normal(0.0, sigma, (int(bad.sum()), 3))
+        bad = np.linalg.norm(eta, axis=1) > beta
+    return eta
+
+
+def ground_truth_associations(pcd0: np.ndarray, pcd1: np.ndarray, radius: float, device: int = 0):
+    """main.cpp:85-91: one-to-one nearest-neighbour associations within `radius`, on the GPU
+    (clipper_hip_distance_based_correspondences). pcd*: n x 3, rows = points."""
+    from . import _abi as abi
+    return abi.distance_based_correspondences(pcd0.T, pcd1.T, 1, radius, True, device=device)
+
+
+def generate_synthetic_correspondences(n0: int, n1: int, Agood: np.ndarray, m: int, rho: float,
+                                       rng: np.random.Generator):
+    """bm_utils.cpp:277-341: m putative associations with outlier ratio rho — round(m (1 - rho))
+    inliers drawn without replacement from Agood (placed last), the rest sampled uniformly without
+    repetition from all n0*n1 pairs that are not in Agood (placed first). Returns (A, Agt) or None
+    when Agood holds too few associations."""
+    if not 0.0 <= rho <= 1.0:
+        raise ValueError("outlier ratio must be in [0, 1]")
+    ni = int(round(m * (1.0 - rho)))
+    no = m - ni
+    if ni > len(Agood):
+        return None
+    Agt = np.asarray(Agood)[rng.permutation(len(Agood))[:ni]].astype(np.int32)
+    good = np.asarray(Agood, dtype=np.int64)
+    good_flat = set((good[:, 0] * n1 + good[:, 1]).tolist())
+    out = np.zeros((no, 2), dtype=np.int32)
+    seen: set = set()
+    k = 0
+    while k < no:
+        cand = rng.integers(0, n0 * n1, size=2 * (no - k) + 8)
+        for flat in cand.tolist():
+            if flat in seen:
+                continue
+            seen.add(flat)
+            if flat in good_flat:
+                continue
+            out[k] = (flat // n1, flat % n1)
+            k += 1
+            if k == no:
+                break
+    return np.concatenate([out, Agt], axis=0), Agt

@@ -179,6 +179,25 @@ int clipper_hip_get_selected_associations(const clipper_hip_t* h, int32_t* A_out
 int clipper_hip_densest_subgraph(clipper_hip_t* h, const int32_t* S, int32_t k,
                                  int32_t* nodes_out, int32_t capacity);
 
+/* ---- before the path: putative associations ------------------------------------------------ */
+
+/* k nearest neighbours in P1 of every point of P0 (both d x n column-major as `clipper::Data`:
+ * each point contiguous; d = 2 | 3; knn <= 16), squared L2 distances ascending, brute force on
+ * the device — what the nanoflann kd-tree queries of benchmarks/bm_utils.cpp:147-176 return.
+ * idx_out / sqd_out (may be NULL): n0 x knn row-major; -1 / 1e300 where P1 has fewer points.
+ * Among exactly equal distances the lower index comes first. Stand-alone: needs no context. */
+int clipper_hip_knn(int device, const double* P0, int64_t n0, const double* P1, int64_t n1, int d,
+                    int knn, int32_t* idx_out, double* sqd_out);
+
+/* utils::distance_based_correspondences (benchmarks/bm_utils.cpp:147-232): associations
+ * (i, nn_k(i)) within `radius`, i ascending / neighbours by distance; with enforce_1to1 one row
+ * per point of P1 (ascending) — its closest claimant. A_out: column-major n x 2 with n = the
+ * return value (<0: error); capacity in rows (n0*knn always suffices). */
+int64_t clipper_hip_distance_based_correspondences(int device, const double* P0, int64_t n0,
+                                                   const double* P1, int64_t n1, int d, int knn,
+                                                   double radius, int enforce_1to1,
+                                                   int32_t* A_out, int64_t capacity);
+
 /* Line-search window: how many consecutive step sizes alpha, alpha*beta, ... of the
  * backtracking line search (clipper.cpp:234-251) one pass over M evaluates at once. The
  * trial sequence, the accepted trial and the result are those of the reference for every
