@@ -1,0 +1,190 @@
+// host_state.hpp — host-side state: constants, the RCCL binding, Shard (one column slice on one device), the context
+// Part of clipper_hip.hip (one translation unit; included there, in order).
+#pragma once
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(e_ == hipErrorOutOfMemory ? CLIPPER_HIP_E_NOMEM : CLIPPER_HIP_E_HIP, \
+                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+                  __LINE__);                                                          \
+  } while (0)
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// mat-vec kernel geometry (tuned on MI355X)
+constexpr int GEMV_NW = 8;      // waves per workgroup
+constexpr int GEMV_WG_PER_CU = 2;
+// rows in flight per wave: 8 x 16 B per lane for fp32 storage and windows up to 6 vectors (one
+// accumulator set per candidate: 48 registers at V = 6); the 8-vector window keeps 4 rows in
+// flight (tools/mv_tune.hip); halved for fp64 storage (32 B per lane and row) and again with an
+// explicit C matrix
+constexpr int gemv_unr(int V, int esize, bool hasc) {
+  int u = (V <= 6) ? 8 : 4;
+  if (esize == 8) u /= 2;
+  if (hasc) u /= 2;
+  return u < 1 ? 1 : u;
+}
+// line-search candidates per pass: 6 from m = 6000 on, 4 from m = 2000 on, else 1 (an iteration
+// is latency-bound there: at m = 100 and 1k the 10 % fewer passes of a window of 4 cost 10 %
+// more per iteration; at m = 5k it is 20 % fewer for 15 %); CLIPPER_HIP_WINDOW = 1|4|6|8 overrides
+constexpr int64_t WINDOW_MIN_M = 6000;
+constexpr int64_t WINDOW4_MIN_M = 2000;
+// multi-process: iterations queued between two state snapshots. Up to two batches of no-op
+// iterations (each still holds its all-gather) run past convergence: keep them short. 16 -> 4
+// changes nothing on a 1-rank world (tools/rank1_probe.py).
+constexpr int SOLVE_BATCH = 4;
+constexpr int RUN_AHEAD = 4;     // one process: iterations kept queued ahead of the device
+constexpr int MAX_EVENT_PAIRS = 256;  // per solve; created when profiling is switched on
+// time every 20th iteration's mat-vec: an event pair costs ~30 us of stream time (the launches
+// around it no longer pipeline) — every 8th was 0.13 ms of a 2.0 ms step at m = 10k
+constexpr int PROFILE_EVERY = 20;
+
+// ---- RCCL, bound at run time so the single-GPU path never loads librccl -----------------
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.lib) return 0;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* n : names) {
+    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(CLIPPER_HIP_E_COMM, "cannot load librccl: %s", dlerror());
+  auto sym = [&](const char* s) { return dlsym(lib, s); };
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
+  g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(sym("ncclAllGather"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+  g_rccl.GetErrorString =
+      reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+    return fail(CLIPPER_HIP_E_COMM, "librccl is missing required symbols");
+  g_rccl.lib = lib;
+  return 0;
+}
+
+// ---- one column slice of M on one device ------------------------------------------------
+struct Shard {
+  int device = 0;
+  int slot = 0;  // global shard index: owns columns [slot*W, slot*W + W)
+  hipStream_t stream = nullptr;
+  void* S = nullptr;   // m x W, element = float | double
+  void* Cs = nullptr;  // explicit constraint matrix, same shape (only when C != pattern(M))
+  double* part = nullptr;  // [ntiles][2][W]
+  double* u0 = nullptr;
+  double* pt = nullptr;    // point slots [2][V][2][mp]
+  double* cab = nullptr;   // (a, b) of the last pair-mode pass [2][mp]
+  double* X[2] = {nullptr, nullptr};  // candidate tables [V+1][mp][VS], see SolveArgs
+  double* ab = nullptr;    // [P][NSLOT][W]
+  double* scal = nullptr;  // [nwg][Q] partial scalars of k_tail
+  SolverState* st = nullptr;      // ST[2], see SolverState
+  uint8_t* marks = nullptr;       // [KIND_CAP] per-iteration pass marks (profiling), see SolveArgs
+  SolveShared* shared = nullptr;
+  // affinity inputs (staged once, reused while the sizes fit)
+  double *P1 = nullptr, *P2 = nullptr;  // gathered point tables [d][pstride]
+  float *P1f = nullptr, *P2f = nullptr; // the same, rounded to fp32 (prefilter input)
+  size_t capPf = 0;
+  int32_t* Adev = nullptr;              // [2][m]
+  double *dD1 = nullptr, *dD2 = nullptr;  // raw D1, D2 as uploaded
+  size_t capP = 0, capA = 0, capD1 = 0, capD2 = 0;
+  hipEvent_t ev_reduced = nullptr, ev_copied = nullptr;
+  size_t bytes_S = 0;
+  size_t part_tiles = 0;  // row tiles `part` has room for
+  // column-compressed copy of M (CLIPPER_HIP_STORE_F32_CSC), see kernels.hip.h
+  uint32_t* cLc = nullptr;
+  uint64_t* cPre = nullptr;
+  float* cvals = nullptr;
+  uint8_t* crows = nullptr;
+  int* ctb = nullptr;
+  CscBuildCtl* cctl = nullptr;
+  size_t ccap_units = 0, ccap_groups = 0, ccap_tb = 0;
+  int c_ntmax = 0;        // row tiles per strip of this shard's plan
+  uint64_t c_units = 0;   // sum of the padded list lengths (units of 128 entries)
+};
+
+}  // namespace
+
+struct clipper_hip_ctx {
+  int storage = CLIPPER_HIP_STORE_F32;
+  int world = 1;        // total shards P
+  bool multiproc = false;
+  std::vector<Shard> sh;  // local shards
+  ncclComm_t comm = nullptr;
+
+  int64_t m = 0;  // associations / matrix dimension
+  int64_t W = 0;  // shard pitch
+  int64_t alloc_m = 0, alloc_W = 0;
+  bool has_matrix = false;
+  bool explicitC = false;
+  bool compressed = false;   // CLIPPER_HIP_STORE_F32_CSC was asked for
+  bool csc_valid = false;    // ... and the compressed copy of the current matrix exists
+  bool csc_emitted = false;  // the fill kernel of this build wrote the groups itself
+  CscOut csc_out{};          // what that kernel was given
+  int csc_nblocks = 0, csc_nstrips = 0;
+  uint32_t* csc_hLc = nullptr;     // pinned host copy of Lc
+  CscBuildCtl* csc_hctl = nullptr; // pinned host copy of the build's counters
+  int* csc_htb = nullptr;          // pinned staging of the tile boundaries
+  size_t csc_hcap_groups = 0, csc_hcap_tb = 0;
+  int staged_d = 0;          // dimension of the staged point tables (0 = nothing staged)
+  double staged_maxabs = 0;  // max |coordinate| of D1, D2: bounds the fp32 prefilter's error
+  bool plain_affinity = false;  // CLIPPER_HIP_AFFINITY=plain: non-compacting fill kernels
+  bool strip_affinity = false;  // CLIPPER_HIP_AFFINITY=strip: compacting strip kernels even where
+                                // the symmetric tile kernel applies (one shard, fp32 storage)
+  int64_t staged_pstride = 0;
+  bool u0_staged = false;
+  int ntiles = 1, rows_per_tile = 0, nstrips = 0;
+  int cus = 256;
+
+  std::vector<int32_t> A;  // column-major m x 2 (host copy)
+  std::vector<int32_t> nodes;
+
+  SolveShared* host_state = nullptr;  // pinned, 2 slots (multi-process snapshots)
+  hipEvent_t ev_poll[2] = {nullptr, nullptr};
+  HostMirror* mirror = nullptr;      // pinned + coherent: progress record written by the device
+  HostMirror* mirror_dev = nullptr;  // its device address
+  uint8_t* kind = nullptr;           // pinned + coherent: per-iteration pass / transition marks
+  uint8_t* kind_dev = nullptr;       // (profiling only), written by the device
+  double* u_pinned = nullptr;        // pinned staging of the final u (the device writes it)
+  double* u_pinned_dev = nullptr;    // its device address
+  size_t u_pinned_cap = 0;
+  int V = 6;               // line-search window: candidate vectors per pass
+  int V_forced = 0;        // CLIPPER_HIP_WINDOW
+  int64_t mp = 0;          // rows of a candidate table
+  int par = 0;             // which table set the next launch reads
+
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created by clipper_hip_set_profiling
+  std::vector<int64_t> ev_launch_index;  // which mat-vec launch of the solve each pair timed
+  int ev_used = 0;
+  int64_t launch_counter = 0;
+  clipper_hip_timings_t tm{};
+
+  size_t esize() const { return storage == CLIPPER_HIP_STORE_F64 ? 8 : 4; }
+};
