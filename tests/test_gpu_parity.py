@@ -539,3 +539,4 @@ def test_dsd_rounding_matches_the_oracle(m, rho, seed):
         sub = Mup[np.ix_(nodes, nodes)]
         return (sub + sub.T).sum() / 2.0 / max(1, len(nodes))
     assert density(sg.nodes.tolist()) >= density(sh.nodes.tolist()) - 1e-12
+
