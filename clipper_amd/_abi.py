@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CLIPPER_HIP_LIB: alternate build of the same library (A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("CLIPPER_HIP_LIB") or os.path.join(_HERE, "lib", "libclipper_hip.so")
 
-STORE_F32, STORE_F64, STORE_F32_CSC = 0, 1, 2
+STORE_F32, STORE_F64, STORE_F32_CSC, STORE_F64_CSC = 0, 1, 2, 3
 ROUNDING_NONZERO, ROUNDING_DSD, ROUNDING_DSD_HEU = 0, 1, 2
 
 # every symbol include/clipper_hip.h declares (checked by tests/test_abi_exports.py)

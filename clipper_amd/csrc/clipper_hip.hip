@@ -146,9 +146,12 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   if (h->mirror) hipHostFree(h->mirror);
   if (h->kind) hipHostFree(h->kind);
   if (h->u_pinned) hipHostFree(h->u_pinned);
-  if (h->csc_hLc) hipHostFree(h->csc_hLc);
+  if (h->ev_aff[0]) hipEventDestroy(h->ev_aff[0]);
+  if (h->ev_aff[1]) hipEventDestroy(h->ev_aff[1]);
+  if (h->csc_hLq) hipHostFree(h->csc_hLq);
   if (h->csc_hctl) hipHostFree(h->csc_hctl);
-  if (h->csc_htb) hipHostFree(h->csc_htb);
+  if (h->csc_htotal) hipHostFree(h->csc_htotal);
+  if (h->csc_hwork) hipHostFree(h->csc_hwork);
   delete h;
 }
 
@@ -193,7 +196,7 @@ int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double
       else
         launch_sym(k_affinity_sym<2, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
                    pstride, A0, A1, prm, none, E2, h->csc_out);
-      h->csc_emitted = (h->csc_out.Lc != nullptr);
+      h->csc_emitted = (h->csc_out.Goff != nullptr);
       return;
     }
     const bool compact = !h->plain_affinity && (d == 2 || d == 3);
@@ -234,7 +237,7 @@ int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, doubl
       const EuclidParams none{};
       launch_sym(k_affinity_sym<3, true>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
                  pstride, s.Adev, s.Adev + mm, none, prm, guarded_threshold_sq(thr), h->csc_out);
-      h->csc_emitted = (h->csc_out.Lc != nullptr);
+      h->csc_emitted = (h->csc_out.Goff != nullptr);
       return;
     }
     if (h->plain_affinity) {
@@ -306,22 +309,41 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
   if (!h || !M || !C || m < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (h->A.size() != static_cast<size_t>(2 * m)) h->A.clear();
   h->nodes.clear();
+  h->has_matrix = false;  // until the new matrix is complete
+  h->csc_valid = false;
   int rc = ensure_problem(h, m);
   if (rc) return rc;
+  h->has_matrix = false;
   h->csc_valid = false;
   if ((rc = ensure_dense(h, false))) return rc;
   const size_t bytes = static_cast<size_t>(m) * m * sizeof(double);
   const int64_t W = h->W;
+  // device temporaries of this call, released on every path
+  struct Temps {
+    std::vector<std::pair<int, void*>> v;
+    ~Temps() {
+      for (auto& p : v) {
+        hipSetDevice(p.first);
+        hipFree(p.second);
+      }
+    }
+    int alloc(int dev, void** p, size_t n) {
+      HIPCHK(hipMalloc(p, n));
+      v.emplace_back(dev, *p);
+      return 0;
+    }
+  } tmp;
   // pass 1: fill S and detect whether C is anything other than pattern(M)
   std::vector<double*> dM(h->sh.size(), nullptr), dC(h->sh.size(), nullptr);
   std::vector<int*> dflag(h->sh.size(), nullptr);
   int mismatch = 0;
+  const unsigned gy = static_cast<unsigned>(std::min<int64_t>(m, 65535));
   for (size_t k = 0; k < h->sh.size(); ++k) {
     Shard& s = h->sh[k];
     HIPCHK(hipSetDevice(s.device));
-    HIPCHK(hipMalloc(&dM[k], bytes));
-    HIPCHK(hipMalloc(&dC[k], bytes));
-    HIPCHK(hipMalloc(&dflag[k], sizeof(int)));
+    if ((rc = tmp.alloc(s.device, reinterpret_cast<void**>(&dM[k]), bytes))) return rc;
+    if ((rc = tmp.alloc(s.device, reinterpret_cast<void**>(&dC[k]), bytes))) return rc;
+    if ((rc = tmp.alloc(s.device, reinterpret_cast<void**>(&dflag[k]), sizeof(int)))) return rc;
     HIPCHK(hipMemsetAsync(dflag[k], 0, sizeof(int), s.stream));
     HIPCHK(hipMemcpyAsync(dM[k], M, bytes, hipMemcpyHostToDevice, s.stream));
     HIPCHK(hipMemcpyAsync(dC[k], C, bytes, hipMemcpyHostToDevice, s.stream));
@@ -329,7 +351,7 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
       hipFree(s.Cs);
       s.Cs = nullptr;
     }
-    dim3 grid(static_cast<unsigned>(ceil_div(W, 256)), static_cast<unsigned>(m)), block(256);
+    dim3 grid(static_cast<unsigned>(ceil_div(W, 256)), gy), block(256);
     const int64_t c0 = static_cast<int64_t>(s.slot) * W;
     if (h->storage == CLIPPER_HIP_STORE_F64)
       hipLaunchKernelGGL((k_from_dense_upper<double>), grid, block, 0, s.stream,
@@ -342,6 +364,7 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
     int f = 0;
     HIPCHK(hipMemcpyAsync(&f, dflag[k], sizeof(int), hipMemcpyDeviceToHost, s.stream));
     HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipGetLastError());
     mismatch |= f;
   }
   // NOTE: in multi-process mode every rank sees the whole (M, C), so `mismatch` agrees.
@@ -364,7 +387,7 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
       Shard& s = h->sh[k];
       HIPCHK(hipSetDevice(s.device));
       HIPCHK(hipMalloc(&s.Cs, s.bytes_S));
-      dim3 grid(static_cast<unsigned>(ceil_div(W, 256)), static_cast<unsigned>(m)), block(256);
+      dim3 grid(static_cast<unsigned>(ceil_div(W, 256)), gy), block(256);
       const int64_t c0 = static_cast<int64_t>(s.slot) * W;
       if (h->storage == CLIPPER_HIP_STORE_F64)
         hipLaunchKernelGGL((k_from_dense_upper<double>), grid, block, 0, s.stream,
@@ -376,48 +399,179 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
                            static_cast<float*>(s.Cs), static_cast<int*>(nullptr));
     }
   }
-  rc = sync_all(h);
-  for (size_t k = 0; k < h->sh.size(); ++k) {
-    hipSetDevice(h->sh[k].device);
-    hipFree(dM[k]);
-    hipFree(dC[k]);
-    hipFree(dflag[k]);
-  }
-  if (rc) return rc;
-  rc = csc_rebuild(h);
-  if (rc) return rc;
+  if ((rc = sync_all(h))) return rc;
+  if ((rc = csc_rebuild(h))) return rc;
   h->has_matrix = true;
   return 0;
 }
 
+// setSparseMatrixData (clipper.cpp:162-166). Every stored (i, j), i != j, is an entry of the
+// symmetric matrix (either triangle; the reference reads the upper one); the diagonal is
+// implicit. With compressed storage and C == pattern(M) the slices are packed straight from the
+// lists (no dense intermediate: O(nnz) memory); otherwise through the dense store.
 int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
                            const int32_t* Mrow, const double* Mval, const int64_t* Ccolptr,
                            const int32_t* Crow, const double* Cval) {
   if (!h || !Mcolptr || !Ccolptr || m < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  // the caller's arrays are not trusted: structure first
+  auto check_csc = [&](const char* what, const int64_t* cp, const int32_t* ri, const double* va) -> int {
+    if (cp[0] != 0) return fail(CLIPPER_HIP_E_INVALID, "%s: colptr[0] must be 0", what);
+    for (int64_t c = 0; c < m; ++c)
+      if (cp[c + 1] < cp[c]) return fail(CLIPPER_HIP_E_INVALID, "%s: colptr decreases at column %lld", what, static_cast<long long>(c));
+    const int64_t nnz = cp[m];
+    if (nnz > 0 && (!ri || !va)) return fail(CLIPPER_HIP_E_INVALID, "%s: null CSC arrays", what);
+    for (int64_t p = 0; p < nnz; ++p)
+      if (ri[p] < 0 || ri[p] >= m)
+        return fail(CLIPPER_HIP_E_INVALID, "%s: row index %d out of range at entry %lld", what, ri[p], static_cast<long long>(p));
+    return 0;
+  };
+  int rc;
+  if ((rc = check_csc("M", Mcolptr, Mrow, Mval))) return rc;
+  if ((rc = check_csc("C", Ccolptr, Crow, Cval))) return rc;
   const int64_t nnzM = Mcolptr[m], nnzC = Ccolptr[m];
-  if ((nnzM > 0 && (!Mrow || !Mval)) || (nnzC > 0 && (!Crow || !Cval)))
-    return fail(CLIPPER_HIP_E_INVALID, "null CSC arrays");
   if (h->A.size() != static_cast<size_t>(2 * m)) h->A.clear();
   h->nodes.clear();
-  int rc = ensure_problem(h, m);
-  if (rc) return rc;
+  h->has_matrix = false;
   h->csc_valid = false;
-  if ((rc = ensure_dense(h, false))) return rc;
+  if ((rc = ensure_problem(h, m))) return rc;
+  h->has_matrix = false;
+  h->csc_valid = false;
   // C == pattern(M)?  (same structure, every stored C equal to 1, every stored M non-zero)
   bool pattern = (nnzM == nnzC) && std::equal(Mcolptr, Mcolptr + m + 1, Ccolptr) &&
-                 std::equal(Mrow, Mrow + nnzM, Crow);
+                 (nnzM == 0 || std::equal(Mrow, Mrow + nnzM, Crow));
   for (int64_t p = 0; pattern && p < nnzM; ++p) pattern = (Cval[p] == 1.0) && (Mval[p] != 0.0);
   h->explicitC = !pattern;
   plan_tiles(h);
   const int64_t W = h->W;
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    if (s.Cs) {
+      hipFree(s.Cs);
+      s.Cs = nullptr;
+    }
+  }
+  struct Temps {
+    std::vector<std::pair<int, void*>> v;
+    ~Temps() {
+      for (auto& p : v) {
+        hipSetDevice(p.first);
+        hipFree(p.second);
+      }
+    }
+    int alloc(int dev, void** p, size_t n) {
+      HIPCHK(hipMalloc(p, std::max<size_t>(n, 16)));
+      v.emplace_back(dev, *p);
+      return 0;
+    }
+  } tmp;
+
+  if (csc_applies(h)) {
+    // ---- lists -> slices. Host: the full symmetric lists (both triangles), rows ascending.
+    drop_dense(h);
+    std::vector<int64_t> cp(static_cast<size_t>(m) + 1, 0);
+    for (int64_t j = 0; j < m; ++j)
+      for (int64_t p = Mcolptr[j]; p < Mcolptr[j + 1]; ++p) {
+        const int64_t i = Mrow[p];
+        if (i == j) continue;
+        ++cp[static_cast<size_t>(i) + 1];
+        ++cp[static_cast<size_t>(j) + 1];
+      }
+    for (int64_t c = 0; c < m; ++c) cp[static_cast<size_t>(c) + 1] += cp[static_cast<size_t>(c)];
+    const int64_t nnz2 = cp[static_cast<size_t>(m)];
+    std::vector<int32_t> ri(static_cast<size_t>(nnz2));
+    std::vector<double> va(static_cast<size_t>(nnz2));
+    {
+      std::vector<int64_t> cur(cp.begin(), cp.end() - 1);
+      for (int64_t j = 0; j < m; ++j)
+        for (int64_t p = Mcolptr[j]; p < Mcolptr[j + 1]; ++p) {
+          const int64_t i = Mrow[p];
+          if (i == j) continue;
+          int64_t& a = cur[static_cast<size_t>(j)];
+          ri[static_cast<size_t>(a)] = static_cast<int32_t>(i);
+          va[static_cast<size_t>(a)] = Mval[p];
+          ++a;
+          int64_t& b = cur[static_cast<size_t>(i)];
+          ri[static_cast<size_t>(b)] = static_cast<int32_t>(j);
+          va[static_cast<size_t>(b)] = Mval[p];
+          ++b;
+        }
+    }
+    // strictly-upper input with ascending rows (what Eigen hands over) comes out sorted; anything
+    // else is sorted here; an entry given twice (e.g. in both triangles) is an error
+    std::vector<std::pair<int32_t, double>> buf;
+    for (int64_t c = 0; c < m; ++c) {
+      const int64_t a = cp[static_cast<size_t>(c)], b = cp[static_cast<size_t>(c) + 1];
+      bool sorted = true;
+      for (int64_t p = a + 1; p < b && sorted; ++p) sorted = ri[static_cast<size_t>(p - 1)] < ri[static_cast<size_t>(p)];
+      if (sorted) continue;
+      buf.clear();
+      for (int64_t p = a; p < b; ++p) buf.emplace_back(ri[static_cast<size_t>(p)], va[static_cast<size_t>(p)]);
+      std::sort(buf.begin(), buf.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+      for (size_t q = 1; q < buf.size(); ++q)
+        if (buf[q - 1].first == buf[q].first)
+          return fail(CLIPPER_HIP_E_INVALID, "entry (%d,%lld) is stored more than once", buf[q].first,
+                      static_cast<long long>(c));
+      for (int64_t p = a; p < b; ++p) {
+        ri[static_cast<size_t>(p)] = buf[static_cast<size_t>(p - a)].first;
+        va[static_cast<size_t>(p)] = buf[static_cast<size_t>(p - a)].second;
+      }
+    }
+    for (auto& s : h->sh) {
+      HIPCHK(hipSetDevice(s.device));
+      int64_t* dcp = nullptr;
+      int32_t* dri = nullptr;
+      double* dva = nullptr;
+      if ((rc = tmp.alloc(s.device, reinterpret_cast<void**>(&dcp), cp.size() * sizeof(int64_t)))) return rc;
+      if ((rc = tmp.alloc(s.device, reinterpret_cast<void**>(&dri), ri.size() * sizeof(int32_t)))) return rc;
+      if ((rc = tmp.alloc(s.device, reinterpret_cast<void**>(&dva), va.size() * sizeof(double)))) return rc;
+      HIPCHK(hipMemcpyAsync(dcp, cp.data(), cp.size() * sizeof(int64_t), hipMemcpyHostToDevice, s.stream));
+      if (nnz2 > 0) {
+        HIPCHK(hipMemcpyAsync(dri, ri.data(), ri.size() * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
+        HIPCHK(hipMemcpyAsync(dva, va.data(), va.size() * sizeof(double), hipMemcpyHostToDevice, s.stream));
+      }
+      const int64_t c0 = static_cast<int64_t>(s.slot) * W;
+      dispatch_vt(h, [&](auto t) {
+        using VT = decltype(t);
+        bool again = true;
+        for (int attempt = 0; again && !rc; ++attempt) {
+          if (attempt >= 3) {
+            rc = fail(CLIPPER_HIP_E_HIP, "compressed storage: the build keeps overflowing");
+            break;
+          }
+          GroupOut<VT> unused;
+          if ((rc = groups_prepare<VT>(h, s, unused))) break;  // sizes the per-slice arrays
+          CscSource<VT> src{};
+          src.colptr = dcp + std::min<int64_t>(c0, m);
+          src.rowidx = dri;
+          src.values = dva;
+          src.ncols = std::max<int64_t>(0, std::min<int64_t>(W, m - c0));
+          if ((rc = slices_enqueue<VT>(h, s, src, nullptr))) break;
+          if (hipStreamSynchronize(s.stream) != hipSuccess) {
+            rc = fail(CLIPPER_HIP_E_HIP, "set_sparse: %s", hipGetErrorString(hipGetLastError()));
+            break;
+          }
+          rc = slices_check<VT>(h, s, false, again);
+        }
+      });
+      if (rc) return rc;
+    }
+    if ((rc = sync_all(h))) return rc;
+    h->csc_valid = true;
+    h->has_matrix = true;
+    return 0;
+  }
+
+  // ---- through the dense store (dense storage modes, or an explicit C) ----------------------
+  if ((rc = ensure_dense(h, false))) return rc;
   auto scatter = [&](Shard& s, void* dst, const int64_t* cp, const int32_t* ri, const double* va,
                      int64_t nnz) -> int {
     int64_t* dcp = nullptr;
     int32_t* dri = nullptr;
     double* dva = nullptr;
-    HIPCHK(hipMalloc(&dcp, static_cast<size_t>(m + 1) * sizeof(int64_t)));
-    HIPCHK(hipMalloc(&dri, std::max<size_t>(1, static_cast<size_t>(nnz)) * sizeof(int32_t)));
-    HIPCHK(hipMalloc(&dva, std::max<size_t>(1, static_cast<size_t>(nnz)) * sizeof(double)));
+    int r;
+    if ((r = tmp.alloc(s.device, reinterpret_cast<void**>(&dcp), static_cast<size_t>(m + 1) * sizeof(int64_t)))) return r;
+    if ((r = tmp.alloc(s.device, reinterpret_cast<void**>(&dri), static_cast<size_t>(nnz) * sizeof(int32_t)))) return r;
+    if ((r = tmp.alloc(s.device, reinterpret_cast<void**>(&dva), static_cast<size_t>(nnz) * sizeof(double)))) return r;
     HIPCHK(hipMemcpyAsync(dcp, cp, static_cast<size_t>(m + 1) * sizeof(int64_t),
                           hipMemcpyHostToDevice, s.stream));
     if (nnz > 0) {
@@ -428,25 +582,19 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
     }
     HIPCHK(hipMemsetAsync(dst, 0, s.bytes_S, s.stream));
     const int64_t c0 = static_cast<int64_t>(s.slot) * W;
-    dim3 grid(static_cast<unsigned>(m)), block(256);
+    dim3 grid(static_cast<unsigned>(std::min<int64_t>(m, 1 << 20))), block(256);
     if (h->storage == CLIPPER_HIP_STORE_F64)
       hipLaunchKernelGGL((k_from_csc<double>), grid, block, 0, s.stream,
                          static_cast<double*>(dst), W, m, c0, W, dcp, dri, dva);
     else
       hipLaunchKernelGGL((k_from_csc<float>), grid, block, 0, s.stream, static_cast<float*>(dst),
                          W, m, c0, W, dcp, dri, dva);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s.stream));
-    hipFree(dcp);
-    hipFree(dri);
-    hipFree(dva);
     return 0;
   };
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
-    if (s.Cs) {
-      hipFree(s.Cs);
-      s.Cs = nullptr;
-    }
     rc = scatter(s, s.S, Mcolptr, Mrow, Mval, nnzM);
     if (rc) return rc;
     if (h->explicitC) {
@@ -912,7 +1060,8 @@ int clipper_hip_window(const clipper_hip_t* h) { return h ? h->V : 0; }
 
 int clipper_hip_storage_in_use(const clipper_hip_t* h) {
   if (!h) return -1;
-  return h->csc_valid ? CLIPPER_HIP_STORE_F32_CSC : h->storage;
+  if (!h->csc_valid) return h->storage;
+  return h->storage == CLIPPER_HIP_STORE_F64 ? CLIPPER_HIP_STORE_F64_CSC : CLIPPER_HIP_STORE_F32_CSC;
 }
 
 int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC) {

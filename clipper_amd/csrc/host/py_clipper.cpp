@@ -266,7 +266,8 @@ PYBIND11_MODULE(clipperpy, m) {
   py::enum_<clipper::CLIPPER::Storage>(m, "Storage")
       .value("F32", clipper::CLIPPER::Storage::F32)
       .value("F64", clipper::CLIPPER::Storage::F64)
-      .value("F32_CSC", clipper::CLIPPER::Storage::F32_CSC);
+      .value("F32_CSC", clipper::CLIPPER::Storage::F32_CSC)
+      .value("F64_CSC", clipper::CLIPPER::Storage::F64_CSC);
 
   py::class_<clipper::CLIPPER>(m, "CLIPPER")
       .def(py::init([](const clipper::invariants::PairwiseInvariantPtr& invariant,

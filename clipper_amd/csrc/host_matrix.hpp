@@ -4,36 +4,47 @@
 
 namespace {
 
-// ---- the column-compressed copy (CLIPPER_HIP_STORE_F32_CSC) ---------------------------------
+// ---- the compressed storage (CLIPPER_HIP_STORE_F32_CSC / _F64_CSC): groups -> slices ----------
 bool csc_applies(const Ctx* h) { return csc_possible(h) && !h->explicitC; }
+constexpr int SL_H = 1;  // sub-blocks per chunk (R = 256 rows): see k_slices.hip.h / DESIGN.md
 
-CscView csc_view(const Ctx* h, const Shard& s) {
-  CscView M;
-  M.vals = s.cvals;
-  M.rows = s.crows;
-  M.Lc = s.cLc;
-  M.Pre = s.cPre;
-  M.tb = s.ctb;
-  M.nblocks = h->csc_nblocks;
-  M.ntmax = s.c_ntmax;
+SliceView slice_view(const Ctx* h, const Shard& s) {
+  SliceView M;
+  M.data = s.sdata;
+  M.Pre = s.sPre;
+  M.work = s.swork;
+  M.nchunks = s.s_nchunks;
+  M.ncg = s.s_ncg;
   return M;
 }
 
+// calls f(value type tag) for the storage's element type
+template <typename F>
+void dispatch_vt(const Ctx* h, F&& f) {
+  if (h->storage == CLIPPER_HIP_STORE_F64) f(double{});
+  else f(float{});
+}
+
 // The dense store of every local shard, allocated if it is not; with `from_csc` its content is
-// materialised from the compressed copy when that is all there is.
+// materialised from the slices when they are all there is.
 int ensure_dense(Ctx* h, bool from_csc) {
   for (auto& s : h->sh) {
     if (s.S) continue;
     HIPCHK(hipSetDevice(s.device));
     if (hipMalloc(&s.S, s.bytes_S) != hipSuccess) {
       s.S = nullptr;
+      (void)hipGetLastError();
       return fail(CLIPPER_HIP_E_NOMEM, "dense store of %zu bytes (this call needs one) does not fit",
                   s.bytes_S);
     }
     if (from_csc && h->csc_valid) {
-      dim3 grid(h->csc_nstrips, static_cast<unsigned>(ceil_div(h->csc_nblocks, 2))), block(256);
-      hipLaunchKernelGGL(k_csc_expand, grid, block, 0, s.stream, csc_view(h, s),
-                         static_cast<float*>(s.S), h->W, h->m);
+      const int64_t nsl = static_cast<int64_t>(s.s_ncg) * s.s_nchunks;
+      dim3 grid(static_cast<unsigned>(ceil_div(nsl, 4))), block(256);
+      dispatch_vt(h, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((k_slice_expand<T, SL_H, T>), grid, block, 0, s.stream, slice_view(h, s),
+                           static_cast<T*>(s.S), h->W, h->m);
+      });
       HIPCHK(hipStreamSynchronize(s.stream));
     }
   }
@@ -49,198 +60,307 @@ void drop_dense(Ctx* h) {
   }
 }
 
-// Before the fill: buffers of the group directory, the arenas' cursors reset. Returns what a
-// kernel that emits groups needs (k_affinity_sym, k_csc_build); out.Lc == null: not in use.
-int csc_prepare(Ctx* h, Shard& s, CscOut& out) {
-  out = CscOut{};
+template <typename T>
+int grow_dev(T*& p, size_t& cap, size_t need, size_t elem = sizeof(T)) {
+  if (need <= cap && p) return 0;
+  if (p) hipFree(p);
+  p = nullptr;
+  cap = 0;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(need, 1) * elem));
+  cap = need;
+  return 0;
+}
+
+// Before a fill: the group directory, the arenas' cursors reset, the per-slice arrays. Returns
+// what a kernel that emits groups needs; out.Goff == null: compressed storage not in use.
+template <typename VT>
+int groups_prepare(Ctx* h, Shard& s, GroupOut<VT>& out) {
+  out = GroupOut<VT>{};
   h->csc_valid = false;
   h->csc_emitted = false;
   if (!csc_applies(h)) return 0;
   HIPCHK(hipSetDevice(s.device));
-  const int nblocks = static_cast<int>(ceil_div(h->m, CSC_RB));
-  h->csc_nstrips = static_cast<int>(ceil_div(h->W, CSC_CW));
-  const size_t G = static_cast<size_t>(h->csc_nstrips) * static_cast<size_t>(nblocks);
-  h->csc_nblocks = nblocks;
-  if (G > s.ccap_groups) {
-    if (s.cLc) hipFree(s.cLc);
-    if (s.cPre) hipFree(s.cPre);
-    s.cLc = nullptr;
-    s.cPre = nullptr;
-    HIPCHK(hipMalloc(&s.cLc, G * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&s.cPre, G * sizeof(uint64_t)));
-    s.ccap_groups = G;
+  h->csc_nblocks = static_cast<int>(ceil_div(h->m, GR_RB));
+  h->csc_nstrips = static_cast<int>(ceil_div(h->W, GR_CW));
+  const size_t G = static_cast<size_t>(h->csc_nstrips) * static_cast<size_t>(h->csc_nblocks);
+  if (G > s.gcap_groups) {
+    if (s.gOff) hipFree(s.gOff);
+    if (s.gPre) hipFree(s.gPre);
+    s.gOff = nullptr;
+    s.gPre = nullptr;
+    s.gcap_groups = 0;
+    HIPCHK(hipMalloc(&s.gOff, G * GR_OFFS * sizeof(uint16_t)));
+    HIPCHK(hipMalloc(&s.gPre, G * sizeof(uint64_t)));
+    s.gcap_groups = G;
   }
   if (!s.cctl) HIPCHK(hipMalloc(&s.cctl, CSC_ARENAS * sizeof(CscBuildCtl)));
-  if (G > h->csc_hcap_groups) {
-    if (h->csc_hLc) hipHostFree(h->csc_hLc);
-    h->csc_hLc = nullptr;
-    HIPCHK(hipHostMalloc(&h->csc_hLc, G * sizeof(uint32_t), hipHostMallocDefault));
-    h->csc_hcap_groups = G;
+  s.s_ncg = static_cast<int>(h->W / SL_W);
+  s.s_nchunks = static_cast<int>(ceil_div(h->m, SL_SUB * SL_H));
+  const size_t nsl = static_cast<size_t>(s.s_ncg) * s.s_nchunks;
+  if (nsl > s.scap_slices) {
+    for (void** p : {reinterpret_cast<void**>(&s.sSizes), reinterpret_cast<void**>(&s.sLq),
+                     reinterpret_cast<void**>(&s.sPre), reinterpret_cast<void**>(&s.sBlk)}) {
+      if (*p) hipFree(*p);
+      *p = nullptr;
+    }
+    s.scap_slices = 0;
+    HIPCHK(hipMalloc(&s.sSizes, nsl * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&s.sLq, nsl * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&s.sPre, nsl * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&s.sBlk, (ceil_div(nsl, SCAN_BLK) + 2) * sizeof(uint64_t)));
+    s.scap_slices = nsl;
   }
-  if (!h->csc_hctl) {
+  if (nsl > h->csc_hcap_slices) {
+    if (h->csc_hLq) hipHostFree(h->csc_hLq);
+    h->csc_hLq = nullptr;
+    h->csc_hcap_slices = 0;
+    HIPCHK(hipHostMalloc(&h->csc_hLq, nsl * sizeof(uint32_t), hipHostMallocDefault));
+    h->csc_hcap_slices = nsl;
+  }
+  if (!h->csc_hctl)
     HIPCHK(hipHostMalloc(&h->csc_hctl, 2 * CSC_ARENAS * sizeof(CscBuildCtl), hipHostMallocDefault));
-  }
+  if (!h->csc_htotal) HIPCHK(hipHostMalloc(&h->csc_htotal, 2 * sizeof(uint64_t), hipHostMallocDefault));
   CscBuildCtl* init = h->csc_hctl + CSC_ARENAS;  // second half: what the device starts from
   for (int k = 0; k < CSC_ARENAS; ++k) {
     init[k].cursor = 0;
-    init[k].capacity = s.ccap_units / CSC_ARENAS;
-    init[k].origin = static_cast<unsigned long long>(k) * (s.ccap_units / CSC_ARENAS);
+    init[k].capacity = s.gcap_units / CSC_ARENAS;
+    init[k].origin = static_cast<unsigned long long>(k) * (s.gcap_units / CSC_ARENAS);
     init[k].overflow = 0;
   }
   HIPCHK(hipMemcpyAsync(s.cctl, init, CSC_ARENAS * sizeof(CscBuildCtl), hipMemcpyHostToDevice,
                         s.stream));
-  out.Lc = s.cLc;
-  out.Pre = s.cPre;
-  out.vals = s.cvals;
-  out.rows = s.crows;
+  out.Goff = s.gOff;
+  out.Gpre = s.gPre;
+  out.vals = static_cast<VT*>(s.gvals);
+  out.rows = s.grows;
   out.ctl = s.cctl;
-  out.nblocks = nblocks;
+  out.nblocks = h->csc_nblocks;
   return 0;
 }
 
-// After the fill: the build from the dense store unless the fill kernel emitted the groups
-// itself, then the copies of the counters to pinned host memory (csc_finish() reads them once
-// the stream was synchronised).
-int csc_enqueue(Ctx* h, Shard& s, const CscOut& O) {
-  if (O.Lc == nullptr) return 0;
+// count -> scan -> pack (the pack returns at once if the groups overflowed or the slice arena is
+// too small) -> copies of the counters to pinned host memory; slices_check() reads them once
+// the stream was synchronised.
+template <typename VT, typename Source>
+int slices_enqueue(Ctx* h, Shard& s, const Source& src, const CscBuildCtl* ctl) {
   HIPCHK(hipSetDevice(s.device));
-  if (!h->csc_emitted) {
-    dim3 grid(h->csc_nstrips, static_cast<unsigned>(ceil_div(h->csc_nblocks, 2))), block(256);
-    hipLaunchKernelGGL(k_csc_build, grid, block, 0, s.stream, static_cast<const float*>(s.S), h->W,
-                       h->m, O);
-  }
-  const size_t G = static_cast<size_t>(h->csc_nstrips) * static_cast<size_t>(h->csc_nblocks);
-  HIPCHK(hipMemcpyAsync(h->csc_hctl, s.cctl, CSC_ARENAS * sizeof(CscBuildCtl),
+  const int64_t nsl = static_cast<int64_t>(s.s_ncg) * s.s_nchunks;
+  const int64_t nblk = ceil_div(nsl, SCAN_BLK);
+  dim3 g4(static_cast<unsigned>(ceil_div(nsl, 4))), b256(256);
+  hipLaunchKernelGGL((k_slice_count<VT, SL_H, Source>), g4, b256, 0, s.stream, src, s.s_ncg,
+                     s.s_nchunks, s.sSizes, s.sLq);
+  hipLaunchKernelGGL(k_slice_scan_local, dim3(static_cast<unsigned>(nblk)), b256, 0, s.stream,
+                     s.sSizes, nsl, s.sPre, s.sBlk);
+  hipLaunchKernelGGL(k_slice_scan_blocks, dim3(1), b256, 0, s.stream, s.sBlk, nblk);
+  if (nblk > 1)
+    hipLaunchKernelGGL(k_slice_scan_add, dim3(static_cast<unsigned>(nblk)), b256, 0, s.stream, s.sPre,
+                       nsl, s.sBlk);
+  const uint64_t cap_units = s.scap_bytes >= SL_TAILPAD ? (s.scap_bytes - SL_TAILPAD) / 16 : 0;
+  hipLaunchKernelGGL((k_slice_pack<VT, SL_H, Source>), g4, b256, 0, s.stream, src, s.s_ncg,
+                     s.s_nchunks, s.sPre, s.sdata, s.sBlk + nblk, cap_units, ctl);
+  if (ctl)
+    HIPCHK(hipMemcpyAsync(h->csc_hctl, s.cctl, CSC_ARENAS * sizeof(CscBuildCtl),
+                          hipMemcpyDeviceToHost, s.stream));
+  HIPCHK(hipMemcpyAsync(h->csc_htotal, s.sBlk + nblk, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                        s.stream));
+  HIPCHK(hipMemcpyAsync(h->csc_hLq, s.sLq, static_cast<size_t>(nsl) * sizeof(uint32_t),
                         hipMemcpyDeviceToHost, s.stream));
-  HIPCHK(hipMemcpyAsync(h->csc_hLc, s.cLc, G * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
   return 0;
 }
 
-// Row tiles of equal cost per strip (cost of a block: its padded list length + a constant for
-// the staging of its x rows). The number of workgroups aims at whole waves of co-resident ones
-// (two 8-wave workgroups per CU measured best: every workgroup repeats the decision), at most
-// ~32 blocks each.
-int csc_plan(Ctx* h, Shard& s) {
-  const int nstrips = h->csc_nstrips, nblocks = h->csc_nblocks;
-  const uint32_t* L = h->csc_hLc;
-  const double slots = static_cast<double>(h->cus) * 2.0;
-  const double G = static_cast<double>(nstrips) * nblocks;
-  double target = slots * std::max(1.0, std::ceil(G / (slots * 32.0)));
+template <typename VT>
+GroupSource<VT> group_source(const Ctx* h, const Shard& s) {
+  GroupSource<VT> g{};
+  g.Goff = s.gOff;
+  g.Gpre = s.gPre;
+  g.vals = static_cast<const VT*>(s.gvals);
+  g.rows = s.grows;
+  g.nblocks = h->csc_nblocks;
+  g.ncols = static_cast<int64_t>(h->csc_nstrips) * GR_CW;
+  return g;
+}
+
+// What a pass's workgroups do (SliceWork), planned per matrix from the slices' costs: per strip
+// of SL_NW column groups, runs of chunks of about equal cost (cost of a chunk: its slowest
+// slice — the waves of a workgroup meet at every chunk — plus a constant for the staging); a
+// chunk that alone exceeds the target is split by step range. Most expensive first.
+int slices_plan(Ctx* h, Shard& s) {
+  const int ncg = s.s_ncg, nchunks = s.s_nchunks;
+  const int nstrips = static_cast<int>(ceil_div(ncg, SL_NW));
+  const uint32_t* L = h->csc_hLq;
+  double target = static_cast<double>(h->cus) * 4.0;
   if (const char* e = std::getenv("CLIPPER_HIP_CSC_WGS")) target = std::max(1.0, std::atof(e));
-  std::vector<double> tot(static_cast<size_t>(nstrips), 0.0);
+  std::vector<int> cost(static_cast<size_t>(nstrips) * nchunks);
   double total = 0.0;
-  for (int st = 0; st < nstrips; ++st) {
-    double t = 0.0;
-    for (int b = 0; b < nblocks; ++b) t += static_cast<double>(L[static_cast<size_t>(st) * nblocks + b]) + 2.0;
-    tot[static_cast<size_t>(st)] = t;
-    total += t;
-  }
-  const double Q = total / target;
-  std::vector<int> nts(static_cast<size_t>(nstrips));
-  int ntmax = 1;
-  for (int st = 0; st < nstrips; ++st) {
-    int n = static_cast<int>(std::max(1.0, std::floor(tot[static_cast<size_t>(st)] / Q + 0.5)));
-    n = std::min(n, nblocks);
-    nts[static_cast<size_t>(st)] = n;
-    ntmax = std::max(ntmax, n);
-  }
-  const size_t ntb = static_cast<size_t>(nstrips) * static_cast<size_t>(ntmax + 1);
-  if (ntb > h->csc_hcap_tb) {
-    if (h->csc_htb) hipHostFree(h->csc_htb);
-    h->csc_htb = nullptr;
-    HIPCHK(hipHostMalloc(&h->csc_htb, ntb * sizeof(int), hipHostMallocDefault));
-    h->csc_hcap_tb = ntb;
-  }
-  for (int st = 0; st < nstrips; ++st) {
-    int* t = h->csc_htb + static_cast<size_t>(st) * (ntmax + 1);
-    const int n = nts[static_cast<size_t>(st)];
-    const double T = tot[static_cast<size_t>(st)];
-    double run = 0.0;
-    int k = 1;
-    t[0] = 0;
-    for (int b = 0; b < nblocks; ++b) {
-      run += static_cast<double>(L[static_cast<size_t>(st) * nblocks + b]) + 2.0;
-      while (k < n && run >= T * k / n) t[k++] = b + 1;
+  uint64_t entries = 0;
+  for (int st = 0; st < nstrips; ++st)
+    for (int k = 0; k < nchunks; ++k) {
+      int c = 0;
+      for (int w = 0; w < SL_NW; ++w) {
+        const int cg = st * SL_NW + w;
+        if (cg >= ncg) break;
+        const uint32_t v = L[static_cast<size_t>(cg) * nchunks + k];
+        c = std::max(c, static_cast<int>(v & 255u));
+        entries += v >> 8;
+      }
+      cost[static_cast<size_t>(st) * nchunks + k] = c;
+      total += c + 2.0;
     }
-    for (; k <= ntmax; ++k) t[k] = nblocks;
+  s.s_entries = entries;
+  const double T = std::max(8.0, total / target);
+  struct Item {
+    double cost;
+    SliceWork w;
+  };
+  std::vector<Item> items;
+  std::vector<int> nslot_of(static_cast<size_t>(nstrips), 0);
+  int nslots = 1;
+  for (int st = 0; st < nstrips; ++st) {
+    int slot = 0, start = 0;
+    double acc = 0.0;
+    auto flush = [&](int end) {
+      if (end > start) items.push_back({acc, SliceWork{st, slot++, start, end, 0, 1 << 30, 0, 0}});
+      start = end;
+      acc = 0.0;
+    };
+    for (int k = 0; k < nchunks; ++k) {
+      const int mq = cost[static_cast<size_t>(st) * nchunks + k];
+      const double c = mq + 2.0;
+      if (c > 1.5 * T && mq >= 2 * SL_SO) {
+        flush(k);
+        const int parts = std::min(static_cast<int>(std::ceil(c / T)), static_cast<int>(ceil_div(mq, SL_SO)));
+        const int per = static_cast<int>(round_up(ceil_div(mq, parts), SL_SO));
+        for (int q0 = 0; q0 < mq; q0 += per)
+          items.push_back({std::min(per, mq - q0) + 2.0,
+                           SliceWork{st, slot++, k, k + 1, q0, std::min(q0 + per, mq), 0, 0}});
+        start = k + 1;
+      } else {
+        acc += c;
+        if (acc >= T) flush(k + 1);
+      }
+    }
+    flush(nchunks);
+    nslot_of[static_cast<size_t>(st)] = slot;
+    nslots = std::max(nslots, slot);
   }
+  for (int st = 0; st < nstrips; ++st)  // every (strip, slot) is written by some workgroup
+    for (int slot = nslot_of[static_cast<size_t>(st)]; slot < nslots; ++slot)
+      items.push_back({0.0, SliceWork{st, slot, 0, 0, 0, 0, 0, 0}});
+  std::stable_sort(items.begin(), items.end(),
+                   [](const Item& a, const Item& b) { return a.cost > b.cost; });
+  const size_t nw = items.size();
+  if (nw > h->csc_hcap_work) {
+    if (h->csc_hwork) hipHostFree(h->csc_hwork);
+    h->csc_hwork = nullptr;
+    h->csc_hcap_work = 0;
+    HIPCHK(hipHostMalloc(&h->csc_hwork, nw * sizeof(SliceWork), hipHostMallocDefault));
+    h->csc_hcap_work = nw;
+  }
+  for (size_t i = 0; i < nw; ++i) h->csc_hwork[i] = items[i].w;
   HIPCHK(hipSetDevice(s.device));
-  if (ntb > s.ccap_tb) {
-    if (s.ctb) hipFree(s.ctb);
-    s.ctb = nullptr;
-    HIPCHK(hipMalloc(&s.ctb, ntb * sizeof(int)));
-    s.ccap_tb = ntb;
-  }
-  HIPCHK(hipMemcpyAsync(s.ctb, h->csc_htb, ntb * sizeof(int), hipMemcpyHostToDevice, s.stream));
+  int rc = grow_dev(s.swork, s.scap_work, nw);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(s.swork, h->csc_hwork, nw * sizeof(SliceWork), hipMemcpyHostToDevice, s.stream));
   const size_t NSLOT = static_cast<size_t>(nslot(h->V));
-  if (static_cast<size_t>(ntmax) > s.part_tiles) {
+  if (static_cast<size_t>(nslots) > s.part_tiles) {
     HIPCHK(hipFree(s.part));
     s.part = nullptr;
-    s.part_tiles = static_cast<size_t>(ntmax) + 8;
+    s.part_tiles = static_cast<size_t>(nslots) + 8;
     HIPCHK(hipMalloc(&s.part, s.part_tiles * NSLOT * static_cast<size_t>(h->W) * sizeof(double)));
   }
-  s.c_ntmax = ntmax;
+  s.s_nwork = static_cast<int>(nw);
+  s.s_nslots = nslots;
   return 0;
 }
 
-// After the stream was synchronised: did the lists fit? If not (always the case for the first
+// After the stream was synchronised: did everything fit? If not (always the case for the first
 // matrix of a size) the buffers are grown and `again` is set — the caller repeats the step that
-// produces the groups; otherwise the tiles are planned and the copy is valid.
-int csc_check(Ctx* h, Shard& s, bool& again) {
+// produces the groups; otherwise the work list is planned and the slices are valid.
+template <typename VT>
+int slices_check(Ctx* h, Shard& s, bool with_groups, bool& again) {
   again = false;
   if (!csc_applies(h)) return 0;
   HIPCHK(hipSetDevice(s.device));
-  bool over = false;
-  size_t worst = 0;
-  uint64_t sum = 0;
-  for (int k = 0; k < CSC_ARENAS; ++k) {
-    over = over || h->csc_hctl[k].overflow != 0;
-    worst = std::max(worst, static_cast<size_t>(h->csc_hctl[k].cursor));
-    sum += h->csc_hctl[k].cursor;
+  if (with_groups) {
+    bool over = false;
+    size_t worst = 0;
+    for (int k = 0; k < CSC_ARENAS; ++k) {
+      over = over || h->csc_hctl[k].overflow != 0;
+      worst = std::max(worst, static_cast<size_t>(h->csc_hctl[k].cursor));
+    }
+    if (over) {
+      const size_t need = worst * CSC_ARENAS;  // every arena as large as the fullest one
+      if (s.gvals) hipFree(s.gvals);
+      if (s.grows) hipFree(s.grows);
+      s.gvals = nullptr;
+      s.grows = nullptr;
+      s.gcap_units = 0;
+      const size_t units = (need + need / 8 + 64 * CSC_ARENAS) / CSC_ARENAS * CSC_ARENAS;
+      HIPCHK(hipMalloc(&s.gvals, units * 4 * sizeof(VT)));
+      HIPCHK(hipMalloc(&s.grows, units * 4));
+      s.gcap_units = units;
+      again = true;
+    }
   }
-  if (over) {
-    const size_t need = worst * CSC_ARENAS;  // every arena as large as the fullest one
-    if (s.cvals) hipFree(s.cvals);
-    if (s.crows) hipFree(s.crows);
-    s.cvals = nullptr;
-    s.crows = nullptr;
-    s.ccap_units = (need + need / 8 + 64 * CSC_ARENAS) / CSC_ARENAS * CSC_ARENAS;
-    HIPCHK(hipMalloc(&s.cvals, s.ccap_units * 128 * sizeof(float)));
-    HIPCHK(hipMalloc(&s.crows, s.ccap_units * 128));
+  const uint64_t bytes = h->csc_htotal[0] * 16;
+  if (bytes + SL_TAILPAD > s.scap_bytes) {
+    if (s.sdata) hipFree(s.sdata);
+    s.sdata = nullptr;
+    s.scap_bytes = 0;
+    const size_t cap = static_cast<size_t>(bytes) + static_cast<size_t>(bytes) / 16 + SL_TAILPAD + 4096;
+    HIPCHK(hipMalloc(&s.sdata, cap));
+    HIPCHK(hipMemsetAsync(s.sdata + bytes, 0, cap - bytes, s.stream));
+    s.scap_bytes = cap;
     again = true;
-    return 0;
   }
-  s.c_units = sum;
-  return csc_plan(h, s);  // the caller declares the copy valid once every shard has one
+  if (again) return 0;
+  s.s_bytes = bytes;
+  return slices_plan(h, s);  // the caller declares the slices valid once every shard has them
 }
 
-// build from the dense store(s) + wait + plan: the setMatrixData paths, and every fill of
-// column shards. Shard by shard (the pinned staging of the counters is shared).
+// groups from the dense store(s) + pack + wait + plan: the setMatrixData paths, and every fill
+// that went through a dense store. Shard by shard (the pinned staging is shared).
 int csc_rebuild(Ctx* h) {
   h->csc_valid = false;
   if (!csc_applies(h)) return 0;
-  for (auto& s : h->sh) {
-    bool again = true;
-    for (int attempt = 0; again; ++attempt) {
-      if (attempt >= 3) return fail(CLIPPER_HIP_E_HIP, "compressed copy: the build keeps overflowing");
-      CscOut O;
-      int rc = csc_prepare(h, s, O);
-      if (rc) return rc;
-      rc = csc_enqueue(h, s, O);
-      if (rc) return rc;
-      HIPCHK(hipStreamSynchronize(s.stream));
-      rc = csc_check(h, s, again);
-      if (rc) return rc;
+  int rc = 0;
+  dispatch_vt(h, [&](auto t) {
+    using VT = decltype(t);
+    for (auto& s : h->sh) {
+      bool again = true;
+      for (int attempt = 0; again; ++attempt) {
+        if (attempt >= 3) {
+          rc = fail(CLIPPER_HIP_E_HIP, "compressed storage: the build keeps overflowing");
+          return;
+        }
+        GroupOut<VT> O;
+        if ((rc = groups_prepare<VT>(h, s, O))) return;
+        dim3 grid(h->csc_nstrips, static_cast<unsigned>(ceil_div(h->csc_nblocks, 2))), block(256);
+        hipLaunchKernelGGL((k_groups_from_dense<VT>), grid, block, 0, s.stream,
+                           static_cast<const VT*>(s.S), h->W, h->m, O);
+        if ((rc = slices_enqueue<VT>(h, s, group_source<VT>(h, s), s.cctl))) return;
+        if (hipStreamSynchronize(s.stream) != hipSuccess) {
+          rc = fail(CLIPPER_HIP_E_HIP, "compressed storage: build failed: %s",
+                    hipGetErrorString(hipGetLastError()));
+          return;
+        }
+        if ((rc = slices_check<VT>(h, s, true, again))) return;
+      }
     }
-  }
+  });
+  if (rc) return rc;
   h->csc_valid = true;
-  return 0;
+  drop_dense(h);  // M lives in the slices from here on (getters materialise a dense copy on demand)
+  return sync_all(h);
 }
 
-// `emits`: the fill kernel `launch` starts writes the compressed copy itself when asked to
-// (k_affinity_sym) — then no dense store is needed at all
+// `emits`: the fill kernel `launch` starts writes the groups itself when asked to
+// (k_affinity_sym, fp32) — then no dense store is needed at all
 template <typename Launch>
 int run_affinity(Ctx* h, bool emits, Launch launch) {
+  h->has_matrix = false;  // until the build has succeeded (a failed rebuild leaves no matrix)
+  h->csc_valid = false;
+  h->nodes.clear();
   // explicit constraint storage is not needed on this path: C == pattern(M)
   for (auto& s : h->sh) {
     if (s.Cs) {
@@ -252,19 +372,21 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
   h->explicitC = false;
   plan_tiles(h);
   int rc = 0;
-  const bool emit = csc_applies(h) && csc_single(h) && emits;
+  const bool emit = csc_applies(h) && csc_single(h) && emits && h->storage == CLIPPER_HIP_STORE_F32;
   if (emit) drop_dense(h);  // a materialised copy would be stale
   else if ((rc = ensure_dense(h, false))) return rc;
-  hipEvent_t e0, e1;
   Shard& s0 = h->sh[0];
   HIPCHK(hipSetDevice(s0.device));
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  if (!h->ev_aff[0]) {
+    HIPCHK(hipEventCreate(&h->ev_aff[0]));
+    HIPCHK(hipEventCreate(&h->ev_aff[1]));
+  }
+  hipEvent_t e0 = h->ev_aff[0], e1 = h->ev_aff[1];
   double build_ms = 0.0;
   for (int attempt = 0;; ++attempt) {
     CscOut O{};
     if (emit) {
-      rc = csc_prepare(h, s0, O);
+      rc = groups_prepare<float>(h, s0, O);
       if (rc) return rc;
     } else {
       h->csc_valid = false;
@@ -275,10 +397,10 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
     HIPCHK(hipEventRecord(e0, s0.stream));
     for (auto& s : h->sh) {
       HIPCHK(hipSetDevice(s.device));
-      launch(s);  // k_affinity_sym emits the compressed copy itself and sets csc_emitted
+      launch(s);  // k_affinity_sym emits the groups itself and sets csc_emitted
     }
-    if (emit) {
-      rc = csc_enqueue(h, s0, O);  // counted as part of the affinity build
+    if (emit) {  // groups -> slices: counted as part of the affinity build
+      rc = slices_enqueue<float>(h, s0, group_source<float>(h, s0), s0.cctl);
       if (rc) return rc;
     }
     HIPCHK(hipSetDevice(s0.device));
@@ -286,7 +408,7 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
     rc = sync_all(h);
     if (rc) return rc;
     if (!emit) {
-      // dense slices (column shards, the other fill kernels): the compressed copies from them
+      // dense slices (column shards, the other fill kernels, fp64 storage): slices from them
       const auto t0 = std::chrono::high_resolution_clock::now();
       rc = csc_rebuild(h);
       if (rc) return rc;
@@ -295,20 +417,18 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
       break;
     }
     bool again = false;
-    rc = csc_check(h, s0, again);
+    rc = slices_check<float>(h, s0, true, again);
     if (rc) return rc;
     if (!again) {
       h->csc_valid = true;
       break;
     }
-    if (attempt >= 2) return fail(CLIPPER_HIP_E_HIP, "compressed copy: the build keeps overflowing");
+    if (attempt >= 2) return fail(CLIPPER_HIP_E_HIP, "compressed storage: the build keeps overflowing");
   }
   float ms = 0.f;
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   h->tm.affinity_kernel_ms = ms + (h->csc_valid ? build_ms : 0.0);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
   h->has_matrix = true;
   return 0;
 }
@@ -319,9 +439,9 @@ constexpr int AFF_ROWS_PER_BLK = 32;
 // (= s*m^2 on one GPU; the zero padding up to the 64-column pitch is not counted), doubled
 // when an explicit constraint matrix is read as well.
 double algorithmic_gemv_bytes(const Ctx* h, bool dense = false) {
-  if (h->csc_valid && !dense)  // the compressed copy: 5 bytes per (padded) entry + the group directory
-    return static_cast<double>(h->sh[0].c_units) * 128.0 * 5.0 +
-           static_cast<double>(h->csc_nstrips) * h->csc_nblocks * 12.0;
+  if (h->csc_valid && !dense)  // the slices (headers, lengths, step offsets, quads) + their directory
+    return static_cast<double>(h->sh[0].s_bytes) +
+           static_cast<double>(h->sh[0].s_ncg) * h->sh[0].s_nchunks * 8.0;
   const int64_t c0 = static_cast<int64_t>(h->sh[0].slot) * h->W;
   const int64_t valid = std::max<int64_t>(0, std::min<int64_t>(h->W, h->m - c0));
   return static_cast<double>(h->esize()) * static_cast<double>(h->m) *

@@ -25,13 +25,19 @@ int free_shard_buffers(Shard& s) {
   fr(s.st);
   fr(s.shared);
   fr(s.marks);
-  fr(s.cLc);
-  fr(s.cPre);
-  fr(s.cvals);
-  fr(s.crows);
-  fr(s.ctb);
+  fr(s.gOff);
+  fr(s.gPre);
+  fr(s.gvals);
+  fr(s.grows);
   fr(s.cctl);
-  s.ccap_units = s.ccap_groups = s.ccap_tb = 0;
+  s.gcap_units = s.gcap_groups = 0;
+  fr(s.sSizes);
+  fr(s.sLq);
+  fr(s.sPre);
+  fr(s.sBlk);
+  fr(s.sdata);
+  fr(s.swork);
+  s.scap_slices = s.scap_bytes = s.scap_work = 0;
   s.part_tiles = 0;
   fr(s.P1);
   fr(s.P2);
@@ -46,10 +52,11 @@ int free_shard_buffers(Shard& s) {
   return 0;
 }
 
-// CLIPPER_HIP_STORE_F32_CSC (C == pattern(M) is checked per matrix). On one unsharded device
-// M exists ONLY compressed (csc_single: the fill kernel emits the groups, no dense store); column
-// shards keep their dense slice and build a compressed copy of it for the solver's passes.
-bool csc_possible(const Ctx* h) { return h->compressed && h->storage == CLIPPER_HIP_STORE_F32; }
+// CLIPPER_HIP_STORE_F32_CSC / _F64_CSC (C == pattern(M) is checked per matrix): M lives in the
+// slices only. On one unsharded device with fp32 values the fill kernel emits the groups the
+// slices are packed from (csc_single: no dense store at any time); otherwise a dense store
+// exists while the matrix is being built and is dropped once the slices are valid.
+bool csc_possible(const Ctx* h) { return h->compressed; }
 bool csc_single(const Ctx* h) { return csc_possible(h) && h->world == 1 && !h->multiproc; }
 
 int plan_unr(const Ctx* h) {
@@ -201,14 +208,17 @@ void launch_plain(Ctx* h, Shard& s, const double* X) {
   });
 }
 
-// G on the compressed copy of M (one shard, C == pattern(M), fp32)
-CscView csc_view(const Ctx* h, const Shard& s);
+// G on the slices of M (one shard, C == pattern(M))
+SliceView slice_view(const Ctx* h, const Shard& s);
 
 template <int V>
 void launch_pass_csc(Ctx* h, Shard& s, const SolveArgs& a) {
-  const CscView M = csc_view(h, s);
-  dim3 grid(h->csc_nstrips, s.c_ntmax), block(GEMV_NW * 64);
-  hipLaunchKernelGGL((k_gemv_csc<V, GEMV_NW>), grid, block, 0, s.stream, M, a);
+  const SliceView M = slice_view(h, s);
+  dim3 grid(static_cast<unsigned>(s.s_nwork)), block(SL_NW * 64);
+  if (h->storage == CLIPPER_HIP_STORE_F64)
+    hipLaunchKernelGGL((k_gemv_slices<double, 1, V>), grid, block, 0, s.stream, M, a);
+  else
+    hipLaunchKernelGGL((k_gemv_slices<float, 1, V>), grid, block, 0, s.stream, M, a);
 }
 
 // calls f(integral_constant<V>) for the context's window size
@@ -295,7 +305,7 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.Xout = s.X[par ^ 1];
   a.ab = s.ab;
   a.part = s.part;
-  a.ntiles = h->csc_valid ? s.c_ntmax : h->ntiles;
+  a.ntiles = h->csc_valid ? s.s_nslots : h->ntiles;
   a.slot = s.slot;
   a.scal = s.scal;
   a.nwg = static_cast<int>(ceil_div(h->m, TAIL_THREADS));
@@ -431,13 +441,14 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     return nullptr;
   }
   if (storage != CLIPPER_HIP_STORE_F32 && storage != CLIPPER_HIP_STORE_F64 &&
-      storage != CLIPPER_HIP_STORE_F32_CSC) {
-    fail(CLIPPER_HIP_E_INVALID, "storage must be CLIPPER_HIP_STORE_F32, _F64 or _F32_CSC");
+      storage != CLIPPER_HIP_STORE_F32_CSC && storage != CLIPPER_HIP_STORE_F64_CSC) {
+    fail(CLIPPER_HIP_E_INVALID, "storage must be CLIPPER_HIP_STORE_F32, _F64, _F32_CSC or _F64_CSC");
     return nullptr;
   }
   Ctx* h = new Ctx();
-  h->compressed = (storage == CLIPPER_HIP_STORE_F32_CSC);
-  h->storage = h->compressed ? CLIPPER_HIP_STORE_F32 : storage;
+  h->compressed = (storage == CLIPPER_HIP_STORE_F32_CSC || storage == CLIPPER_HIP_STORE_F64_CSC);
+  h->storage = (storage == CLIPPER_HIP_STORE_F32_CSC) ? CLIPPER_HIP_STORE_F32
+               : (storage == CLIPPER_HIP_STORE_F64_CSC) ? CLIPPER_HIP_STORE_F64 : storage;
   h->world = world;
   h->multiproc = multiproc;
   h->sh.resize(static_cast<size_t>(nlocal));
@@ -447,7 +458,7 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     s.slot = first_slot + p;
     if (s.device < 0 || s.device >= ndev) {
       fail(CLIPPER_HIP_E_INVALID, "device %d out of range (%d visible)", s.device, ndev);
-      delete h;
+      clipper_hip_destroy(h);
       return nullptr;
     }
     if (hipSetDevice(s.device) != hipSuccess ||
@@ -455,7 +466,7 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
         hipEventCreateWithFlags(&s.ev_reduced, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming) != hipSuccess) {
       fail(CLIPPER_HIP_E_HIP, "cannot create stream/events on device %d", s.device);
-      delete h;
+      clipper_hip_destroy(h);
       return nullptr;
     }
   }
@@ -481,7 +492,7 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
       hipEventCreateWithFlags(&h->ev_poll[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_poll[1], hipEventDisableTiming) != hipSuccess) {
     fail(CLIPPER_HIP_E_HIP, "cannot allocate pinned solver state");
-    delete h;
+    clipper_hip_destroy(h);
     return nullptr;
   }
   // progress record the deciding workgroup writes straight into host memory (coherent, mapped)
@@ -490,7 +501,7 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
       hipHostGetDevicePointer(reinterpret_cast<void**>(&h->mirror_dev), h->mirror, 0) !=
           hipSuccess) {
     fail(CLIPPER_HIP_E_HIP, "cannot allocate the pinned progress record");
-    delete h;
+    clipper_hip_destroy(h);
     return nullptr;
   }
   std::memset(h->mirror, 0, sizeof(HostMirror));
@@ -498,7 +509,7 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
                     hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer(reinterpret_cast<void**>(&h->kind_dev), h->kind, 0) != hipSuccess) {
     fail(CLIPPER_HIP_E_HIP, "cannot allocate the pinned iteration marks");
-    delete h;
+    clipper_hip_destroy(h);
     return nullptr;
   }
   std::memset(h->kind, 0, KIND_CAP);

@@ -117,16 +117,27 @@ struct Shard {
   hipEvent_t ev_reduced = nullptr, ev_copied = nullptr;
   size_t bytes_S = 0;
   size_t part_tiles = 0;  // row tiles `part` has room for
-  // column-compressed copy of M (CLIPPER_HIP_STORE_F32_CSC), see kernels.hip.h
-  uint32_t* cLc = nullptr;
-  uint64_t* cPre = nullptr;
-  float* cvals = nullptr;
-  uint8_t* crows = nullptr;
-  int* ctb = nullptr;
-  CscBuildCtl* cctl = nullptr;
-  size_t ccap_units = 0, ccap_groups = 0, ccap_tb = 0;
-  int c_ntmax = 0;        // row tiles per strip of this shard's plan
-  uint64_t c_units = 0;   // sum of the padded list lengths (units of 128 entries)
+  // compressed storage of M (CLIPPER_HIP_STORE_F32_CSC / _F64_CSC), see k_csc.hip.h, k_slices.hip.h
+  // -- groups: what the fill kernels emit (transient input of the packers, kept for reuse)
+  uint16_t* gOff = nullptr;     // [ngroups][GR_OFFS]
+  uint64_t* gPre = nullptr;     // [ngroups]
+  void* gvals = nullptr;        // float | double [4 * gcap_units]
+  uint8_t* grows = nullptr;     // [4 * gcap_units]
+  CscBuildCtl* cctl = nullptr;  // [CSC_ARENAS]
+  size_t gcap_units = 0, gcap_groups = 0;
+  // -- slices: what the passes stream
+  uint32_t* sSizes = nullptr;   // [nslices] size / 16
+  uint32_t* sLq = nullptr;      // [nslices] maxq | entries << 8
+  uint64_t* sPre = nullptr;     // [nslices]
+  uint64_t* sBlk = nullptr;     // scan block sums [nblk + 1]; the last one = total units
+  uint8_t* sdata = nullptr;
+  SliceWork* swork = nullptr;
+  size_t scap_slices = 0, scap_bytes = 0, scap_work = 0;
+  int s_ncg = 0, s_nchunks = 0;
+  int s_nwork = 0;        // workgroups of a pass
+  int s_nslots = 0;       // partial-sum slots per column (what the tail adds)
+  uint64_t s_bytes = 0;   // bytes of the slices
+  uint64_t s_entries = 0; // stored entries (both triangles)
 };
 
 }  // namespace
@@ -143,15 +154,16 @@ struct clipper_hip_ctx {
   int64_t alloc_m = 0, alloc_W = 0;
   bool has_matrix = false;
   bool explicitC = false;
-  bool compressed = false;   // CLIPPER_HIP_STORE_F32_CSC was asked for
-  bool csc_valid = false;    // ... and the compressed copy of the current matrix exists
+  bool compressed = false;   // CLIPPER_HIP_STORE_F32_CSC / _F64_CSC was asked for
+  bool csc_valid = false;    // ... and the slices of the current matrix exist
   bool csc_emitted = false;  // the fill kernel of this build wrote the groups itself
   CscOut csc_out{};          // what that kernel was given
-  int csc_nblocks = 0, csc_nstrips = 0;
-  uint32_t* csc_hLc = nullptr;     // pinned host copy of Lc
+  int csc_nblocks = 0, csc_nstrips = 0;  // 64-row blocks, 128-column strips of the groups
+  uint32_t* csc_hLq = nullptr;     // pinned host copy of sLq
   CscBuildCtl* csc_hctl = nullptr; // pinned host copy of the build's counters
-  int* csc_htb = nullptr;          // pinned staging of the tile boundaries
-  size_t csc_hcap_groups = 0, csc_hcap_tb = 0;
+  uint64_t* csc_htotal = nullptr;  // pinned: total slice units of the last count
+  SliceWork* csc_hwork = nullptr;  // pinned staging of the work list
+  size_t csc_hcap_slices = 0, csc_hcap_work = 0;
   int staged_d = 0;          // dimension of the staged point tables (0 = nothing staged)
   double staged_maxabs = 0;  // max |coordinate| of D1, D2: bounds the fp32 prefilter's error
   bool plain_affinity = false;  // CLIPPER_HIP_AFFINITY=plain: non-compacting fill kernels
@@ -167,6 +179,7 @@ struct clipper_hip_ctx {
 
   SolveShared* host_state = nullptr;  // pinned, 2 slots (multi-process snapshots)
   hipEvent_t ev_poll[2] = {nullptr, nullptr};
+  hipEvent_t ev_aff[2] = {nullptr, nullptr};  // timing of the affinity build
   HostMirror* mirror = nullptr;      // pinned + coherent: progress record written by the device
   HostMirror* mirror_dev = nullptr;  // its device address
   uint8_t* kind = nullptr;           // pinned + coherent: per-iteration pass / transition marks

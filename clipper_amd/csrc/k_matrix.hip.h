@@ -23,24 +23,25 @@ __global__ __launch_bounds__(256) void k_from_dense_upper(T* __restrict__ S, int
                                                            T* __restrict__ Cs,
                                                            int* __restrict__ mismatch) {
   const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const int64_t j = blockIdx.y;
   if (c >= ld) return;
   const int64_t g = c0 + c;
-  double mv = 0.0, cv = 0.0;
-  if (g < m && g != j) {
-    const int64_t lo = (j < g) ? j : g, hi = (j < g) ? g : j;
-    mv = Md[lo + hi * m];
-    cv = Cd[lo + hi * m];
-    if (mismatch != nullptr) {
-      const double want = (mv != 0.0) ? 1.0 : 0.0;
-      if (cv != want) *mismatch = 1;
+  for (int64_t j = blockIdx.y; j < m; j += gridDim.y) {  // grid.y is capped at 65535 rows
+    double mv = 0.0, cv = 0.0;
+    if (g < m && g != j) {
+      const int64_t lo = (j < g) ? j : g, hi = (j < g) ? g : j;
+      mv = Md[lo + hi * m];
+      cv = Cd[lo + hi * m];
+      if (mismatch != nullptr) {
+        const double want = (mv != 0.0) ? 1.0 : 0.0;
+        if (cv != want) *mismatch = 1;
+      }
     }
+    T sv = static_cast<T>(mv);
+    if (mv != 0.0 && sv == T(0)) sv = (mv > 0) ? static_cast<T>(1.17549435e-38)
+                                               : static_cast<T>(-1.17549435e-38);
+    S[j * ld + c] = sv;
+    if (Cs != nullptr) Cs[j * ld + c] = static_cast<T>(cv);
   }
-  T sv = static_cast<T>(mv);
-  if (mv != 0.0 && sv == T(0)) sv = (mv > 0) ? static_cast<T>(1.17549435e-38)
-                                             : static_cast<T>(-1.17549435e-38);
-  S[j * ld + c] = sv;
-  if (Cs != nullptr) Cs[j * ld + c] = static_cast<T>(cv);
 }
 
 // out[a*k + b] = M(idx[a], idx[b]) for the columns idx[b] this slice owns (others untouched):
@@ -64,15 +65,15 @@ __global__ __launch_bounds__(256) void k_from_csc(T* __restrict__ S, int64_t ld,
                                                    const int64_t* __restrict__ colptr,
                                                    const int32_t* __restrict__ row,
                                                    const double* __restrict__ val) {
-  const int64_t j = blockIdx.x;  // CSC column
-  for (int64_t p = colptr[j] + threadIdx.x; p < colptr[j + 1]; p += 256) {
-    const int64_t i = row[p];
-    if (i == j) continue;  // the solver treats the diagonal as implicit identity
-    const T v = static_cast<T>(val[p]);
-    // element (i,j): lives at S[i][j-c0] if j is an owned column, and at S[j][i-c0] if i is
-    if (j >= c0 && j < c0 + W) S[i * ld + (j - c0)] = v;
-    if (i >= c0 && i < c0 + W) S[j * ld + (i - c0)] = v;
-  }
+  for (int64_t j = blockIdx.x; j < m; j += gridDim.x)  // CSC columns
+    for (int64_t p = colptr[j] + threadIdx.x; p < colptr[j + 1]; p += 256) {
+      const int64_t i = row[p];
+      if (i == j) continue;  // the solver treats the diagonal as implicit identity
+      const T v = static_cast<T>(val[p]);
+      // element (i,j): lives at S[i][j-c0] if j is an owned column, and at S[j][i-c0] if i is
+      if (j >= c0 && j < c0 + W) S[i * ld + (j - c0)] = v;
+      if (i >= c0 && i < c0 + W) S[j * ld + (i - c0)] = v;
+    }
 }
 
 }  // namespace clipper_hip

@@ -1,0 +1,737 @@
+// k_slices.hip.h — the compressed storage of M that the solver's passes stream: the layout
+// ("slices"), the pass (slice_core, k_gemv_slices), the packers (k_slice_count, k_slice_scan*,
+// k_slice_pack) and k_slice_expand.
+// Part of kernels.hip.h (include that one): hand-written gfx950 device code of the CLIPPER hot path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "k_solver.hip.h"
+
+namespace clipper_hip {
+
+// ------------------------------------------------------------------------------------------
+// Slices: the un-padded column lists of M (CLIPPER_HIP_STORE_F32_CSC / _F64_CSC)
+// ------------------------------------------------------------------------------------------
+// The reference keeps M_ as Eigen::SparseMatrix<double> (include/clipper/types.h:15) and every
+// product of findDenseClique walks its stored entries only (src/clipper.cpp:194-271). Here the
+// stored entries of BOTH triangles (zero diagonal) are kept as per-column lists, cut into
+//   slice (cg, k) = columns [64 cg, 64 cg + 64) x rows [R k, R k + R),  R = 256 H  (a "chunk")
+// — one column per lane of a wave, rows addressed by one byte inside a 256-row sub-block. A
+// lane's list in a slice is the concatenation of its H sub-block lists, each rounded up to
+// whole QUADS of 4 entries (padding: value 0, row 0 — adds exact zeros). Nothing is padded to a
+// neighbour's length: step q of a slice stores the quads of only those lanes that still have a
+// q-th quad ("compact ELL"), lane-ordered, so the wave's load of a step is one contiguous run:
+//
+//   slice := head[16 B] = {u32 nquads, u32 maxq, u32 bytes, u32 0}
+//            nq[H][64]  u8   quads of lane l in sub-block h
+//            so[ceil(maxq / 16)] u32, padded to 16 B: byte offset (from the slice's start) of
+//                            steps 0, 16, 32, ... — where a workgroup that takes only a range
+//                            of the steps of a heavy slice starts
+//            step 0, step 1, ... step maxq-1
+//   step q := the value quads (4 x VT each) of the active lanes (q < tot_l = sum_h nq[h][l]),
+//            in lane order, then their row quads (4 x u8 each), the step padded to 16 bytes.
+//
+// A lane finds its quad of step q at  stepbase + rank * sizeof(quad)  with rank = number of
+// active lanes below it (ballot + mbcnt), and stepbase advances by wave-uniform arithmetic on
+// the ballot's population count. Bytes held: (4 sizeof(VT) + 4) per quad + ~100 per slice:
+// 5.35 B per stored entry at the headline problem (m = 10k, 11 % dense) against the 12.3 B of
+// column lists padded to the longest of 128 neighbours that this replaces (round 1). Lanes whose
+// list is shorter than the slice's longest idle inside a slice (issue slots), they cost no bytes.
+//
+// Slices of one column group are contiguous and chunk-ordered in the arena; their offsets come
+// from a scan of their sizes, so the layout is a pure function of the matrix. Directory:
+//   Pre[cg * nchunks + k]  byte offset / 16 of the slice
+//   Lq [cg * nchunks + k]  maxq | entries << 8 (the cost of the slice in lock-step steps and
+//                          its stored entries; planning and reporting only)
+//   work[wg]               what workgroup wg does, most expensive first (SliceWork)
+constexpr int SL_W = 64;      // columns per slice
+constexpr int SL_SUB = 256;   // rows per sub-block
+constexpr int SL_SO = 16;     // steps between two recorded step offsets
+constexpr int SL_TAILPAD = 4096;  // bytes behind the last slice a load front may touch
+
+// One workgroup = NW adjacent column groups ("strip", one per wave) x chunks [t0, t1) — or, for
+// the slices of a dense block (the inliers of a registration problem: a chain of dependent
+// steps ten times as long as the average), ONE chunk and the step range [q0, q1) of it. Its
+// partial sums go to part[slot][.][columns of the strip]; every (strip, slot < nslots) is
+// written by exactly one workgroup (empty ones write zeros), the tail adds the slots in order.
+struct SliceWork {
+  int strip, slot, t0, t1;
+  int q0, q1, pad0, pad1;
+};
+
+struct SliceView {
+  const uint8_t* data;
+  const uint64_t* Pre;
+  const SliceWork* work;
+  int nchunks;  // chunks of R rows
+  int ncg;      // column groups
+};
+
+constexpr int sl_xpitch(int V) { return V <= 2 ? 2 : (V <= 4 ? 4 : (V <= 6 ? 6 : 8)); }  // doubles per staged row (window mode)
+constexpr int sl_lds_doubles(int V, int H, int NW) {
+  const int a = 2 * SL_SUB * H * sl_xpitch(V);  // two x buffers
+  const int b = NW * 64 + NW * 2 * V + 8;       // the decision's scratch
+  return a > b ? a : b;
+}
+__host__ __device__ constexpr int sl_so_bytes(int maxq) {
+  return ((maxq + SL_SO - 1) / SL_SO * 4 + 15) & ~15;
+}
+
+template <typename VT>
+struct SliceQuad;
+template <>
+struct SliceQuad<float> {
+  float v[4];
+  __device__ __forceinline__ void load(const uint8_t* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void store(uint8_t* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <>
+struct SliceQuad<double> {
+  double v[4];
+  __device__ __forceinline__ void load(const uint8_t* p) {
+    const double2 t0 = reinterpret_cast<const double2*>(p)[0];
+    const double2 t1 = reinterpret_cast<const double2*>(p)[1];
+    v[0] = t0.x; v[1] = t0.y; v[2] = t1.x; v[3] = t1.y;
+  }
+  __device__ __forceinline__ void store(uint8_t* p) const {
+    reinterpret_cast<double2*>(p)[0] = make_double2(v[0], v[1]);
+    reinterpret_cast<double2*>(p)[1] = make_double2(v[2], v[3]);
+  }
+};
+
+__device__ __forceinline__ uint32_t sl_lane_rank(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+// Stage the x rows of chunk k ([R][XP] doubles, row pitch XP) — window mode: candidates 0..XP-1
+// of table row r = X[r * VS + .]; pair mode: X[r * xstride]. Pieces of 16 bytes, thread-linear.
+template <bool WINDOW, int XP, int R, int NT>
+struct SliceXStage {
+  static constexpr int PIECES = WINDOW ? R * XP / 2 : R;  // 16-byte (window) / 8-byte (pair) pieces
+  static constexpr int PER = (PIECES + NT - 1) / NT;
+  double2 w[WINDOW ? PER : 1];
+  double s[WINDOW ? 1 : PER];
+  __device__ __forceinline__ void load(const double* __restrict__ X, int xstride, int64_t r0,
+                                       int64_t m) {
+    if constexpr (WINDOW) {
+      constexpr int PPR = XP / 2;  // pieces per row
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int p = threadIdx.x + i * NT;
+        const int row = p / PPR, part = p - row * PPR;
+        const int64_t r = r0 + row;
+        w[i] = make_double2(0.0, 0.0);
+        if (p < PIECES && r < m) w[i] = *reinterpret_cast<const double2*>(X + r * VS + 2 * part);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int p = threadIdx.x + i * NT;
+        const int64_t r = r0 + p;
+        s[i] = (p < PIECES && r < m) ? X[r * xstride] : 0.0;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double* xs) const {
+    if constexpr (WINDOW) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int p = threadIdx.x + i * NT;
+        if (p < PIECES) *reinterpret_cast<double2*>(xs + 2 * p) = w[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int p = threadIdx.x + i * NT;
+        if (p < PIECES) xs[p] = s[i];
+      }
+    }
+  }
+};
+
+// what a wave needs of a slice before it can address the steps
+template <int H>
+struct SliceHead {
+  const uint8_t* sp;
+  int maxq;
+  uint32_t bytes;  // the next chunk's slice of the same column group starts at sp + bytes
+  int nq[H];
+  __device__ __forceinline__ void load(const uint8_t* p, int lane) {
+    sp = p;
+    const uint4 hd = *reinterpret_cast<const uint4*>(p);
+    maxq = static_cast<int>(hd.y);
+    bytes = hd.z;
+#pragma unroll
+    for (int h = 0; h < H; ++h) nq[h] = p[16 + h * 64 + lane];
+  }
+};
+
+// slice_begin() is everything of a workgroup's job that does not depend on the decision at the
+// head of the launch — issued before it, so that the decision hides its latency
+template <int H, int NW>
+struct SliceJob {
+  int strip, slot, cg, t0, t1, q0, q1;
+  SliceHead<H> first;
+};
+
+template <int H, int NW>
+__device__ __forceinline__ void slice_begin(const SliceView& M, SliceJob<H, NW>& J) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const SliceWork w = M.work[blockIdx.x];
+  J.strip = w.strip;
+  J.slot = w.slot;
+  J.cg = J.strip * NW + wave;
+  J.t0 = w.t0;
+  J.t1 = w.t1;
+  J.q0 = w.q0;
+  J.q1 = w.q1;
+  J.first.maxq = 0;
+  J.first.sp = M.data;
+  J.first.bytes = 0;
+#pragma unroll
+  for (int h = 0; h < H; ++h) J.first.nq[h] = 0;
+  if (J.cg < M.ncg && J.t0 < J.t1)
+    J.first.load(M.data + 16 * M.Pre[static_cast<int64_t>(J.cg) * M.nchunks + J.t0], threadIdx.x & 63);
+}
+
+// The streaming part of a pass on the slices: this workgroup's partial sums ->
+// part[slot][.][ld]. Wave w of the workgroup owns column group strip * NW + w (a lane = a
+// column: no cross-lane or cross-wave combine), the x rows of a chunk are staged once per
+// workgroup (double buffered). WINDOW / pair mode and the slots as in gemv_core (k_gemv.hip.h).
+// D = steps of a slice kept in flight per lane.
+template <typename VT, int H, bool WINDOW, int V, int NSLOT, int NW, int D>
+__device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H, NW>& J, int64_t ld,
+                                           int64_t m, double d, const double* __restrict__ X,
+                                           int xstride, double* __restrict__ part, double* lds) {
+  constexpr int NS = WINDOW ? V + 1 : 2;
+  constexpr int XP = WINDOW ? sl_xpitch(V) : 1;
+  constexpr int R = SL_SUB * H;
+  constexpr int NT = NW * 64;
+  constexpr int QB = 4 * static_cast<int>(sizeof(VT));  // bytes of a value quad
+  const int lane = threadIdx.x & 63;
+  const int cg = J.cg, t0 = J.t0, t1 = J.t1;
+  const bool mine = cg < M.ncg;
+
+  double acc[NS];
+#pragma unroll
+  for (int v = 0; v < NS; ++v) acc[v] = 0.0;
+
+  SliceXStage<WINDOW, XP, R, NT> xst;
+  __syncthreads();  // the decision at the head of the launch used the same LDS
+  if (t0 < t1) {
+    xst.load(X, xstride, static_cast<int64_t>(t0) * R, m);
+    xst.store(lds);
+  }
+  __syncthreads();
+  SliceHead<H> cur = J.first;
+  for (int k = t0; k < t1; ++k) {
+    const double* xs = lds + ((k - t0) & 1) * (R * XP);
+    double* xnext = lds + (((k - t0) & 1) ^ 1) * (R * XP);
+    const bool more = k + 1 < t1;
+    SliceHead<H> nxt = cur;
+    if (more) {
+      xst.load(X, xstride, static_cast<int64_t>(k + 1) * R, m);
+      if (mine) nxt.load(cur.sp + cur.bytes, lane);
+    }
+    if (mine) {
+      const int maxq = __builtin_amdgcn_readfirstlane(cur.maxq);
+      const int qend = maxq < J.q1 ? maxq : J.q1;
+      int tot = 0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) tot += cur.nq[h];
+      // load front (wave-uniform): step q0 of the slice
+      const uint8_t* fbase = cur.sp + 16 + H * 64 + sl_so_bytes(maxq);
+      if (J.q0 > 0 && J.q0 < maxq)
+        fbase = cur.sp + reinterpret_cast<const uint32_t*>(cur.sp + 16 + H * 64)[J.q0 / SL_SO];
+      SliceQuad<VT> mv[D];
+      uint32_t rw[D];
+      // Every lane issues every load of every step (an idle lane re-reads the step's first quad,
+      // a step past the end the bytes behind the slice): the number of loads in flight is then
+      // the same on every path, and the compiler's s_waitcnt bookkeeping keeps D steps in
+      // flight instead of draining the queue at every divergent join.
+      auto issue = [&](int q, SliceQuad<VT>& vq, uint32_t& rq) {
+        const bool active = q < tot && q < qend;
+        const uint64_t mask = __ballot(active);
+        const int cnt = __builtin_amdgcn_readfirstlane(__popcll(mask));
+        const uint32_t rank = active ? sl_lane_rank(mask) : 0u;
+        vq.load(fbase + rank * QB);
+        rq = *reinterpret_cast<const uint32_t*>(fbase + cnt * QB + rank * 4);
+        fbase += cnt * QB + ((cnt * 4 + 15) & ~15);
+      };
+#pragma unroll
+      for (int j = 0; j < D; ++j) issue(J.q0 + j, mv[j], rw[j]);
+      for (int qb = J.q0; qb < qend; qb += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const int q = qb + j;
+          if (q < tot && q < qend) {
+            int rowbase = 0;
+            if constexpr (H > 1) {
+              int edge = cur.nq[0];
+#pragma unroll
+              for (int h = 1; h < H; ++h) {
+                rowbase = (q >= edge) ? h * SL_SUB : rowbase;
+                edge += cur.nq[h];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const VT mf = mv[j].v[e];
+              const double mm = static_cast<double>(mf);
+              const double ii = mf != VT(0) ? 1.0 : 0.0;
+              const uint32_t row = rowbase + ((rw[j] >> (8 * e)) & 255u);
+              if constexpr (WINDOW) {
+                const double* xr = xs + row * XP;
+                double xv[XP];
+#pragma unroll
+                for (int v = 0; v < XP; v += 2) {
+                  const double2 t2 = *reinterpret_cast<const double2*>(xr + v);
+                  xv[v] = t2.x;
+                  xv[v + 1] = t2.y;
+                }
+                acc[0] = fma(mm, xv[0], acc[0]);
+                acc[V] = fma(ii, xv[0], acc[V]);
+                if (V > 1) {
+                  const double w = fma(d, ii, mm);
+#pragma unroll
+                  for (int v = 1; v < V; ++v) acc[v] = fma(w, xv[v], acc[v]);
+                }
+              } else {
+                const double xv = xs[row];
+                acc[0] = fma(mm, xv, acc[0]);
+                acc[1] = fma(ii, xv, acc[1]);
+              }
+            }
+          }
+          issue(q + D, mv[j], rw[j]);
+        }
+      }
+    }
+    if (more) xst.store(xnext);
+    cur = nxt;
+    __syncthreads();
+  }
+
+  const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
+  if (c < ld) {
+#pragma unroll
+    for (int v = 0; v < NS; ++v) {
+      const int slot = (v == NS - 1) ? NSLOT - 1 : v;
+      part[(static_cast<int64_t>(J.slot) * NSLOT + slot) * ld + c] = acc[v];
+    }
+  }
+}
+
+// window or pair mode by the plan of this iteration
+template <typename VT, int H, int V, int NW, int D>
+__device__ __forceinline__ void slices_by_plan(const SliceView& M, const SliceJob<H, NW>& J,
+                                               const SolveArgs& A, const PassPlan& plan,
+                                               double* lds) {
+  if (plan.phase == PH_TRIAL) {
+    slice_core<VT, H, true, V, nslot(V), NW, D>(
+        M, J, A.W, A.m, plan.d, A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS, VS, A.part, lds);
+  } else if (plan.from_u >= 0) {
+    slice_core<VT, H, false, V, nslot(V), NW, D>(
+        M, J, A.W, A.m, 0.0, A.pt + static_cast<int64_t>(plan.from_u) * 2 * A.mp, 1, A.part, lds);
+  } else {
+    slice_core<VT, H, false, V, nslot(V), NW, D>(
+        M, J, A.W, A.m, 0.0, A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS, VS, A.part, lds);
+  }
+}
+
+constexpr int SL_NW = 4;  // waves (= column groups) per workgroup
+constexpr int SL_D = 4;   // steps in flight per lane
+
+// G of a solver iteration on the slices (one shard): decision, then the pass
+template <typename VT, int H, int V>
+__global__ __launch_bounds__(SL_NW * 64, 2) void k_gemv_slices(SliceView M, SolveArgs A) {
+  __shared__ __attribute__((aligned(16))) double lds[sl_lds_doubles(V, H, SL_NW)];
+  __shared__ __attribute__((aligned(16))) SolverState stash;
+  SliceJob<H, SL_NW> J;
+  slice_begin<H, SL_NW>(M, J);
+  PassPlan plan;
+  if (!iteration_head<V, SL_NW * 64>(A, lds, &stash, plan)) return;
+  slices_by_plan<VT, H, V, SL_NW, SL_D>(M, J, A, plan, lds);
+  flush_state(A, &stash);
+}
+
+// the pair-mode product alone on table X (matvec API, micro-benchmark): a -> slot 0, b -> slot 1
+template <typename VT, int H>
+__global__ __launch_bounds__(SL_NW * 64, 2) void k_gemv_slices_plain(SliceView M, int64_t ld,
+                                                                      int64_t m,
+                                                                      const double* __restrict__ X,
+                                                                      double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) double lds[2 * SL_SUB * H];
+  SliceJob<H, SL_NW> J;
+  slice_begin<H, SL_NW>(M, J);
+  slice_core<VT, H, false, 1, 2, SL_NW, SL_D>(M, J, ld, m, 0.0, X, VS, part, lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// Packers: (source of column lists) -> slices, in three launches
+//   k_slice_count   one wave per slice: its size in 16-byte units and its maxq
+//   k_slice_scan*   exclusive scan of the sizes (column group major, chunk minor) -> Pre
+//   k_slice_pack    one wave per slice: header, lengths, step offsets, steps
+// A source hands every lane (= column) the sub-block lists of its slice: prepare_sub()
+// positions it on one 256-row sub-block, count() = its entries, fetch(i) = entry i (rows
+// ascending).
+// ------------------------------------------------------------------------------------------
+
+// Source 1: "groups" — what the fill kernels emit (k_csc.hip.h): per (128-column strip s,
+// 64-row block b) group g = s * nblocks + b the lists of its columns back to back,
+//   Goff[g * GR_OFFS + cl]  (u16) where column cl's list starts, relative to the group's start;
+//                           Goff[g * GR_OFFS + 128] = the group's entry count
+//   Gpre[g]                 the group's start in vals / rows, in units of 4 entries
+constexpr int GR_CW = 128;    // columns per group
+constexpr int GR_RB = 64;     // rows per group
+constexpr int GR_OFFS = 130;  // u16 per group in Goff (129 used)
+
+// arena cursors of a group build (k_csc.hip.h): the pack kernel only looks at `overflow`
+constexpr int CSC_ARENAS = 64;
+struct alignas(128) CscArena {
+  unsigned long long cursor;    // units of 4 entries claimed so far in this arena
+  unsigned long long capacity;  // units available to it
+  unsigned long long origin;    // where the arena starts, same units
+  int overflow;
+};
+typedef CscArena CscBuildCtl;  // [CSC_ARENAS]
+
+template <typename VT>
+struct GroupSource {
+  const uint16_t* Goff;
+  const uint64_t* Gpre;
+  const VT* vals;
+  const uint8_t* rows;
+  int nblocks;   // 64-row blocks of the matrix
+  int64_t ncols; // columns the groups cover (local)
+  // per-lane state: the 4 blocks of one sub-block at a time
+  int64_t start[4];
+  int cnt[4];
+  __device__ __forceinline__ void prepare_sub(int64_t c, int64_t r0) {
+    const int64_t s = c / GR_CW;
+    const int cl = static_cast<int>(c - s * GR_CW);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t b = r0 / GR_RB + j;
+      start[j] = 0;
+      cnt[j] = 0;
+      if (c < ncols && b < nblocks) {
+        const int64_t g = s * nblocks + b;
+        const uint32_t o0 = Goff[g * GR_OFFS + cl], o1 = Goff[g * GR_OFFS + cl + 1];
+        start[j] = static_cast<int64_t>(Gpre[g]) * 4 + o0;
+        cnt[j] = static_cast<int>(o1 - o0);
+      }
+    }
+  }
+  __device__ __forceinline__ int count() const { return cnt[0] + cnt[1] + cnt[2] + cnt[3]; }
+  // entry i (< count()) of the prepared sub-block: value and row byte (row inside the sub-block)
+  __device__ __forceinline__ void fetch(int i, VT& v, uint32_t& row) const {
+    const int c01 = cnt[0] + cnt[1], c012 = c01 + cnt[2];
+    int j, k;
+    int64_t st;
+    if (i < cnt[0]) { j = 0; k = i; st = start[0]; }
+    else if (i < c01) { j = 1; k = i - cnt[0]; st = start[1]; }
+    else if (i < c012) { j = 2; k = i - c01; st = start[2]; }
+    else { j = 3; k = i - c012; st = start[3]; }
+    v = vals[st + k];
+    row = static_cast<uint32_t>(j * GR_RB) + rows[st + k];
+  }
+};
+
+// Source 2: full symmetric CSC (both triangles, rows ascending per column) of this shard's
+// columns — clipper_hip_set_sparse (the reference's setSparseMatrixData, clipper.cpp:162-166)
+template <typename VT>
+struct CscSource {
+  const int64_t* colptr;
+  const int32_t* rowidx;
+  const double* values;
+  int64_t ncols;
+  int64_t start;
+  int cnt;
+  int64_t r0_;
+  __device__ __forceinline__ int64_t lower_bound(int64_t lo, int64_t hi, int64_t key) const {
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (rowidx[mid] < key) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  }
+  __device__ __forceinline__ void prepare_sub(int64_t c, int64_t r0) {
+    start = 0;
+    cnt = 0;
+    r0_ = r0;
+    if (c < ncols) {
+      const int64_t a = colptr[c], b = colptr[c + 1];
+      start = lower_bound(a, b, r0);
+      cnt = static_cast<int>(lower_bound(start, b, r0 + SL_SUB) - start);
+    }
+  }
+  __device__ __forceinline__ int count() const { return cnt; }
+  __device__ __forceinline__ void fetch(int i, VT& v, uint32_t& row) const {
+    const double x = values[start + i];
+    v = static_cast<VT>(x);
+    if (v == VT(0) && x != 0.0) v = static_cast<VT>(1.17549435e-38);  // an underflow keeps the pattern
+    row = static_cast<uint32_t>(rowidx[start + i] - r0_);
+  }
+};
+
+// wave-level integer helpers (all 64 lanes active)
+__device__ __forceinline__ int sl_wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(v, o);
+    v = v > t ? v : t;
+  }
+  return v;
+}
+__device__ __forceinline__ int sl_wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// size (bytes) of the steps of a slice whose lanes have `tot` quads: wave-uniform
+__device__ __forceinline__ uint32_t sl_steps_bytes(int tot, int maxq, int QB) {
+  uint32_t bytes = 0;
+  for (int q = 0; q < maxq; ++q) {
+    const int cnt = __popcll(__ballot(q < tot));
+    bytes += cnt * QB + ((cnt * 4 + 15) & ~15);
+  }
+  return bytes;
+}
+
+template <typename VT, int H, typename Source>
+__global__ __launch_bounds__(256) void k_slice_count(Source S, int ncg, int nchunks,
+                                                      uint32_t* __restrict__ sizes,
+                                                      uint32_t* __restrict__ Lq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (s >= static_cast<int64_t>(ncg) * nchunks) return;  // whole wave
+  const int cg = static_cast<int>(s / nchunks), k = static_cast<int>(s - static_cast<int64_t>(cg) * nchunks);
+  const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
+  int tot = 0, ent = 0;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    S.prepare_sub(c, (static_cast<int64_t>(k) * H + h) * SL_SUB);
+    ent += S.count();
+    tot += (S.count() + 3) >> 2;
+  }
+  const int maxq = sl_wave_max(tot);
+  const int entries = sl_wave_sum(ent);
+  const uint32_t bytes = 16 + H * 64 + sl_so_bytes(maxq) + sl_steps_bytes(tot, maxq, 4 * sizeof(VT));
+  if (lane == 0) {
+    sizes[s] = bytes >> 4;
+    Lq[s] = static_cast<uint32_t>(maxq) | (static_cast<uint32_t>(entries) << 8);  // maxq <= 64 H
+  }
+}
+
+// exclusive scan of n u32 sizes -> u64 offsets, in two levels of 1024-element blocks
+constexpr int SCAN_BLK = 1024;
+__global__ __launch_bounds__(256) void k_slice_scan_local(const uint32_t* __restrict__ sizes,
+                                                           int64_t n, uint64_t* __restrict__ Pre,
+                                                           uint64_t* __restrict__ blocksum) {
+  __shared__ uint64_t wsum[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * SCAN_BLK + threadIdx.x * 4;
+  uint64_t v[4], run = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = (base + j < n) ? sizes[base + j] : 0;
+    run += v[j];
+  }
+  // inclusive scan of `run` across the wave, then across the 4 waves
+  uint64_t inc = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t t = __shfl_up(inc, o);
+    if ((threadIdx.x & 63) >= o) inc += t;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint64_t off = 0;
+  for (int w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
+  uint64_t excl = off + inc - run;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (base + j < n) Pre[base + j] = excl;
+    excl += v[j];
+  }
+  if (threadIdx.x == 255) blocksum[blockIdx.x] = off + inc;
+}
+// one workgroup: exclusive scan of the block sums in place; total -> blocksum[nb]
+__global__ __launch_bounds__(256) void k_slice_scan_blocks(uint64_t* __restrict__ blocksum, int64_t nb) {
+  __shared__ uint64_t carry;
+  __shared__ uint64_t wsum[4];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < nb; b0 += 256) {
+    const int64_t i = b0 + threadIdx.x;
+    const uint64_t v = (i < nb) ? blocksum[i] : 0;
+    uint64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t t = __shfl_up(inc, o);
+      if ((threadIdx.x & 63) >= o) inc += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint64_t off = carry;
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
+    if (i < nb) blocksum[i] = off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blocksum[nb] = carry;
+}
+__global__ __launch_bounds__(256) void k_slice_scan_add(uint64_t* __restrict__ Pre, int64_t n,
+                                                         const uint64_t* __restrict__ blocksum) {
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * SCAN_BLK + threadIdx.x * 4;
+  const uint64_t off = blocksum[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < n) Pre[base + j] += off;
+}
+
+template <typename VT, int H, typename Source>
+__global__ __launch_bounds__(256) void k_slice_pack(Source S, int ncg, int nchunks,
+                                                     const uint64_t* __restrict__ Pre,
+                                                     uint8_t* __restrict__ data,
+                                                     const uint64_t* __restrict__ total_units,
+                                                     uint64_t cap_units,
+                                                     const CscBuildCtl* __restrict__ ctl) {
+  constexpr int QB = 4 * static_cast<int>(sizeof(VT));
+  const int lane = threadIdx.x & 63;
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (s >= static_cast<int64_t>(ncg) * nchunks) return;  // whole wave
+  // nothing to pack into, or nothing to pack from: the host grows the buffers and repeats
+  if (total_units[0] > cap_units) return;
+  if (ctl != nullptr && __ballot(ctl[lane].overflow != 0) != 0) return;
+  const int cg = static_cast<int>(s / nchunks), k = static_cast<int>(s - static_cast<int64_t>(cg) * nchunks);
+  const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
+  int nq[H], n[H];
+  int tot = 0;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    S.prepare_sub(c, (static_cast<int64_t>(k) * H + h) * SL_SUB);
+    n[h] = S.count();
+    nq[h] = (n[h] + 3) >> 2;
+    tot += nq[h];
+  }
+  const int maxq = sl_wave_max(tot);
+  const int nquads = sl_wave_sum(tot);
+  uint8_t* sp = data + 16 * Pre[s];
+#pragma unroll
+  for (int h = 0; h < H; ++h) sp[16 + h * 64 + lane] = static_cast<uint8_t>(nq[h]);
+  uint32_t* so = reinterpret_cast<uint32_t*>(sp + 16 + H * 64);
+  const int sob = sl_so_bytes(maxq);
+  if (lane * 4 < sob) so[lane] = 0;  // maxq <= 64 H: at most 4 H entries + padding
+  uint32_t off = 16 + H * 64 + sob;  // wave-uniform
+  int hcur = -1;   // sub-block the source is positioned on (per lane)
+  int edge = 0;    // first step behind that sub-block
+  int qbase = 0;   // its first step
+  for (int q = 0; q < maxq; ++q) {
+    const bool active = q < tot;
+    const uint64_t mask = __ballot(active);
+    const int cnt = __popcll(mask);
+    if ((q % SL_SO) == 0 && lane == 0) so[q / SL_SO] = off;
+    if (active) {
+      while (q >= edge) {  // this lane's steps of sub-block hcur are used up: next one
+        ++hcur;
+        qbase = edge;
+        int nn = 0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) nn = (h == hcur) ? nq[h] : nn;
+        edge += nn;
+        if (nn > 0) S.prepare_sub(c, (static_cast<int64_t>(k) * H + hcur) * SL_SUB);
+      }
+      int nh = 0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) nh = (h == hcur) ? n[h] : nh;
+      const uint32_t rank = sl_lane_rank(mask);
+      SliceQuad<VT> vq;
+      uint32_t rq = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = (q - qbase) * 4 + e;
+        VT v = VT(0);
+        uint32_t row = 0;
+        if (i < nh) S.fetch(i, v, row);
+        vq.v[e] = v;
+        rq |= row << (8 * e);
+      }
+      vq.store(sp + off + rank * QB);
+      *reinterpret_cast<uint32_t*>(sp + off + cnt * QB + rank * 4) = rq;
+    }
+    {  // zero the step's padding (the row quads are padded to 16 bytes)
+      const int padw = (((cnt * 4 + 15) & ~15) - cnt * 4) >> 2;  // dwords
+      if (lane < padw) *reinterpret_cast<uint32_t*>(sp + off + cnt * QB + cnt * 4 + lane * 4) = 0;
+    }
+    off += cnt * QB + ((cnt * 4 + 15) & ~15);
+  }
+  if (lane == 0) {
+    uint32_t* hd = reinterpret_cast<uint32_t*>(sp);
+    hd[0] = static_cast<uint32_t>(nquads);
+    hd[1] = static_cast<uint32_t>(maxq);
+    hd[2] = off;
+    hd[3] = 0;
+  }
+}
+
+// k_slice_expand — the dense store S[j][c] (row pitch ld, element ST) back from the slices of
+// this shard's columns (getters, the exact DSD rounding's gather, the matvec API's dense path):
+// one wave per slice, a lane zeroes its column's rows of the chunk and scatters its entries.
+template <typename VT, int H, typename ST>
+__global__ __launch_bounds__(256) void k_slice_expand(SliceView M, ST* __restrict__ S, int64_t ld,
+                                                       int64_t m) {
+  constexpr int QB = 4 * static_cast<int>(sizeof(VT));
+  constexpr int R = SL_SUB * H;
+  const int lane = threadIdx.x & 63;
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (s >= static_cast<int64_t>(M.ncg) * M.nchunks) return;
+  const int cg = static_cast<int>(s / M.nchunks), k = static_cast<int>(s - static_cast<int64_t>(cg) * M.nchunks);
+  const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
+  const int64_t r0 = static_cast<int64_t>(k) * R;
+  if (c < ld)
+    for (int q = 0; q < R; ++q)
+      if (r0 + q < m) S[(r0 + q) * ld + c] = ST(0);
+  SliceHead<H> hd;
+  hd.load(M.data + 16 * M.Pre[s], lane);
+  const int maxq = __builtin_amdgcn_readfirstlane(hd.maxq);
+  int tot = 0;
+#pragma unroll
+  for (int h = 0; h < H; ++h) tot += hd.nq[h];
+  const uint8_t* fbase = hd.sp + 16 + H * 64 + sl_so_bytes(maxq);
+  for (int q = 0; q < maxq; ++q) {
+    const bool active = q < tot;
+    const uint64_t mask = __ballot(active);
+    const int cnt = __popcll(mask);
+    if (active) {
+      const uint32_t rank = sl_lane_rank(mask);
+      SliceQuad<VT> vq;
+      vq.load(fbase + rank * QB);
+      const uint32_t rq = *reinterpret_cast<const uint32_t*>(fbase + cnt * QB + rank * 4);
+      int rowbase = 0, edge = hd.nq[0];
+#pragma unroll
+      for (int h = 1; h < H; ++h) {
+        rowbase = (q >= edge) ? h * SL_SUB : rowbase;
+        edge += hd.nq[h];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (vq.v[e] != VT(0) && c < ld)
+          S[(r0 + rowbase + ((rq >> (8 * e)) & 255u)) * ld + c] = static_cast<ST>(vq.v[e]);
+    }
+    fbase += cnt * QB + ((cnt * 4 + 15) & ~15);
+  }
+}
+
+}  // namespace clipper_hip

@@ -83,7 +83,7 @@ struct Solution {
 class CLIPPER {
  public:
   /// Element type of the dense M kept in HBM (vectors and accumulators are always fp64).
-  enum class Storage { F32 = 0, F64 = 1, F32_CSC = 2 };  ///< see clipper_hip.h (CLIPPER_HIP_STORE_*)
+  enum class Storage { F32 = 0, F64 = 1, F32_CSC = 2, F64_CSC = 3 };  ///< see clipper_hip.h (CLIPPER_HIP_STORE_*)
 
   CLIPPER(const invariants::PairwiseInvariantPtr& invariant, const Params& params);
   ~CLIPPER();

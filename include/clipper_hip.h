@@ -44,7 +44,12 @@ extern "C" {
 
 typedef struct clipper_hip_ctx clipper_hip_t;
 
-enum { CLIPPER_HIP_STORE_F32 = 0, CLIPPER_HIP_STORE_F64 = 1, CLIPPER_HIP_STORE_F32_CSC = 2 };
+enum {
+  CLIPPER_HIP_STORE_F32 = 0,
+  CLIPPER_HIP_STORE_F64 = 1,
+  CLIPPER_HIP_STORE_F32_CSC = 2,
+  CLIPPER_HIP_STORE_F64_CSC = 3
+};
 
 enum {
   CLIPPER_HIP_OK = 0,

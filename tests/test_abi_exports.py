@@ -57,15 +57,15 @@ def test_enumerators_match_header(tmp_path):
     and the C++ facade's Storage enum (a C program prints them; gcc only, no GPU)."""
     import subprocess
     src = tmp_path / "enums.c"
-    src.write_text('#include <stdio.h>\n#include "clipper_hip.h"\nint main(void){printf("%d %d %d %d %d %d %d %d\\n",'
-                   'CLIPPER_HIP_STORE_F32, CLIPPER_HIP_STORE_F64, CLIPPER_HIP_STORE_F32_CSC,'
+    src.write_text('#include <stdio.h>\n#include "clipper_hip.h"\nint main(void){printf("%d %d %d %d %d %d %d %d %d\\n",'
+                   'CLIPPER_HIP_STORE_F32, CLIPPER_HIP_STORE_F64, CLIPPER_HIP_STORE_F32_CSC, CLIPPER_HIP_STORE_F64_CSC,'
                    'CLIPPER_ROUNDING_NONZERO, CLIPPER_ROUNDING_DSD, CLIPPER_ROUNDING_DSD_HEU,'
                    'CLIPPER_HIP_E_NOMEM, CLIPPER_HIP_E_SCOPE);return 0;}\n')
     exe = tmp_path / "enums"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert got[:3] == [abi.STORE_F32, abi.STORE_F64, abi.STORE_F32_CSC] == [0, 1, 2]
-    assert got[3:6] == [abi.ROUNDING_NONZERO, abi.ROUNDING_DSD, abi.ROUNDING_DSD_HEU]
-    assert got[6:] == [-2, -7]
+    assert got[:4] == [abi.STORE_F32, abi.STORE_F64, abi.STORE_F32_CSC, abi.STORE_F64_CSC] == [0, 1, 2, 3]
+    assert got[4:7] == [abi.ROUNDING_NONZERO, abi.ROUNDING_DSD, abi.ROUNDING_DSD_HEU]
+    assert got[7:] == [-2, -7]
     facade = open(os.path.join(ROOT, "include", "clipper", "clipper.h")).read()
-    assert "enum class Storage { F32 = 0, F64 = 1, F32_CSC = 2 }" in facade
+    assert "enum class Storage { F32 = 0, F64 = 1, F32_CSC = 2, F64_CSC = 3 }" in facade
