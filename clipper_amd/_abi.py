@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
     "clipper_hip_affinity_pointnormal_staged", "clipper_hip_stage_u0",
-    "clipper_hip_solve_staged",
+    "clipper_hip_solve_staged", "clipper_hip_debug_stamps",
 ]
 
 
@@ -151,6 +151,7 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.clipper_hip_bench_matvec.argtypes = [vp, C.c_int, dp]
     L.clipper_hip_device_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(i64)]
+    L.clipper_hip_debug_stamps.argtypes = [vp, C.POINTER(i64), C.c_int]
     _lib = L
     return L
 
@@ -396,6 +397,13 @@ class HipClipper:
         us = C.c_double()
         self._check(self.L.clipper_hip_bench_matvec(self.h, reps, C.byref(us)))
         return us.value
+
+    def debug_stamps(self):
+        """per workgroup of the last pass launch: (start, decision done, end, info); needs
+        CLIPPER_HIP_STAMPS=1 in the environment when the context is created"""
+        out = np.zeros(4096 * 4, dtype=np.int64)
+        self._check(self.L.clipper_hip_debug_stamps(self.h, out.ctypes.data_as(C.POINTER(C.c_int64)), out.size))
+        return out.reshape(4096, 4)
 
     def device_info(self):
         name = C.create_string_buffer(64)

@@ -146,6 +146,7 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   if (h->mirror) hipHostFree(h->mirror);
   if (h->kind) hipHostFree(h->kind);
   if (h->u_pinned) hipHostFree(h->u_pinned);
+  if (h->stamps_dev) hipFree(h->stamps_dev);
   if (h->ev_aff[0]) hipEventDestroy(h->ev_aff[0]);
   if (h->ev_aff[1]) hipEventDestroy(h->ev_aff[1]);
   if (h->csc_hLq) hipHostFree(h->csc_hLq);
@@ -196,7 +197,7 @@ int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double
       else
         launch_sym(k_affinity_sym<2, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
                    pstride, A0, A1, prm, none, E2, h->csc_out);
-      h->csc_emitted = (h->csc_out.Goff != nullptr);
+      h->csc_emitted = (h->csc_out.Pre != nullptr);
       return;
     }
     const bool compact = !h->plain_affinity && (d == 2 || d == 3);
@@ -237,7 +238,7 @@ int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, doubl
       const EuclidParams none{};
       launch_sym(k_affinity_sym<3, true>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
                  pstride, s.Adev, s.Adev + mm, none, prm, guarded_threshold_sq(thr), h->csc_out);
-      h->csc_emitted = (h->csc_out.Goff != nullptr);
+      h->csc_emitted = (h->csc_out.Pre != nullptr);
       return;
     }
     if (h->plain_affinity) {
@@ -1135,6 +1136,16 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   *avg_us = static_cast<double>(ms) * 1e3 / reps;
   h->tm.gemv_bytes = algorithmic_gemv_bytes(h, /*dense=*/true);
   return 0;
+}
+
+int clipper_hip_debug_stamps(clipper_hip_t* h, int64_t* out, int capacity) {
+  if (!h || !out || capacity < 0) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (!h->stamps_dev) return fail(CLIPPER_HIP_E_STATE, "CLIPPER_HIP_STAMPS was not set when the context was created");
+  const int n = std::min(capacity, 4096 * 4);
+  HIPCHK(hipSetDevice(h->sh[0].device));
+  HIPCHK(hipStreamSynchronize(h->sh[0].stream));
+  HIPCHK(hipMemcpy(out, h->stamps_dev, static_cast<size_t>(n) * sizeof(long long), hipMemcpyDeviceToHost));
+  return n;
 }
 
 int clipper_hip_device_info(const clipper_hip_t* h, char* name64, int* cus, int64_t* hbm_bytes) {

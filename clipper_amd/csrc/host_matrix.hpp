@@ -71,7 +71,108 @@ int grow_dev(T*& p, size_t& cap, size_t need, size_t elem = sizeof(T)) {
   return 0;
 }
 
-// Before a fill: the group directory, the arenas' cursors reset, the per-slice arrays. Returns
+// the per-slice arrays (directory, sizes, costs) and the pinned staging of this build
+int slices_arrays(Ctx* h, Shard& s) {
+  HIPCHK(hipSetDevice(s.device));
+  if (!s.cctl) HIPCHK(hipMalloc(&s.cctl, CSC_ARENAS * sizeof(CscBuildCtl)));
+  s.s_ncg = static_cast<int>(h->W / SL_W);
+  s.s_nchunks = static_cast<int>(ceil_div(h->m, SL_SUB * SL_H));
+  const size_t nsl = static_cast<size_t>(s.s_ncg) * s.s_nchunks;
+  if (nsl > s.scap_slices) {
+    for (void** p : {reinterpret_cast<void**>(&s.sSizes), reinterpret_cast<void**>(&s.sLq),
+                     reinterpret_cast<void**>(&s.sPre), reinterpret_cast<void**>(&s.sBlk)}) {
+      if (*p) hipFree(*p);
+      *p = nullptr;
+    }
+    s.scap_slices = 0;
+    HIPCHK(hipMalloc(&s.sSizes, nsl * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&s.sLq, nsl * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&s.sPre, nsl * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&s.sBlk, (ceil_div(nsl, SCAN_BLK) + 4) * sizeof(uint64_t)));
+    s.scap_slices = nsl;
+  }
+  if (nsl > h->csc_hcap_slices) {
+    if (h->csc_hLq) hipHostFree(h->csc_hLq);
+    h->csc_hLq = nullptr;
+    h->csc_hcap_slices = 0;
+    HIPCHK(hipHostMalloc(&h->csc_hLq, nsl * sizeof(uint32_t), hipHostMallocDefault));
+    h->csc_hcap_slices = nsl;
+  }
+  if (!h->csc_hctl)
+    HIPCHK(hipHostMalloc(&h->csc_hctl, 2 * CSC_ARENAS * sizeof(CscBuildCtl), hipHostMallocDefault));
+  if (!h->csc_htotal) HIPCHK(hipHostMalloc(&h->csc_htotal, 2 * sizeof(uint64_t), hipHostMallocDefault));
+  return 0;
+}
+
+// Before a fill that writes the slices itself (k_affinity_sym): the arenas of the slice store
+// reset. out.Pre == null: compressed storage not in use.
+int emit_prepare(Ctx* h, Shard& s, SliceOut& out) {
+  out = SliceOut{};
+  h->csc_valid = false;
+  h->csc_emitted = false;
+  if (!csc_applies(h)) return 0;
+  if (int rc = slices_arrays(h, s)) return rc;
+  const size_t units = s.scap_bytes >= SL_TAILPAD ? (s.scap_bytes - SL_TAILPAD) / 16 : 0;
+  CscBuildCtl* init = h->csc_hctl + CSC_ARENAS;  // second half: what the device starts from
+  for (int k = 0; k < CSC_ARENAS; ++k) {
+    init[k].cursor = 0;
+    init[k].capacity = units / CSC_ARENAS;
+    init[k].origin = static_cast<unsigned long long>(k) * (units / CSC_ARENAS);
+    init[k].overflow = 0;
+  }
+  HIPCHK(hipMemcpyAsync(s.cctl, init, CSC_ARENAS * sizeof(CscBuildCtl), hipMemcpyHostToDevice,
+                        s.stream));
+  out.Pre = s.sPre;
+  out.Lq = s.sLq;
+  out.data = s.sdata;
+  out.ctl = s.cctl;
+  out.nchunks = s.s_nchunks;
+  out.ncg = s.s_ncg;
+  return 0;
+}
+
+// After such a fill: the counters to pinned host memory; emit_check() reads them once the stream
+// was synchronised, grows the arena if a slice did not fit (`again`), else plans the passes.
+int emit_enqueue(Ctx* h, Shard& s) {
+  HIPCHK(hipSetDevice(s.device));
+  const size_t nsl = static_cast<size_t>(s.s_ncg) * s.s_nchunks;
+  HIPCHK(hipMemcpyAsync(h->csc_hctl, s.cctl, CSC_ARENAS * sizeof(CscBuildCtl), hipMemcpyDeviceToHost,
+                        s.stream));
+  HIPCHK(hipMemcpyAsync(h->csc_hLq, s.sLq, nsl * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+  return 0;
+}
+
+int slices_plan(Ctx* h, Shard& s);
+
+int emit_check(Ctx* h, Shard& s, bool& again) {
+  again = false;
+  HIPCHK(hipSetDevice(s.device));
+  bool over = false;
+  size_t worst = 0;
+  uint64_t sum = 0;
+  for (int k = 0; k < CSC_ARENAS; ++k) {
+    over = over || h->csc_hctl[k].overflow != 0;
+    worst = std::max(worst, static_cast<size_t>(h->csc_hctl[k].cursor));
+    sum += h->csc_hctl[k].cursor;
+  }
+  if (over) {
+    const size_t need = worst * CSC_ARENAS;  // every arena as large as the fullest one
+    if (s.sdata) hipFree(s.sdata);
+    s.sdata = nullptr;
+    s.scap_bytes = 0;
+    const size_t units = (need + need / 8 + 256 * CSC_ARENAS) / CSC_ARENAS * CSC_ARENAS;
+    const size_t cap = units * 16 + SL_TAILPAD;
+    HIPCHK(hipMalloc(&s.sdata, cap));
+    HIPCHK(hipMemsetAsync(s.sdata + units * 16, 0, SL_TAILPAD, s.stream));
+    s.scap_bytes = cap;
+    again = true;
+    return 0;
+  }
+  s.s_bytes = sum * 16;
+  return slices_plan(h, s);
+}
+
+// Before a build through groups: the group directory, the arenas' cursors reset, the per-slice arrays. Returns
 // what a kernel that emits groups needs; out.Goff == null: compressed storage not in use.
 template <typename VT>
 int groups_prepare(Ctx* h, Shard& s, GroupOut<VT>& out) {
@@ -93,33 +194,7 @@ int groups_prepare(Ctx* h, Shard& s, GroupOut<VT>& out) {
     HIPCHK(hipMalloc(&s.gPre, G * sizeof(uint64_t)));
     s.gcap_groups = G;
   }
-  if (!s.cctl) HIPCHK(hipMalloc(&s.cctl, CSC_ARENAS * sizeof(CscBuildCtl)));
-  s.s_ncg = static_cast<int>(h->W / SL_W);
-  s.s_nchunks = static_cast<int>(ceil_div(h->m, SL_SUB * SL_H));
-  const size_t nsl = static_cast<size_t>(s.s_ncg) * s.s_nchunks;
-  if (nsl > s.scap_slices) {
-    for (void** p : {reinterpret_cast<void**>(&s.sSizes), reinterpret_cast<void**>(&s.sLq),
-                     reinterpret_cast<void**>(&s.sPre), reinterpret_cast<void**>(&s.sBlk)}) {
-      if (*p) hipFree(*p);
-      *p = nullptr;
-    }
-    s.scap_slices = 0;
-    HIPCHK(hipMalloc(&s.sSizes, nsl * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&s.sLq, nsl * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&s.sPre, nsl * sizeof(uint64_t)));
-    HIPCHK(hipMalloc(&s.sBlk, (ceil_div(nsl, SCAN_BLK) + 2) * sizeof(uint64_t)));
-    s.scap_slices = nsl;
-  }
-  if (nsl > h->csc_hcap_slices) {
-    if (h->csc_hLq) hipHostFree(h->csc_hLq);
-    h->csc_hLq = nullptr;
-    h->csc_hcap_slices = 0;
-    HIPCHK(hipHostMalloc(&h->csc_hLq, nsl * sizeof(uint32_t), hipHostMallocDefault));
-    h->csc_hcap_slices = nsl;
-  }
-  if (!h->csc_hctl)
-    HIPCHK(hipHostMalloc(&h->csc_hctl, 2 * CSC_ARENAS * sizeof(CscBuildCtl), hipHostMallocDefault));
-  if (!h->csc_htotal) HIPCHK(hipHostMalloc(&h->csc_htotal, 2 * sizeof(uint64_t), hipHostMallocDefault));
+  if (int rc = slices_arrays(h, s)) return rc;
   CscBuildCtl* init = h->csc_hctl + CSC_ARENAS;  // second half: what the device starts from
   for (int k = 0; k < CSC_ARENAS; ++k) {
     init[k].cursor = 0;
@@ -148,16 +223,28 @@ int slices_enqueue(Ctx* h, Shard& s, const Source& src, const CscBuildCtl* ctl) 
   const int64_t nblk = ceil_div(nsl, SCAN_BLK);
   dim3 g4(static_cast<unsigned>(ceil_div(nsl, 4))), b256(256);
   hipLaunchKernelGGL((k_slice_count<VT, SL_H, Source>), g4, b256, 0, s.stream, src, s.s_ncg,
-                     s.s_nchunks, s.sSizes, s.sLq);
-  hipLaunchKernelGGL(k_slice_scan_local, dim3(static_cast<unsigned>(nblk)), b256, 0, s.stream,
-                     s.sSizes, nsl, s.sPre, s.sBlk);
-  hipLaunchKernelGGL(k_slice_scan_blocks, dim3(1), b256, 0, s.stream, s.sBlk, nblk);
-  if (nblk > 1)
+                     s.s_nchunks, s.sSizes, s.sLq, ctl, s.sBlk + nblk + 1);
+  if (nsl <= 32768) {
+    hipLaunchKernelGGL(k_slice_scan_small, dim3(1), dim3(1024), 0, s.stream, s.sSizes, nsl, s.sPre,
+                       s.sBlk + nblk);
+  } else {
+    hipLaunchKernelGGL(k_slice_scan_local, dim3(static_cast<unsigned>(nblk)), b256, 0, s.stream,
+                       s.sSizes, nsl, s.sPre, s.sBlk);
+    hipLaunchKernelGGL(k_slice_scan_blocks, dim3(1), b256, 0, s.stream, s.sBlk, nblk);
     hipLaunchKernelGGL(k_slice_scan_add, dim3(static_cast<unsigned>(nblk)), b256, 0, s.stream, s.sPre,
                        nsl, s.sBlk);
+  }
   const uint64_t cap_units = s.scap_bytes >= SL_TAILPAD ? (s.scap_bytes - SL_TAILPAD) / 16 : 0;
-  hipLaunchKernelGGL((k_slice_pack<VT, SL_H, Source>), g4, b256, 0, s.stream, src, s.s_ncg,
-                     s.s_nchunks, s.sPre, s.sdata, s.sBlk + nblk, cap_units, ctl);
+  int heavy_only = 0;
+  if constexpr (std::is_same<Source, GroupSource<VT>>::value && SL_H == 1) {
+    // the common case through LDS (coalesced), only the slices of dense blocks by per-lane gathers
+    hipLaunchKernelGGL((k_slice_pack_staged<VT>), g4, b256, 0, s.stream, src, s.s_ncg, s.s_nchunks,
+                       s.sPre, s.sdata, s.sBlk + nblk, cap_units);
+    heavy_only = 1;
+  }
+  hipLaunchKernelGGL((k_slice_pack<VT, SL_H, Source>), dim3(static_cast<unsigned>(nsl)),
+                     dim3(SL_PACKW * 64), 0, s.stream, src, s.s_ncg, s.s_nchunks, s.sPre, s.sdata,
+                     s.sBlk + nblk, cap_units, s.sLq, heavy_only);
   if (ctl)
     HIPCHK(hipMemcpyAsync(h->csc_hctl, s.cctl, CSC_ARENAS * sizeof(CscBuildCtl),
                           hipMemcpyDeviceToHost, s.stream));
@@ -354,8 +441,8 @@ int csc_rebuild(Ctx* h) {
   return sync_all(h);
 }
 
-// `emits`: the fill kernel `launch` starts writes the groups itself when asked to
-// (k_affinity_sym, fp32) — then no dense store is needed at all
+// `emits`: the fill kernel `launch` starts writes the slices itself when asked to
+// (k_affinity_sym, fp32) — then neither a dense store nor groups are needed
 template <typename Launch>
 int run_affinity(Ctx* h, bool emits, Launch launch) {
   h->has_matrix = false;  // until the build has succeeded (a failed rebuild leaves no matrix)
@@ -386,7 +473,7 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
   for (int attempt = 0;; ++attempt) {
     CscOut O{};
     if (emit) {
-      rc = groups_prepare<float>(h, s0, O);
+      rc = emit_prepare(h, s0, O);
       if (rc) return rc;
     } else {
       h->csc_valid = false;
@@ -397,10 +484,10 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
     HIPCHK(hipEventRecord(e0, s0.stream));
     for (auto& s : h->sh) {
       HIPCHK(hipSetDevice(s.device));
-      launch(s);  // k_affinity_sym emits the groups itself and sets csc_emitted
+      launch(s);  // k_affinity_sym writes the slices itself and sets csc_emitted
     }
-    if (emit) {  // groups -> slices: counted as part of the affinity build
-      rc = slices_enqueue<float>(h, s0, group_source<float>(h, s0), s0.cctl);
+    if (emit) {
+      rc = emit_enqueue(h, s0);
       if (rc) return rc;
     }
     HIPCHK(hipSetDevice(s0.device));
@@ -417,7 +504,7 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
       break;
     }
     bool again = false;
-    rc = slices_check<float>(h, s0, true, again);
+    rc = emit_check(h, s0, again);
     if (rc) return rc;
     if (!again) {
       h->csc_valid = true;

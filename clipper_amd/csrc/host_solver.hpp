@@ -318,6 +318,7 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.marks = (h->profiling && &s == &h->sh[0]) ? s.marks : nullptr;
   a.kind = (a.marks && !h->multiproc) ? h->kind_dev : nullptr;
   a.host_u = (!h->multiproc && &s == &h->sh[0]) ? h->u_pinned_dev : nullptr;
+  a.stamps = (&s == &h->sh[0]) ? h->stamps_dev : nullptr;
   return a;
 }
 
@@ -513,6 +514,11 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     return nullptr;
   }
   std::memset(h->kind, 0, KIND_CAP);
+  if (std::getenv("CLIPPER_HIP_STAMPS")) {  // measurement only
+    if (hipMalloc(&h->stamps_dev, 4096 * 4 * sizeof(long long)) == hipSuccess)
+      (void)hipMemset(h->stamps_dev, 0, 4096 * 4 * sizeof(long long));
+    else h->stamps_dev = nullptr;
+  }
   // CLIPPER_HIP_WINDOW = 1 | 4 | 6 | 8: line-search candidates multiplied per pass over M
   if (const char* w = std::getenv("CLIPPER_HIP_WINDOW")) {
     const int v = std::atoi(w);

@@ -192,6 +192,7 @@ struct clipper_hip_ctx {
   int64_t mp = 0;          // rows of a candidate table
   int par = 0;             // which table set the next launch reads
 
+  long long* stamps_dev = nullptr;  // CLIPPER_HIP_STAMPS=1: [4096][4], see SolveArgs::stamps
   bool profiling = false;
   std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created by clipper_hip_set_profiling
   std::vector<int64_t> ev_launch_index;  // which mat-vec launch of the solve each pair timed

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
     const double* __restrict__ P2, const float* __restrict__ P1f, const float* __restrict__ P2f,
     int64_t pstride, const int32_t* __restrict__ A0, const int32_t* __restrict__ A1,
     EuclidParams eprm, PointNormalParams nprm, float E2 /* guarded threshold squared, rounded up */,
-    CscOut O /* O.Goff != null: also emit the tile's groups (k_csc.hip.h) */) {
+    CscOut O /* O.Pre != null: also write the tile's slices (k_csc.hip.h) */) {
   // 72.5 KiB of dynamic LDS (two workgroups per CU fit the 160 KiB): the image, then the queues
   extern __shared__ __attribute__((aligned(16))) char sym_smem[];
   float* img = reinterpret_cast<float*>(sym_smem);
@@ -642,22 +642,21 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
   }
   __syncthreads();
 
-  // ---- the compressed copy: row blocks 2I, 2I+1 of strip J, and of the mirror image row blocks
-  // 2J, 2J+1 of strip I, one column per thread straight from the image (csc_emit) ---------------
-  if (O.Goff != nullptr) {
-    static_assert(AT_WAVES == 8 && AT == GR_CW && AT == 2 * GR_RB, "four groups per tile");
-    int* red = reinterpret_cast<int*>(sym_smem + AT_SYM_IMG_BYTES);  // the queues are drained
-    unsigned long long* base_s = reinterpret_cast<unsigned long long*>(red + 8);
-    const int t = threadIdx.x, gi = t >> 7, cl = t & 127;
-    const int rb = gi & 1;
-    const bool mirror = gi >= 2;
-    // element q of the thread's column: tile (rb*64 + q, cl), or (cl, rb*64 + q) of the mirror
-    const float* col = mirror ? img + cl * AT_PITCH + rb * GR_RB : img + rb * GR_RB * AT_PITCH + cl;
-    const int strip = mirror ? I : J;
-    const int b = 2 * (mirror ? J : I) + rb;
-    const int64_t g = (b < O.nblocks && !(mirror && I == J))
-                          ? static_cast<int64_t>(strip) * O.nblocks + b : -1;
-    csc_emit_lds<4>(col, mirror ? 1 : AT_PITCH, g, O, red, base_s);
+  // ---- the slices (k_slices.hip.h) of the tile and of its mirror image, straight from the image:
+  // (column group 2J + e, chunk I) and (column group 2I + e, chunk J), two waves per slice ----------
+  if (O.Pre != nullptr) {
+    static_assert(AT_WAVES == 8 && AT == SL_SUB && AT == 2 * SL_W, "four slices per tile");
+    unsigned long long* base_s = reinterpret_cast<unsigned long long*>(sym_smem + AT_SYM_IMG_BYTES);  // the queues are drained
+    const int sl = wave & 3, half = wave >> 2;
+    const int e = sl & 1;
+    const bool mirror = sl >= 2;
+    // element q of the lane's column: tile (q, 64 e + lane), or (64 e + lane, q) of the mirror
+    const float* col = mirror ? img + (64 * e + lane) * AT_PITCH : img + 64 * e + lane;
+    const int cg = 2 * (mirror ? I : J) + e;
+    const int k = mirror ? J : I;
+    const int64_t s = (cg < O.ncg && k < O.nchunks && !(mirror && I == J))
+                          ? static_cast<int64_t>(cg) * O.nchunks + k : -1;
+    slice_emit_lds(col, mirror ? 1 : AT_PITCH, s, sl, half, O, base_s);
   }
 
   // ---- the tile as it stands: this wave's rows, 512-byte segments -----------------------------

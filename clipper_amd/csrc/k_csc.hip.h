@@ -1,5 +1,5 @@
-// k_csc.hip.h — "groups": the column lists of M as the fill kernels emit them (csc_emit*,
-// k_groups_from_dense), the intermediate the slice packers read (k_slices.hip.h: GroupSource).
+// k_csc.hip.h — producers of the slices: slice_emit_lds (k_affinity_sym writes them itself) and
+// "groups" (gr_emit, k_groups_from_dense), the intermediate the slice packers read (GroupSource).
 // Part of kernels.hip.h (include that one): hand-written gfx950 device code of the CLIPPER hot path.
 #pragma once
 
@@ -12,15 +12,13 @@ namespace clipper_hip {
 
 // ------------------------------------------------------------------------------------------
 // M of a registration problem is sparse by construction (the consistent pairs: ~11 % at the
-// headline configuration); the solver streams it as slices (k_slices.hip.h). A fill kernel
-// cannot write slices directly: a slice spans 256 rows, a tile of k_affinity_sym 128, and where
-// a lane's quad lands depends on the lengths of all 64 columns over the whole chunk. So the
-// fill kernels emit GROUPS — per (128-column strip s, 64-row block b) the nonzeros of every
-// column, un-padded, column after column, as (value, row-in-block u8) — and three small
-// launches repack them (k_slice_count / scan / k_slice_pack). A group is as wide as a tile of
-// k_affinity_sym, which emits the groups of the tiles it computes (and of their mirror images)
-// straight from its LDS image; k_groups_from_dense does the same from a dense store (the other
-// fill kernels, setMatrixData).
+// headline configuration); the solver streams it as slices (k_slices.hip.h). The
+// symmetric fill kernel k_affinity_sym writes finished slices itself (slice_emit_lds below: a
+// slice is as tall as its tile). Every other producer — the strip fill kernels, setMatrixData,
+// fp64 values, column shards — goes through a dense store and GROUPS: per (128-column strip s,
+// 64-row block b) the nonzeros of every column, un-padded, column after column, as (value,
+// row-in-block u8), written by k_groups_from_dense and repacked by three small launches
+// (k_slice_count / scan / k_slice_pack).
 //   Goff[g * GR_OFFS + cl]   u16: where column cl's list starts inside group g = s * nblocks + b;
 //                            entry 128 = the group's entry count
 //   Gpre[g]                  where the group starts in vals / rows, in units of 4 entries
@@ -40,7 +38,17 @@ struct GroupOut {
   CscBuildCtl* ctl;
   int nblocks;
 };
-typedef GroupOut<float> CscOut;  // what k_affinity_sym takes (Goff == null: not in use)
+
+// What k_affinity_sym takes to write finished slices itself (Pre == null: not in use): a slice is
+// as tall as its tile and half as wide, so a tile and its mirror image are four slices.
+struct SliceOut {
+  uint64_t* Pre;     // [ncg * nchunks] where the slice starts in `data`, in units of 16 bytes
+  uint32_t* Lq;      // [ncg * nchunks] maxq | entries << 8
+  uint8_t* data;
+  CscBuildCtl* ctl;  // arena cursors in units of 16 bytes
+  int nchunks, ncg;
+};
+typedef SliceOut CscOut;
 
 // Emission of NG groups by one workgroup of NG*128 threads: thread t owns column (t & 127) of
 // group (t >> 7); g = its group id or -1 (nothing to emit: the whole group, uniformly).
@@ -107,38 +115,100 @@ __device__ __forceinline__ void gr_emit(const VT (&v)[GR_RB], int64_t g, const G
     }
 }
 
-// from a column of an LDS image (k_affinity_sym): col[q * stride], q = 0..63. A first sweep
-// builds the bit mask of the nonzeros; only those are visited again (an ~11 % dense column: ~7
-// of 64), the trip count of a wave being its longest column.
-template <int NG>
-__device__ __forceinline__ void csc_emit_lds(const float* col, int stride, int64_t g,
-                                             const CscOut& O, int* red,
-                                             unsigned long long* base_s) {
-  uint32_t mlo = 0, mhi = 0;
-#pragma unroll
-  for (int q = 0; q < 32; ++q) mlo |= (col[q * stride] != 0.f ? 1u : 0u) << q;
-#pragma unroll
-  for (int q = 0; q < 32; ++q) mhi |= (col[(q + 32) * stride] != 0.f ? 1u : 0u) << q;
-  const int cnt = __popc(mlo) + __popc(mhi);
-  int off;
-  unsigned long long base;
-  if (!gr_claim<NG>(cnt, g, O, red, base_s, off, base)) return;
-  float* vp = O.vals + base * 4 + off;
-  uint8_t* rp = O.rows + base * 4 + off;
-  int k = 0;
-  while (mlo) {
-    const int q = __ffs(mlo) - 1;
-    mlo &= mlo - 1;
-    vp[k] = col[q * stride];
-    rp[k] = static_cast<uint8_t>(q);
-    ++k;
+// Emission of one slice (k_slices.hip.h) by TWO waves of a workgroup straight from an LDS image:
+// lane = column, col[q * stride] = its entry of row q of the tile (q < SL_SUB = 128). Both waves
+// know where every step starts (the lanes' lengths: ALU only); wave `half` writes the steps of
+// its parity. `s` = slice id cg * nchunks + k, or -1 (nothing to emit: both waves, uniformly).
+// Space is claimed with one atomic per slice on one of the arena cursors; a slice that does not fit
+// only records its size and maxq (the host grows the arena and repeats the fill).
+// Contains ONE __syncthreads (every wave of the workgroup must call it). `base_s`: LDS, one
+// unsigned long long per slice of the workgroup, this slice's at index `sl`.
+__device__ __forceinline__ void slice_emit_lds(const float* col, int stride, int64_t s, int sl,
+                                               int half, const SliceOut& O,
+                                               unsigned long long* base_s) {
+  static_assert(SL_SUB == 128, "a slice is as tall as a tile of k_affinity_sym");
+  constexpr int QB = 16;
+  const int lane = threadIdx.x & 63;
+  uint64_t mlo = 0, mhi = 0;
+#pragma unroll 16
+  for (int q = 0; q < 64; ++q) mlo |= static_cast<uint64_t>(col[q * stride] != 0.f ? 1u : 0u) << q;
+#pragma unroll 16
+  for (int q = 0; q < 64; ++q) mhi |= static_cast<uint64_t>(col[(q + 64) * stride] != 0.f ? 1u : 0u) << q;
+  const int n = __popcll(mlo) + __popcll(mhi);
+  const int tot = (n + 3) >> 2;
+  const int maxq = sl_wave_max(tot);
+  const uint32_t bytes = 16 + 64 + sl_so_bytes(maxq) + sl_steps_bytes(tot, maxq, QB);
+  if (half == 0 && s >= 0) {
+    const int nquads = sl_wave_sum(tot), entries = sl_wave_sum(n);
+    if (lane == 0) {
+      const unsigned long long U = bytes >> 4;
+      CscArena* ar = O.ctl + static_cast<int>((s * 11 + (s >> 6)) & (CSC_ARENAS - 1));
+      unsigned long long bb = atomicAdd(&ar->cursor, U);
+      if (bb + U > ar->capacity) {
+        ar->overflow = 1;
+        bb = ~0ull;
+      } else {
+        bb += ar->origin;
+      }
+      O.Pre[s] = bb;
+      O.Lq[s] = static_cast<uint32_t>(maxq) | (static_cast<uint32_t>(entries) << 8);
+      base_s[sl] = bb;
+      if (bb != ~0ull) {
+        uint32_t* hd = reinterpret_cast<uint32_t*>(O.data + 16 * bb);
+        hd[0] = static_cast<uint32_t>(nquads);
+        hd[1] = static_cast<uint32_t>(maxq);
+        hd[2] = bytes;
+        hd[3] = 0;
+      }
+    }
   }
-  while (mhi) {
-    const int q = __ffs(mhi) - 1 + 32;
-    mhi &= mhi - 1;
-    vp[k] = col[q * stride];
-    rp[k] = static_cast<uint8_t>(q);
-    ++k;
+  __syncthreads();
+  if (s < 0) return;
+  const unsigned long long base = base_s[sl];
+  if (base == ~0ull) return;
+  uint8_t* sp = O.data + 16 * base;
+  uint32_t* so = reinterpret_cast<uint32_t*>(sp + 16 + 64);
+  const int sob = sl_so_bytes(maxq);
+  if (half == 0) {
+    sp[16 + lane] = static_cast<uint8_t>(tot);
+    if (lane * 4 < sob && lane >= (maxq + SL_SO - 1) / SL_SO) so[lane] = 0;  // the table's padding
+  }
+  uint32_t off = 16 + 64 + sob;
+  for (int q = 0; q < maxq; ++q) {
+    const bool active = q < tot;
+    const uint64_t mask = __ballot(active);
+    const int cnt = __popcll(mask);
+    const bool own = (q & 1) == half;  // uniform
+    if (own && (q % SL_SO) == 0 && lane == 0) so[q / SL_SO] = off;
+    if (active) {
+      float v4[4] = {0.f, 0.f, 0.f, 0.f};
+      uint32_t rq = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int row = -1;
+        if (mlo) {
+          row = __ffsll(static_cast<unsigned long long>(mlo)) - 1;
+          mlo &= mlo - 1;
+        } else if (mhi) {
+          row = 64 + __ffsll(static_cast<unsigned long long>(mhi)) - 1;
+          mhi &= mhi - 1;
+        }
+        if (own && row >= 0) {
+          v4[e] = col[row * stride];
+          rq |= static_cast<uint32_t>(row) << (8 * e);
+        }
+      }
+      if (own) {
+        const uint32_t rank = sl_lane_rank(mask);
+        *reinterpret_cast<float4*>(sp + off + rank * QB) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        *reinterpret_cast<uint32_t*>(sp + off + cnt * QB + rank * 4) = rq;
+      }
+    }
+    if (own) {  // zero the step's padding (the row quads are padded to 16 bytes)
+      const int padw = (((cnt * 4 + 15) & ~15) - cnt * 4) >> 2;
+      if (lane < padw) *reinterpret_cast<uint32_t*>(sp + off + cnt * QB + cnt * 4 + lane * 4) = 0;
+    }
+    off += cnt * QB + ((cnt * 4 + 15) & ~15);
   }
 }
 

@@ -17,8 +17,9 @@ namespace clipper_hip {
 // The reference keeps M_ as Eigen::SparseMatrix<double> (include/clipper/types.h:15) and every
 // product of findDenseClique walks its stored entries only (src/clipper.cpp:194-271). Here the
 // stored entries of BOTH triangles (zero diagonal) are kept as per-column lists, cut into
-//   slice (cg, k) = columns [64 cg, 64 cg + 64) x rows [R k, R k + R),  R = 256 H  (a "chunk")
-// — one column per lane of a wave, rows addressed by one byte inside a 256-row sub-block. A
+//   slice (cg, k) = columns [64 cg, 64 cg + 64) x rows [R k, R k + R),  R = 128 H  (a "chunk")
+// — one column per lane of a wave, rows addressed by one byte inside a 128-row sub-block (the
+// height of a tile of k_affinity_sym, which therefore writes finished slices itself). A
 // lane's list in a slice is the concatenation of its H sub-block lists, each rounded up to
 // whole QUADS of 4 entries (padding: value 0, row 0 — adds exact zeros). Nothing is padded to a
 // neighbour's length: step q of a slice stores the quads of only those lanes that still have a
@@ -40,14 +41,18 @@ namespace clipper_hip {
 // column lists padded to the longest of 128 neighbours that this replaces (round 1). Lanes whose
 // list is shorter than the slice's longest idle inside a slice (issue slots), they cost no bytes.
 //
-// Slices of one column group are contiguous and chunk-ordered in the arena; their offsets come
-// from a scan of their sizes, so the layout is a pure function of the matrix. Directory:
+// Where a slice lies in the arena is arbitrary (the fill kernel claims the space of a slice with
+// one atomic; the packers of the other sources lay them out by a scan): its CONTENT is a pure
+// function of the matrix, and with it every sum. Directory:
 //   Pre[cg * nchunks + k]  byte offset / 16 of the slice
 //   Lq [cg * nchunks + k]  maxq | entries << 8 (the cost of the slice in lock-step steps and
 //                          its stored entries; planning and reporting only)
 //   work[wg]               what workgroup wg does, most expensive first (SliceWork)
 constexpr int SL_W = 64;      // columns per slice
-constexpr int SL_SUB = 256;   // rows per sub-block
+#ifndef CLIPPER_SL_SUB
+#define CLIPPER_SL_SUB 128
+#endif
+constexpr int SL_SUB = CLIPPER_SL_SUB;   // rows per sub-block (<= 256: one row byte)
 constexpr int SL_SO = 16;     // steps between two recorded step offsets
 constexpr int SL_TAILPAD = 4096;  // bytes behind the last slice a load front may touch
 
@@ -69,7 +74,12 @@ struct SliceView {
   int ncg;      // column groups
 };
 
-constexpr int sl_xpitch(int V) { return V <= 2 ? 2 : (V <= 4 ? 4 : (V <= 6 ? 6 : 8)); }  // doubles per staged row (window mode)
+// Window mode stages candidates 0 .. sl_xload(V)-1 of a table row at a pitch of sl_xpitch(V)
+// doubles: an ODD number of 16-byte units (1, 3, 5), so that the rows of a sub-block spread over
+// all 16 slots a ds_read_b128 lane group can serve in one LDS cycle (pitch 32 B would use 8
+// of them, 64 B only 4).
+constexpr int sl_xload(int V) { return V <= 2 ? 2 : (V <= 4 ? 4 : (V <= 6 ? 6 : 8)); }
+constexpr int sl_xpitch(int V) { return V <= 2 ? 2 : (V <= 6 ? 6 : 10); }
 constexpr int sl_lds_doubles(int V, int H, int NW) {
   const int a = 2 * SL_SUB * H * sl_xpitch(V);  // two x buffers
   const int b = NW * 64 + NW * 2 * V + 8;       // the decision's scratch
@@ -113,16 +123,16 @@ __device__ __forceinline__ uint32_t sl_lane_rank(uint64_t mask) {
 
 // Stage the x rows of chunk k ([R][XP] doubles, row pitch XP) — window mode: candidates 0..XP-1
 // of table row r = X[r * VS + .]; pair mode: X[r * xstride]. Pieces of 16 bytes, thread-linear.
-template <bool WINDOW, int XP, int R, int NT>
+template <bool WINDOW, int XL, int XP, int R, int NT>
 struct SliceXStage {
-  static constexpr int PIECES = WINDOW ? R * XP / 2 : R;  // 16-byte (window) / 8-byte (pair) pieces
+  static constexpr int PIECES = WINDOW ? R * XL / 2 : R;  // 16-byte (window) / 8-byte (pair) pieces
   static constexpr int PER = (PIECES + NT - 1) / NT;
   double2 w[WINDOW ? PER : 1];
   double s[WINDOW ? 1 : PER];
   __device__ __forceinline__ void load(const double* __restrict__ X, int xstride, int64_t r0,
                                        int64_t m) {
     if constexpr (WINDOW) {
-      constexpr int PPR = XP / 2;  // pieces per row
+      constexpr int PPR = XL / 2;  // pieces per row
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int p = threadIdx.x + i * NT;
@@ -142,10 +152,12 @@ struct SliceXStage {
   }
   __device__ __forceinline__ void store(double* xs) const {
     if constexpr (WINDOW) {
+      constexpr int PPR = XL / 2;
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int p = threadIdx.x + i * NT;
-        if (p < PIECES) *reinterpret_cast<double2*>(xs + 2 * p) = w[i];
+        const int row = p / PPR, part = p - row * PPR;
+        if (p < PIECES) *reinterpret_cast<double2*>(xs + row * XP + 2 * part) = w[i];
       }
     } else {
 #pragma unroll
@@ -162,13 +174,10 @@ template <int H>
 struct SliceHead {
   const uint8_t* sp;
   int maxq;
-  uint32_t bytes;  // the next chunk's slice of the same column group starts at sp + bytes
   int nq[H];
   __device__ __forceinline__ void load(const uint8_t* p, int lane) {
     sp = p;
-    const uint4 hd = *reinterpret_cast<const uint4*>(p);
-    maxq = static_cast<int>(hd.y);
-    bytes = hd.z;
+    maxq = static_cast<int>(reinterpret_cast<const uint32_t*>(p)[1]);
 #pragma unroll
     for (int h = 0; h < H; ++h) nq[h] = p[16 + h * 64 + lane];
   }
@@ -180,6 +189,7 @@ template <int H, int NW>
 struct SliceJob {
   int strip, slot, cg, t0, t1, q0, q1;
   SliceHead<H> first;
+  uint64_t pre1;  // Pre of the slice after the first one (its header is requested one chunk ahead)
 };
 
 template <int H, int NW>
@@ -195,11 +205,14 @@ __device__ __forceinline__ void slice_begin(const SliceView& M, SliceJob<H, NW>&
   J.q1 = w.q1;
   J.first.maxq = 0;
   J.first.sp = M.data;
-  J.first.bytes = 0;
+  J.pre1 = 0;
 #pragma unroll
   for (int h = 0; h < H; ++h) J.first.nq[h] = 0;
-  if (J.cg < M.ncg && J.t0 < J.t1)
-    J.first.load(M.data + 16 * M.Pre[static_cast<int64_t>(J.cg) * M.nchunks + J.t0], threadIdx.x & 63);
+  if (J.cg < M.ncg && J.t0 < J.t1) {
+    const uint64_t* pre = M.Pre + static_cast<int64_t>(J.cg) * M.nchunks + J.t0;
+    J.first.load(M.data + 16 * pre[0], threadIdx.x & 63);
+    if (J.t0 + 1 < J.t1) J.pre1 = pre[1];
+  }
 }
 
 // The streaming part of a pass on the slices: this workgroup's partial sums ->
@@ -213,6 +226,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
                                            int xstride, double* __restrict__ part, double* lds) {
   constexpr int NS = WINDOW ? V + 1 : 2;
   constexpr int XP = WINDOW ? sl_xpitch(V) : 1;
+  constexpr int XL = WINDOW ? sl_xload(V) : 1;
   constexpr int R = SL_SUB * H;
   constexpr int NT = NW * 64;
   constexpr int QB = 4 * static_cast<int>(sizeof(VT));  // bytes of a value quad
@@ -224,7 +238,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
 #pragma unroll
   for (int v = 0; v < NS; ++v) acc[v] = 0.0;
 
-  SliceXStage<WINDOW, XP, R, NT> xst;
+  SliceXStage<WINDOW, XL, XP, R, NT> xst;
   __syncthreads();  // the decision at the head of the launch used the same LDS
   if (t0 < t1) {
     xst.load(X, xstride, static_cast<int64_t>(t0) * R, m);
@@ -232,14 +246,18 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
   }
   __syncthreads();
   SliceHead<H> cur = J.first;
+  uint64_t pre_next = J.pre1;  // Pre of slice k + 1, requested a chunk ago
+  const uint64_t* pre_row = M.Pre + static_cast<int64_t>(mine ? cg : 0) * M.nchunks;
   for (int k = t0; k < t1; ++k) {
     const double* xs = lds + ((k - t0) & 1) * (R * XP);
     double* xnext = lds + (((k - t0) & 1) ^ 1) * (R * XP);
     const bool more = k + 1 < t1;
     SliceHead<H> nxt = cur;
+    uint64_t pre_next2 = 0;
     if (more) {
       xst.load(X, xstride, static_cast<int64_t>(k + 1) * R, m);
-      if (mine) nxt.load(cur.sp + cur.bytes, lane);
+      if (mine) nxt.load(M.data + 16 * pre_next, lane);
+      if (k + 2 < t1) pre_next2 = pre_row[k + 2];
     }
     if (mine) {
       const int maxq = __builtin_amdgcn_readfirstlane(cur.maxq);
@@ -317,6 +335,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
     }
     if (more) xst.store(xnext);
     cur = nxt;
+    pre_next = pre_next2;
     __syncthreads();
   }
 
@@ -338,29 +357,40 @@ __device__ __forceinline__ void slices_by_plan(const SliceView& M, const SliceJo
   if (plan.phase == PH_TRIAL) {
     slice_core<VT, H, true, V, nslot(V), NW, D>(
         M, J, A.W, A.m, plan.d, A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS, VS, A.part, lds);
-  } else if (plan.from_u >= 0) {
-    slice_core<VT, H, false, V, nslot(V), NW, D>(
-        M, J, A.W, A.m, 0.0, A.pt + static_cast<int64_t>(plan.from_u) * 2 * A.mp, 1, A.part, lds);
-  } else {
-    slice_core<VT, H, false, V, nslot(V), NW, D>(
-        M, J, A.W, A.m, 0.0, A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS, VS, A.part, lds);
+  } else {  // pair mode: straight on the u array of a point slot, or on candidate 0 of a table
+    const bool fu = plan.from_u >= 0;
+    const double* X = fu ? A.pt + static_cast<int64_t>(plan.from_u) * 2 * A.mp
+                         : A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS;
+    slice_core<VT, H, false, V, nslot(V), NW, D>(M, J, A.W, A.m, 0.0, X, fu ? 1 : VS, A.part, lds);
   }
 }
 
 constexpr int SL_NW = 4;  // waves (= column groups) per workgroup
 constexpr int SL_D = 4;   // steps in flight per lane
+#ifndef CLIPPER_SL_OCC
+#define CLIPPER_SL_OCC 5
+#endif
+constexpr int SL_OCC = CLIPPER_SL_OCC;  // waves per SIMD the pass kernel is compiled for (5 workgroups per CU)
 
 // G of a solver iteration on the slices (one shard): decision, then the pass
 template <typename VT, int H, int V>
-__global__ __launch_bounds__(SL_NW * 64, 2) void k_gemv_slices(SliceView M, SolveArgs A) {
+__global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M, SolveArgs A) {
   __shared__ __attribute__((aligned(16))) double lds[sl_lds_doubles(V, H, SL_NW)];
   __shared__ __attribute__((aligned(16))) SolverState stash;
+  const long long c0 = A.stamps ? wall_clock64() : 0;
   SliceJob<H, SL_NW> J;
   slice_begin<H, SL_NW>(M, J);
   PassPlan plan;
   if (!iteration_head<V, SL_NW * 64>(A, lds, &stash, plan)) return;
+  const long long c1 = A.stamps ? wall_clock64() : 0;
   slices_by_plan<VT, H, V, SL_NW, SL_D>(M, J, A, plan, lds);
   flush_state(A, &stash);
+  if (A.stamps && threadIdx.x == 0 && blockIdx.x < 4096) {
+    A.stamps[blockIdx.x * 4 + 0] = c0;
+    A.stamps[blockIdx.x * 4 + 1] = c1;
+    A.stamps[blockIdx.x * 4 + 2] = wall_clock64();
+    A.stamps[blockIdx.x * 4 + 3] = (static_cast<long long>(J.t1 - J.t0) << 32) | static_cast<unsigned>(plan.phase);
+  }
 }
 
 // the pair-mode product alone on table X (matvec API, micro-benchmark): a -> slot 0, b -> slot 1
@@ -412,7 +442,7 @@ struct GroupSource {
   const uint8_t* rows;
   int nblocks;   // 64-row blocks of the matrix
   int64_t ncols; // columns the groups cover (local)
-  // per-lane state: the 4 blocks of one sub-block at a time
+  // per-lane state: the SL_SUB / 64 blocks of one sub-block at a time (unused ones: empty)
   int64_t start[4];
   int cnt[4];
   __device__ __forceinline__ void prepare_sub(int64_t c, int64_t r0) {
@@ -423,7 +453,7 @@ struct GroupSource {
       const int64_t b = r0 / GR_RB + j;
       start[j] = 0;
       cnt[j] = 0;
-      if (c < ncols && b < nblocks) {
+      if (j < SL_SUB / GR_RB && c < ncols && b < nblocks) {
         const int64_t g = s * nblocks + b;
         const uint32_t o0 = Goff[g * GR_OFFS + cl], o1 = Goff[g * GR_OFFS + cl + 1];
         start[j] = static_cast<int64_t>(Gpre[g]) * 4 + o0;
@@ -432,17 +462,21 @@ struct GroupSource {
     }
   }
   __device__ __forceinline__ int count() const { return cnt[0] + cnt[1] + cnt[2] + cnt[3]; }
-  // entry i (< count()) of the prepared sub-block: value and row byte (row inside the sub-block)
+  // entry i of the prepared sub-block: value and row byte (row inside the sub-block); i >=
+  // count(): value 0, row 0. Branch-free, so that the loads of a quad are issued together.
   __device__ __forceinline__ void fetch(int i, VT& v, uint32_t& row) const {
-    const int c01 = cnt[0] + cnt[1], c012 = c01 + cnt[2];
-    int j, k;
-    int64_t st;
-    if (i < cnt[0]) { j = 0; k = i; st = start[0]; }
-    else if (i < c01) { j = 1; k = i - cnt[0]; st = start[1]; }
-    else if (i < c012) { j = 2; k = i - c01; st = start[2]; }
-    else { j = 3; k = i - c012; st = start[3]; }
-    v = vals[st + k];
-    row = static_cast<uint32_t>(j * GR_RB) + rows[st + k];
+    const int n = count();
+    const bool valid = i < n;
+    const int ii = valid ? i : 0;
+    const int c0 = cnt[0], c01 = c0 + cnt[1], c012 = c01 + cnt[2];
+    const int j = (ii >= c0 ? 1 : 0) + (ii >= c01 ? 1 : 0) + (ii >= c012 ? 1 : 0);
+    const int before = j == 0 ? 0 : (j == 1 ? c0 : (j == 2 ? c01 : c012));
+    const int64_t st = j == 0 ? start[0] : (j == 1 ? start[1] : (j == 2 ? start[2] : start[3]));
+    const int64_t a = valid ? st + (ii - before) : 0;
+    const VT lv = vals[a];
+    const uint32_t lr = rows[a];
+    v = valid ? lv : VT(0);
+    row = valid ? static_cast<uint32_t>(j * GR_RB) + lr : 0u;
   }
 };
 
@@ -477,10 +511,14 @@ struct CscSource {
   }
   __device__ __forceinline__ int count() const { return cnt; }
   __device__ __forceinline__ void fetch(int i, VT& v, uint32_t& row) const {
-    const double x = values[start + i];
-    v = static_cast<VT>(x);
-    if (v == VT(0) && x != 0.0) v = static_cast<VT>(1.17549435e-38);  // an underflow keeps the pattern
-    row = static_cast<uint32_t>(rowidx[start + i] - r0_);
+    const bool valid = i < cnt;
+    const int64_t a = valid ? start + i : 0;
+    const double x = values[a];
+    const int32_t r = rowidx[a];
+    VT t = static_cast<VT>(x);
+    if (t == VT(0) && x != 0.0) t = static_cast<VT>(1.17549435e-38);  // an underflow keeps the pattern
+    v = valid ? t : VT(0);
+    row = valid ? static_cast<uint32_t>(r - r0_) : 0u;
   }
 };
 
@@ -509,13 +547,22 @@ __device__ __forceinline__ uint32_t sl_steps_bytes(int tot, int maxq, int QB) {
   return bytes;
 }
 
+// also folds the 64 arenas' overflow marks of the group build into ONE word (`ovf`), which is
+// all the pack kernels look at (a strided read of the 64 marks by each of their waves cost more
+// than the packing)
 template <typename VT, int H, typename Source>
 __global__ __launch_bounds__(256) void k_slice_count(Source S, int ncg, int nchunks,
                                                       uint32_t* __restrict__ sizes,
-                                                      uint32_t* __restrict__ Lq) {
+                                                      uint32_t* __restrict__ Lq,
+                                                      const CscBuildCtl* __restrict__ ctl,
+                                                      uint64_t* __restrict__ ovf) {
   const int lane = threadIdx.x & 63;
   const int64_t s = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (s >= static_cast<int64_t>(ncg) * nchunks) return;  // whole wave
+  if (s == 0) {
+    const bool o = ctl != nullptr && __ballot(ctl[lane].overflow != 0) != 0;
+    if (lane == 0) ovf[0] = o ? 1 : 0;
+  }
   const int cg = static_cast<int>(s / nchunks), k = static_cast<int>(s - static_cast<int64_t>(cg) * nchunks);
   const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
   int tot = 0, ent = 0;
@@ -601,81 +648,222 @@ __global__ __launch_bounds__(256) void k_slice_scan_add(uint64_t* __restrict__ P
     if (base + j < n) Pre[base + j] += off;
 }
 
+// One workgroup of SL_PACKW waves per slice: every wave knows where every step starts (the
+// lanes' lengths: ALU only), wave w writes steps w, w + SL_PACKW, ... — the slices of a dense
+// block are 64 dependent load->store steps long, one wave alone would be the build's critical
+// path. Returns at once if there is nothing to pack into (slice arena too small) or from (the
+// groups overflowed): the host grows the buffers and repeats.
+constexpr int SL_PACKW = 8;
+constexpr int SL_STAGE_CAP = 2048;  // entries of a slice k_slice_pack_staged stages in LDS
 template <typename VT, int H, typename Source>
-__global__ __launch_bounds__(256) void k_slice_pack(Source S, int ncg, int nchunks,
-                                                     const uint64_t* __restrict__ Pre,
-                                                     uint8_t* __restrict__ data,
-                                                     const uint64_t* __restrict__ total_units,
-                                                     uint64_t cap_units,
-                                                     const CscBuildCtl* __restrict__ ctl) {
+__global__ __launch_bounds__(SL_PACKW * 64) void k_slice_pack(Source S, int ncg, int nchunks,
+                                                               const uint64_t* __restrict__ Pre,
+                                                               uint8_t* __restrict__ data,
+                                                               const uint64_t* __restrict__ total_units,
+                                                               uint64_t cap_units,
+                                                               const uint32_t* __restrict__ Lq,
+                                                               int heavy_only) {
   constexpr int QB = 4 * static_cast<int>(sizeof(VT));
   const int lane = threadIdx.x & 63;
-  const int64_t s = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (s >= static_cast<int64_t>(ncg) * nchunks) return;  // whole wave
-  // nothing to pack into, or nothing to pack from: the host grows the buffers and repeats
-  if (total_units[0] > cap_units) return;
-  if (ctl != nullptr && __ballot(ctl[lane].overflow != 0) != 0) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t s = blockIdx.x;
+  // heavy_only: slices of at most SL_STAGE_CAP entries were packed by k_slice_pack_staged
+  if (heavy_only && (Lq[s] >> 8) <= static_cast<uint32_t>(SL_STAGE_CAP)) return;
+  if (total_units[0] > cap_units || total_units[1] != 0) return;  // [1]: the groups overflowed
   const int cg = static_cast<int>(s / nchunks), k = static_cast<int>(s - static_cast<int64_t>(cg) * nchunks);
   const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
-  int nq[H], n[H];
+  int nq[H];
   int tot = 0;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     S.prepare_sub(c, (static_cast<int64_t>(k) * H + h) * SL_SUB);
-    n[h] = S.count();
-    nq[h] = (n[h] + 3) >> 2;
+    nq[h] = (S.count() + 3) >> 2;
     tot += nq[h];
   }
   const int maxq = sl_wave_max(tot);
-  const int nquads = sl_wave_sum(tot);
   uint8_t* sp = data + 16 * Pre[s];
-#pragma unroll
-  for (int h = 0; h < H; ++h) sp[16 + h * 64 + lane] = static_cast<uint8_t>(nq[h]);
   uint32_t* so = reinterpret_cast<uint32_t*>(sp + 16 + H * 64);
   const int sob = sl_so_bytes(maxq);
-  if (lane * 4 < sob) so[lane] = 0;  // maxq <= 64 H: at most 4 H entries + padding
+  if (wave == 0) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) sp[16 + h * 64 + lane] = static_cast<uint8_t>(nq[h]);
+    if (lane * 4 < sob && lane >= (maxq + SL_SO - 1) / SL_SO) so[lane] = 0;  // the table's padding
+  }
   uint32_t off = 16 + H * 64 + sob;  // wave-uniform
-  int hcur = -1;   // sub-block the source is positioned on (per lane)
-  int edge = 0;    // first step behind that sub-block
-  int qbase = 0;   // its first step
+  int hcur = H == 1 ? 0 : -1;  // sub-block the source is positioned on (per lane)
+  int edge = H == 1 ? nq[0] : 0;    // first step behind that sub-block
+  int qbase = 0;                    // its first step
   for (int q = 0; q < maxq; ++q) {
     const bool active = q < tot;
     const uint64_t mask = __ballot(active);
     const int cnt = __popcll(mask);
+    if ((q % SL_PACKW) == wave) {  // uniform
+      if ((q % SL_SO) == 0 && lane == 0) so[q / SL_SO] = off;
+      if (active) {
+        if constexpr (H > 1) {
+          while (q >= edge) {  // this lane's steps of sub-block hcur are used up: next one
+            ++hcur;
+            qbase = edge;
+            int nn = 0;
+#pragma unroll
+            for (int h = 0; h < H; ++h) nn = (h == hcur) ? nq[h] : nn;
+            edge += nn;
+            if (nn > 0) S.prepare_sub(c, (static_cast<int64_t>(k) * H + hcur) * SL_SUB);
+          }
+        }
+        const uint32_t rank = sl_lane_rank(mask);
+        SliceQuad<VT> vq;
+        uint32_t rq = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t row;
+          S.fetch((q - qbase) * 4 + e, vq.v[e], row);
+          rq |= row << (8 * e);
+        }
+        vq.store(sp + off + rank * QB);
+        *reinterpret_cast<uint32_t*>(sp + off + cnt * QB + rank * 4) = rq;
+      }
+      // zero the step's padding (the row quads are padded to 16 bytes)
+      const int padw = (((cnt * 4 + 15) & ~15) - cnt * 4) >> 2;  // dwords
+      if (lane < padw) *reinterpret_cast<uint32_t*>(sp + off + cnt * QB + cnt * 4 + lane * 4) = 0;
+    }
+    off += cnt * QB + ((cnt * 4 + 15) & ~15);
+  }
+  const int nquads = sl_wave_sum(tot);
+  if (wave == 0 && lane == 0) {
+    uint32_t* hd = reinterpret_cast<uint32_t*>(sp);
+    hd[0] = static_cast<uint32_t>(nquads);
+    hd[1] = static_cast<uint32_t>(maxq);
+    hd[2] = off;
+    hd[3] = 0;
+  }
+}
+
+// k_slice_pack_staged — the packer of the common case (source = groups, H = 1, a slice of at most
+// SL_STAGE_CAP entries): one wave per slice. The lists of the slice's 64 columns in one 64-row
+// block are ONE contiguous run of the group (columns are stored back to back), so the wave
+// copies its four runs into LDS with coalesced loads and the lanes pick their entries from
+// there; k_slice_pack's per-lane gathers from global memory touch ~40 cache lines per load
+// instruction and cost 10x as much. Heavier slices (dense blocks) are left to k_slice_pack
+// (`heavy_only`), whose lanes then read long, nearly contiguous lists anyway.
+template <typename VT>
+__device__ __forceinline__ int sl_slice_entries(const GroupSource<VT>& S, int cg, int k, int lane) {
+  // entries of slice (cg, k): the four runs' lengths (wave-uniform)
+  const int64_t s = cg >> 1;
+  const int cl0 = (cg & 1) * 64;
+  int total = 0;
+#pragma unroll
+  for (int j = 0; j < SL_SUB / GR_RB; ++j) {
+    const int64_t b = static_cast<int64_t>(k) * (SL_SUB / GR_RB) + j;
+    if (b < S.nblocks) {
+      const int64_t g = s * S.nblocks + b;
+      total += static_cast<int>(S.Goff[g * GR_OFFS + cl0 + 64]) - static_cast<int>(S.Goff[g * GR_OFFS + cl0]);
+    }
+  }
+  return total;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_slice_pack_staged(GroupSource<VT> S, int ncg, int nchunks,
+                                                            const uint64_t* __restrict__ Pre,
+                                                            uint8_t* __restrict__ data,
+                                                            const uint64_t* __restrict__ total_units,
+                                                            uint64_t cap_units) {
+  constexpr int QB = 4 * static_cast<int>(sizeof(VT));
+  __shared__ VT valsL[4][SL_STAGE_CAP];
+  __shared__ uint8_t rowsL[4][SL_STAGE_CAP];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  if (s >= static_cast<int64_t>(ncg) * nchunks) return;  // whole wave
+  if (total_units[0] > cap_units || total_units[1] != 0) return;  // [1]: the groups overflowed
+  const int cg = static_cast<int>(s / nchunks), k = static_cast<int>(s - static_cast<int64_t>(cg) * nchunks);
+  if (sl_slice_entries(S, cg, k, lane) > SL_STAGE_CAP) return;  // k_slice_pack's
+  const int64_t strip = cg >> 1;
+  const int cl0 = (cg & 1) * 64, cl = cl0 + lane;
+  // the four runs -> LDS; this lane's list of block j starts at lst[j], cnt[j] entries
+  int lst[4], cnt[4];
+  int roff = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t b = static_cast<int64_t>(k) * (SL_SUB / GR_RB) + j;
+    lst[j] = 0;
+    cnt[j] = 0;
+    if (j < SL_SUB / GR_RB && b < S.nblocks) {  // uniform
+      const int64_t g = strip * S.nblocks + b;
+      const uint16_t* go = S.Goff + g * GR_OFFS;
+      const int r0 = go[cl0], r1 = go[cl0 + 64];
+      const int o0 = go[cl], o1 = go[cl + 1];
+      const int64_t base = static_cast<int64_t>(S.Gpre[g]) * 4 + r0;
+      const int len = r1 - r0;
+      // 512 entries per trip, every load issued before the first store (idle lanes re-read the
+      // run's last entry: no divergent branch around a load, see slice_core)
+      for (int i0 = 0; i0 < len; i0 += 512) {
+        VT tv[8];
+        uint8_t tr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * 64 + lane;
+          const int ic = i < len ? i : len - 1;
+          tv[u] = S.vals[base + ic];
+          tr[u] = S.rows[base + ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * 64 + lane;
+          if (i < len) {
+            valsL[wave][roff + i] = tv[u];
+            rowsL[wave][roff + i] = tr[u];
+          }
+        }
+      }
+      lst[j] = roff + (o0 - r0);
+      cnt[j] = o1 - o0;
+      roff += len;
+    }
+  }
+  const int n = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  const int tot = (n + 3) >> 2;
+  const int maxq = sl_wave_max(tot);
+  const int nquads = sl_wave_sum(tot);
+  uint8_t* sp = data + 16 * Pre[s];
+  sp[16 + lane] = static_cast<uint8_t>(tot);
+  uint32_t* so = reinterpret_cast<uint32_t*>(sp + 16 + 64);
+  const int sob = sl_so_bytes(maxq);
+  if (lane * 4 < sob && lane >= (maxq + SL_SO - 1) / SL_SO) so[lane] = 0;
+  uint32_t off = 16 + 64 + sob;
+  const int c0 = cnt[0], c01 = c0 + cnt[1], c012 = c01 + cnt[2];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int q = 0; q < maxq; ++q) {
+    const bool active = q < tot;
+    const uint64_t mask = __ballot(active);
+    const int cntq = __popcll(mask);
     if ((q % SL_SO) == 0 && lane == 0) so[q / SL_SO] = off;
     if (active) {
-      while (q >= edge) {  // this lane's steps of sub-block hcur are used up: next one
-        ++hcur;
-        qbase = edge;
-        int nn = 0;
-#pragma unroll
-        for (int h = 0; h < H; ++h) nn = (h == hcur) ? nq[h] : nn;
-        edge += nn;
-        if (nn > 0) S.prepare_sub(c, (static_cast<int64_t>(k) * H + hcur) * SL_SUB);
-      }
-      int nh = 0;
-#pragma unroll
-      for (int h = 0; h < H; ++h) nh = (h == hcur) ? n[h] : nh;
       const uint32_t rank = sl_lane_rank(mask);
       SliceQuad<VT> vq;
       uint32_t rq = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = (q - qbase) * 4 + e;
-        VT v = VT(0);
-        uint32_t row = 0;
-        if (i < nh) S.fetch(i, v, row);
-        vq.v[e] = v;
-        rq |= row << (8 * e);
+        const int i = q * 4 + e;
+        const bool valid = i < n;
+        const int ii = valid ? i : 0;
+        const int j = (ii >= c0 ? 1 : 0) + (ii >= c01 ? 1 : 0) + (ii >= c012 ? 1 : 0);
+        const int before = j == 0 ? 0 : (j == 1 ? c0 : (j == 2 ? c01 : c012));
+        const int st = j == 0 ? lst[0] : (j == 1 ? lst[1] : (j == 2 ? lst[2] : lst[3]));
+        const int a = valid ? st + (ii - before) : 0;
+        const VT lv = valsL[wave][a];
+        const uint32_t lr = rowsL[wave][a];
+        vq.v[e] = valid ? lv : VT(0);
+        rq |= (valid ? static_cast<uint32_t>(j * GR_RB) + lr : 0u) << (8 * e);
       }
       vq.store(sp + off + rank * QB);
-      *reinterpret_cast<uint32_t*>(sp + off + cnt * QB + rank * 4) = rq;
+      *reinterpret_cast<uint32_t*>(sp + off + cntq * QB + rank * 4) = rq;
     }
-    {  // zero the step's padding (the row quads are padded to 16 bytes)
-      const int padw = (((cnt * 4 + 15) & ~15) - cnt * 4) >> 2;  // dwords
-      if (lane < padw) *reinterpret_cast<uint32_t*>(sp + off + cnt * QB + cnt * 4 + lane * 4) = 0;
-    }
-    off += cnt * QB + ((cnt * 4 + 15) & ~15);
+    const int padw = (((cntq * 4 + 15) & ~15) - cntq * 4) >> 2;  // dwords of the step's padding
+    if (lane < padw) *reinterpret_cast<uint32_t*>(sp + off + cntq * QB + cntq * 4 + lane * 4) = 0;
+    off += cntq * QB + ((cntq * 4 + 15) & ~15);
   }
   if (lane == 0) {
     uint32_t* hd = reinterpret_cast<uint32_t*>(sp);
@@ -684,6 +872,35 @@ __global__ __launch_bounds__(256) void k_slice_pack(Source S, int ncg, int nchun
     hd[2] = off;
     hd[3] = 0;
   }
+}
+
+// exclusive scan by ONE workgroup (n up to a few 10^4: three launches cost more than the scan)
+__global__ __launch_bounds__(1024) void k_slice_scan_small(const uint32_t* __restrict__ sizes,
+                                                            int64_t n, uint64_t* __restrict__ Pre,
+                                                            uint64_t* __restrict__ total) {
+  __shared__ uint64_t wsum[16];
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < n; b0 += 1024) {
+    const int64_t i = b0 + threadIdx.x;
+    const uint64_t v = (i < n) ? sizes[i] : 0;
+    uint64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t t = __shfl_up(inc, o);
+      if ((threadIdx.x & 63) >= o) inc += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint64_t off = carry_s;
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
+    if (i < n) Pre[i] = off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[0] = carry_s;
 }
 
 // k_slice_expand — the dense store S[j][c] (row pitch ld, element ST) back from the slices of

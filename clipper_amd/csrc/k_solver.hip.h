@@ -144,6 +144,8 @@ struct SolveArgs {
   uint8_t* marks;
   uint8_t* kind;
   double* host_u; // pinned host memory [m] (may be null): the final u, written before `done`
+  long long* stamps;  // measurement only (may be null): per workgroup {start, head done, end} of the
+                      // last pass launch, 100 MHz wall clock (clipper_hip_debug_stamps)
 };
 constexpr int KIND_CAP = 1 << 16;
 
@@ -256,9 +258,64 @@ constexpr int VU = 4;  // elements per thread per sweep step (all NT threads of 
   _Pragma("unroll") for (int k = 0; k < VU; ++k) \
     if (const int64_t i = base + static_cast<int64_t>(k) * NT; i < m)
 
+// What the head of a launch loads before it knows whether it needs it: the scalar state and this
+// thread's chain of the tail's partial scalars. Requested together, up front — one round trip
+// to L2 instead of three dependent ones (done/stage -> state -> partials).
+struct HeadLoads {
+  int done, stage, phase;
+  double d, F, alpha, s;
+  int i, j, k, ubp, ubv, sel;
+  int64_t n_passes, n_trials, n_iters;
+  double chain;  // this thread's share of sum_w scal[w][q]
+};
+
 template <int V, int NT>
-__device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverState* stash,
-                                       PassPlan& plan) {
+__device__ __forceinline__ void head_loads(const SolveArgs& A, HeadLoads& L) {
+  constexpr int NR = 2 + 2 * V;
+  constexpr int Q = V * NR + 2 * V + 2;
+  constexpr int QPAD = pow2_at_least(Q);
+  constexpr int NCH = NT / QPAD;
+  const SolverState* st = A.st_cur;
+  L.done = A.shared->done;
+  L.stage = st->stage;
+  L.phase = st->phase;
+  L.d = st->d;
+  L.F = st->F;
+  L.alpha = st->alpha;
+  L.s = st->s;
+  L.i = st->i;
+  L.j = st->j;
+  L.k = st->k;
+  L.ubp = st->ubp;
+  L.ubv = st->ubv;
+  L.sel = st->sel;
+  L.n_passes = st->n_passes;
+  L.n_trials = st->n_trials;
+  L.n_iters = st->n_iters;
+  // sums[q] = sum over the tail workgroups w of scal[w][q]: NCH interleaved chains per
+  // quantity (w = c, c + NCH, ...), added in chain order
+  const int tid = threadIdx.x;
+  const int q = tid & (QPAD - 1), c = tid / QPAD;
+  double acc = 0.0;
+  if (q < Q) {
+    constexpr int U = 20;  // loads in flight per chain (all of them up to m = 10k)
+    const double* p = A.scal_in + q;
+    int w = c;
+    for (; w + NCH * (U - 1) < A.nwg_in; w += NCH * U) {
+      double x[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) x[k] = p[static_cast<int64_t>(w + NCH * k) * Q];
+#pragma unroll
+      for (int k = 0; k < U; ++k) acc += x[k];
+    }
+    for (; w < A.nwg_in; w += NCH) acc += p[static_cast<int64_t>(w) * Q];
+  }
+  L.chain = acc;
+}
+
+template <int V, int NT>
+__device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, double* red,
+                                       SolverState* stash, PassPlan& plan) {
   constexpr int NR = 2 + 2 * V;
   constexpr int PEN = V * NR + 2 * V;  // speculative penalty sums of candidate 0
   constexpr int Q = PEN + 2;
@@ -273,11 +330,11 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
   const SolverParams P = A.prm;
   const bool writer = (blockIdx.x == 0 && blockIdx.y == 0);
 
-  const int phase = st->phase;
-  double d = st->d, F = st->F, alpha = st->alpha, s = st->s;
-  int i_ = st->i, j_ = st->j, k_ = st->k, ubp = st->ubp, ubv = st->ubv, sel = st->sel;
-  int64_t n_passes = st->n_passes, n_trials = st->n_trials;
-  const int64_t n_iters = st->n_iters + 1;
+  const int phase = L.phase;
+  double d = L.d, F = L.F, alpha = L.alpha, s = L.s;
+  int i_ = L.i, j_ = L.j, k_ = L.k, ubp = L.ubp, ubv = L.ubv, sel = L.sel;
+  int64_t n_passes = L.n_passes, n_trials = L.n_trials;
+  const int64_t n_iters = L.n_iters + 1;
   double nrm[V], sx[V];
 #pragma unroll
   for (int l = 0; l < V; ++l) {
@@ -291,25 +348,9 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, double* red, SolverSt
   bool need_pair = false;  // the pass of this iteration is a pair-mode pass on the accepted x
 
   if (phase == PH_TRIAL || phase == PH_BUILD) {
-    // sums[q] = sum over the tail workgroups w of scal[w][q]: NCH interleaved chains per
-    // quantity (w = c, c + NCH, ...), added in chain order
+    // sums[q] = the chains of head_loads(), added in chain order
     {
-      const int q = tid & (QPAD - 1), c = tid / QPAD;
-      double acc = 0.0;
-      if (q < Q) {
-        constexpr int U = 10;  // loads in flight per chain
-        const double* p = A.scal_in + q;
-        int w = c;
-        for (; w + NCH * (U - 1) < A.nwg_in; w += NCH * U) {
-          double x[U];
-#pragma unroll
-          for (int k = 0; k < U; ++k) x[k] = p[static_cast<int64_t>(w + NCH * k) * Q];
-#pragma unroll
-          for (int k = 0; k < U; ++k) acc += x[k];
-        }
-        for (; w < A.nwg_in; w += NCH) acc += p[static_cast<int64_t>(w) * Q];
-      }
-      red[tid] = acc;
+      red[tid] = L.chain;
       __syncthreads();
       double tot = 0.0;
       if (tid < QPAD) {
@@ -604,9 +645,10 @@ template <int V, int NT>
 __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
                                                SolverState* stash, PassPlan& plan) {
   const SolverState* st = A.st_cur;
-  const int done = A.shared->done, stage = st->stage;  // one round trip, not two
-  if (done) return false;
-  if (stage == ST_RESULTS) return decide<V, NT>(A, lds, stash, plan);
+  HeadLoads L;
+  head_loads<V, NT>(A, L);
+  if (L.done) return false;
+  if (L.stage == ST_RESULTS) return decide<V, NT>(A, L, lds, stash, plan);
   // the pass was prepared by a transition iteration (or by k_init): run it as it stands
   plan.phase = st->phase;
   plan.sel = st->sel;
@@ -704,15 +746,28 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
       const double* p = A.part + static_cast<int64_t>(v) * A.W + i;
       const int64_t ts = static_cast<int64_t>(NSLOT) * A.W;
       int t = 0;
-      for (; t + 8 <= A.ntiles; t += 8) {
-        double va[8], vb[8];
+      for (; t + 16 <= A.ntiles; t += 16) {
+        double va[16], vb[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 16; ++q) {
           va[q] = p[static_cast<int64_t>(t + q) * ts];
           vb[q] = p[static_cast<int64_t>(t + q) * ts + o1];
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 16; ++q) {
+          p0 += va[q];
+          p1 += vb[q];
+        }
+      }
+      for (; t + 4 <= A.ntiles; t += 4) {
+        double va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          va[q] = p[static_cast<int64_t>(t + q) * ts];
+          vb[q] = p[static_cast<int64_t>(t + q) * ts + o1];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
           p0 += va[q];
           p1 += vb[q];
         }

@@ -230,6 +230,10 @@ int clipper_hip_get_timings(const clipper_hip_t* h, clipper_hip_timings_t* out);
  * mean kernel time in microseconds (events on the launch stream). */
 int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us);
 /* Device name, CU count, HBM bytes (for bench.py's report). */
+/* Measurement only (context created with CLIPPER_HIP_STAMPS=1 in the environment): per workgroup of
+ * the last pass launch {start, decision done, end, info} on the 100 MHz device wall clock. */
+int clipper_hip_debug_stamps(clipper_hip_t* h, int64_t* out, int capacity);
+
 int clipper_hip_device_info(const clipper_hip_t* h, char* name64, int* cus, int64_t* hbm_bytes);
 
 #ifdef __cplusplus

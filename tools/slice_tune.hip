@@ -50,8 +50,47 @@ struct Packed {
   size_t quads = 0, entries = 0, steps = 0;
 };
 
+// Conflict-aware order of the entries inside every (lane, sub-block) list: the 16 lanes that one
+// LDS cycle of a ds_read_b128 serves should hit 16 different 16-byte slots of the staged x rows
+// (slot = 3 * row mod 16 at the 48-byte row pitch). Greedy, step by step, per LDS lane group.
+static const int LDS_GROUP[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                     {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                     {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                     {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+static int PITCH16 = 3;  // 16-byte units per staged row (3 for windows of 4 and 6, 5 for 8, 1 for 1)
+void reorder_greedy(std::vector<std::vector<Entry>>& sub, int H) {
+  for (int h = 0; h < H; ++h)
+    for (int g = 0; g < 4; ++g) {
+      std::vector<Entry> rem[16], out[16];
+      for (int j = 0; j < 16; ++j) rem[j] = sub[static_cast<size_t>(LDS_GROUP[g][j]) * H + h];
+      for (;;) {
+        int order[16], n = 0;
+        for (int j = 0; j < 16; ++j) if (!rem[j].empty()) order[n++] = j;
+        if (n == 0) break;
+        std::stable_sort(order, order + n, [&](int a, int b) { return rem[a].size() > rem[b].size(); });
+        int used[16];
+        for (int j = 0; j < 16; ++j) used[j] = -1;
+        for (int t = 0; t < n; ++t) {
+          auto& r = rem[order[t]];
+          size_t pick = 0;
+          bool found = false;
+          for (size_t i = 0; i < r.size(); ++i) {
+            const int slot = (PITCH16 * r[i].row) & 15;
+            if (used[slot] < 0 || used[slot] == r[i].row) { pick = i; found = true; break; }
+          }
+          (void)found;
+          const Entry e = r[pick];
+          r.erase(r.begin() + static_cast<long>(pick));
+          if (used[(PITCH16 * e.row) & 15] < 0) used[(PITCH16 * e.row) & 15] = e.row;
+          out[order[t]].push_back(e);
+        }
+      }
+      for (int j = 0; j < 16; ++j) sub[static_cast<size_t>(LDS_GROUP[g][j]) * H + h] = out[j];
+    }
+}
+
 template <typename VT>
-Packed<VT> pack(const std::vector<std::vector<Entry>>& cols, int64_t m, int H) {
+Packed<VT> pack(const std::vector<std::vector<Entry>>& cols, int64_t m, int H, int order = 0) {
   const int R = SL_SUB * H;
   Packed<VT> P;
   P.nchunks = static_cast<int>((m + R - 1) / R);
@@ -90,6 +129,7 @@ Packed<VT> pack(const std::vector<std::vector<Entry>>& cols, int64_t m, int H) {
         maxq = std::max(maxq, tot[l]);
         nquads += tot[l];
       }
+      if (order == 1) reorder_greedy(sub, H);
       while (P.data.size() % 16) P.data.push_back(0);
       const size_t start = P.data.size();
       P.Pre[static_cast<size_t>(cg) * P.nchunks + k] = start / 16;
@@ -100,7 +140,13 @@ Packed<VT> pack(const std::vector<std::vector<Entry>>& cols, int64_t m, int H) {
       P.data.insert(P.data.end(), reinterpret_cast<uint8_t*>(head), reinterpret_cast<uint8_t*>(head) + 16);
       for (int h = 0; h < H; ++h)
         for (int l = 0; l < 64; ++l) P.data.push_back(static_cast<uint8_t>(nq[h][l]));
+      const size_t so_at = P.data.size();
+      P.data.resize(P.data.size() + sl_so_bytes(maxq), 0);
       for (int q = 0; q < maxq; ++q) {
+        if (q % SL_SO == 0) {
+          const uint32_t o = static_cast<uint32_t>(P.data.size() - start);
+          std::memcpy(P.data.data() + so_at + 4 * (q / SL_SO), &o, 4);
+        }
         std::vector<VT> vv;
         std::vector<uint8_t> rr;
         for (int l = 0; l < 64; ++l) {
@@ -131,62 +177,62 @@ Packed<VT> pack(const std::vector<std::vector<Entry>>& cols, int64_t m, int H) {
   return P;
 }
 
-// tiles of equal cost per strip of NW column groups; cost of a chunk = the slowest of its NW
-// slices (the waves of a workgroup meet at every chunk) + a constant for the staging
-std::vector<int> plan(const std::vector<uint32_t>& Lq, int ncg, int nchunks, int NW, double target,
-                      int& nstrips, int& ntmax, std::vector<int2>& work, bool heavy_first) {
-  nstrips = (ncg + NW - 1) / NW;
-  std::vector<std::vector<double>> cost(static_cast<size_t>(nstrips), std::vector<double>(static_cast<size_t>(nchunks)));
-  std::vector<double> tot(static_cast<size_t>(nstrips), 0.0);
+// the work list of a pass: mirror of slices_plan (clipper_amd/csrc/host_matrix.hpp)
+std::vector<SliceWork> plan(const std::vector<uint32_t>& Lq, int ncg, int nchunks, int NW, double target,
+                            int& nslots, bool split, bool heavy_first) {
+  const int nstrips = (ncg + NW - 1) / NW;
+  std::vector<int> cost(static_cast<size_t>(nstrips) * nchunks);
   double total = 0.0;
-  for (int s = 0; s < nstrips; ++s)
+  for (int st = 0; st < nstrips; ++st)
     for (int k = 0; k < nchunks; ++k) {
-      double c = 0.0;
+      int c = 0;
       for (int w = 0; w < NW; ++w) {
-        const int cg = s * NW + w;
-        if (cg < ncg) c = std::max(c, static_cast<double>(Lq[static_cast<size_t>(cg) * nchunks + k]));
+        const int cg = st * NW + w;
+        if (cg < ncg) c = std::max(c, static_cast<int>(Lq[static_cast<size_t>(cg) * nchunks + k]));
       }
-      c += 2.0;
-      cost[s][k] = c;
-      tot[s] += c;
-      total += c;
+      cost[static_cast<size_t>(st) * nchunks + k] = c;
+      total += c + 2.0;
     }
-  const double Q = total / target;
-  std::vector<int> nts(static_cast<size_t>(nstrips));
-  ntmax = 1;
-  for (int s = 0; s < nstrips; ++s) {
-    int n = static_cast<int>(std::max(1.0, std::floor(tot[s] / Q + 0.5)));
-    n = std::min(n, nchunks);
-    nts[s] = n;
-    ntmax = std::max(ntmax, n);
-  }
-  std::vector<int> tb(static_cast<size_t>(nstrips) * (ntmax + 1));
-  for (int s = 0; s < nstrips; ++s) {
-    int* t = tb.data() + static_cast<size_t>(s) * (ntmax + 1);
-    const int n = nts[s];
-    double run = 0.0;
-    int kk = 1;
-    t[0] = 0;
+  const double T = std::max(8.0, total / target);
+  struct Item { double cost; SliceWork w; };
+  std::vector<Item> items;
+  std::vector<int> nslot_of(static_cast<size_t>(nstrips), 0);
+  nslots = 1;
+  for (int st = 0; st < nstrips; ++st) {
+    int slot = 0, start = 0;
+    double acc = 0.0;
+    auto flush = [&](int end) {
+      if (end > start) items.push_back({acc, SliceWork{st, slot++, start, end, 0, 1 << 30, 0, 0}});
+      start = end;
+      acc = 0.0;
+    };
     for (int k = 0; k < nchunks; ++k) {
-      run += cost[s][k];
-      while (kk < n && run >= tot[s] * kk / n) t[kk++] = k + 1;
+      const int mq = cost[static_cast<size_t>(st) * nchunks + k];
+      const double c = mq + 2.0;
+      if (split && c > 1.5 * T && mq >= 2 * SL_SO) {
+        flush(k);
+        const int parts = std::min(static_cast<int>(std::ceil(c / T)), (mq + SL_SO - 1) / SL_SO);
+        const int per = ((mq + parts - 1) / parts + SL_SO - 1) / SL_SO * SL_SO;
+        for (int q0 = 0; q0 < mq; q0 += per)
+          items.push_back({std::min(per, mq - q0) + 2.0, SliceWork{st, slot++, k, k + 1, q0, std::min(q0 + per, mq), 0, 0}});
+        start = k + 1;
+      } else {
+        acc += c;
+        if (acc >= T) flush(k + 1);
+      }
     }
-    for (; kk <= ntmax; ++kk) t[kk] = nchunks;
+    flush(nchunks);
+    nslot_of[static_cast<size_t>(st)] = slot;
+    nslots = std::max(nslots, slot);
   }
-  std::vector<std::pair<double, int2>> wl;
-  for (int s = 0; s < nstrips; ++s)
-    for (int t = 0; t < ntmax; ++t) {
-      const int a = tb[static_cast<size_t>(s) * (ntmax + 1) + t], b = tb[static_cast<size_t>(s) * (ntmax + 1) + t + 1];
-      if (a >= b) continue;
-      double c = 0.0;
-      for (int k = a; k < b; ++k) c += cost[s][k];
-      wl.push_back({c, make_int2(s, t)});
-    }
+  for (int st = 0; st < nstrips; ++st)
+    for (int slot = nslot_of[static_cast<size_t>(st)]; slot < nslots; ++slot)
+      items.push_back({0.0, SliceWork{st, slot, 0, 0, 0, 0, 0, 0}});
   if (heavy_first)
-    std::stable_sort(wl.begin(), wl.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
-  work.clear();
-  for (auto& w : wl) work.push_back(w.second);
-  return tb;
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+  std::vector<SliceWork> out;
+  for (auto& it : items) out.push_back(it.w);
+  return out;
 }
 
 template <typename VT, int H, bool WINDOW, int V, int NW, int D, int OCC>
@@ -233,30 +279,26 @@ void host_ref(const Ctx& c, int V, std::vector<double>& out /* [V+1][m] */) {
 
 template <typename VT, int H, int V, int NW, int D, int OCC>
 void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const std::vector<double>& ref,
-                 bool heavy_first = true) {
-  int nstrips, ntmax;
-  std::vector<int2> work;
-  std::vector<int> tb = plan(P.Lq, P.ncg, P.nchunks, NW, wg_target, nstrips, ntmax, work, heavy_first);
-  int2* dwork;
-  CK(hipMalloc(&dwork, work.size() * sizeof(int2)));
-  CK(hipMemcpy(dwork, work.data(), work.size() * sizeof(int2), hipMemcpyHostToDevice));
+                 bool split = true, const char* tag = "") {
+  int nslots;
+  std::vector<SliceWork> work = plan(P.Lq, P.ncg, P.nchunks, NW, wg_target, nslots, split, true);
+  SliceWork* dwork;
+  CK(hipMalloc(&dwork, work.size() * sizeof(SliceWork)));
+  CK(hipMemcpy(dwork, work.data(), work.size() * sizeof(SliceWork), hipMemcpyHostToDevice));
   uint8_t* ddata;
   uint64_t* dPre;
-  int* dtb;
   double* dpart;
   const int64_t ld = (c.m + 63) / 64 * 64;
   CK(hipMalloc(&ddata, P.data.size()));
   CK(hipMalloc(&dPre, P.Pre.size() * 8));
-  CK(hipMalloc(&dtb, tb.size() * 4));
   constexpr int VV = V > 0 ? V : 1;
-  const size_t npart = static_cast<size_t>(ntmax) * (VV + 1) * ld;
+  const size_t npart = static_cast<size_t>(nslots) * (VV + 1) * ld;
   CK(hipMalloc(&dpart, npart * 8));
   CK(hipMemset(dpart, 0, npart * 8));
   CK(hipMemcpy(ddata, P.data.data(), P.data.size(), hipMemcpyHostToDevice));
   CK(hipMemcpy(dPre, P.Pre.data(), P.Pre.size() * 8, hipMemcpyHostToDevice));
-  CK(hipMemcpy(dtb, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
-  SliceView M{ddata, dPre, dtb, dwork, P.nchunks, P.ncg, ntmax};
-  auto kern = k_pass<VT, H, (V > 0), (V > 0 ? V : 1), NW, D, OCC>;
+  SliceView M{ddata, dPre, dwork, P.nchunks, P.ncg};
+  auto kern = k_pass<VT, H, (V > 0), VV, NW, D, OCC>;
   const size_t lds_bytes = static_cast<size_t>(2) * SL_SUB * H * ((V > 0) ? sl_xpitch(VV) : 1) * 8;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                          static_cast<int>(lds_bytes)));
@@ -273,7 +315,6 @@ void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const 
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / reps;
-  // validate: sum tiles in order
   std::vector<double> hp(npart);
   CK(hipMemcpy(hp.data(), dpart, npart * 8, hipMemcpyDeviceToHost));
   double maxerr = 0.0, maxref = 0.0;
@@ -281,17 +322,20 @@ void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const 
   const int nout = (V > 0) ? V + 1 : 2;
   for (int v = 0; v < nout; ++v) {
     const int slot = (v == nout - 1) ? NSL - 1 : v;
-    const int rv = (V > 0) ? v : (v == 0 ? 0 : 1);  // pair mode compares a and b of candidate 0
     for (int64_t col = 0; col < c.m; ++col) {
-      double s = 0.0;
-      for (int t = 0; t < ntmax; ++t) s += hp[(static_cast<size_t>(t) * NSL + slot) * ld + col];
-      const double r = ref[static_cast<size_t>((V > 0) ? v : (rv == 0 ? 0 : VV)) * c.m + col];
-      maxerr = std::max(maxerr, std::fabs(s - r));
+      double sum = 0.0;
+      for (int t = 0; t < nslots; ++t) sum += hp[(static_cast<size_t>(t) * NSL + slot) * ld + col];
+      const double r = ref[static_cast<size_t>((V > 0) ? v : (v == 0 ? 0 : VV)) * c.m + col];
+      maxerr = std::max(maxerr, std::fabs(sum - r));
       maxref = std::max(maxref, std::fabs(r));
     }
   }
-  const int wgs = static_cast<int>(work.size());
-  if (c.timeline) {  // one more launch with per-wave time stamps (100 MHz wall clock)
+  const double bytes = static_cast<double>(P.data.size()) + P.Pre.size() * 8.0;
+  printf("  %s VT=%zu H=%d V=%d NW=%d D=%d %s target=%.0f WGs=%zu slots=%d : %8.2f us  %7.1f GB/s  relerr %.1e %s\n", tag,
+         sizeof(VT), H, V, NW, D, split ? "split" : "whole", wg_target, work.size(), nslots, us, bytes / us * 1e-3,
+         maxerr / (maxref + 1e-300), (maxerr <= 1e-9 * (maxref + 1.0)) ? "ok" : "MISMATCH");
+  fflush(stdout);
+  if (c.timeline) {
     long long* dst;
     const size_t ns = work.size() * NW * 2;
     CK(hipMalloc(&dst, ns * 8));
@@ -302,36 +346,16 @@ void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const 
     CK(hipMemcpy(st.data(), dst, ns * 8, hipMemcpyDeviceToHost));
     long long lo = st[0], hi = 0;
     for (size_t i = 0; i < ns; i += 2) { lo = std::min(lo, st[i]); hi = std::max(hi, st[i + 1]); }
-    std::vector<double> dur, endt, begt;
-    for (size_t i = 0; i < ns; i += 2) { dur.push_back((st[i + 1] - st[i]) * 0.01); endt.push_back((st[i + 1] - lo) * 0.01); begt.push_back((st[i] - lo) * 0.01); }
-    std::vector<double> sd = dur, se = endt, sb = begt;
-    std::sort(sd.begin(), sd.end()); std::sort(se.begin(), se.end()); std::sort(sb.begin(), sb.end());
+    std::vector<double> dur, endt;
+    for (size_t i = 0; i < ns; i += 2) { dur.push_back((st[i + 1] - st[i]) * 0.01); endt.push_back((st[i + 1] - lo) * 0.01); }
+    std::sort(dur.begin(), dur.end()); std::sort(endt.begin(), endt.end());
     auto pc = [](const std::vector<double>& v, double f) { return v[static_cast<size_t>(f * (v.size() - 1))]; };
-    printf("    timeline: span %.2f us; wave start p50 %.2f p99 %.2f max %.2f; wave duration p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f; wave end p50 %.2f p90 %.2f p99 %.2f\n",
-           (hi - lo) * 0.01, pc(sb, .5), pc(sb, .99), sb.back(), pc(sd, .1), pc(sd, .5), pc(sd, .9), pc(sd, .99), sd.back(), pc(se, .5), pc(se, .9), pc(se, .99));
-    // the five waves that end last
-    std::vector<size_t> idx(dur.size());
-    for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
-    std::partial_sort(idx.begin(), idx.begin() + 5, idx.end(), [&](size_t a, size_t b) { return endt[a] > endt[b]; });
-    for (int q = 0; q < 5; ++q) {
-      const size_t w = idx[q];
-      const int2 wk = work[w / NW];
-      const int a = tb[static_cast<size_t>(wk.x) * (ntmax + 1) + wk.y], b = tb[static_cast<size_t>(wk.x) * (ntmax + 1) + wk.y + 1];
-      unsigned steps = 0;
-      const int cg = wk.x * NW + static_cast<int>(w % NW);
-      for (int k = a; k < b; ++k) if (cg < P.ncg) steps += P.Lq[static_cast<size_t>(cg) * P.nchunks + k];
-      printf("      last: wg %zu wave %zu strip %d chunks [%d,%d) steps %u  start %.2f end %.2f\n", w / NW, w % NW, wk.x, a, b, steps, begt[w], endt[w]);
-    }
+    printf("    timeline: span %.2f us; wave duration p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f; wave end p10 %.2f p50 %.2f p90 %.2f p99 %.2f\n",
+           (hi - lo) * 0.01, pc(dur, .1), pc(dur, .5), pc(dur, .9), pc(dur, .99), dur.back(), pc(endt, .1), pc(endt, .5), pc(endt, .9), pc(endt, .99));
     (void)hipFree(dst);
   }
-  const double bytes = static_cast<double>(P.data.size()) + P.Pre.size() * 8.0;
-  printf("  VT=%zu H=%d V=%d NW=%d D=%d occ=%d %s strips=%d ntmax=%d (%d WGs) : %8.2f us  %7.1f GB/s  relerr %.2e %s\n",
-         sizeof(VT), H, V, NW, D, OCC, heavy_first ? "heavy-first" : "grid-order", nstrips, ntmax, wgs, us, bytes / us * 1e-3, maxerr / (maxref + 1e-300),
-         (maxerr <= 1e-9 * (maxref + 1.0)) ? "ok" : "MISMATCH");
-  fflush(stdout);
   (void)hipFree(ddata);
   (void)hipFree(dPre);
-  (void)hipFree(dtb);
   (void)hipFree(dwork);
   (void)hipFree(dpart);
   (void)hipEventDestroy(e0);
@@ -379,48 +403,19 @@ int main(int argc, char** argv) {
   host_ref(c, 4, ref4);
   host_ref(c, 1, ref1);
   host_ref(c, 8, ref8);
-  const double slots = c.cus * 2.0;
-  const bool tl = c.timeline;
-  for (int H : {1, 2}) {
-    Packed<float> P = pack<float>(c.cols, m, H);
-    printf("H=%d: %zu quads (%.3f padded entries per entry), %zu lock-step steps, lane efficiency %.3f, %.2f MB (%.2f B/entry)\n",
-           H, P.quads, P.quads * 4.0 / P.entries, P.steps, P.quads / (64.0 * P.steps), P.data.size() * 1e-6,
-           double(P.data.size()) / P.entries);
-    for (double tgt : {slots, 1.5 * slots, 2.0 * slots, 3.0 * slots}) {
-      printf(" target %.0f workgroups\n", tgt);
-      c.timeline = tl && tgt == 2.0 * slots;
-      if (H == 1) {
-        run_variant<float, 1, 6, 4, 4, 2>(c, P, tgt, reps, ref6, false);
-        run_variant<float, 1, 6, 4, 4, 2>(c, P, tgt, reps, ref6);
-        c.timeline = false;
-        run_variant<float, 1, 6, 4, 6, 2>(c, P, tgt, reps, ref6);
-        run_variant<float, 1, 6, 4, 8, 2>(c, P, tgt, reps, ref6);
-        run_variant<float, 1, 6, 8, 4, 2>(c, P, tgt, reps, ref6);
-        run_variant<float, 1, 6, 2, 4, 2>(c, P, tgt, reps, ref6);
-        c.timeline = tl && tgt == 2.0 * slots;
-        run_variant<float, 1, 0, 4, 8, 2>(c, P, tgt, reps, ref1);
-        c.timeline = false;
-        run_variant<float, 1, 0, 4, 4, 2>(c, P, tgt, reps, ref1);
-      } else {
-        run_variant<float, 2, 6, 4, 4, 2>(c, P, tgt, reps, ref6);
-        run_variant<float, 2, 6, 4, 8, 2>(c, P, tgt, reps, ref6);
-        run_variant<float, 2, 6, 8, 4, 2>(c, P, tgt, reps, ref6);
-        run_variant<float, 2, 0, 4, 8, 2>(c, P, tgt, reps, ref1);
-      }
-    }
-    c.timeline = false;
-    if (H == 1) {
-      printf(" other windows (target %.0f)\n", 2.0 * slots);
-      run_variant<float, 1, 1, 4, 8, 2>(c, P, 2.0 * slots, reps, ref1);
-      run_variant<float, 1, 4, 4, 8, 2>(c, P, 2.0 * slots, reps, ref4);
-      run_variant<float, 1, 8, 4, 4, 2>(c, P, 2.0 * slots, reps, ref8);
-    }
+  const double cu = c.cus;
+  Packed<float> P = pack<float>(c.cols, m, 1, 0);
+  printf("SL_SUB=%d H=1: %zu quads (%.3f padded entries per entry), %zu lock-step steps, lane efficiency %.3f, %.2f MB (%.2f B/entry)\n",
+         SL_SUB, P.quads, P.quads * 4.0 / P.entries, P.steps, P.quads / (64.0 * P.steps), P.data.size() * 1e-6,
+         double(P.data.size()) / P.entries);
+  for (double tgt : {3.0 * cu, 4.0 * cu, 5.0 * cu, 6.0 * cu}) {
+    run_variant<float, 1, 6, 4, 4, 2>(c, P, tgt, reps, ref6, true, "rows-ascending");
+    run_variant<float, 1, 6, 4, 2, 2>(c, P, tgt, reps, ref6, true, "rows-ascending");
+    run_variant<float, 1, 6, 8, 4, 2>(c, P, tgt, reps, ref6, true, "rows-ascending");
+    run_variant<float, 1, 1, 4, 4, 2>(c, P, tgt, reps, ref1, true, "rows-ascending");
+    run_variant<float, 1, 0, 4, 4, 2>(c, P, tgt, reps, ref1, true, "rows-ascending");
   }
-  {
-    Packed<double> P = pack<double>(c.cols, m, 1);
-    printf("fp64 values, H=1: %.2f MB (%.2f B/entry)\n", P.data.size() * 1e-6, double(P.data.size()) / P.entries);
-    run_variant<double, 1, 6, 4, 4, 2>(c, P, 2.0 * slots, reps, ref6);
-    run_variant<double, 1, 6, 4, 8, 2>(c, P, 2.0 * slots, reps, ref6);
-  }
+  run_variant<float, 1, 4, 4, 4, 2>(c, P, 4.0 * cu, reps, ref4, true, "rows-ascending");
+  run_variant<float, 1, 8, 4, 4, 2>(c, P, 4.0 * cu, reps, ref8, true, "rows-ascending");
   return 0;
 }
