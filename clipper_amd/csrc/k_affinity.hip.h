@@ -591,16 +591,32 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
   // The survivors of the fp32 prefilter go into a per-wave ring; whenever 64 are waiting they are
   // evaluated by a full wave (the exact score is ~150 fp64-rate instructions: no idle lanes).
   uint32_t head = 0, tail = 0;  // wave-uniform
+  // this wave's rows: lane i fetches row i's association and points ONCE (one vector load per
+  // quantity); the row loop broadcasts them with v_readlane — a scalar load per row and quantity
+  // was a chain of AT_ROWS_PER_WAVE dependent L2 round trips
+  int32_t va0, va1;
+  float vp1[D], vp2[D];
+  {
+    const int64_t rw = r0 + wave * AT_ROWS_PER_WAVE + (lane < AT_ROWS_PER_WAVE ? lane : 0);
+    const int64_t ri = rw < m ? rw : (m - 1);
+    va0 = A0[ri];
+    va1 = A1[ri];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      vp1[k] = P1f[k * pstride + ri];
+      vp2[k] = P2f[k * pstride + ri];
+    }
+  }
   for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
     const int rl = wave * AT_ROWS_PER_WAVE + rr;  // tile row
     const int64_t r = r0 + rl;
     if (r < m) {  // uniform
-      const int32_t a0r = A0[r], a1r = A1[r];
+      const int32_t a0r = __builtin_amdgcn_readlane(va0, rr), a1r = __builtin_amdgcn_readlane(va1, rr);
       float p1r[D], p2r[D];
 #pragma unroll
       for (int k = 0; k < D; ++k) {
-        p1r[k] = P1f[k * pstride + r];
-        p2r[k] = P2f[k * pstride + r];
+        p1r[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vp1[k]), rr));
+        p2r[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vp2[k]), rr));
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {

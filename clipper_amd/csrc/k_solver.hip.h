@@ -109,8 +109,12 @@ struct SolverParams {
   int32_t maxiniters, maxoliters, maxlsiters;
 };
 
-constexpr int TAIL_THREADS = 256;
+constexpr int TAIL_THREADS = 256;  // elements per tail workgroup
 constexpr int TAIL_WAVES = TAIL_THREADS / 64;
+// One shard (FUSED_REDUCE): the tail adds the pass's partial-sum slots itself. TAIL_SPLIT groups
+// of TAIL_THREADS threads could each add a part of the slots and combine through LDS — measured
+// at m = 10k with 4 groups (1024-thread workgroups): 12.6 us instead of 9.5; one group it is.
+constexpr int TAIL_SPLIT = 1;
 
 struct SolveArgs {
   const SolverState* st_cur;  // ST[k & 1]: what iteration k starts from
@@ -245,6 +249,13 @@ constexpr int pow2_at_least(int x) {
 // Transitions (everything that sweeps whole vectors): workgroup (0,0) alone, the others leave.
 // ------------------------------------------------------------------------------------------
 
+// The workgroup that records the decided state (and alone performs the transition sweeps): the
+// LAST one of the grid — on the slices the workgroups are ordered most expensive first, so this
+// is the one with the least to stream.
+__device__ __forceinline__ bool is_writer_block() {
+  return blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1;
+}
+
 struct PassPlan {
   int phase;
   int sel;     // table of Xin that holds the pending window, or
@@ -328,7 +339,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   const int tid = threadIdx.x;
   const int64_t m = A.m;
   const SolverParams P = A.prm;
-  const bool writer = (blockIdx.x == 0 && blockIdx.y == 0);
+  const bool writer = is_writer_block();
 
   const int phase = L.phase;
   double d = L.d, F = L.F, alpha = L.alpha, s = L.s;
@@ -387,11 +398,13 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
         sel = V;
         action = ACT_PASS;
+        if (writer) {  // the norms are only recorded (for the tail): no other workgroup needs them
 #pragma unroll
-        for (int l = 0; l < V; ++l) {
-          const double z = sums[V * NR + 2 * l];
-          nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
-          sx[l] = sums[V * NR + 2 * l + 1] / nrm[l];
+          for (int l = 0; l < V; ++l) {
+            const double z = sums[V * NR + 2 * l];
+            nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
+            sx[l] = sums[V * NR + 2 * l + 1] / nrm[l];
+          }
         }
       } else {
         const double deltau = sqrt(sums[jstar * NR + 1]);
@@ -423,11 +436,13 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
           k_ = 0;
           sel = jstar;  // the tail already built max(x + beta^l gradFnew, 0) in table jstar
           action = ACT_PASS;
+          if (writer) {
 #pragma unroll
-          for (int l = 0; l < V; ++l) {
-            const double z = sums[jstar * NR + 2 + 2 * l];
-            nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
-            sx[l] = sums[jstar * NR + 3 + 2 * l] / nrm[l];
+            for (int l = 0; l < V; ++l) {
+              const double z = sums[jstar * NR + 2 + 2 * l];
+              nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
+              sx[l] = sums[jstar * NR + 3 + 2 * l] / nrm[l];
+            }
           }
         }
       }
@@ -441,11 +456,13 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         k_ = 0;
         sel = 0;
         action = ACT_PASS;
+        if (writer) {
 #pragma unroll
-        for (int l = 0; l < V; ++l) {
-          const double z = sums[2 + 2 * l];
-          nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
-          sx[l] = sums[3 + 2 * l] / nrm[l];
+          for (int l = 0; l < V; ++l) {
+            const double z = sums[2 + 2 * l];
+            nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
+            sx[l] = sums[3 + 2 * l] / nrm[l];
+          }
         }
       }
     }
@@ -654,7 +671,7 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
   plan.sel = st->sel;
   plan.from_u = -1;
   plan.d = st->d;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (is_writer_block() && threadIdx.x == 0) {
     *stash = *st;
     stash->stage = ST_RESULTS;
     stash->n_passes = st->n_passes + 1;
@@ -666,7 +683,7 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
 // End of a pass iteration: workgroup (0,0) writes the state it decided on where the tail and
 // the next iteration read it, marks the iteration as a pass and reports progress to the host.
 __device__ __forceinline__ void flush_state(const SolveArgs& A, const SolverState* stash) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (is_writer_block() && threadIdx.x == 0) {
     *A.st_next = *stash;
     const int64_t n_iters = stash->n_iters;
     if (A.marks != nullptr && n_iters <= KIND_CAP) A.marks[n_iters - 1] = 1;
@@ -718,17 +735,20 @@ __global__ __launch_bounds__(128) void k_scal_fold(const double* __restrict__ sc
 }
 
 template <int V, bool FUSED_REDUCE>
-__global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
+__global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) void k_tail(SolveArgs A) {
   constexpr int NR = 2 + 2 * V;
   constexpr int PEN = V * NR + 2 * V;
   constexpr int Q = PEN + 2;
   constexpr int NRED = NR + 2 * V + 2;  // what a v = 0 workgroup reduces
   constexpr int NSLOT = nslot(V);
-  __shared__ double red[TAIL_WAVES * NRED];
+  constexpr int NTW = TAIL_WAVES * (FUSED_REDUCE ? TAIL_SPLIT : 1);  // waves of the workgroup
+  __shared__ double red[NTW * NRED > 2 * TAIL_SPLIT * TAIL_THREADS ? NTW * NRED : 2 * TAIL_SPLIT * TAIL_THREADS];
   const int v = blockIdx.y;
   const SolverState* st = A.st_next;
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + threadIdx.x;
-  const bool valid = i < A.m;
+  const int te = threadIdx.x & (TAIL_THREADS - 1);  // element of the workgroup
+  const int grp = threadIdx.x / TAIL_THREADS;        // slot quarter (FUSED_REDUCE), else 0
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * TAIL_THREADS + te;
+  const bool valid = i < A.m && grp == 0;
   // everything this launch needs of the solver state, requested up front: one round trip in the
   // shadow of the partial sums instead of a chain of dependent scalar loads after them
   const int done = A.shared->done;
@@ -740,13 +760,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
   // raw sums of slot v (and of slot V, the b of candidate 0, for the v = 0 workgroups): these
   // loads do not depend on the solver state
   double p0 = 0.0, p1 = 0.0;
-  if (valid) {
+  if (FUSED_REDUCE) {  // single shard: W >= m; this group's quarter of the slots, in slot order
     const int64_t o1 = (v == 0) ? static_cast<int64_t>(V) * A.W : 0;  // slot V relative to slot 0
-    if (FUSED_REDUCE) {  // single shard: W >= m; partials in tile order, 8 tiles in flight
+    const int per = (A.ntiles + TAIL_SPLIT - 1) / TAIL_SPLIT;
+    const int t0 = grp * per, t1 = (t0 + per < A.ntiles) ? t0 + per : A.ntiles;
+    if (i < A.m) {
       const double* p = A.part + static_cast<int64_t>(v) * A.W + i;
       const int64_t ts = static_cast<int64_t>(NSLOT) * A.W;
-      int t = 0;
-      for (; t + 16 <= A.ntiles; t += 16) {
+      int t = t0;
+      for (; t + 16 <= t1; t += 16) {
         double va[16], vb[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -759,7 +781,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
           p1 += vb[q];
         }
       }
-      for (; t + 4 <= A.ntiles; t += 4) {
+      for (; t + 4 <= t1; t += 4) {
         double va[4], vb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -772,17 +794,31 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
           p1 += vb[q];
         }
       }
-      for (; t < A.ntiles; ++t) {
+      for (; t < t1; ++t) {
         p0 += p[static_cast<int64_t>(t) * ts];
         p1 += p[static_cast<int64_t>(t) * ts + o1];
       }
-    } else {  // block pb = i / W of the gathered [P][NSLOT][W] layout (32-bit division)
-      const uint32_t pb = static_cast<uint32_t>(i) / static_cast<uint32_t>(A.W);
-      const int64_t off = i - static_cast<int64_t>(pb) * A.W;
-      const double* blk = A.ab + (static_cast<int64_t>(pb) * NSLOT) * A.W;
-      p0 = blk[static_cast<int64_t>(v) * A.W + off];
-      p1 = blk[o1 + off];
     }
+    if constexpr (TAIL_SPLIT > 1) {
+      red[(grp * 2 + 0) * TAIL_THREADS + te] = p0;
+      red[(grp * 2 + 1) * TAIL_THREADS + te] = p1;
+      __syncthreads();
+      p0 = red[te];
+      p1 = red[TAIL_THREADS + te];
+#pragma unroll
+      for (int g = 1; g < TAIL_SPLIT; ++g) {
+        p0 += red[(g * 2 + 0) * TAIL_THREADS + te];
+        p1 += red[(g * 2 + 1) * TAIL_THREADS + te];
+      }
+      __syncthreads();  // `red` is reused by the reduction at the end
+    }
+  } else if (valid) {  // block pb = i / W of the gathered [P][NSLOT][W] layout (32-bit division)
+    const int64_t o1 = (v == 0) ? static_cast<int64_t>(V) * A.W : 0;
+    const uint32_t pb = static_cast<uint32_t>(i) / static_cast<uint32_t>(A.W);
+    const int64_t off = i - static_cast<int64_t>(pb) * A.W;
+    const double* blk = A.ab + (static_cast<int64_t>(pb) * NSLOT) * A.W;
+    p0 = blk[static_cast<int64_t>(v) * A.W + off];
+    p1 = blk[o1 + off];
   }
   if (done) return;
   if (stage != ST_RESULTS) return;  // a pass was only prepared: nothing to evaluate
@@ -882,7 +918,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(SolveArgs A) {
       }
     }
   }
-  const double tot = block_reduce_pick<NRED, TAIL_WAVES>(r, red);
+  const double tot = block_reduce_pick<NRED, NTW>(r, red);
   double* out = A.scal + static_cast<int64_t>(blockIdx.x) * Q;
   if (threadIdx.x < NR) out[v * NR + threadIdx.x] = tot;
   if (v == 0 && threadIdx.x >= NR && threadIdx.x < NRED)
