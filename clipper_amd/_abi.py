@@ -41,6 +41,10 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+class ClipperError(RuntimeError):
+    """a C ABI entry point returned a negative status (CLIPPER_HIP_E_*)"""
+
+
 class Params(C.Structure):
     """clipper_params_t == clipper::Params (reference include/clipper/clipper.h:27-60)."""
 
@@ -216,9 +220,9 @@ class HipClipper:
         except Exception:
             pass
 
-    def _check(self, rc):
+    def _check(self, rc):  # raises ClipperError (a RuntimeError) for a negative status
         if rc < 0:
-            raise RuntimeError(f"clipper_hip error {rc}: {self.last_error()}")
+            raise ClipperError(f"clipper_hip error {rc}: {self.last_error()}")
         return rc
 
     # ---- communicator (multi-process shards) ----------------------------------------------
@@ -246,6 +250,8 @@ class HipClipper:
     def score_pairwise_consistency_pointnormal(self, D1, D2, A=(), sigp=0.5, epsp=0.5, sign=0.10,
                                                epsn=0.35):
         D1, D2 = _f64_colmajor(D1), _f64_colmajor(D2)
+        if D1.shape[0] != 6 or D2.shape[0] != 6:
+            raise ValueError("PointNormalDistance data are 6 x n (xyz + unit normal)")
         Ac, m = _assoc_colmajor(A)
         self._check(self.L.clipper_hip_affinity_pointnormal(
             self.h, _dp(D1), D1.shape[0], D1.shape[1], _dp(D2), D2.shape[1],

@@ -1078,7 +1078,7 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
                        s.stream, s.u0, m, s.X[0]);
   }
   h->u0_staged = false;
-  int rc = ensure_dense(h, true);
+  int rc = h->csc_valid ? 0 : ensure_dense(h, true);
   if (rc) return rc;
   if ((rc = enqueue_gemv_plain(h))) return rc;
   if ((rc = enqueue_reduce_exchange(h))) return rc;
@@ -1118,7 +1118,8 @@ int clipper_hip_get_timings(const clipper_hip_t* h, clipper_hip_timings_t* out) 
 int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   if (!h || reps < 1 || !avg_us) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
-  if (int rc = ensure_dense(h, true)) return rc;
+  if (!h->csc_valid)
+    if (int rc = ensure_dense(h, true)) return rc;
   Shard& s = h->sh[0];
   HIPCHK(hipSetDevice(s.device));
   hipEvent_t e0, e1;
@@ -1134,7 +1135,7 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   *avg_us = static_cast<double>(ms) * 1e3 / reps;
-  h->tm.gemv_bytes = algorithmic_gemv_bytes(h, /*dense=*/true);
+  h->tm.gemv_bytes = algorithmic_gemv_bytes(h, /*dense=*/!h->csc_valid);
   return 0;
 }
 

@@ -242,7 +242,8 @@ int slices_enqueue(Ctx* h, Shard& s, const Source& src, const CscBuildCtl* ctl) 
                        s.sPre, s.sdata, s.sBlk + nblk, cap_units);
     heavy_only = 1;
   }
-  hipLaunchKernelGGL((k_slice_pack<VT, SL_H, Source>), dim3(static_cast<unsigned>(nsl)),
+  hipLaunchKernelGGL((k_slice_pack<VT, SL_H, Source>),
+                     dim3(static_cast<unsigned>(std::min<int64_t>(nsl, 1 << 20))),
                      dim3(SL_PACKW * 64), 0, s.stream, src, s.s_ncg, s.s_nchunks, s.sPre, s.sdata,
                      s.sBlk + nblk, cap_units, s.sLq, heavy_only);
   if (ctl)
@@ -277,6 +278,8 @@ int slices_plan(Ctx* h, Shard& s) {
   const uint32_t* L = h->csc_hLq;
   double target = static_cast<double>(h->cus) * 4.0;
   if (const char* e = std::getenv("CLIPPER_HIP_CSC_WGS")) target = std::max(1.0, std::atof(e));
+  double C0 = 2.0;  // what a chunk costs besides its steps (staging, barrier, header), in steps
+  if (const char* e = std::getenv("CLIPPER_HIP_CSC_C0")) C0 = std::max(0.0, std::atof(e));
   std::vector<int> cost(static_cast<size_t>(nstrips) * nchunks);
   double total = 0.0;
   uint64_t entries = 0;
@@ -291,7 +294,7 @@ int slices_plan(Ctx* h, Shard& s) {
         entries += v >> 8;
       }
       cost[static_cast<size_t>(st) * nchunks + k] = c;
-      total += c + 2.0;
+      total += c + C0;
     }
   s.s_entries = entries;
   const double T = std::max(8.0, total / target);
@@ -312,13 +315,13 @@ int slices_plan(Ctx* h, Shard& s) {
     };
     for (int k = 0; k < nchunks; ++k) {
       const int mq = cost[static_cast<size_t>(st) * nchunks + k];
-      const double c = mq + 2.0;
+      const double c = mq + C0;
       if (c > 1.5 * T && mq >= 2 * SL_SO) {
         flush(k);
         const int parts = std::min(static_cast<int>(std::ceil(c / T)), static_cast<int>(ceil_div(mq, SL_SO)));
         const int per = static_cast<int>(round_up(ceil_div(mq, parts), SL_SO));
         for (int q0 = 0; q0 < mq; q0 += per)
-          items.push_back({std::min(per, mq - q0) + 2.0,
+          items.push_back({std::min(per, mq - q0) + C0,
                            SliceWork{st, slot++, k, k + 1, q0, std::min(q0 + per, mq), 0, 0}});
         start = k + 1;
       } else {

@@ -201,8 +201,19 @@ void launch_pass(Ctx* h, Shard& s, const SolveArgs& a) {
   });
 }
 
+SliceView slice_view(const Ctx* h, const Shard& s);
+
 // the pair-mode mat-vec alone on table X (matvec API, micro-benchmark)
 void launch_plain(Ctx* h, Shard& s, const double* X) {
+  if (h->csc_valid) {  // on the slices: part[slot][2][W]
+    const SliceView M = slice_view(h, s);
+    dim3 grid(static_cast<unsigned>(s.s_nwork)), block(SL_NW * 64);
+    if (h->storage == CLIPPER_HIP_STORE_F64)
+      hipLaunchKernelGGL((k_gemv_slices_plain<double, 1>), grid, block, 0, s.stream, M, h->W, h->m, X, s.part);
+    else
+      hipLaunchKernelGGL((k_gemv_slices_plain<float, 1>), grid, block, 0, s.stream, M, h->W, h->m, X, s.part);
+    return;
+  }
   dispatch_storage(h, [&](auto t, auto c) {
     launch_plain_t<decltype(t), decltype(c)::value>(h, s, X);
   });
@@ -235,7 +246,8 @@ void dispatch_window(const Ctx* h, F&& f) {
 // plain reduction of `nslots` partial slots into this shard's block (matvec API)
 void launch_reduce(Ctx* h, Shard& s, int nslots) {
   dim3 grid(static_cast<unsigned>(ceil_div(static_cast<int64_t>(nslots) * h->W, 256))), block(256);
-  hipLaunchKernelGGL(k_reduce, grid, block, 0, s.stream, s.part, h->ntiles, nslots, h->W,
+  hipLaunchKernelGGL(k_reduce, grid, block, 0, s.stream, s.part,
+                     h->csc_valid ? s.s_nslots : h->ntiles, nslots, h->W,
                      s.ab + static_cast<int64_t>(s.slot) * nslots * h->W);
 }
 

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   const long long c1 = A.stamps ? wall_clock64() : 0;
   slices_by_plan<VT, H, V, SL_NW, SL_D>(M, J, A, plan, lds);
   flush_state(A, &stash);
-  if (A.stamps && threadIdx.x == 0 && blockIdx.x < 4096) {
+  if (A.stamps && threadIdx.x == 0 && blockIdx.x < 2048) {
     A.stamps[blockIdx.x * 4 + 0] = c0;
     A.stamps[blockIdx.x * 4 + 1] = c1;
     A.stamps[blockIdx.x * 4 + 2] = wall_clock64();
@@ -666,10 +666,21 @@ __global__ __launch_bounds__(SL_PACKW * 64) void k_slice_pack(Source S, int ncg,
   constexpr int QB = 4 * static_cast<int>(sizeof(VT));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t s = blockIdx.x;
-  // heavy_only: slices of at most SL_STAGE_CAP entries were packed by k_slice_pack_staged
-  if (heavy_only && (Lq[s] >> 8) <= static_cast<uint32_t>(SL_STAGE_CAP)) return;
   if (total_units[0] > cap_units || total_units[1] != 0) return;  // [1]: the groups overflowed
+  // (a dispatch holds at most 2^32 work-items: the slices of a large sparse matrix — 11 M at
+  // m = 300k — are walked with a grid stride)
+  for (int64_t s = blockIdx.x; s < static_cast<int64_t>(ncg) * nchunks; s += gridDim.x) {
+  // heavy_only: slices of at most SL_STAGE_CAP entries were packed by k_slice_pack_staged
+  if (heavy_only && (Lq[s] >> 8) <= static_cast<uint32_t>(SL_STAGE_CAP)) continue;
+  if ((Lq[s] & 255u) == 0) {  // an empty slice: the header and the lengths only
+    if (wave == 0) {
+      uint8_t* sp0 = data + 16 * Pre[s];
+#pragma unroll
+      for (int h = 0; h < H; ++h) sp0[16 + h * 64 + lane] = 0;
+      if (lane < 4) reinterpret_cast<uint32_t*>(sp0)[lane] = (lane == 2) ? 16 + H * 64 : 0;
+    }
+    continue;
+  }
   const int cg = static_cast<int>(s / nchunks), k = static_cast<int>(s - static_cast<int64_t>(cg) * nchunks);
   const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
   int nq[H];
@@ -737,6 +748,7 @@ __global__ __launch_bounds__(SL_PACKW * 64) void k_slice_pack(Source S, int ncg,
     hd[2] = off;
     hd[3] = 0;
   }
+  }  // slices of this workgroup
 }
 
 // k_slice_pack_staged — the packer of the common case (source = groups, H = 1, a slice of at most

@@ -744,6 +744,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   constexpr int NTW = TAIL_WAVES * (FUSED_REDUCE ? TAIL_SPLIT : 1);  // waves of the workgroup
   __shared__ double red[NTW * NRED > 2 * TAIL_SPLIT * TAIL_THREADS ? NTW * NRED : 2 * TAIL_SPLIT * TAIL_THREADS];
   const int v = blockIdx.y;
+  const long long c0 = A.stamps ? wall_clock64() : 0;
   const SolverState* st = A.st_next;
   const int te = threadIdx.x & (TAIL_THREADS - 1);  // element of the workgroup
   const int grp = threadIdx.x / TAIL_THREADS;        // slot quarter (FUSED_REDUCE), else 0
@@ -767,36 +768,23 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
     if (i < A.m) {
       const double* p = A.part + static_cast<int64_t>(v) * A.W + i;
       const int64_t ts = static_cast<int64_t>(NSLOT) * A.W;
-      int t = t0;
-      for (; t + 16 <= t1; t += 16) {
+      // 16 slots per round trip, every load issued (a slot past the end re-reads the last one and
+      // is not added): ~28 slots at m = 10k are two round trips (32 at once measured slower)
+      for (int t = t0; t < t1; t += 16) {
         double va[16], vb[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          va[q] = p[static_cast<int64_t>(t + q) * ts];
-          vb[q] = p[static_cast<int64_t>(t + q) * ts + o1];
+          const int tt = (t + q < t1) ? t + q : t1 - 1;
+          va[q] = p[static_cast<int64_t>(tt) * ts];
+          vb[q] = p[static_cast<int64_t>(tt) * ts + o1];
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          p0 += va[q];
-          p1 += vb[q];
+          if (t + q < t1) {
+            p0 += va[q];
+            p1 += vb[q];
+          }
         }
-      }
-      for (; t + 4 <= t1; t += 4) {
-        double va[4], vb[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          va[q] = p[static_cast<int64_t>(t + q) * ts];
-          vb[q] = p[static_cast<int64_t>(t + q) * ts + o1];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          p0 += va[q];
-          p1 += vb[q];
-        }
-      }
-      for (; t < t1; ++t) {
-        p0 += p[static_cast<int64_t>(t) * ts];
-        p1 += p[static_cast<int64_t>(t) * ts + o1];
       }
     }
     if constexpr (TAIL_SPLIT > 1) {
@@ -822,6 +810,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   }
   if (done) return;
   if (stage != ST_RESULTS) return;  // a pass was only prepared: nothing to evaluate
+  const long long c1 = A.stamps ? wall_clock64() + (p0 > 1e300 ? 1 : 0) : 0;
 
   if (phase != PH_TRIAL && phase != PH_BUILD) {
     // pair-mode passes carry one vector (candidate 0, nrm = 1): a = M_off x, b = C_off x
@@ -920,6 +909,15 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   }
   const double tot = block_reduce_pick<NRED, NTW>(r, red);
   double* out = A.scal + static_cast<int64_t>(blockIdx.x) * Q;
+  if (A.stamps && threadIdx.x == 0) {
+    const int w = 2048 + static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x);
+    if (w < 4096) {
+      A.stamps[w * 4 + 0] = c0;
+      A.stamps[w * 4 + 1] = c1;
+      A.stamps[w * 4 + 2] = wall_clock64();
+      A.stamps[w * 4 + 3] = phase;
+    }
+  }
   if (threadIdx.x < NR) out[v * NR + threadIdx.x] = tot;
   if (v == 0 && threadIdx.x >= NR && threadIdx.x < NRED)
     out[V * NR + (threadIdx.x - NR)] = tot;  // "all rejected" window sums, then the penalty sums

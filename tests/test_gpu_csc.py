@@ -1,8 +1,10 @@
-"""GPU tests of the compressed storage (CLIPPER_HIP_STORE_F32_CSC): M kept as blocked column
-lists, written by k_affinity_sym / k_csc_build, read by k_gemv_csc, expanded on demand by
-k_csc_expand. Everything the parity suite runs per storage mode (tests/test_gpu_parity.py,
-STORAGES) covers it too; here are the cases specific to the format: block / strip edges, empty
-and fully dense groups, growth of the buffers, the fall-back to the dense store."""
+"""GPU tests of the compressed storage (CLIPPER_HIP_STORE_F32_CSC / _F64_CSC): M kept as slices
+(k_slices.hip.h), written by k_affinity_sym itself or packed from groups / CSC lists
+(k_slice_count / scan / k_slice_pack), read by k_gemv_slices, expanded on demand by
+k_slice_expand. Everything the parity suite runs per storage mode (tests/test_gpu_parity.py,
+STORAGES) covers it too; here are the cases specific to the format: slice edges, empty and fully
+dense slices, growth of the buffers, fp64 values, setSparseMatrixData without a dense
+intermediate, the fall-back to the dense store."""
 import numpy as np
 import pytest
 
@@ -21,7 +23,8 @@ def _affinity(storage, p, **inv):
     return g
 
 
-# groups are 64 rows x 128 columns: sizes on and around their edges, and a ragged last tile
+# slices are 128 rows x 64 columns (tiles of the fill kernel 128 x 128): sizes on and around
+# their edges, and a ragged last tile
 @pytest.mark.parametrize("m", [2, 63, 64, 65, 127, 128, 129, 191, 193, 257, 640, 1000, 2049])
 def test_matrix_round_trip_bitwise(m):
     p = synth.make_euclidean_problem(m, 0.7, seed=m)
@@ -31,9 +34,9 @@ def test_matrix_round_trip_bitwise(m):
     assert np.array_equal(Md, Mc)
     assert np.array_equal(gd.get_constraint_matrix(), gc.get_constraint_matrix())
     x = np.random.default_rng(m).random(m)
-    yd, yc = gd.matvec(x), gc.matvec(x)
-    assert np.array_equal(yd[0], yc[0]) and np.array_equal(yd[1], yc[1])
-    # the solver (compressed passes) after the dense store was materialised for the getters
+    yd, yc = gd.matvec(x), gc.matvec(x)   # dense pass vs the pass on the slices: the order of the sums differs
+    assert np.allclose(yd[0], yc[0], rtol=1e-13, atol=1e-13) and np.allclose(yd[1], yc[1], rtol=1e-13, atol=1e-13)
+    # the solver (passes on the slices) after the dense store was materialised for the getters
     sd, sc = gd.solve(p.u0), gc.solve(p.u0)
     assert sorted(sd.nodes.tolist()) == sorted(sc.nodes.tolist())
     assert abs(sd.score - sc.score) <= 1e-9 * max(1.0, abs(sd.score))
@@ -214,3 +217,129 @@ def test_full_size_10k_compressed_parity():
     sd = d.solve(p.u0)
     assert sorted(sd.nodes.tolist()) == sorted(sg.nodes.tolist())
     assert abs(sd.score - sg.score) <= 1e-9 * abs(sd.score)
+
+
+# ------------------------------------------------------------------------------------------
+# fp64 values in the slices (CLIPPER_HIP_STORE_F64_CSC): the parity-exact mode at compressed cost
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("m,rho,seed", [(129, 0.7, 1), (1037, 0.8, 7), (2500, 0.9, 11)])
+def test_f64_slices_equal_the_dense_f64_store(m, rho, seed):
+    p = synth.make_euclidean_problem(m, rho, seed=seed)
+    gd, gc = _affinity(abi.STORE_F64, p), _affinity(abi.STORE_F64_CSC, p)
+    assert gc.storage_in_use == abi.STORE_F64_CSC and gd.storage_in_use == abi.STORE_F64
+    assert np.array_equal(gd.get_affinity_matrix(), gc.get_affinity_matrix())   # fp64 values, bit for bit
+    x = np.random.default_rng(m).random(m)
+    yd, yc = gd.matvec(x), gc.matvec(x)
+    assert np.allclose(yd[0], yc[0], rtol=1e-13, atol=1e-13) and np.allclose(yd[1], yc[1], rtol=1e-13, atol=1e-13)
+    sd, sc = gd.solve(p.u0), gc.solve(p.u0)
+    assert sd.nodes.tolist() == sc.nodes.tolist() and sd.ifinal == sc.ifinal
+    assert sd.n_trials == sc.n_trials
+    assert abs(sd.score - sc.score) <= 1e-12 * max(1.0, abs(sd.score))
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    sr = r.solve(p.u0)
+    assert sc.nodes.tolist() == sr.nodes.tolist() and sc.n_trials == sr.n_trials
+    assert abs(sc.score - sr.score) <= 1e-9 * abs(sr.score)
+
+
+# ------------------------------------------------------------------------------------------
+# setSparseMatrixData (clipper.cpp:162-166): lists -> slices, no dense intermediate
+# ------------------------------------------------------------------------------------------
+
+def _upper_csc(M):
+    import scipy.sparse as sp
+    U = sp.csc_matrix(np.triu(M, 1))
+    U.sort_indices()
+    return U
+
+
+@pytest.mark.parametrize("storage", [abi.STORE_F32_CSC, abi.STORE_F64_CSC])
+@pytest.mark.parametrize("m", [77, 640, 1500])
+def test_set_sparse_equals_set_matrix(m, storage):
+    import scipy.sparse as sp
+    M, C = _random_symmetric(m, 0.07, seed=m)
+    U = _upper_csc(M)
+    P = sp.csc_matrix((np.ones_like(U.data), U.indices, U.indptr), shape=U.shape)
+    u0 = np.random.default_rng(3).random(m)
+    a, b = abi.HipClipper(storage=storage), abi.HipClipper(storage=storage)
+    a.set_matrix_data(M, C)
+    b.set_sparse_matrix_data(m, U.indptr, U.indices, U.data, P.indptr, P.indices, P.data)
+    assert b.storage_in_use == storage
+    assert np.array_equal(a.get_affinity_matrix(), b.get_affinity_matrix())
+    assert np.array_equal(a.get_constraint_matrix(), b.get_constraint_matrix())
+    sa, sb = a.solve(u0), b.solve(u0)
+    assert sa.nodes.tolist() == sb.nodes.tolist() and sa.score == sb.score and np.array_equal(sa.u, sb.u)
+    # the LOWER triangle handed over instead (rows > column): the same symmetric matrix
+    L = sp.csc_matrix(np.tril(M, -1))
+    L.sort_indices()
+    PL = sp.csc_matrix((np.ones_like(L.data), L.indices, L.indptr), shape=L.shape)
+    c = abi.HipClipper(storage=storage)
+    c.set_sparse_matrix_data(m, L.indptr, L.indices, L.data, PL.indptr, PL.indices, PL.data)
+    assert np.array_equal(a.get_affinity_matrix(), c.get_affinity_matrix())
+
+
+def test_set_sparse_rejects_malformed_input():
+    m = 50
+    M, C = _random_symmetric(m, 0.2, seed=2)
+    U = _upper_csc(M)
+    ones = np.ones_like(U.data)
+    g = abi.HipClipper(storage=abi.STORE_F32_CSC)
+    ok = (m, U.indptr, U.indices, U.data, U.indptr, U.indices, ones)
+    g.set_sparse_matrix_data(*ok)
+    s0 = g.solve(np.ones(m))
+    bad_ptr = U.indptr.copy()
+    bad_ptr[5] = bad_ptr[6] + 1                      # decreasing
+    bad_row = U.indices.copy()
+    bad_row[3] = m                                   # out of range
+    neg_row = U.indices.copy()
+    neg_row[0] = -1
+    first = U.indptr.copy()
+    first[0] = 1
+    for args in [(m, bad_ptr, U.indices, U.data, bad_ptr, U.indices, ones),
+                 (m, U.indptr, bad_row, U.data, U.indptr, bad_row, ones),
+                 (m, U.indptr, neg_row, U.data, U.indptr, neg_row, ones),
+                 (m, first, U.indices, U.data, first, U.indices, ones)]:
+        with pytest.raises(abi.ClipperError):
+            g.set_sparse_matrix_data(*args)
+        s1 = g.solve(np.ones(m))       # rejected before anything was touched: the old matrix is intact
+        assert s1.nodes.tolist() == s0.nodes.tolist() and s1.score == s0.score
+    # the same entry in both triangles (found while the lists are merged: no matrix afterwards)
+    import scipy.sparse as sp
+    B = sp.csc_matrix(M - np.eye(m))
+    B.sort_indices()
+    with pytest.raises(abi.ClipperError):
+        g.set_sparse_matrix_data(m, B.indptr, B.indices, B.data, B.indptr, B.indices, np.ones_like(B.data))
+    with pytest.raises(abi.ClipperError):
+        g.solve(np.ones(m))
+    g.set_sparse_matrix_data(*ok)                       # and the context is still usable
+    s2 = g.solve(np.ones(m))
+    assert s2.nodes.tolist() == s0.nodes.tolist() and s2.score == s0.score
+
+
+def test_set_sparse_large_without_a_dense_store():
+    """m = 300 000 (BASELINE's last configuration): a dense fp32 store would be 360 GB — it cannot
+    exist on one MI355X. 0.02 % density = 9 M stored entries upload, pack and multiply in
+    O(nnz) memory; the product is checked against scipy."""
+    import scipy.sparse as sp
+    m = 300_000
+    rng = np.random.default_rng(8)
+    nnz = 9_000_000
+    i = rng.integers(0, m, nnz)
+    j = rng.integers(0, m, nnz)
+    keep = i < j
+    U = sp.csc_matrix((rng.uniform(0.1, 1.0, int(keep.sum())), (i[keep], j[keep])), shape=(m, m))
+    U.sum_duplicates()
+    U.sort_indices()
+    ones = np.ones_like(U.data)
+    g = abi.HipClipper(storage=abi.STORE_F32_CSC)
+    g.set_sparse_matrix_data(m, U.indptr, U.indices, U.data, U.indptr, U.indices, ones)
+    assert g.storage_in_use == abi.STORE_F32_CSC
+    x = rng.random(m)
+    yM, yC = g.matvec(x)
+    S32 = sp.csc_matrix((U.data.astype(np.float32).astype(np.float64), U.indices, U.indptr), shape=(m, m))
+    P = sp.csc_matrix((ones, U.indices, U.indptr), shape=(m, m))
+    assert np.allclose(yM, S32 @ x + S32.T @ x, rtol=1e-12, atol=1e-12)
+    assert np.allclose(yC, P @ x + P.T @ x, rtol=1e-12, atol=1e-12)
+    s = g.solve(rng.random(m))
+    assert len(s.nodes) >= 2 and np.isfinite(s.score)

@@ -19,7 +19,8 @@ from oracle import clipper_ref as ref
 
 pytestmark = pytest.mark.gpu
 
-STORAGES = [abi.STORE_F32, abi.STORE_F64, abi.STORE_F32_CSC]
+STORAGES = [abi.STORE_F32, abi.STORE_F64, abi.STORE_F32_CSC, abi.STORE_F64_CSC]
+F64S = (abi.STORE_F64, abi.STORE_F64_CSC)   # fp64 values: the parity-exact modes
 REL_SCORE = 1e-6
 
 
@@ -32,7 +33,7 @@ def _check_affinity(g, r, storage, f64_rel=4 * 2.3e-16):
     assert Mg.shape == Mr.shape
     assert np.array_equal(Mg != 0, Mr != 0), "non-zero pattern differs"
     assert np.array_equal(Mg, Mg.T)
-    if storage != abi.STORE_F64:
+    if storage not in F64S:
         assert np.array_equal(Mg.astype(np.float32), Mr.astype(np.float32)) or \
             np.max(np.abs(Mg - Mr.astype(np.float32).astype(np.float64))) <= 1.2e-7
     else:
@@ -162,13 +163,13 @@ def test_euclidean_parity(storage, m, rho, seed):
     # one mat-vec pass in isolation
     x = np.random.default_rng(seed + 5).random(m)
     (aM, aC), (rM, rC) = c.matvec(x), r.matvec(x)
-    tol = 1e-6 if storage != abi.STORE_F64 else 1e-12
+    tol = 1e-6 if storage not in F64S else 1e-12
     assert np.allclose(aM, rM, rtol=tol, atol=tol)
     assert np.allclose(aC, rC, rtol=1e-12, atol=1e-12)
     sg, sr = c.solve(p.u0), r.solve(p.u0)
-    _check_solution(sg, sr, exact_counts=(storage == abi.STORE_F64))
+    _check_solution(sg, sr, exact_counts=(storage in F64S))
     assert np.array_equal(c.get_selected_associations(), r.get_selected_associations())
-    if storage == abi.STORE_F64:
+    if storage in F64S:
         assert abs(sg.score - sr.score) <= 1e-9 * abs(sr.score)
         assert np.allclose(sg.u, sr.u, rtol=0, atol=1e-9)
     # a pass evaluates a window of line-search trials: never more passes than trials (+ the 2
@@ -395,7 +396,7 @@ def test_window_sizes_agree(monkeypatch, m, rho, seed):
             for rep in range(2):   # repeated solves on one context: counters re-arm themselves
                 s = g.solve(p.u0)
                 sols[(V, storage, rep)] = s
-                _check_solution(s, sr, exact_counts=(storage == abi.STORE_F64))
+                _check_solution(s, sr, exact_counts=(storage in F64S))
             g.close()
     monkeypatch.delenv("CLIPPER_HIP_WINDOW")
     for storage in STORAGES:

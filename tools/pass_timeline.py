@@ -17,7 +17,8 @@ g = abi.HipClipper(device=0, storage=abi.STORE_F32_CSC)
 for rep in range(3):
     g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
     s = g.solve(p.u0)
-st = g.debug_stamps()
+allst = g.debug_stamps()
+st = allst[:2048]
 st = st[st[:, 2] > 0]
 t0 = st[:, 0].min()
 pc = lambda v, f: float(np.sort(v)[int(f * (len(v) - 1))])
@@ -26,3 +27,12 @@ body = (st[:, 2] - st[:, 1]) * 0.01
 print(f"m={m} workgroups stamped {len(st)} passes {s.n_passes}")
 for name, v in (("start", start), ("head (launch -> decision done)", head), ("body", body), ("end", end)):
     print(f"  {name:32s} p10 {pc(v,.1):6.2f} p50 {pc(v,.5):6.2f} p90 {pc(v,.9):6.2f} p99 {pc(v,.99):6.2f} max {v.max():6.2f} us")
+tl = allst[2048:]
+tl = tl[tl[:, 2] > 0]
+if len(tl):
+    t1 = tl[:, 0].min()
+    print(f"tail workgroups stamped {len(tl)}; tail starts {(t1 - t0) * 0.01:.2f} us after the pass started, "
+          f"{(t1 - st[:, 2].max()) * 0.01:.2f} us after its last workgroup ended")
+    for name, v in (("start", (tl[:, 0] - t1) * 0.01), ("state + slot sums", (tl[:, 1] - tl[:, 0]) * 0.01),
+                    ("elementwise + reduce", (tl[:, 2] - tl[:, 1]) * 0.01), ("end", (tl[:, 2] - t1) * 0.01)):
+        print(f"  {name:32s} p10 {pc(v,.1):6.2f} p50 {pc(v,.5):6.2f} p90 {pc(v,.9):6.2f} p99 {pc(v,.99):6.2f} max {v.max():6.2f} us")
