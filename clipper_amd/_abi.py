@@ -37,8 +37,12 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
     "clipper_hip_affinity_pointnormal_staged", "clipper_hip_stage_u0",
-    "clipper_hip_solve_staged", "clipper_hip_debug_stamps",
+    "clipper_hip_solve_staged", "clipper_hip_debug_stamps", "clipper_hip_comm_init_callback",
 ]
+
+
+# int fn(void* user, const void* sendbuf, void* recvbuf, size_t bytes) — clipper_hip_allgather_fn
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class ClipperError(RuntimeError):
@@ -156,6 +160,7 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_bench_matvec.argtypes = [vp, C.c_int, dp]
     L.clipper_hip_device_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(i64)]
     L.clipper_hip_debug_stamps.argtypes = [vp, C.POINTER(i64), C.c_int]
+    L.clipper_hip_comm_init_callback.argtypes = [vp, ALLGATHER_FN, vp]
     _lib = L
     return L
 
@@ -403,6 +408,23 @@ class HipClipper:
         us = C.c_double()
         self._check(self.L.clipper_hip_bench_matvec(self.h, reps, C.byref(us)))
         return us.value
+
+    def comm_init_callback(self, allgather):
+        """exchange through `allgather(block: np.ndarray[float64]) -> np.ndarray` (the blocks of all
+        ranks, rank order, concatenated) instead of RCCL — e.g. a torch.distributed gloo all-gather"""
+        def thunk(user, send, recv, nbytes):
+            try:
+                n = nbytes // 8
+                blk = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(n,))
+                out = np.ascontiguousarray(allgather(blk.copy()), dtype=np.float64)
+                np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(out.size,))[:] = out
+                return 0
+            except Exception:      # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._xchg = ALLGATHER_FN(thunk)   # keep the trampoline alive
+        self._check(self.L.clipper_hip_comm_init_callback(self.h, self._xchg, None))
 
     def debug_stamps(self):
         """per workgroup of the last pass launch: (start, decision done, end, info); needs

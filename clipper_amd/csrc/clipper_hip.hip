@@ -38,6 +38,7 @@
 #include "../../include/clipper_hip.h"
 #include "kernels.hip.h"
 #include "dsd_host.h"
+#include "host_batch.hpp"
 
 using namespace clipper_hip;
 
@@ -125,6 +126,14 @@ int clipper_hip_comm_init(clipper_hip_t* h, const void* id128) {
   return 0;
 }
 
+int clipper_hip_comm_init_callback(clipper_hip_t* h, clipper_hip_allgather_fn fn, void* user) {
+  if (!h || !fn) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (!h->multiproc) return 0;  // nothing to exchange
+  h->xchg_fn = fn;
+  h->xchg_user = user;
+  return 0;
+}
+
 void clipper_hip_destroy(clipper_hip_t* h) {
   if (!h) return;
   for (auto& s : h->sh) {
@@ -147,6 +156,8 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   if (h->kind) hipHostFree(h->kind);
   if (h->u_pinned) hipHostFree(h->u_pinned);
   if (h->stamps_dev) hipFree(h->stamps_dev);
+  if (h->xchg_send) hipHostFree(h->xchg_send);
+  if (h->xchg_recv) hipHostFree(h->xchg_recv);
   if (h->ev_aff[0]) hipEventDestroy(h->ev_aff[0]);
   if (h->ev_aff[1]) hipEventDestroy(h->ev_aff[1]);
   if (h->csc_hLq) hipHostFree(h->csc_hLq);
@@ -784,26 +795,25 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     // Multi-process: every rank must queue the same number of iterations (each holds a
     // collective), so the decision to stop rests on state snapshots only, which are
     // bit-identical on all ranks. Batch n+1 is queued before the snapshot after batch n is read.
-    int slot = 0;
-    bool have_prev = false;
-    bool done = false;
     int batch = SOLVE_BATCH;
     if (const char* e = std::getenv("CLIPPER_HIP_SOLVE_BATCH")) batch = std::max(1, std::atoi(e));  // tuning knob, same on every rank
-    while (!done) {
-      for (int it = 0; it < batch; ++it) {
-        if ((rc = enqueue_iteration(h, prm))) return rc;
-      }
-      HIPCHK(hipSetDevice(s0.device));
-      HIPCHK(hipMemcpyAsync(&h->host_state[slot], s0.shared, sizeof(SolveShared),
-                            hipMemcpyDeviceToHost, s0.stream));
-      HIPCHK(hipEventRecord(h->ev_poll[slot], s0.stream));
-      if (have_prev) {
-        HIPCHK(hipEventSynchronize(h->ev_poll[slot ^ 1]));
-        if (h->host_state[slot ^ 1].done) done = true;
-      }
-      have_prev = true;
-      slot ^= 1;
-    }
+    HIPCHK(hipSetDevice(s0.device));
+    rc = run_batched_until_done(
+        batch, [&]() { return enqueue_iteration(h, prm); },
+        [&](int slot) -> int {
+          HIPCHK(hipSetDevice(s0.device));
+          HIPCHK(hipMemcpyAsync(&h->host_state[slot], s0.shared, sizeof(SolveShared),
+                                hipMemcpyDeviceToHost, s0.stream));
+          HIPCHK(hipEventRecord(h->ev_poll[slot], s0.stream));
+          return 0;
+        },
+        [&](int slot, bool& d) -> int {
+          HIPCHK(hipEventSynchronize(h->ev_poll[slot]));
+          d = h->host_state[slot].done != 0;
+          return 0;
+        },
+        nullptr);
+    if (rc) return rc;
     if ((rc = sync_all(h))) return rc;
     HIPCHK(hipSetDevice(s0.device));
     HIPCHK(hipMemcpy(&fin, s0.shared, sizeof(fin), hipMemcpyDeviceToHost));

@@ -256,6 +256,30 @@ int exchange(Ctx* h, int nslots) {
   if (h->world == 1 && !h->multiproc) return 0;
   const int64_t blk_elems = static_cast<int64_t>(nslots) * h->W;
   const size_t blk = static_cast<size_t>(blk_elems) * sizeof(double);
+  if (h->multiproc && h->xchg_fn) {
+    // through the caller: own block -> pinned host memory -> callback (e.g. a gloo all-gather) ->
+    // every rank's block back to the device. One host round trip per pass: a portability and test
+    // back-end (two processes on one GPU), not a fast path.
+    Shard& s = h->sh[0];
+    HIPCHK(hipSetDevice(s.device));
+    const size_t need = static_cast<size_t>(h->world) * blk;
+    if (need > h->xchg_cap) {
+      if (h->xchg_send) hipHostFree(h->xchg_send);
+      if (h->xchg_recv) hipHostFree(h->xchg_recv);
+      h->xchg_send = h->xchg_recv = nullptr;
+      h->xchg_cap = 0;
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->xchg_send), blk, hipHostMallocDefault));
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->xchg_recv), need, hipHostMallocDefault));
+      h->xchg_cap = need;
+    }
+    HIPCHK(hipMemcpyAsync(h->xchg_send, s.ab + static_cast<int64_t>(s.slot) * blk_elems, blk,
+                          hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    if (int rc = h->xchg_fn(h->xchg_user, h->xchg_send, h->xchg_recv, blk))
+      return fail(CLIPPER_HIP_E_COMM, "the exchange callback returned %d", rc);
+    HIPCHK(hipMemcpyAsync(s.ab, h->xchg_recv, need, hipMemcpyHostToDevice, s.stream));
+    return 0;
+  }
   if (h->multiproc) {
     if (!h->comm) return fail(CLIPPER_HIP_E_COMM, "clipper_hip_comm_init was not called");
     Shard& s = h->sh[0];

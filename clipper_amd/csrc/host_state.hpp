@@ -148,6 +148,12 @@ struct clipper_hip_ctx {
   bool multiproc = false;
   std::vector<Shard> sh;  // local shards
   ncclComm_t comm = nullptr;
+  // exchange through the caller (clipper_hip_comm_init_callback) instead of RCCL
+  clipper_hip_allgather_fn xchg_fn = nullptr;
+  void* xchg_user = nullptr;
+  double* xchg_send = nullptr;  // pinned staging of this rank's block / of the gathered blocks
+  double* xchg_recv = nullptr;
+  size_t xchg_cap = 0;
 
   int64_t m = 0;  // associations / matrix dimension
   int64_t W = 0;  // shard pitch

@@ -36,6 +36,8 @@
 #ifndef CLIPPER_HIP_H
 #define CLIPPER_HIP_H
 
+#include <stddef.h>
+
 #include "clipper_abi.h"
 
 #ifdef __cplusplus
@@ -96,6 +98,14 @@ clipper_hip_t* clipper_hip_create_rank(int device, int storage, int rank, int wo
 int clipper_hip_comm_unique_id(void* id128);
 /* ncclCommInitRank on this context's device with the broadcast id. */
 int clipper_hip_comm_init(clipper_hip_t* h, const void* id128);
+/* The same exchange through the CALLER instead of RCCL: once per pass the library hands `fn` this
+ * rank's block (`bytes` bytes of host memory) and a buffer of world * bytes for the blocks of all
+ * ranks, rank order (e.g. a torch.distributed / MPI all-gather). `fn` returns 0, or non-zero to
+ * abort the solve with CLIPPER_HIP_E_COMM. Called from the thread that runs clipper_hip_solve.
+ * One host round trip per pass: a portability and test back-end (it lets several processes share
+ * ONE device), not a fast path. */
+typedef int (*clipper_hip_allgather_fn)(void* user, const void* sendbuf, void* recvbuf, size_t bytes);
+int clipper_hip_comm_init_callback(clipper_hip_t* h, clipper_hip_allgather_fn fn, void* user);
 
 void clipper_hip_destroy(clipper_hip_t* h);
 const char* clipper_hip_last_error(void);
