@@ -13,16 +13,27 @@ u0) are staged into HBM before the timed region; every step re-runs the affinity
 the full solver. With N > 1 the SAME problem is column-sharded over the N GPUs (one process
 per GPU, per-pass RCCL all-gather of the (M_off x, C_off x) slices): strong scaling.
 
+`value` is the step with the inputs resident in HBM (the measurement contract); the same step
+with host buffers handed to the drop-in entry points (H2D of D1, D2, A, u0 and D2H of u inside,
+SURVEY 8d's wording) is timed over the same number of warmed steps as `ms_per_step_host_buffers`.
+
 Prints ONE JSON line on rank 0 (see the contract in the task statement), extended with
-  "roofline"     achieved HBM GB/s of the dominant kernel (the mat-vec: one pass over M for a
-                 whole line-search window), from HIP events recorded on the solver stream
-                 around every 20th launch in the timed region (an event pair costs ~30 us of stream time). Default storage "csc" (one GPU):
-                 k_gemv_csc streams the compressed copy of M — bytes per launch = what that
-                 copy holds (5 B per padded entry + the group directory), NOT s*m^2; the
-                 dense-equivalent rate is reported beside it and is not a roofline figure.
+  "roofline"     achieved GB/s of the dominant kernel (the pass: one sweep over M for a whole
+                 line-search window), from HIP events recorded on the solver stream around every
+                 20th launch in the timed region (an event pair costs ~30 us of stream time).
+                 Default storage "csc" (one GPU): k_gemv_slices streams the slices of M — bytes per
+                 launch = what the slices hold (headers, lengths, value and row quads), NOT
+                 s*m^2; `useful_bytes_per_launch` / `frac_useful` count stored entries only
+                 (value + row byte, no quad padding); the dense-equivalent rate is not a
+                 roofline figure. `regime` says whether those bytes fit the 256 MiB Infinity
+                 Cache (then every pass after the first is served on-die and "hbm" names the
+                 peak it is normalised by, not the wire it crossed). `traffic` = HBM-side bytes
+                 per launch from the PMC run recorded in profiles/gemv_traffic.json
+                 (`traffic_source` names the entry and the commit it was measured at).
                  --storage f32: k_gemv on the dense store, bytes per launch = 4*m*W
+  "roofline_affinity"  the fill kernel: bytes of M written per build / its duration.
   "cpu_baseline" the oracle (oracle/libclipper_ref.so, a port of the reference) timed on
-                 this box's host cores on the same problem (rank 0, N = 1 only).
+                 this box's host cores on the same problem, median of 3 (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -46,9 +57,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--m", type=int, default=10000, help="putative associations")
     ap.add_argument("--rho", type=float, default=None, help="outlier ratio (default 0.95; 0.90 at m<=1000)")
-    ap.add_argument("--storage", choices=["f32", "f64", "csc"], default="csc",
-                    help="how M is kept in HBM: csc = fp32 values, nonzeros only (the solver's passes "
-                         "skip the zeros; one GPU), f32 / f64 = dense (vectors/accumulators are always f64)")
+    ap.add_argument("--storage", choices=["f32", "f64", "csc", "csc64"], default="csc",
+                    help="how M is kept in HBM: csc / csc64 = stored entries only (fp32 / fp64 values; the "
+                         "solver's passes skip the zeros), f32 / f64 = dense (vectors/accumulators are always f64)")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true",
@@ -62,20 +73,27 @@ def cpu_baseline(problem, args):
     from clipper_amd import synth
     from oracle import clipper_ref as ref
 
-    r = ref.RefClipper()
-    t0 = time.perf_counter()
-    r.score_pairwise_consistency_euclidean(problem.D1, problem.D2, problem.A,
-                                           **synth.EUCLID_BENCH_PARAMS)
-    t1 = time.perf_counter()
-    s = r.solve(problem.u0)
-    t2 = time.perf_counter()
+    reps = 3 if args.m <= 12000 else 1
+    runs = []
+    for _ in range(reps):
+        r = ref.RefClipper()
+        t0 = time.perf_counter()
+        r.score_pairwise_consistency_euclidean(problem.D1, problem.D2, problem.A,
+                                               **synth.EUCLID_BENCH_PARAMS)
+        t1 = time.perf_counter()
+        s = r.solve(problem.u0)
+        t2 = time.perf_counter()
+        runs.append((t2 - t0, t1 - t0, t2 - t1))
+    runs.sort()
+    tot, ta, ts = runs[len(runs) // 2]   # the median step
     return {
-        "value": round((t2 - t0) * 1e3, 3), "unit": "ms", "cores": ref.omp_threads(),
+        "value": round(tot * 1e3, 3), "unit": "ms", "cores": ref.omp_threads(),
         "kind": "port",
-        "sample": (f"1 full step at m={args.m}: affinity {1e3 * (t1 - t0):.1f} ms on "
-                   f"{ref.omp_threads()} OpenMP threads + solve {1e3 * (t2 - t1):.1f} ms on 1 thread "
-                   f"({s.n_passes} reference-counted passes, nnz={r.nnz})"),
-        "affinity_ms": round((t1 - t0) * 1e3, 3), "solve_ms": round((t2 - t1) * 1e3, 3),
+        "sample": (f"median of {reps} full steps at m={args.m}: affinity {1e3 * ta:.1f} ms on "
+                   f"{ref.omp_threads()} OpenMP threads + solve {1e3 * ts:.1f} ms on 1 thread "
+                   f"({s.n_passes} reference-counted passes, nnz={r.nnz}); all steps "
+                   f"{[round(1e3 * x[0], 1) for x in runs]} ms"),
+        "affinity_ms": round(ta * 1e3, 3), "solve_ms": round(ts * 1e3, 3),
         "nproc": os.cpu_count(),
     }, s
 
@@ -116,7 +134,8 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    storage = {"f32": abi.STORE_F32, "f64": abi.STORE_F64, "csc": abi.STORE_F32_CSC}[args.storage]
+    storage = {"f32": abi.STORE_F32, "f64": abi.STORE_F64, "csc": abi.STORE_F32_CSC,
+               "csc64": abi.STORE_F64_CSC}[args.storage]
     problem = synth.make_euclidean_problem(args.m, rho, seed=args.seed)  # identical on every rank
     if N > 1:
         g = abi.HipClipper(device=local_rank, storage=storage, rank=rank, world=N)
@@ -166,25 +185,46 @@ def main():
     gemv_bytes = tm.gemv_bytes  # s * m * W_local: algorithmic bytes of ONE launch on THIS rank
     achieved = gemv_bytes / (gemv_avg_us * 1e-6) / 1e9 if gemv_avg_us > 0 else 0.0
 
-    # PCIe-inclusive variant (host buffers handed to the drop-in entry points), for DESIGN.md
-    th0 = time.perf_counter()
+    # PCIe-inclusive variant (host buffers handed to the drop-in entry points: H2D of the inputs
+    # and D2H of u inside), same number of steps, warmed — for DESIGN.md, never `value`
     g.score_pairwise_consistency_euclidean(problem.D1, problem.D2, problem.A, **inv)
-    sol_h = g.solve(problem.u0)
-    host_ms = (time.perf_counter() - th0) * 1e3
+    g.solve(problem.u0)
+    barrier_sync()
+    th0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.score_pairwise_consistency_euclidean(problem.D1, problem.D2, problem.A, **inv)
+        sol_h = g.solve(problem.u0)
+    barrier_sync()
+    host_ms = (time.perf_counter() - th0) * 1e3 / args.steps
     if N > 1:
-        dist.barrier(device_ids=[local_rank])
+        host_ms = cdist.max_over_ranks(host_ms)
 
     out = None
     if rank == 0:
         name, cus, hbm = g.device_info()
-        in_use = {abi.STORE_F32: "f32", abi.STORE_F64: "f64", abi.STORE_F32_CSC: "csc"}[g.storage_in_use]
-        traffic = None
+        in_use = {abi.STORE_F32: "f32", abi.STORE_F64: "f64", abi.STORE_F32_CSC: "csc",
+                  abi.STORE_F64_CSC: "csc64"}[g.storage_in_use]
+        compressed = in_use in ("csc", "csc64")
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "gemv_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"m{args.m}_{in_use}_bytes_per_launch")
+                rec = json.load(open(pmc))
+                key = f"r02_m{args.m}_{in_use}_bytes_per_launch"
+                traffic = rec.get(key)
+                if traffic is not None:
+                    traffic_source = {"file": "profiles/gemv_traffic.json", "key": key,
+                                      "measured_at_commit": rec.get("r02_commit"),
+                                      "kernel_bytes_then": rec.get(f"r02_m{args.m}_{in_use}_algorithmic_bytes")}
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
+        useful = tm.gemv_useful_bytes
+        achieved_useful = useful / (gemv_avg_us * 1e-6) / 1e9 if gemv_avg_us > 0 else 0.0
+        regime = ("Infinity-Cache-resident: %.0f MB per pass < 256 MiB, re-read every pass — served "
+                  "on-die after the first pass; peak = HBM spec as the normalising figure" % (gemv_bytes / 1e6)
+                  if gemv_bytes < 256 * 2 ** 20 else "HBM-streaming: %.2f GB per pass" % (gemv_bytes / 1e9))
+        aff_kernel_ms = tm.affinity_kernel_ms
+        aff_achieved = tm.affinity_bytes / (aff_kernel_ms * 1e-3) / 1e9 if aff_kernel_ms > 0 else 0.0
         out = {
             "metric": "affinity+solve ms and GEMV HBM GB/s, n=10k assoc, 95% outliers, 1/8 GPU",
             "value": round(ms_per_step, 4),
@@ -196,7 +236,7 @@ def main():
             "higher_is_better": False,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64" if in_use == "f64" else "f64 (M stored f32)",
+            "dtype": "f64" if in_use in ("f64", "csc64") else "f64 (M stored f32)",
             "data": "synthetic",
             "config": {
                 "workload": (f"synthetic 3-D registration, m={args.m} putative associations, "
@@ -220,10 +260,22 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "kernel": "k_gemv_csc" if in_use == "csc" else "k_gemv",
+                "traffic_source": traffic_source,
+                "kernel": "k_gemv_slices" if compressed else "k_gemv",
                 "bytes_per_launch": gemv_bytes,
+                "useful_bytes_per_launch": useful,
+                "frac_useful": round(achieved_useful / HBM_PEAK_GBPS, 4),
+                "regime": regime,
                 "dense_equivalent_GBps": round(4.0 * args.m * args.m / (gemv_avg_us * 1e-6) / 1e9, 1)
-                if (in_use == "csc" and gemv_avg_us > 0) else None,
+                if (compressed and gemv_avg_us > 0) else None,
+            },
+            "roofline_affinity": {
+                "bound": "hbm", "achieved": round(aff_achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(aff_achieved / HBM_PEAK_GBPS, 4),
+                "kernel": "k_affinity_sym (writes the slices itself)" if compressed else "affinity fill",
+                "bytes_per_launch": tm.affinity_bytes, "kernel_ms": round(aff_kernel_ms, 4),
+                "note": "store floor only: the fill is bound by fp64 VALU issue and dependent latency "
+                        "(prefilter + exact scores of the survivors), see profiles/ and DESIGN.md",
             },
         }
         if N == 1 and not args.no_cpu_baseline:

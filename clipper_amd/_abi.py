@@ -83,6 +83,7 @@ class Timings(C.Structure):
         ("affinity_kernel_ms", C.c_double), ("affinity_total_ms", C.c_double),
         ("solve_total_ms", C.c_double), ("gemv_avg_us", C.c_double),
         ("gemv_min_us", C.c_double), ("gemv_launches", C.c_int64), ("gemv_bytes", C.c_double),
+        ("gemv_useful_bytes", C.c_double), ("affinity_bytes", C.c_double),
     ]
 
 

@@ -873,6 +873,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   h->tm.gemv_avg_us = h->tm.gemv_min_us = 0.0;
   h->tm.gemv_launches = 0;
   h->tm.gemv_bytes = algorithmic_gemv_bytes(h);
+  h->tm.gemv_useful_bytes = h->csc_valid ? static_cast<double>(h->sh[0].s_entries) * (h->esize() + 1.0) : h->tm.gemv_bytes;
   if (h->profiling && h->ev_used > 0) {
     // only launches that streamed M count: the device marked every iteration as pass (1) or
     // transition (0); launches queued past convergence have no mark

@@ -519,6 +519,8 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
   HIPCHK(hipSetDevice(s0.device));
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   h->tm.affinity_kernel_ms = ms + (h->csc_valid ? build_ms : 0.0);
+  h->tm.affinity_bytes = h->csc_valid ? static_cast<double>(h->sh[0].s_bytes)
+                                      : static_cast<double>(h->sh[0].bytes_S);
   h->has_matrix = true;
   return 0;
 }

@@ -74,7 +74,12 @@ typedef struct clipper_hip_timings_t {
                                 (only when profiling is on; else 0)                     */
   double gemv_min_us;
   int64_t gemv_launches;     /* number of mat-vec launches that were timed              */
-  double gemv_bytes;         /* algorithmic bytes of one launch: s*m*(owned columns)    */
+  double gemv_bytes;         /* algorithmic bytes of one launch: s*m*(owned columns) for a
+                                dense store; for the compressed storage the bytes the slices
+                                hold (headers, lengths, value and row quads) + their directory */
+  double gemv_useful_bytes;  /* compressed storage: stored entries (both triangles, no quad
+                                padding) x (value + row byte); dense store: = gemv_bytes     */
+  double affinity_bytes;     /* bytes of M the last affinity build wrote (dense store or slices) */
 } clipper_hip_timings_t;
 
 /* ---- life cycle --------------------------------------------------------------------- */

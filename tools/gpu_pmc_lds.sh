@@ -10,4 +10,4 @@ for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTI
 done
 python tools/rocpd_pmc.py $(find $OUT -name '*.db') > $OUT/pmc_lds.txt 2>&1
 find $OUT -name '*.db' -size +20M -delete
-grep -E "k_gemv_csc|k_tail|k_affinity|\.db" $OUT/pmc_lds.txt
+grep -E "k_gemv_slices|k_tail|k_affinity|\.db" $OUT/pmc_lds.txt
