@@ -38,6 +38,8 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
     "clipper_hip_affinity_pointnormal_staged", "clipper_hip_stage_u0",
     "clipper_hip_solve_staged", "clipper_hip_debug_stamps", "clipper_hip_comm_init_callback",
+    "clipper_hip_read_ply_xyz", "clipper_hip_generate_synthetic_correspondences",
+    "clipper_hip_precision_recall", "clipper_hip_estimate_rigid_transform",
 ]
 
 
@@ -162,6 +164,12 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_device_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(i64)]
     L.clipper_hip_debug_stamps.argtypes = [vp, C.POINTER(i64), C.c_int]
     L.clipper_hip_comm_init_callback.argtypes = [vp, ALLGATHER_FN, vp]
+    L.clipper_hip_read_ply_xyz.argtypes = [C.c_char_p, dp, i64]
+    L.clipper_hip_read_ply_xyz.restype = i64
+    L.clipper_hip_generate_synthetic_correspondences.argtypes = [i64, i64, ip, i64, i64, C.c_double, C.c_uint64,
+                                                                 ip, ip, C.POINTER(i64)]
+    L.clipper_hip_precision_recall.argtypes = [ip, i64, ip, i64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.clipper_hip_estimate_rigid_transform.argtypes = [dp, i64, dp, i64, ip, i64, dp]
     _lib = L
     return L
 
@@ -439,6 +447,62 @@ class HipClipper:
         cus, hbm = C.c_int(), C.c_int64()
         self._check(self.L.clipper_hip_device_info(self.h, name, C.byref(cus), C.byref(hbm)))
         return name.value.decode(), cus.value, hbm.value
+
+
+# ---- host-side neighbours of the path, through the C ABI (no device needed) ----------------------
+
+def _status(rc):
+    if rc < 0:
+        raise ClipperError(f"clipper_hip error {rc}: {_last_error()}")
+    return rc
+
+
+def read_ply_xyz(path: str) -> np.ndarray:
+    """utils::read_ply: vertex positions as a 3 x n float64 array (one datum per column)"""
+    L = load_library()
+    n = _status(L.clipper_hip_read_ply_xyz(path.encode(), None, 0))
+    pts = np.zeros((n, 3), dtype=np.float64)
+    _status(L.clipper_hip_read_ply_xyz(path.encode(), _dp(pts), n))
+    return np.ascontiguousarray(pts.T)
+
+
+def generate_synthetic_correspondences(n0: int, n1: int, Agood, m: int, rho: float, seed: int):
+    """utils::generate_synthetic_correspondences -> (A m x 2, Agt ni x 2)"""
+    L = load_library()
+    Agood = np.asarray(Agood, dtype=np.int32).reshape(-1, 2)
+    p = Agood.shape[0]
+    gcm = np.ascontiguousarray(Agood.T).reshape(-1)
+    A = np.zeros(2 * m, dtype=np.int32)
+    Agt = np.zeros(2 * m, dtype=np.int32)
+    ni = C.c_int64()
+    _status(L.clipper_hip_generate_synthetic_correspondences(n0, n1, _ip(gcm), p, m, rho, seed, _ip(A), _ip(Agt),
+                                                             C.byref(ni)))
+    k = ni.value
+    return A.reshape(2, m).T.copy(), Agt[:2 * k].reshape(2, k).T.copy()
+
+
+def precision_recall(A, Agt):
+    """utils::get_precision_recall"""
+    L = load_library()
+    A = np.asarray(A, dtype=np.int32).reshape(-1, 2)
+    Agt = np.asarray(Agt, dtype=np.int32).reshape(-1, 2)
+    a, g = np.ascontiguousarray(A.T).reshape(-1), np.ascontiguousarray(Agt.T).reshape(-1)
+    p, r = C.c_double(), C.c_double()
+    _status(L.clipper_hip_precision_recall(_ip(a) if a.size else None, A.shape[0], _ip(g) if g.size else None,
+                                           Agt.shape[0], C.byref(p), C.byref(r)))
+    return p.value, r.value
+
+
+def estimate_rigid_transform(D1, D2, A) -> np.ndarray:
+    """4 x 4 T with D2[:, A[i,1]] ~ R D1[:, A[i,0]] + t (D1, D2: 3 x n)"""
+    L = load_library()
+    D1, D2 = _f64_colmajor(D1), _f64_colmajor(D2)
+    A = np.asarray(A, dtype=np.int32).reshape(-1, 2)
+    a = np.ascontiguousarray(A.T).reshape(-1)
+    T = np.zeros(16, dtype=np.float64)
+    _status(L.clipper_hip_estimate_rigid_transform(_dp(D1), D1.shape[1], _dp(D2), D2.shape[1], _ip(a), A.shape[0],
+                                                   _dp(T)))
+    return T.reshape(4, 4).T.copy()
 
 
 def device_count() -> int:

@@ -45,6 +45,7 @@ using namespace clipper_hip;
 #include "host_state.hpp"
 #include "host_solver.hpp"
 #include "host_matrix.hpp"
+#include "host_registration.hpp"
 
 // ============================================================================================
 // brute-force nearest neighbours: launch of the two kernels for one (K, D)

@@ -58,6 +58,8 @@ def read_ply_xyz(path: str) -> np.ndarray:
         if fmt == "ascii":
             rows = [f.readline().split() for _ in range(nvert)]
             arr = np.array([[float(r[names.index(k)]) for k in "xyz"] for r in rows], dtype=np.float64)
+            for c, k in enumerate("xyz"):      # through the declared type, as a binary file would carry it
+                arr[:, c] = arr[:, c].astype(dict(props)[k]).astype(np.float64)
         elif fmt in ("binary_little_endian", "binary_big_endian"):
             end = "<" if fmt == "binary_little_endian" else ">"
             dt = np.dtype([(n, end + t) for n, t in props])

@@ -245,6 +245,33 @@ int clipper_hip_get_timings(const clipper_hip_t* h, clipper_hip_timings_t* out);
  * mean kernel time in microseconds (events on the launch stream). */
 int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us);
 /* Device name, CU count, HBM bytes (for bench.py's report). */
+/* ---- host-side neighbours of the path (no device work) -----------------
+ * utils::read_ply (benchmarks/bm_utils.cpp:24-79): x, y, z of the `vertex` element of an ascii or
+ * binary PLY file -> pts_out, column-major 3 x n (one datum per column, as invariants::Data).
+ * pts_out == NULL: returns the vertex count only. Returns n or a negative status. */
+int64_t clipper_hip_read_ply_xyz(const char* path, double* pts_out, int64_t capacity);
+/* utils::generate_synthetic_correspondences (bm_utils.cpp:277-341): m putative associations with
+ * outlier ratio rho — ni = round(m (1 - rho)) inliers drawn without replacement from the p good
+ * associations Agood (column-major p x 2), placed LAST; m - ni outliers sampled uniformly without
+ * repetition from all n0 * n1 pairs that are not in Agood, placed FIRST. A_out: m x 2, Agt_out:
+ * ni x 2 (capacity m x 2), both column-major; *ni_out = ni. The reference seeds a mt19937 from
+ * random_device; here the seed is an argument (mt19937_64), so a call is reproducible.
+ * CLIPPER_HIP_E_STATE when Agood holds fewer than ni associations (the reference returns {}). */
+int clipper_hip_generate_synthetic_correspondences(int64_t n0, int64_t n1, const int32_t* Agood,
+                                                   int64_t p, int64_t m, double rho, uint64_t seed,
+                                                   int32_t* A_out, int32_t* Agt_out,
+                                                   int64_t* ni_out);
+/* utils::get_precision_recall (bm_utils.cpp:345-371): TP counted row by row of A (na x 2) against
+ * the set of rows of Agt (ngt x 2); (0, 0) when either is empty. */
+int clipper_hip_precision_recall(const int32_t* A, int64_t na, const int32_t* Agt, int64_t ngt,
+                                 double* precision, double* recall);
+/* Least-squares rigid transform T (column-major 4 x 4) with D2[:, A(i,1)] ~ R D1[:, A(i,0)] + t over
+ * the k >= 3 associations A (column-major k x 2): centroids, 3 x 3 cross-covariance, SVD, reflection
+ * fix (Arun / Horn) — the consumer of the selected associations in examples/python/ex4_bunny.ipynb.
+ * D1: 3 x n1, D2: 3 x n2, column-major. */
+int clipper_hip_estimate_rigid_transform(const double* D1, int64_t n1, const double* D2, int64_t n2,
+                                         const int32_t* A, int64_t k, double* T_out);
+
 /* Measurement only (context created with CLIPPER_HIP_STAMPS=1 in the environment): per workgroup of
  * the last pass launch {start, decision done, end, info} on the 100 MHz device wall clock. */
 int clipper_hip_debug_stamps(clipper_hip_t* h, int64_t* out, int capacity);
