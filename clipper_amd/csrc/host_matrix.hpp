@@ -128,6 +128,7 @@ int emit_prepare(Ctx* h, Shard& s, SliceOut& out) {
   out.ctl = s.cctl;
   out.nchunks = s.s_nchunks;
   out.ncg = s.s_ncg;
+  out.stamps = h->stamps_dev ? h->stamps_dev + 8192 : nullptr;
   return 0;
 }
 

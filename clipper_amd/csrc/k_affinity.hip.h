@@ -515,7 +515,8 @@ constexpr int AT_WAVES = CLIPPER_AT_WAVES;       // waves per workgroup
 constexpr int AT_ROWS_PER_WAVE = AT / AT_WAVES;  // tile rows a wave owns
 constexpr int AT_QUEUE = 256;     // ring entries per wave: < 64 waiting + one row's 128 candidates
 constexpr int AT_SYM_IMG_BYTES = (AT * AT_PITCH * 4 + 15) / 16 * 16;
-constexpr int AT_SYM_LDS_BYTES = AT_SYM_IMG_BYTES + AT_WAVES * AT_QUEUE * 4;
+constexpr int AT_SYM_MASK_BYTES = 2 * AT * 16;  // nonzero masks of the tile's columns and of its rows
+constexpr int AT_SYM_LDS_BYTES = AT_SYM_IMG_BYTES + AT_WAVES * AT_QUEUE * 4 + AT_SYM_MASK_BYTES;
 
 // linear index t of the upper block triangle (row-major: (0,0) (0,1) ... (1,1) ...) -> (I, J)
 __device__ __forceinline__ void tile_of(int t, int nT, int& I, int& J) {
@@ -537,8 +538,11 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
     int64_t pstride, const int32_t* __restrict__ A0, const int32_t* __restrict__ A1,
     EuclidParams eprm, PointNormalParams nprm, float E2 /* guarded threshold squared, rounded up */,
     CscOut O /* O.Pre != null: also write the tile's slices (k_csc.hip.h) */) {
-  // 72.5 KiB of dynamic LDS (two workgroups per CU fit the 160 KiB): the image, then the queues
+  // 76.5 KiB of dynamic LDS (two workgroups per CU fit the 160 KiB): the image, the queues, the masks
   extern __shared__ __attribute__((aligned(16))) char sym_smem[];
+  const bool stamp = O.stamps != nullptr && blockIdx.x < 800 && threadIdx.x == 0;
+  long long ts[5] = {0, 0, 0, 0, 0};
+  if (stamp) ts[0] = wall_clock64();
   float* img = reinterpret_cast<float*>(sym_smem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -565,15 +569,21 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
       p2c[q][k] = P2f[k * pstride + gi];
     }
   }
-  // zero this wave's rows of the image
+  // colmask[cl][4] / rowmask[rl][4]: which rows of tile column cl / columns of tile row rl hold a
+  // nonzero — set by the scatter below, read by the emission of the slices
+  uint32_t* colmask = reinterpret_cast<uint32_t*>(sym_smem + AT_SYM_IMG_BYTES + AT_WAVES * AT_QUEUE * 4);
+  uint32_t* rowmask = colmask + AT * 4;
+  colmask[threadIdx.x] = 0;
+  rowmask[threadIdx.x] = 0;
+  if (S != nullptr) {  // the dense store gets the whole image: zero this wave's rows of it
 #pragma unroll 4
-  for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
-    float* row = img + (wave * AT_ROWS_PER_WAVE + rr) * AT_PITCH;
-    row[2 * lane] = 0.f;
-    row[2 * lane + 1] = 0.f;
+    for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
+      float* row = img + (wave * AT_ROWS_PER_WAVE + rr) * AT_PITCH;
+      row[2 * lane] = 0.f;
+      row[2 * lane + 1] = 0.f;
+    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();  // the column masks are shared by all waves
 
   // exact fp64 score of queue entries [head, head + n), scattered into the image
   auto drain = [&](uint32_t head, uint32_t n) {
@@ -584,7 +594,12 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
       double scr;
       if (POINTNORMAL) scr = exact_pointnormal_score<float>(P1, P2, pstride, r0 + rl, c0 + cl, nprm);
       else scr = exact_euclid_score<float, D>(P1, P2, pstride, r0 + rl, c0 + cl, eprm);
-      img[rl * AT_PITCH + cl] = store_score<float>(scr, affinityeps);
+      const float v = store_score<float>(scr, affinityeps);
+      img[rl * AT_PITCH + cl] = v;
+      if (v != 0.f) {
+        atomicOr(&colmask[cl * 4 + (rl >> 5)], 1u << (rl & 31));
+        atomicOr(&rowmask[rl * 4 + (cl >> 5)], 1u << (cl & 31));
+      }
     }
   };
 
@@ -656,6 +671,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
     drain(head, n);
     head += n;
   }
+  if (stamp) ts[1] = wall_clock64();
   __syncthreads();
 
   // ---- the slices (k_slices.hip.h) of the tile and of its mirror image, straight from the image:
@@ -668,11 +684,18 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
     const bool mirror = sl >= 2;
     // element q of the lane's column: tile (q, 64 e + lane), or (64 e + lane, q) of the mirror
     const float* col = mirror ? img + (64 * e + lane) * AT_PITCH : img + 64 * e + lane;
+    const uint4 mk = *reinterpret_cast<const uint4*>((mirror ? rowmask : colmask) + (64 * e + lane) * 4);
+    const uint64_t mlo = static_cast<uint64_t>(mk.x) | (static_cast<uint64_t>(mk.y) << 32);
+    const uint64_t mhi = static_cast<uint64_t>(mk.z) | (static_cast<uint64_t>(mk.w) << 32);
     const int cg = 2 * (mirror ? I : J) + e;
     const int k = mirror ? J : I;
     const int64_t s = (cg < O.ncg && k < O.nchunks && !(mirror && I == J))
                           ? static_cast<int64_t>(cg) * O.nchunks + k : -1;
-    slice_emit_lds(col, mirror ? 1 : AT_PITCH, s, sl, half, O, base_s);
+    slice_emit_lds(col, mirror ? 1 : AT_PITCH, mlo, mhi, s, sl, half, O, base_s, stamp ? ts + 2 : nullptr);
+    if (stamp) {
+      ts[4] = wall_clock64();
+      for (int i = 0; i < 5; ++i) O.stamps[blockIdx.x * 5 + i] = ts[i];
+    }
   }
 
   // ---- the tile as it stands: this wave's rows, 512-byte segments -----------------------------

@@ -47,6 +47,8 @@ struct SliceOut {
   uint8_t* data;
   CscBuildCtl* ctl;  // arena cursors in units of 16 bytes
   int nchunks, ncg;
+  long long* stamps; // measurement only (may be null): per tile {start, scores done, masks, space
+                     // claimed, written} on the 100 MHz wall clock
 };
 typedef SliceOut CscOut;
 
@@ -116,28 +118,27 @@ __device__ __forceinline__ void gr_emit(const VT (&v)[GR_RB], int64_t g, const G
 }
 
 // Emission of one slice (k_slices.hip.h) by TWO waves of a workgroup straight from an LDS image:
-// lane = column, col[q * stride] = its entry of row q of the tile (q < SL_SUB = 128). Both waves
+// lane = column, col[q * stride] = its entry of row q of the tile (q < SL_SUB = 128), (mlo, mhi) =
+// the bit mask of its nonzero rows (set with LDS atomics while the image was filled: sweeping the
+// 128 rows of every column for them cost more than the writing). Both waves
 // know where every step starts (the lanes' lengths: ALU only); wave `half` writes the steps of
 // its parity. `s` = slice id cg * nchunks + k, or -1 (nothing to emit: both waves, uniformly).
 // Space is claimed with one atomic per slice on one of the arena cursors; a slice that does not fit
 // only records its size and maxq (the host grows the arena and repeats the fill).
 // Contains ONE __syncthreads (every wave of the workgroup must call it). `base_s`: LDS, one
 // unsigned long long per slice of the workgroup, this slice's at index `sl`.
-__device__ __forceinline__ void slice_emit_lds(const float* col, int stride, int64_t s, int sl,
-                                               int half, const SliceOut& O,
-                                               unsigned long long* base_s) {
+__device__ __forceinline__ void slice_emit_lds(const float* col, int stride, uint64_t mlo,
+                                               uint64_t mhi, int64_t s, int sl, int half,
+                                               const SliceOut& O, unsigned long long* base_s,
+                                               long long* tstamp) {
   static_assert(SL_SUB == 128, "a slice is as tall as a tile of k_affinity_sym");
   constexpr int QB = 16;
   const int lane = threadIdx.x & 63;
-  uint64_t mlo = 0, mhi = 0;
-#pragma unroll 16
-  for (int q = 0; q < 64; ++q) mlo |= static_cast<uint64_t>(col[q * stride] != 0.f ? 1u : 0u) << q;
-#pragma unroll 16
-  for (int q = 0; q < 64; ++q) mhi |= static_cast<uint64_t>(col[(q + 64) * stride] != 0.f ? 1u : 0u) << q;
   const int n = __popcll(mlo) + __popcll(mhi);
   const int tot = (n + 3) >> 2;
   const int maxq = sl_wave_max(tot);
   const uint32_t bytes = 16 + 64 + sl_so_bytes(maxq) + sl_steps_bytes(tot, maxq, QB);
+  if (tstamp) tstamp[0] = wall_clock64() + (bytes == 1 ? 1 : 0);
   if (half == 0 && s >= 0) {
     const int nquads = sl_wave_sum(tot), entries = sl_wave_sum(n);
     if (lane == 0) {
@@ -163,6 +164,7 @@ __device__ __forceinline__ void slice_emit_lds(const float* col, int stride, int
     }
   }
   __syncthreads();
+  if (tstamp) tstamp[1] = wall_clock64();
   if (s < 0) return;
   const unsigned long long base = base_s[sl];
   if (base == ~0ull) return;

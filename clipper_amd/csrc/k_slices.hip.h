@@ -344,7 +344,10 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
 #pragma unroll
     for (int v = 0; v < NS; ++v) {
       const int slot = (v == NS - 1) ? NSLOT - 1 : v;
-      part[(static_cast<int64_t>(J.slot) * NSLOT + slot) * ld + c] = acc[v];
+      // write-through (sc1): the partial sums leave the XCD's L2 while the launch still runs,
+      // instead of as ~14 MB of dirty lines the kernel boundary has to write back before the tail
+      __hip_atomic_store(&part[(static_cast<int64_t>(J.slot) * NSLOT + slot) * ld + c], acc[v],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -366,7 +369,10 @@ __device__ __forceinline__ void slices_by_plan(const SliceView& M, const SliceJo
 }
 
 constexpr int SL_NW = 4;  // waves (= column groups) per workgroup
-constexpr int SL_D = 4;   // steps in flight per lane
+#ifndef CLIPPER_SL_D
+#define CLIPPER_SL_D 4
+#endif
+constexpr int SL_D = CLIPPER_SL_D;   // steps in flight per lane
 #ifndef CLIPPER_SL_OCC
 #define CLIPPER_SL_OCC 5
 #endif
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   const long long c1 = A.stamps ? wall_clock64() : 0;
   slices_by_plan<VT, H, V, SL_NW, SL_D>(M, J, A, plan, lds);
   flush_state(A, &stash);
-  if (A.stamps && threadIdx.x == 0 && blockIdx.x < 2048) {
+  if (A.stamps && threadIdx.x == 0 && blockIdx.x < 1536) {
     A.stamps[blockIdx.x * 4 + 0] = c0;
     A.stamps[blockIdx.x * 4 + 1] = c1;
     A.stamps[blockIdx.x * 4 + 2] = wall_clock64();

@@ -910,8 +910,8 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   const double tot = block_reduce_pick<NRED, NTW>(r, red);
   double* out = A.scal + static_cast<int64_t>(blockIdx.x) * Q;
   if (A.stamps && threadIdx.x == 0) {
-    const int w = 2048 + static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x);
-    if (w < 4096) {
+    const int w = 1536 + static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x);
+    if (w < 2048) {
       A.stamps[w * 4 + 0] = c0;
       A.stamps[w * 4 + 1] = c1;
       A.stamps[w * 4 + 2] = wall_clock64();
