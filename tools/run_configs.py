@@ -76,7 +76,9 @@ def run(name, cfg, reps, storage, with_cpu):
         gemv.append(g.timings().gemv_avg_us)
     tm = g.timings()
     row = dict(config=name, kind=cfg["kind"], m=m, rho=rho,
-               storage={abi.STORE_F32: "f32", abi.STORE_F64: "f64", abi.STORE_F32_CSC: "csc"}[storage],
+               storage={abi.STORE_F32: "f32", abi.STORE_F64: "f64", abi.STORE_F32_CSC: "csc",
+                        abi.STORE_F64_CSC: "csc64"}[storage],
+               pass_bytes=tm.gemv_bytes, useful_bytes=tm.gemv_useful_bytes, window=g.window,
                gpu_affinity_ms=round(float(np.median(ta)), 4), gpu_solve_ms=round(float(np.median(ts)), 4),
                passes=int(sol.n_passes), gemv_us=round(float(np.median(gemv)), 2),
                gemv_GBps=round(tm.gemv_bytes / max(float(np.median(gemv)), 1e-9) * 1e-3, 1),
@@ -111,7 +113,8 @@ def main():
     ap.add_argument("--storage", default="f32")
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
-    storage = {"f32": abi.STORE_F32, "f64": abi.STORE_F64, "csc": abi.STORE_F32_CSC}[a.storage]
+    storage = {"f32": abi.STORE_F32, "f64": abi.STORE_F64, "csc": abi.STORE_F32_CSC,
+               "csc64": abi.STORE_F64_CSC}[a.storage]
     for name in a.configs.split(","):
         run(name, CONFIGS[name], a.reps, storage, not a.no_cpu)
 
