@@ -69,6 +69,9 @@ def build_pymodule(force: bool = False) -> str | None:
         os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs]
     if force or not _newer(out, srcs + [HIP_LIB]):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp",
+              # the module's type casters are written for the stand-in containers of
+              # include/clipper/types.h: choose that type family explicitly
+              "-DCLIPPER_NO_EIGEN",
               "-I", os.path.join(ROOT, "include"), "-I", pybind11.get_include(),
               "-I", sysconfig.get_paths()["include"],
               src, os.path.join(host, "clipper.cpp"),

@@ -7,12 +7,14 @@
  *
  * Differences a maintainer should know (all additive):
  *   - the built-in invariants expose params() (the GPU dispatcher needs them);
- *   - setDevice()/setStorage() choose the GPU and the storage type of M (fp32 compressed | fp32 dense | fp64 dense);
+ *   - setDevice()/setStorage() choose the GPU and the storage of M (slices with fp32 or fp64
+ *     values — the default is fp32 —, or dense fp32 / fp64);
  *   - failures of the GPU path throw std::runtime_error (the reference has no error path;
  *     there is deliberately NO silent CPU fallback for the built-in invariants);
- *   - solveAsMaximumClique / solveAsMSRCSDR / Rounding::DSD are outside this build and
- *     report so, exactly like a reference build without PMC / SCS (maxclique.cpp:141-145,
- *     sdp.cpp:298-302).
+ *   - Rounding::DSD (clipper.cpp:294-300) is supported: the exact densest subgraph of the
+ *     sub-matrix induced by nnz(u), gathered from the device (include/clipper/dsd.h);
+ *   - solveAsMaximumClique / solveAsMSRCSDR are outside this build and report so, exactly
+ *     like a reference build without PMC / SCS (maxclique.cpp:141-145, sdp.cpp:298-302).
  */
 #pragma once
 

@@ -16,22 +16,25 @@
  *   - There is NO CPU fallback: without a usable HIP device every call fails loudly.
  *
  * Storage of the affinity matrix on device
- *   M_off (strict off-diagonal, symmetric, both triangles) is kept dense in HBM as
- *   column slices: a context that owns global columns [c0, c0+W) stores S[j][c] =
- *   M(j, c0+c) for all m rows j, row pitch W (multiple of 64 elements, zero padded).
- *   Element type is fp32 (CLIPPER_HIP_STORE_F32: 4*m^2 bytes, what BASELINE.json's
- *   "~360 GB fp32 M at m=300k" implies) or fp64 (CLIPPER_HIP_STORE_F64). All vectors,
- *   accumulators and scalars of the solver are fp64 in either mode.
- *   On the scorePairwiseConsistency path C == pattern(M) (clipper.cpp:63-64) and is not
- *   stored: the mat-vec kernel derives C_off*x from the same pass over M. setMatrixData
- *   with any other C stores a second dense matrix.
- *   CLIPPER_HIP_STORE_F32_CSC keeps M column-compressed (nonzeros only: fp32 value + row
- *   byte, blocked and padded for 64-wide waves); the SOLVER's passes read that instead of a
- *   dense store — the same fp32 values, the same fp64 products, only the zeros are skipped. It applies whenever C == pattern(M); otherwise the
- *   context behaves as CLIPPER_HIP_STORE_F32. One unsharded device holds M ONLY in this form
- *   (a dense store is materialised when a getter / the matvec API needs one); column shards
- *   keep their dense slice and add a compressed copy of it. gemv_bytes then reports the bytes
- *   of the compressed copy one pass streams.
+ *   CLIPPER_HIP_STORE_F32_CSC (the default of every front end) and CLIPPER_HIP_STORE_F64_CSC
+ *   hold ONLY the stored (nonzero) entries of M_off — both triangles, as the reference's
+ *   Eigen::SparseMatrix does (include/clipper/types.h:15) — as per-column lists of (value,
+ *   row byte) cut into slices of 64 columns x 128 rows, padded to groups of 4 entries and to
+ *   nothing else (5.7 bytes per stored entry with fp32 values, 9.6 with fp64).
+ *   The solver's passes stream the slices; a dense store is materialised only while a getter,
+ *   the exact-DSD gather or an explicit C needs one and is dropped again. Column shards hold
+ *   the slices of their own columns. The values, the fp64 products and every decision are
+ *   those of the dense storage of the same value type; only the zeros are skipped. These
+ *   storages apply whenever C == pattern(M) (always on the scorePairwiseConsistency path,
+ *   clipper.cpp:63-64); setMatrixData with any other C falls back to the dense store of the
+ *   same value type. gemv_bytes reports the bytes the slices hold = what one pass streams.
+ *   CLIPPER_HIP_STORE_F32 / _F64 keep M_off dense in HBM as column slices: a context that
+ *   owns global columns [c0, c0+W) stores S[j][c] = M(j, c0+c) for all m rows j, row pitch W
+ *   (multiple of 64 elements, zero padded): 4*m^2 (8*m^2) bytes. On the
+ *   scorePairwiseConsistency path C is not stored: the mat-vec kernel derives C_off*x from
+ *   the same pass over M. setMatrixData with any other C stores a second dense matrix.
+ *   All vectors, accumulators, scalars and branch operands of the solver are fp64 in every
+ *   mode; fp32 is a STORAGE type of M's entries only.
  */
 #ifndef CLIPPER_HIP_H
 #define CLIPPER_HIP_H
