@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_get_matrix", "clipper_hip_solve", "clipper_hip_get_nodes",
     "clipper_hip_get_selected_associations", "clipper_hip_matvec", "clipper_hip_set_profiling",
     "clipper_hip_set_window", "clipper_hip_window", "clipper_hip_densest_subgraph",
+    "clipper_hip_set_resident", "clipper_hip_last_solver",
     "clipper_hip_storage_in_use", "clipper_hip_knn", "clipper_hip_distance_based_correspondences",
     "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
@@ -153,6 +154,8 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_densest_subgraph.argtypes = [vp, ip, C.c_int32, ip, C.c_int32]
     L.clipper_hip_set_window.argtypes = [vp, C.c_int]
     L.clipper_hip_window.argtypes = [vp]
+    L.clipper_hip_set_resident.argtypes = [vp, C.c_int]
+    L.clipper_hip_last_solver.argtypes = [vp]
     L.clipper_hip_storage_in_use.argtypes = [vp]
     L.clipper_hip_knn.argtypes = [C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_int, C.c_int, ip, dp]
     L.clipper_hip_distance_based_correspondences.argtypes = [
@@ -400,6 +403,15 @@ class HipClipper:
     @property
     def window(self) -> int:
         return int(self.L.clipper_hip_window(self.h))
+
+    def set_resident(self, mode: int):
+        """0 = the resident (one-launch) solver where the slices fit on chip, 1 = never."""
+        self._check(self.L.clipper_hip_set_resident(self.h, int(mode)))
+
+    @property
+    def last_solver(self) -> int:
+        """What the last solve ran on: 0 = streaming launches, 1 = resident."""
+        return int(self.L.clipper_hip_last_solver(self.h))
 
     @property
     def storage_in_use(self) -> int:

@@ -45,6 +45,7 @@ using namespace clipper_hip;
 #include "host_state.hpp"
 #include "host_solver.hpp"
 #include "host_matrix.hpp"
+#include "host_resident.hpp"
 #include "host_registration.hpp"
 
 // ============================================================================================
@@ -164,6 +165,7 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   if (h->csc_hLq) hipHostFree(h->csc_hLq);
   if (h->csc_hctl) hipHostFree(h->csc_hctl);
   if (h->csc_htotal) hipHostFree(h->csc_htotal);
+  resident_free(h);
   if (h->csc_hwork) hipHostFree(h->csc_hwork);
   delete h;
 }
@@ -747,6 +749,14 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->u_pinned_dev), h->u_pinned, 0));
     h->u_pinned_cap = vbytes;
   }
+  Shard& s0 = h->sh[0];
+  SolveShared fin;
+  std::memset(&fin, 0, sizeof(fin));
+  int rc = 0;
+  bool resident = false;
+  if ((rc = resident_solve(h, prm, P->rescale_u0 != 0, fin, resident))) return rc;
+  h->last_solver = resident ? 1 : 0;
+  if (!resident) {
   // prologue, one launch per shard: pending vector = u0 (T pair 0, nrm = 1), state, counters
   h->par = 0;
   std::memset(h->mirror, 0, sizeof(HostMirror));
@@ -757,11 +767,6 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     hipLaunchKernelGGL(k_init, dim3(static_cast<unsigned>(ceil_div(m, 256))), dim3(256), 0,
                        s.stream, a, init, s.st, s.X[0]);
   }
-  int rc = 0;
-
-  Shard& s0 = h->sh[0];
-  SolveShared fin;
-  std::memset(&fin, 0, sizeof(fin));
   if (!h->multiproc) {
     // One process: the deciding workgroup reports progress into pinned host memory; the host
     // keeps RUN_AHEAD iterations queued ahead of what the device has retired and stops
@@ -819,6 +824,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     HIPCHK(hipSetDevice(s0.device));
     HIPCHK(hipMemcpy(&fin, s0.shared, sizeof(fin), hipMemcpyDeviceToHost));
   }
+
+  }  // !resident
 
   // final u
   HIPCHK(hipSetDevice(s0.device));
@@ -1070,6 +1077,15 @@ int clipper_hip_set_window(clipper_hip_t* h, int window) {
 }
 
 int clipper_hip_window(const clipper_hip_t* h) { return h ? h->V : 0; }
+
+int clipper_hip_set_resident(clipper_hip_t* h, int mode) {
+  if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (mode != 0 && mode != 1) return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic) or 1 (never)");
+  h->resident_mode = mode;
+  return 0;
+}
+
+int clipper_hip_last_solver(const clipper_hip_t* h) { return h ? h->last_solver : -1; }
 
 int clipper_hip_storage_in_use(const clipper_hip_t* h) {
   if (!h) return -1;

@@ -144,6 +144,7 @@ int emit_enqueue(Ctx* h, Shard& s) {
 }
 
 int slices_plan(Ctx* h, Shard& s);
+int resident_plan(Ctx* h, Shard& s);
 
 int emit_check(Ctx* h, Shard& s, bool& again) {
   again = false;
@@ -361,7 +362,7 @@ int slices_plan(Ctx* h, Shard& s) {
   }
   s.s_nwork = static_cast<int>(nw);
   s.s_nslots = nslots;
-  return 0;
+  return resident_plan(h, s);  // small problems: the whole solve as one launch
 }
 
 // After the stream was synchronised: did everything fit? If not (always the case for the first

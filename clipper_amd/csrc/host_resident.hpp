@@ -1,0 +1,282 @@
+// host_resident.hpp — planning and launch of the resident solver (k_resident.hip.h)
+// Part of clipper_hip.hip (one translation unit; included there, in order).
+#pragma once
+
+namespace {
+
+constexpr uint32_t RS_LDS_MAX = 159u * 1024u;  // dynamic LDS of a workgroup: the 160 KB of a gfx950 CU less the kernel's few static words
+constexpr int RS_MAX_UNITS = 192;               // workgroups of 512 threads, one per CU, with a margin
+
+bool rs_debug() {
+  static const bool on = std::getenv("CLIPPER_HIP_RESIDENT_DEBUG") != nullptr;
+  return on;
+}
+
+void resident_free(Ctx* h) {
+  Resident& r = h->res;
+  if (r.host_plan) hipHostFree(r.host_plan);
+  if (r.xb) hipFree(r.xb);
+  if (r.flags) hipFree(r.flags);
+  const int vf = r.V_forced;
+  r = Resident{};
+  r.V_forced = vf;
+}
+
+// upper bound of the bytes of a slice from its directory word (maxq | entries << 8)
+uint32_t rs_slice_bound(uint32_t lq, uint32_t quad_bytes) {
+  const uint32_t maxq = lq & 255u, entries = lq >> 8;
+  if (maxq == 0) return 16 + 64 + sl_so_bytes(0);
+  const uint32_t nquads = std::min<uint32_t>((entries + 3u * 64u) / 4u, 64u * maxq);
+  return 16 + 64 + sl_so_bytes(static_cast<int>(maxq)) + nquads * (quad_bytes + 4u) + maxq * 12u;
+}
+
+// Decide whether the current slices fit the resident solver and lay out its units. Called when a
+// build's directory (csc_hLq) is on the host. Leaves r.ready = false when the problem does not fit.
+int resident_plan(Ctx* h, Shard& s) {
+  Resident& r = h->res;
+  r.ready = false;
+  r.failed = false;
+  if (h->resident_mode == 1 || h->V_forced != 0 || h->world != 1 || h->multiproc || h->explicitC) return 0;
+  const int64_t m = h->m, mp = h->mp;
+  if (m > RS_MAXE * RS_NT || mp > RS_MAXE * RS_NT) return 0;  // above: the streaming launches win
+  const int E = (mp <= RS_NT) ? 1 : (mp <= 2 * RS_NT ? 2 : 4);
+  const int ncg = s.s_ncg, nchunks = s.s_nchunks;
+  const uint32_t* L = h->csc_hLq;
+  const uint32_t QBY = 4u * static_cast<uint32_t>(h->esize());
+  std::vector<uint32_t> ub(static_cast<size_t>(ncg) * nchunks);
+  uint64_t total = 0;
+  for (size_t i = 0; i < ub.size(); ++i) {
+    ub[i] = rs_slice_bound(L[i], QBY);
+    total += ub[i];
+  }
+  int vmax = 1;  // at these sizes the line search rarely rejects: a window only adds arithmetic
+  if (r.V_forced) vmax = r.V_forced;
+  auto pow2 = [](int x) {
+    int p = 1;
+    while (p < x) p *= 2;
+    return p;
+  };
+  std::vector<ResidentUnit> units;
+  std::vector<uint8_t> nsl(static_cast<size_t>(ncg), 0);
+  int V = 0;
+  uint32_t lds_slices = 0, lds_total = 0;
+  for (int v = vmax; v >= 1; v = (r.V_forced ? 0 : v / 2)) {
+    units.clear();
+    const uint32_t fixed = rs_xt_bytes(v, mp) + RS_RED_BYTES + RS_TAB_BYTES;
+    // everything in ONE workgroup: no exchange at all
+    if (ncg <= RS_NWV) {
+      const uint32_t fixed1 = fixed + rs_y_bytes(v, mp, true);
+      const int wpg = RS_NWV / pow2(ncg);
+      if (fixed1 + RS_SLICE_PAD < RS_LDS_MAX && total <= RS_LDS_MAX - fixed1 - RS_SLICE_PAD &&
+          ceil_div(nchunks, wpg) <= RS_SMAX) {
+        units.push_back(ResidentUnit{0, ncg, 0, nchunks, 0, wpg, 0, 0});
+        std::fill(nsl.begin(), nsl.end(), static_cast<uint8_t>(1));
+        V = v;
+        lds_slices = RS_LDS_MAX - fixed1;
+        lds_total = RS_LDS_MAX;
+        break;
+      }
+    }
+    if (fixed + RS_SLICE_PAD + 4096 >= RS_LDS_MAX) continue;
+    const uint32_t cap = RS_LDS_MAX - fixed - RS_SLICE_PAD;
+    bool ok = true;
+    for (int cg = 0; cg < ncg && ok; ++cg) {
+      int slot = 0, k0 = 0;
+      uint32_t acc = 0;
+      for (int k = 0; k < nchunks; ++k) {
+        const uint32_t b = ub[static_cast<size_t>(cg) * nchunks + k];
+        if (b > cap) {
+          ok = false;
+          break;
+        }
+        if (acc + b > cap || k - k0 >= RS_NWV * RS_SMAX) {
+          units.push_back(ResidentUnit{cg, 1, k0, k, slot++, RS_NWV, 0, 0});
+          k0 = k;
+          acc = 0;
+        }
+        acc += b;
+      }
+      units.push_back(ResidentUnit{cg, 1, k0, nchunks, slot++, RS_NWV, 0, 0});
+      nsl[static_cast<size_t>(cg)] = static_cast<uint8_t>(slot);
+    }
+    if (ok && static_cast<int>(units.size()) <= std::min(RS_MAX_UNITS, h->cus - 8)) {
+      V = v;
+      lds_slices = RS_LDS_MAX - fixed;
+      lds_total = RS_LDS_MAX;
+      break;
+    }
+  }
+  if (rs_debug())
+    std::fprintf(stderr, "[resident] plan m=%lld ncg=%d nchunks=%d total_ub=%llu -> V=%d E=%d units=%zu\n",
+                 static_cast<long long>(m), ncg, nchunks, static_cast<unsigned long long>(total), V, E,
+                 units.size());
+  if (V == 0) return 0;
+  int maxslots = 1;
+  for (uint8_t x : nsl) maxslots = std::max<int>(maxslots, x);
+
+  HIPCHK(hipSetDevice(s.device));
+  // plan in mapped pinned memory: the kernel reads it through the bus once, nothing is copied
+  const size_t plan_bytes = units.size() * sizeof(ResidentUnit) + static_cast<size_t>(ncg) + 64;
+  if (plan_bytes > r.host_plan_cap) {
+    if (r.host_plan) hipHostFree(r.host_plan);
+    r.host_plan = nullptr;
+    r.host_plan_cap = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r.host_plan), plan_bytes + 4096,
+                         hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.host_plan_dev), r.host_plan, 0));
+    r.host_plan_cap = plan_bytes + 4096;
+  }
+  std::memcpy(r.host_plan, units.data(), units.size() * sizeof(ResidentUnit));
+  std::memcpy(r.host_plan + units.size() * sizeof(ResidentUnit), nsl.data(), static_cast<size_t>(ncg));
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  const size_t xb_bytes = 2ull * maxslots * (V + 1) * static_cast<size_t>(mp) * sizeof(double);
+  if (xb_bytes > r.xb_cap) {
+    if (r.xb) HIPCHK(hipFree(r.xb));
+    r.xb = nullptr;
+    HIPCHK(hipMalloc(&r.xb, xb_bytes));
+    r.xb_cap = xb_bytes;
+  }
+  if (units.size() + 1 > r.flags_cap) {
+    if (r.flags) HIPCHK(hipFree(r.flags));
+    r.flags = nullptr;
+    r.flags_cap = units.size() + 64;
+    HIPCHK(hipMalloc(&r.flags, (r.flags_cap + 1) * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(r.flags, 0, (r.flags_cap + 1) * sizeof(unsigned long long), s.stream));
+    r.epoch = 0;
+  }
+  r.V = V;
+  r.E = E;
+  r.nunits = static_cast<int>(units.size());
+  r.maxslots = maxslots;
+  r.lds_slices = lds_slices;
+  r.lds_total = lds_total;
+  r.ready = true;
+  return 0;
+}
+
+template <typename VT, int V, int E>
+int resident_launch_t(Ctx* h, Shard& s, const ResidentArgs& a) {
+  Resident& r = h->res;
+  auto kern = k_solve_resident<VT, V, E>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(RS_LDS_MAX));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      if (rs_debug()) {
+        hipFuncAttributes fa{};
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+        int optin = 0, perblk = 0;
+        (void)hipDeviceGetAttribute(&perblk, hipDeviceAttributeMaxSharedMemoryPerBlock, s.device);
+        (void)hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, s.device);
+        std::fprintf(stderr, "[resident] hipFuncSetAttribute: %s (static LDS %zu, max dynamic %d, device per block %d, optin %d)\n",
+                     hipGetErrorString(e), fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes, perblk, optin);
+      }
+      return 1;  // this device does not give a workgroup 160 KB of LDS: not an error, no resident solver
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(r.nunits)), dim3(RS_NT), r.lds_total, s.stream, a);
+  return 0;
+}
+
+template <typename VT>
+int resident_launch_v(Ctx* h, Shard& s, const ResidentArgs& a) {
+  const Resident& r = h->res;
+  switch (r.V * 10 + r.E) {
+    case 21: return resident_launch_t<VT, 2, 1>(h, s, a);
+    case 22: return resident_launch_t<VT, 2, 2>(h, s, a);
+    case 24: return resident_launch_t<VT, 2, 4>(h, s, a);
+    case 11: return resident_launch_t<VT, 1, 1>(h, s, a);
+    case 12: return resident_launch_t<VT, 1, 2>(h, s, a);
+    case 14: return resident_launch_t<VT, 1, 4>(h, s, a);
+    default: return 1;
+  }
+}
+
+// Runs the whole solve as one launch. ran = false: the resident solver did not apply or gave up
+// (nothing of the solver state was touched: the caller runs the streaming solver).
+int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& fin, bool& ran) {
+  ran = false;
+  Resident& r = h->res;
+  if (rs_debug())
+    std::fprintf(stderr, "[resident] solve: ready=%d failed=%d csc_valid=%d mode=%d Vf=%d\n", r.ready, r.failed,
+                 h->csc_valid, h->resident_mode, h->V_forced);
+  if (!r.ready || r.failed || !h->csc_valid || h->resident_mode == 1 || h->V_forced != 0) return 0;
+  Shard& s = h->sh[0];
+  HIPCHK(hipSetDevice(s.device));
+  ResidentArgs a;
+  a.M = slice_view(h, s);
+  a.units = reinterpret_cast<const ResidentUnit*>(r.host_plan_dev);
+  a.nunits = r.nunits;
+  a.nslots_of_cg = r.host_plan_dev + static_cast<size_t>(r.nunits) * sizeof(ResidentUnit);
+  a.maxslots = r.maxslots;
+  a.m = h->m;
+  a.mp = h->mp;
+  a.prm = prm;
+  a.rescale = rescale ? 1 : 0;
+  a.u0 = s.u0;
+  a.xb = r.xb;
+  a.flags = r.flags;
+  a.epoch0 = r.epoch;
+  a.err = reinterpret_cast<uint32_t*>(r.flags + r.flags_cap);
+  a.lds_slices = r.lds_slices;
+  a.u_dev = s.pt;  // point slot (0, 0), array u
+  a.host_u = h->u_pinned_dev;
+  a.host = h->mirror_dev;
+  a.shared = s.shared;
+  a.stamps = h->stamps_dev;
+  a.timeout_ticks = 50000000ll;  // 0.5 s on the 100 MHz wall clock
+  std::memset(h->mirror, 0, sizeof(HostMirror));
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  int lr = 1;
+  dispatch_vt(h, [&](auto tag) {
+    using VT = decltype(tag);
+    lr = resident_launch_v<VT>(h, s, a);
+  });
+  if (lr != 0) {
+    if (rs_debug()) std::fprintf(stderr, "[resident] launch refused (V=%d E=%d)\n", r.V, r.E);
+    r.failed = true;
+    return 0;
+  }
+  HIPCHK(hipGetLastError());
+  volatile HostMirror* hm = h->mirror;
+  uint64_t spins = 0;
+  bool finished = true;
+  while (!hm->done) {
+    if ((++spins & 0x3fff) == 0) {
+      hipError_t q = hipStreamQuery(s.stream);
+      if (q != hipSuccess && q != hipErrorNotReady)
+        return fail(CLIPPER_HIP_E_HIP, "resident solver failed: %s", hipGetErrorString(q));
+      if (q == hipSuccess && !hm->done) {  // the launch is over and did not finish the solve
+        finished = false;
+        break;
+      }
+    }
+  }
+  if (!finished) {
+    uint32_t err = 0;
+    HIPCHK(hipMemcpy(&err, a.err, sizeof(err), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(a.err, 0, sizeof(uint32_t)));
+    r.failed = true;  // until the next build
+    r.last_error = static_cast<int>(err);
+    if (rs_debug()) std::fprintf(stderr, "[resident] gave up: error %u\n", err);
+    r.epoch += 1ull << 32;
+    return 0;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  fin.F = hm->F;
+  fin.d = hm->d;
+  fin.n_passes = hm->n_passes;
+  fin.n_trials = hm->n_trials;
+  fin.ifinal = hm->ifinal;
+  fin.ubp = 0;
+  fin.ubv = 0;
+  r.epoch += static_cast<unsigned long long>(hm->iters) + 8ull;
+  ran = true;
+  return 0;
+}
+
+}  // namespace

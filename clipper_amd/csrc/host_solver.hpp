@@ -560,6 +560,13 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     const int v = std::atoi(w);
     if (v == 1 || v == 4 || v == 6 || v == 8) h->V_forced = v;
   }
+  // CLIPPER_HIP_RESIDENT = 0: never the resident solver; CLIPPER_HIP_RESIDENT_V = 1 | 2: its window
+  if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT"))
+    if (std::atoi(e) == 0) h->resident_mode = 1;
+  if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT_V")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2) h->res.V_forced = v;
+  }
   return h;
 }
 

@@ -140,6 +140,24 @@ struct Shard {
   uint64_t s_entries = 0; // stored entries (both triangles)
 };
 
+// the resident solver (k_resident.hip.h): plan of the current slices and its buffers
+struct Resident {
+  bool ready = false;    // the current slices fit: `plan` is valid
+  bool failed = false;   // a launch gave up on this matrix (the streaming solver took over)
+  int last_error = 0;
+  int V = 0, E = 0, nunits = 0, maxslots = 0;
+  uint32_t lds_slices = 0, lds_total = 0;
+  uint8_t* host_plan = nullptr;      // pinned + mapped: units, then slots per column group
+  uint8_t* host_plan_dev = nullptr;
+  size_t host_plan_cap = 0;
+  double* xb = nullptr;              // exchange buffer [2][maxslots][V+1][mp]
+  size_t xb_cap = 0;
+  unsigned long long* flags = nullptr;  // [flags_cap] epochs, then the error word
+  size_t flags_cap = 0;
+  unsigned long long epoch = 0;
+  int V_forced = 0;                  // CLIPPER_HIP_RESIDENT_V
+};
+
 }  // namespace
 
 struct clipper_hip_ctx {
@@ -197,6 +215,9 @@ struct clipper_hip_ctx {
   int V_forced = 0;        // CLIPPER_HIP_WINDOW
   int64_t mp = 0;          // rows of a candidate table
   int par = 0;             // which table set the next launch reads
+  Resident res;
+  int resident_mode = 0;   // 0 = use the resident solver where the slices fit, 1 = never
+  int last_solver = 0;     // what the last solve ran on: 0 = streaming launches, 1 = resident
 
   long long* stamps_dev = nullptr;  // CLIPPER_HIP_STAMPS=1: [4096][4], see SolveArgs::stamps
   bool profiling = false;

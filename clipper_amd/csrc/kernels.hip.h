@@ -27,7 +27,9 @@
 // Files (all in namespace clipper_hip):
 //   k_solver.hip.h    solver state, decide (the head of every pass launch), k_init, k_tail, k_scal_fold
 //   k_gemv.hip.h      the dense pass: k_gemv, k_gemv_plain, k_reduce_pass (column shards), k_reduce, k_spread
-//   k_csc.hip.h       the compressed storage: layout, emission, k_csc_build, k_csc_expand, k_gemv_csc
+//   k_slices.hip.h    the compressed storage: layout, the pass on it (k_gemv_slices), packers, k_slice_expand
+//   k_csc.hip.h       producers of the slices: emission from the fill kernel's LDS image, groups
+//   k_resident.hip.h  the resident solver: findDenseClique as one launch for problems that fit on chip
 //   k_affinity.hip.h  k_gather_points, k_affinity_* (plain, compacting strips, symmetric tiles + emission)
 //   k_matrix.hip.h    k_from_dense_upper, k_from_csc, k_gather_sub
 //   k_knn.hip.h       brute-force k-nearest neighbours (putative associations)
@@ -36,6 +38,7 @@
 #include "k_solver.hip.h"
 #include "k_gemv.hip.h"
 #include "k_csc.hip.h"
+#include "k_resident.hip.h"
 #include "k_affinity.hip.h"
 #include "k_matrix.hip.h"
 #include "k_knn.hip.h"

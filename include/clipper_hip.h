@@ -230,6 +230,15 @@ int64_t clipper_hip_distance_based_correspondences(int device, const double* P0,
 int clipper_hip_set_window(clipper_hip_t* h, int window);
 int clipper_hip_window(const clipper_hip_t* h);
 
+/* The resident solver: when the slices of the current matrix fit the LDS of the workgroups that
+ * share them (m up to a few thousand, one device, C == pattern(M), automatic window), the whole of
+ * findDenseClique (clipper.cpp:172-323) runs as ONE launch that keeps M on chip; otherwise — and
+ * always with mode 1, or CLIPPER_HIP_RESIDENT=0 in the environment — as the streaming launches
+ * (decision + pass, tail) per iteration. Same trial sequence and result either way.
+ * clipper_hip_last_solver: what the last solve ran on, 0 = streaming launches, 1 = resident. */
+int clipper_hip_set_resident(clipper_hip_t* h, int mode);
+int clipper_hip_last_solver(const clipper_hip_t* h);
+
 /* How the current matrix is stored: CLIPPER_HIP_STORE_F32_CSC only while the compressed copy is
  * in use (one shard, C == pattern(M)); a context created with it otherwise reports _F32. */
 int clipper_hip_storage_in_use(const clipper_hip_t* h);

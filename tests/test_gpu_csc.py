@@ -235,7 +235,7 @@ def test_f64_slices_equal_the_dense_f64_store(m, rho, seed):
     sd, sc = gd.solve(p.u0), gc.solve(p.u0)
     assert sd.nodes.tolist() == sc.nodes.tolist() and sd.ifinal == sc.ifinal
     assert sd.n_trials == sc.n_trials
-    assert abs(sd.score - sc.score) <= 1e-12 * max(1.0, abs(sd.score))
+    assert abs(sd.score - sc.score) <= 1e-10 * max(1.0, abs(sd.score))   # the order of the additions differs (resident solver)
     r = ref.RefClipper()
     r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
     sr = r.solve(p.u0)

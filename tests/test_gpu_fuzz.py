@@ -1,6 +1,7 @@
 """Differential fuzz of the GPU path against the oracle, in the suite: 60 random small problems
 (fixed seed) — sizes on and off the slice edges, outlier ratios, invariant and solver parameters,
-window sizes — each in ALL four storages.
+window sizes — each in ALL four storages, and with the automatic window the compressed storages
+both ways: resident (one launch) and streaming launches.
 
 What is asserted, without waivers:
   * every storage: the GPU result equals the oracle's on the matrix that storage holds (the
@@ -48,29 +49,35 @@ def _cases():
             kw["maxoliters"] = min(kw["maxoliters"], 10)
         inv = dict(sigma=float(rng.choice([0.01, 0.015, 0.05])), epsilon=float(rng.choice([0.02, 0.05, 0.2])),
                    mindist=float(rng.choice([0.0, 0.0, 0.05])))
-        V = int(rng.choice([0, 1, 4, 6, 8]))
+        V = int(rng.choice([0, 0, 1, 4, 6, 8]))   # 0 = automatic (the compressed storages then solve resident)
         yield case, m, rho, kw, inv, V, int(rng.integers(1 << 30))
 
 
 def test_fuzz_against_the_oracle_on_the_stored_matrix():
     lines, failures = [], []
-    differs_from_f64_oracle = {name: 0 for name in STORAGES.values()}
+    differs_from_f64_oracle = {}
     for case, m, rho, kw, inv, V, pseed in _cases():
         p = synth.make_euclidean_problem(m, rho, seed=pseed)
         r = ref.RefClipper(ref.Params(**kw))
         r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **inv)
         sr = r.solve(p.u0)
-        for storage, name in STORAGES.items():
+        runs = [(st, nm, 0) for st, nm in STORAGES.items()]
+        if V == 0:  # the resident solver took the compressed storages: the streaming launches too
+            runs += [(st, nm + "/streaming", 1) for st, nm in STORAGES.items() if nm.endswith("csc")]
+        for storage, name, mode in runs:
             g = abi.HipClipper(abi.Params(**kw), storage=storage)
             g.set_window(V)
+            g.set_resident(mode)
             g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **inv)
             sg = g.solve(p.u0)
+            if name.endswith("csc") and V == 0:
+                assert g.last_solver == 1, "the resident solver was expected to run"
             rs = ref.RefClipper(ref.Params(**kw))          # the oracle on what this storage holds
             rs.set_matrix_data(g.get_affinity_matrix(), g.get_constraint_matrix())
             ss = rs.solve(p.u0)
             on_stored, on_f64 = _same(sg, ss), _same(sg, sr)
-            differs_from_f64_oracle[name] += 0 if on_f64 else 1
-            lines.append(f"case {case:2d} m={m:4d} rho={rho:.2f} V={V} {name:8s} nodes={len(sg.nodes):4d} "
+            differs_from_f64_oracle[name] = differs_from_f64_oracle.get(name, 0) + (0 if on_f64 else 1)
+            lines.append(f"case {case:2d} m={m:4d} rho={rho:.2f} V={V} {name:17s} solver={g.last_solver} nodes={len(sg.nodes):4d} "
                          f"score={sg.score:.9f} ifinal={sg.ifinal} trials={sg.n_trials} "
                          f"== oracle(stored M): {on_stored}  == oracle(fp64 M): {on_f64}  {kw} {inv}")
             if not on_stored or (name.startswith("f64") and not on_f64):

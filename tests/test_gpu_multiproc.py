@@ -62,15 +62,27 @@ def _worker(rank, world, port, m, storage, out_dir):
 
 @pytest.mark.parametrize("m,storage_name", [(1500, "F32_CSC"), (6500, "F32_CSC"), (6500, "F32"), (1500, "F64_CSC")])
 def test_two_processes_share_one_gpu(tmp_path, m, storage_name):
-    import torch.multiprocessing as mp
+    # stdlib multiprocessing, not torch.multiprocessing: importing torch HERE, after libclipper_hip.so
+    # has loaded the system HIP runtime, would put a second HIP runtime (torch's bundled one) into
+    # this process (runtime notes); the workers import torch first, as documented
+    import multiprocessing as mp
 
     from clipper_amd import _abi as abi
     from clipper_amd import synth
 
     storage = getattr(abi, "STORE_" + storage_name)
     world, port = 2, _free_port()
-    mp.start_processes(_worker, args=(world, port, m, storage, str(tmp_path)), nprocs=world, join=True,
-                       start_method="spawn")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, m, storage, str(tmp_path))) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(timeout=240)
+    for pr in procs:
+        if pr.is_alive():
+            pr.terminate()
+            pytest.fail("a rank did not terminate")
+        assert pr.exitcode == 0
     r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
     assert np.array_equal(r0["u"], r1["u"]) and r0["score"] == r1["score"]
     assert np.array_equal(r0["nodes"], r1["nodes"])
