@@ -80,9 +80,11 @@ def run(name, cfg, reps, storage, with_cpu):
                         abi.STORE_F64_CSC: "csc64"}[storage],
                pass_bytes=tm.gemv_bytes, useful_bytes=tm.gemv_useful_bytes, window=g.window,
                gpu_affinity_ms=round(float(np.median(ta)), 4), gpu_solve_ms=round(float(np.median(ts)), 4),
-               passes=int(sol.n_passes), gemv_us=round(float(np.median(gemv)), 2),
-               gemv_GBps=round(tm.gemv_bytes / max(float(np.median(gemv)), 1e-9) * 1e-3, 1),
-               frac_of_8TBps=round(tm.gemv_bytes / max(float(np.median(gemv)), 1e-9) / 8e6, 4),
+               passes=int(sol.n_passes), solver=["streaming", "resident"][g.last_solver],
+               # the resident solver is one launch: no per-pass timings
+               gemv_us=round(float(np.median(gemv)), 2) if np.median(gemv) > 0 else None,
+               gemv_GBps=round(tm.gemv_bytes / float(np.median(gemv)) * 1e-3, 1) if np.median(gemv) > 0 else None,
+               frac_of_8TBps=round(tm.gemv_bytes / float(np.median(gemv)) / 8e6, 4) if np.median(gemv) > 0 else None,
                score=sol.score, nodes=int(len(sol.nodes)), ifinal=int(sol.ifinal))
     prec, rec = synth.precision_recall(g.get_selected_associations(), p.Agt)
     row.update(precision=round(prec, 4), recall=round(rec, 4))
