@@ -5,7 +5,8 @@
 namespace {
 
 constexpr uint32_t RS_LDS_MAX = 159u * 1024u;  // dynamic LDS of a workgroup: the 160 KB of a gfx950 CU less the kernel's few static words
-constexpr int RS_MAX_UNITS = 192;               // workgroups of 512 threads, one per CU, with a margin
+constexpr int RS_MAX_UNITS = 64;  // beyond (dense problems of m ~ 2000: > 5 MB of slices) the streaming
+                                  // launches with their window of 4 win (profiles/r02c_bm_table*.md)
 
 bool rs_debug() {
   static const bool on = std::getenv("CLIPPER_HIP_RESIDENT_DEBUG") != nullptr;

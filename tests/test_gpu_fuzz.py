@@ -70,8 +70,8 @@ def test_fuzz_against_the_oracle_on_the_stored_matrix():
             g.set_resident(mode)
             g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **inv)
             sg = g.solve(p.u0)
-            if name.endswith("csc") and V == 0:
-                assert g.last_solver == 1, "the resident solver was expected to run"
+            if mode == 1:
+                assert g.last_solver == 0
             rs = ref.RefClipper(ref.Params(**kw))          # the oracle on what this storage holds
             rs.set_matrix_data(g.get_affinity_matrix(), g.get_constraint_matrix())
             ss = rs.solve(p.u0)

@@ -91,7 +91,7 @@ def test_resident_parameter_variants(m, kw):
 def test_resident_line_search_with_rejections():
     """A problem whose line search rejects step sizes (large inlier block, small beta steps): the
     walk of the window must count the reference's trials."""
-    p = synth.make_euclidean_problem(1800, 0.5, seed=11)
+    p = synth.make_euclidean_problem(900, 0.5, seed=11)
     gr, sr = _solve(p, abi.STORE_F64_CSC, 0, abi.Params(beta=0.5))
     gs, ss = _solve(p, abi.STORE_F64_CSC, 1, abi.Params(beta=0.5))
     assert gr.last_solver == 1
@@ -129,13 +129,15 @@ def test_resident_steps_aside():
     sm = g.solve(p.u0)
     assert g.last_solver == 1
     _assert_same(sm, s0)
-    # too large for the chip
-    pl = synth.make_euclidean_problem(2500, 0.9, seed=6)
-    gl = abi.HipClipper(storage=abi.STORE_F32_CSC)
-    gl.score_pairwise_consistency_euclidean(pl.D1, pl.D2, pl.A, **INV)
-    gl.solve(pl.u0)
-    assert gl.last_solver == 0
-    for x in (g, gd, gl):
+    # too large for the chip; too dense to win (more than 64 units: the streaming launches)
+    for m, rho in ((2500, 0.9), (2000, 0.1)):
+        pl = synth.make_euclidean_problem(m, rho, seed=6)
+        gl = abi.HipClipper(storage=abi.STORE_F32_CSC)
+        gl.score_pairwise_consistency_euclidean(pl.D1, pl.D2, pl.A, **INV)
+        gl.solve(pl.u0)
+        assert gl.last_solver == 0
+        gl.close()
+    for x in (g, gd):
         x.close()
 
 
