@@ -404,8 +404,15 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, par);
     dim3 grid(static_cast<unsigned>(a.nwg), V);
-    if (sharded) hipLaunchKernelGGL((k_tail<V, false>), grid, dim3(TAIL_THREADS), 0, s.stream, a);
-    else hipLaunchKernelGGL((k_tail<V, true>), grid, dim3(TAIL_THREADS * TAIL_SPLIT), 0, s.stream, a);
+    // the pass on the slices builds its window from the point slot: no candidate tables to write
+    const bool tables = !h->csc_valid;
+    if (sharded) {
+      if (tables) hipLaunchKernelGGL((k_tail<V, false, true>), grid, dim3(TAIL_THREADS), 0, s.stream, a);
+      else hipLaunchKernelGGL((k_tail<V, false, false>), grid, dim3(TAIL_THREADS), 0, s.stream, a);
+    } else {
+      if (tables) hipLaunchKernelGGL((k_tail<V, true, true>), grid, dim3(TAIL_THREADS * TAIL_SPLIT), 0, s.stream, a);
+      else hipLaunchKernelGGL((k_tail<V, true, false>), grid, dim3(TAIL_THREADS * TAIL_SPLIT), 0, s.stream, a);
+    }
     if (a.nwg_in != a.nwg)
       hipLaunchKernelGGL(k_scal_fold, dim3(static_cast<unsigned>(a.nwg_in)), dim3(128), 0, s.stream,
                          a.scal, a.nwg, V * (2 + 2 * V) + 2 * V + 2,

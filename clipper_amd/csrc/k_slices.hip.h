@@ -121,48 +121,55 @@ __device__ __forceinline__ uint32_t sl_lane_rank(uint64_t mask) {
                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
-// Stage the x rows of chunk k ([R][XP] doubles, row pitch XP) — window mode: candidates 0..XP-1
-// of table row r = X[r * VS + .]; pair mode: X[r * xstride]. Pieces of 16 bytes, thread-linear.
+// Stage the x rows of chunk k ([R][XP] doubles, row pitch XP). Window mode: the candidates are
+// BUILT here — row r, candidate l = max(u'[r] + alpha0 beta^l g'[r], 0) (clipper.cpp:235-236) from
+// the point slot the window starts from, 16 bytes read per row instead of a 64-byte table row that
+// the tail would have had to write for every outcome it speculates on. The expression, the chain of
+// multiplications behind alpha0 beta^l and hence the bits are those of the tail (k_solver.hip.h).
+// Pair mode: X[r * xstride]. Pieces of 16 bytes (two candidates), thread-linear.
+struct WindowSource {
+  const double* U;   // u' [mp]
+  const double* G;   // g' [mp]
+  double alpha0, beta;
+};
 template <bool WINDOW, int XL, int XP, int R, int NT>
 struct SliceXStage {
-  static constexpr int PIECES = WINDOW ? R * XL / 2 : R;  // 16-byte (window) / 8-byte (pair) pieces
+  static constexpr int PIECES = R;  // one row per piece (window: all its candidates; pair: its x)
   static constexpr int PER = (PIECES + NT - 1) / NT;
-  double2 w[WINDOW ? PER : 1];
+  double wu[WINDOW ? PER : 1], wg[WINDOW ? PER : 1];
   double s[WINDOW ? 1 : PER];
-  __device__ __forceinline__ void load(const double* __restrict__ X, int xstride, int64_t r0,
-                                       int64_t m) {
-    if constexpr (WINDOW) {
-      constexpr int PPR = XL / 2;  // pieces per row
+  __device__ __forceinline__ void load(const WindowSource& W, const double* __restrict__ X, int xstride,
+                                       int64_t r0, int64_t m) {
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int p = threadIdx.x + i * NT;
-        const int row = p / PPR, part = p - row * PPR;
-        const int64_t r = r0 + row;
-        w[i] = make_double2(0.0, 0.0);
-        if (p < PIECES && r < m) w[i] = *reinterpret_cast<const double2*>(X + r * VS + 2 * part);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int p = threadIdx.x + i * NT;
-        const int64_t r = r0 + p;
-        s[i] = (p < PIECES && r < m) ? X[r * xstride] : 0.0;
+    for (int i = 0; i < PER; ++i) {
+      const int p = threadIdx.x + i * NT;
+      const int64_t r = r0 + p;
+      const bool in = p < PIECES && r < m;
+      if constexpr (WINDOW) {
+        wu[i] = in ? W.U[r] : 0.0;
+        wg[i] = in ? W.G[r] : 0.0;
+      } else {
+        s[i] = in ? X[r * xstride] : 0.0;
       }
     }
   }
-  __device__ __forceinline__ void store(double* xs) const {
-    if constexpr (WINDOW) {
-      constexpr int PPR = XL / 2;
+  __device__ __forceinline__ void store(const WindowSource& W, double* xs) const {
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int p = threadIdx.x + i * NT;
-        const int row = p / PPR, part = p - row * PPR;
-        if (p < PIECES) *reinterpret_cast<double2*>(xs + row * XP + 2 * part) = w[i];
-      }
-    } else {
+    for (int i = 0; i < PER; ++i) {
+      const int p = threadIdx.x + i * NT;
+      if constexpr (WINDOW) {
+        double al = W.alpha0;
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int p = threadIdx.x + i * NT;
+        for (int l = 0; l < XL; l += 2) {
+          double t0 = wu[i] + al * wg[i];
+          t0 = (t0 > 0.0) ? t0 : 0.0;
+          al = al * W.beta;
+          double t1 = wu[i] + al * wg[i];
+          t1 = (t1 > 0.0) ? t1 : 0.0;
+          al = al * W.beta;
+          if (p < PIECES) *reinterpret_cast<double2*>(xs + p * XP + l) = make_double2(t0, t1);
+        }
+      } else {
         if (p < PIECES) xs[p] = s[i];
       }
     }
@@ -222,8 +229,9 @@ __device__ __forceinline__ void slice_begin(const SliceView& M, SliceJob<H, NW>&
 // D = steps of a slice kept in flight per lane.
 template <typename VT, int H, bool WINDOW, int V, int NSLOT, int NW, int D>
 __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H, NW>& J, int64_t ld,
-                                           int64_t m, double d, const double* __restrict__ X,
-                                           int xstride, double* __restrict__ part, double* lds) {
+                                           int64_t m, double d, const WindowSource& WS,
+                                           const double* __restrict__ X, int xstride,
+                                           double* __restrict__ part, double* lds) {
   constexpr int NS = WINDOW ? V + 1 : 2;
   constexpr int XP = WINDOW ? sl_xpitch(V) : 1;
   constexpr int XL = WINDOW ? sl_xload(V) : 1;
@@ -241,8 +249,8 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
   SliceXStage<WINDOW, XL, XP, R, NT> xst;
   __syncthreads();  // the decision at the head of the launch used the same LDS
   if (t0 < t1) {
-    xst.load(X, xstride, static_cast<int64_t>(t0) * R, m);
-    xst.store(lds);
+    xst.load(WS, X, xstride, static_cast<int64_t>(t0) * R, m);
+    xst.store(WS, lds);
   }
   __syncthreads();
   SliceHead<H> cur = J.first;
@@ -255,7 +263,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
     SliceHead<H> nxt = cur;
     uint64_t pre_next2 = 0;
     if (more) {
-      xst.load(X, xstride, static_cast<int64_t>(k + 1) * R, m);
+      xst.load(WS, X, xstride, static_cast<int64_t>(k + 1) * R, m);
       if (mine) nxt.load(M.data + 16 * pre_next, lane);
       if (k + 2 < t1) pre_next2 = pre_row[k + 2];
     }
@@ -333,7 +341,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
         }
       }
     }
-    if (more) xst.store(xnext);
+    if (more) xst.store(WS, xnext);
     cur = nxt;
     pre_next = pre_next2;
     __syncthreads();
@@ -358,13 +366,15 @@ __device__ __forceinline__ void slices_by_plan(const SliceView& M, const SliceJo
                                                const SolveArgs& A, const PassPlan& plan,
                                                double* lds) {
   if (plan.phase == PH_TRIAL) {
-    slice_core<VT, H, true, V, nslot(V), NW, D>(
-        M, J, A.W, A.m, plan.d, A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS, VS, A.part, lds);
+    const WindowSource WS{A.pt + static_cast<int64_t>(plan.src) * 2 * A.mp,
+                          A.pt + (static_cast<int64_t>(plan.src) * 2 + 1) * A.mp, plan.alpha0, A.prm.beta};
+    slice_core<VT, H, true, V, nslot(V), NW, D>(M, J, A.W, A.m, plan.d, WS, nullptr, 0, A.part, lds);
   } else {  // pair mode: straight on the u array of a point slot, or on candidate 0 of a table
     const bool fu = plan.from_u >= 0;
     const double* X = fu ? A.pt + static_cast<int64_t>(plan.from_u) * 2 * A.mp
                          : A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS;
-    slice_core<VT, H, false, V, nslot(V), NW, D>(M, J, A.W, A.m, 0.0, X, fu ? 1 : VS, A.part, lds);
+    slice_core<VT, H, false, V, nslot(V), NW, D>(M, J, A.W, A.m, 0.0, WindowSource{}, X, fu ? 1 : VS,
+                                                 A.part, lds);
   }
 }
 
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(SL_NW * 64, 2) void k_gemv_slices_plain(SliceView M
   __shared__ __attribute__((aligned(16))) double lds[2 * SL_SUB * H];
   SliceJob<H, SL_NW> J;
   slice_begin<H, SL_NW>(M, J);
-  slice_core<VT, H, false, 1, 2, SL_NW, SL_D>(M, J, ld, m, 0.0, X, VS, part, lds);
+  slice_core<VT, H, false, 1, 2, SL_NW, SL_D>(M, J, ld, m, 0.0, WindowSource{}, X, VS, part, lds);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -261,6 +261,10 @@ struct PassPlan {
   int sel;     // table of Xin that holds the pending window, or
   int from_u;  // -1, or (p*V + v): pair-mode pass straight on the u array of point slot (p, v)
   double d;
+  // the pending window without its table: candidate l = max(u' + alpha0 beta^l g', 0) with (u', g')
+  // the arrays of point slot `src` (p*V + v) — what the pass on the slices stages (k_slices.hip.h)
+  int src;
+  double alpha0;
 };
 
 constexpr int VU = 4;  // elements per thread per sweep step (all NT threads of the workgroup sweep)
@@ -651,6 +655,11 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   plan.from_u = __builtin_amdgcn_readfirstlane(need_pair ? ubp * V + ubv : -1);
   plan.d = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(d)),
                             __builtin_amdgcn_readfirstlane(__double2loint(d)));
+  // every window the decision can leave pending starts from the point it ends on: the accepted
+  // candidate (alpha = 1), or the unchanged point with the V factors of beta the walk multiplied in
+  plan.src = __builtin_amdgcn_readfirstlane(ubp * V + ubv);
+  plan.alpha0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(alpha)),
+                                 __builtin_amdgcn_readfirstlane(__double2loint(alpha)));
   return action == ACT_PASS;
 }
 #undef VEC_CHUNKS
@@ -671,6 +680,8 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
   plan.sel = st->sel;
   plan.from_u = -1;
   plan.d = st->d;
+  plan.src = 0;  // (pair-mode passes only: never read)
+  plan.alpha0 = 1.0;
   if (is_writer_block() && threadIdx.x == 0) {
     *stash = *st;
     stash->stage = ST_RESULTS;
@@ -734,7 +745,11 @@ __global__ __launch_bounds__(128) void k_scal_fold(const double* __restrict__ sc
   }
 }
 
-template <int V, bool FUSED_REDUCE>
+//   TABLES: write the candidate tables of the next windows (the dense pass reads its multipliers
+//           from them with scalar loads). The pass on the slices builds a window from the point
+//           slot itself while it stages the rows (PassPlan::src): no tables — 64 bytes less to
+//           store per element and outcome, and nothing for the kernel boundary to write back.
+template <int V, bool FUSED_REDUCE, bool TABLES = true>
 __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) void k_tail(SolveArgs A) {
   constexpr int NR = 2 + 2 * V;
   constexpr int PEN = V * NR + 2 * V;
@@ -845,12 +860,20 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
         r[3 + 2 * l] = t;
         al = al * beta;
       }
-      store_row(A.Xout + i * VS, row);
+      if constexpr (TABLES) store_row(A.Xout + i * VS, row);
     }
   } else {
     if (valid) {
-      const double xraw = A.Xin[(static_cast<int64_t>(sel) * A.mp + i) * VS + v];
       const double ui = pt_arr(A, V, ubp, ubv, 0)[i];
+      double xraw;
+      if constexpr (TABLES) {
+        xraw = A.Xin[(static_cast<int64_t>(sel) * A.mp + i) * VS + v];
+      } else {  // candidate v of the window the pass staged: the same expression, the same bits
+        double al = alpha;
+        for (int l = 0; l < v; ++l) al = al * beta;
+        const double t = ui + al * pt_arr(A, V, ubp, ubv, 1)[i];
+        xraw = (t > 0.0) ? t : 0.0;
+      }
       const double xi = xraw / nrmv;  // clipper.cpp:237
       double gn;
       if (v == 0) {
@@ -886,7 +909,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
         r[3 + 2 * l] = t;
         al = al * beta;
       }
-      store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
+      if constexpr (TABLES) store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
       if (v == 0) {
         // next window if all V candidates are rejected: V more factors of beta (:248)
         const double gi = pt_arr(A, V, ubp, ubv, 1)[i];
@@ -903,7 +926,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
           r[NR + 2 * l + 1] = t;
           al = al * beta;
         }
-        store_row(A.Xout + (static_cast<int64_t>(V) * A.mp + i) * VS, row2);
+        if constexpr (TABLES) store_row(A.Xout + (static_cast<int64_t>(V) * A.mp + i) * VS, row2);
       }
     }
   }

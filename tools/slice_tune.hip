@@ -293,7 +293,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_pass(SliceView M, int64_t ld, 
   const long long c0 = stamps ? wall_clock64() : 0;
   SliceJob<H, NW> J;
   slice_begin<H, NW>(M, J);
-  slice_core<VT, H, WINDOW, V, nslot(V), NW, D>(M, J, ld, m, d, X, VS, part, lds);
+  // window mode: candidate l = max(U + 0.5^l G, 0); U, G lie behind the table (main())
+  const int64_t mp = (m + 63) / 64 * 64;
+  const WindowSource WS{X + mp * VS, X + mp * VS + mp, 1.0, 0.5};
+  slice_core<VT, H, WINDOW, V, nslot(V), NW, D>(M, J, ld, m, d, WS, X, VS, part, lds);
   if (stamps && (threadIdx.x & 63) == 0) {
     stamps[(blockIdx.x * NW + (threadIdx.x >> 6)) * 2] = c0;
     stamps[(blockIdx.x * NW + (threadIdx.x >> 6)) * 2 + 1] = wall_clock64();
@@ -441,9 +444,21 @@ int main(int argc, char** argv) {
       nnz += 2;
     }
   for (auto& col : c.cols) std::sort(col.begin(), col.end(), [](const Entry& a, const Entry& b) { return a.row < b.row; });
-  c.X.assign(static_cast<size_t>(c.mp) * VS, 0.0);
-  for (int64_t r = 0; r < m; ++r)
-    for (int v = 0; v < VS; ++v) c.X[static_cast<size_t>(r) * VS + v] = (mix(r * 8 + v + 12345) & 0xFFFFF) / 1048576.0 / (1 + v);
+  // table rows [mp][VS], then U [mp], then G [mp]; row r of the table = the window the pass builds
+  // from (U, G): candidate l = max(U + 0.5^l G, 0) with the pass's own chain of multiplications
+  c.X.assign(static_cast<size_t>(c.mp) * VS + 2 * static_cast<size_t>(c.mp), 0.0);
+  for (int64_t r = 0; r < m; ++r) {
+    const double u = (mix(r * 8 + 12345) & 0xFFFFF) / 1048576.0;
+    const double g = (mix(r * 8 + 12346) & 0xFFFFF) / 1048576.0 - 0.7;
+    c.X[static_cast<size_t>(c.mp) * VS + r] = u;
+    c.X[static_cast<size_t>(c.mp) * VS + c.mp + r] = g;
+    double al = 1.0;
+    for (int v = 0; v < VS; ++v) {
+      const double t = u + al * g;
+      c.X[static_cast<size_t>(r) * VS + v] = t > 0.0 ? t : 0.0;
+      al = al * 0.5;
+    }
+  }
   CK(hipMalloc(&c.dX, c.X.size() * 8));
   CK(hipMemcpy(c.dX, c.X.data(), c.X.size() * 8, hipMemcpyHostToDevice));
   printf("stored entries (both triangles) %zu = %.2f %% ; 5 B/entry = %.1f MB\n", nnz, 100.0 * nnz / (double(m) * m), nnz * 5e-6);
