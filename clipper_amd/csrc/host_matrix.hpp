@@ -86,7 +86,8 @@ int slices_arrays(Ctx* h, Shard& s) {
     }
     s.scap_slices = 0;
     HIPCHK(hipMalloc(&s.sSizes, nsl * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&s.sLq, nsl * sizeof(uint32_t)));
+    // (room behind the directory words for the arena counters of a direct emission: one read-back)
+    HIPCHK(hipMalloc(&s.sLq, round_up(nsl, 32) * sizeof(uint32_t) + CSC_ARENAS * sizeof(CscBuildCtl)));
     HIPCHK(hipMalloc(&s.sPre, nsl * sizeof(uint64_t)));
     HIPCHK(hipMalloc(&s.sBlk, (ceil_div(nsl, SCAN_BLK) + 4) * sizeof(uint64_t)));
     s.scap_slices = nsl;
@@ -95,7 +96,8 @@ int slices_arrays(Ctx* h, Shard& s) {
     if (h->csc_hLq) hipHostFree(h->csc_hLq);
     h->csc_hLq = nullptr;
     h->csc_hcap_slices = 0;
-    HIPCHK(hipHostMalloc(&h->csc_hLq, nsl * sizeof(uint32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&h->csc_hLq, round_up(nsl, 32) * sizeof(uint32_t) + CSC_ARENAS * sizeof(CscBuildCtl),
+                         hipHostMallocDefault));
     h->csc_hcap_slices = nsl;
   }
   if (!h->csc_hctl)
@@ -120,12 +122,21 @@ int emit_prepare(Ctx* h, Shard& s, SliceOut& out) {
     init[k].origin = static_cast<unsigned long long>(k) * (units / CSC_ARENAS);
     init[k].overflow = 0;
   }
-  HIPCHK(hipMemcpyAsync(s.cctl, init, CSC_ARENAS * sizeof(CscBuildCtl), hipMemcpyHostToDevice,
-                        s.stream));
+  // the counters live right behind this build's directory words: both come back in ONE copy
+  CscBuildCtl* ectl = reinterpret_cast<CscBuildCtl*>(
+      s.sLq + round_up(static_cast<int64_t>(s.s_ncg) * s.s_nchunks, 32));
+  void* idev = nullptr;
+  if (hipHostGetDevicePointer(&idev, init, 0) == hipSuccess && idev) {  // 2 KB: a launch beats a DMA copy
+    hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(256), 0, s.stream, reinterpret_cast<const uint4*>(idev),
+                       reinterpret_cast<uint4*>(ectl), static_cast<int64_t>(CSC_ARENAS * sizeof(CscBuildCtl) / 16));
+  } else {
+    (void)hipGetLastError();
+    HIPCHK(hipMemcpyAsync(ectl, init, CSC_ARENAS * sizeof(CscBuildCtl), hipMemcpyHostToDevice, s.stream));
+  }
   out.Pre = s.sPre;
   out.Lq = s.sLq;
   out.data = s.sdata;
-  out.ctl = s.cctl;
+  out.ctl = ectl;
   out.nchunks = s.s_nchunks;
   out.ncg = s.s_ncg;
   out.stamps = h->stamps_dev ? h->stamps_dev + 8192 : nullptr;
@@ -136,10 +147,18 @@ int emit_prepare(Ctx* h, Shard& s, SliceOut& out) {
 // was synchronised, grows the arena if a slice did not fit (`again`), else plans the passes.
 int emit_enqueue(Ctx* h, Shard& s) {
   HIPCHK(hipSetDevice(s.device));
-  const size_t nsl = static_cast<size_t>(s.s_ncg) * s.s_nchunks;
-  HIPCHK(hipMemcpyAsync(h->csc_hctl, s.cctl, CSC_ARENAS * sizeof(CscBuildCtl), hipMemcpyDeviceToHost,
-                        s.stream));
-  HIPCHK(hipMemcpyAsync(h->csc_hLq, s.sLq, nsl * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+  const size_t nsl8 = static_cast<size_t>(round_up(static_cast<int64_t>(s.s_ncg) * s.s_nchunks, 32));
+  const size_t bytes = nsl8 * sizeof(uint32_t) + CSC_ARENAS * sizeof(CscBuildCtl);
+  void* hdev = nullptr;
+  if (bytes <= (1u << 20) && hipHostGetDevicePointer(&hdev, h->csc_hLq, 0) == hipSuccess && hdev) {
+    const int64_t n16 = static_cast<int64_t>(bytes / 16);  // (both terms are multiples of 32 bytes)
+    hipLaunchKernelGGL(k_copy_words, dim3(static_cast<unsigned>(std::min<int64_t>(ceil_div(n16, 256), 64))),
+                       dim3(256), 0, s.stream, reinterpret_cast<const uint4*>(s.sLq),
+                       reinterpret_cast<uint4*>(hdev), n16);
+  } else {
+    (void)hipGetLastError();
+    HIPCHK(hipMemcpyAsync(h->csc_hLq, s.sLq, bytes, hipMemcpyDeviceToHost, s.stream));
+  }
   return 0;
 }
 
@@ -152,10 +171,12 @@ int emit_check(Ctx* h, Shard& s, bool& again) {
   bool over = false;
   size_t worst = 0;
   uint64_t sum = 0;
+  const CscBuildCtl* rb = reinterpret_cast<const CscBuildCtl*>(
+      h->csc_hLq + round_up(static_cast<int64_t>(s.s_ncg) * s.s_nchunks, 32));
   for (int k = 0; k < CSC_ARENAS; ++k) {
-    over = over || h->csc_hctl[k].overflow != 0;
-    worst = std::max(worst, static_cast<size_t>(h->csc_hctl[k].cursor));
-    sum += h->csc_hctl[k].cursor;
+    over = over || rb[k].overflow != 0;
+    worst = std::max(worst, static_cast<size_t>(rb[k].cursor));
+    sum += rb[k].cursor;
   }
   if (over) {
     const size_t need = worst * CSC_ARENAS;  // every arena as large as the fullest one
@@ -278,53 +299,62 @@ int slices_plan(Ctx* h, Shard& s) {
   const int ncg = s.s_ncg, nchunks = s.s_nchunks;
   const int nstrips = static_cast<int>(ceil_div(ncg, SL_NW));
   const uint32_t* L = h->csc_hLq;
-  double target = static_cast<double>(h->cus) * 4.0;
-  if (const char* e = std::getenv("CLIPPER_HIP_CSC_WGS")) target = std::max(1.0, std::atof(e));
-  double C0 = 2.0;  // what a chunk costs besides its steps (staging, barrier, header), in steps
-  if (const char* e = std::getenv("CLIPPER_HIP_CSC_C0")) C0 = std::max(0.0, std::atof(e));
-  std::vector<int> cost(static_cast<size_t>(nstrips) * nchunks);
+  static const double target_env = std::getenv("CLIPPER_HIP_CSC_WGS") ? std::max(1.0, std::atof(std::getenv("CLIPPER_HIP_CSC_WGS"))) : 0.0;
+  static const double c0_env = std::getenv("CLIPPER_HIP_CSC_C0") ? std::max(0.0, std::atof(std::getenv("CLIPPER_HIP_CSC_C0"))) : -1.0;
+  const double target = target_env > 0.0 ? target_env : static_cast<double>(h->cus) * 4.0;
+  const double C0 = c0_env >= 0.0 ? c0_env : 2.0;  // what a chunk costs besides its steps (staging, barrier, header), in steps
+  // (this runs between the fill and the first pass of every build: buffers are kept, the order is
+  // a counting sort)
+  static thread_local std::vector<int> cost;
+  static thread_local std::vector<SliceWork> items;
+  static thread_local std::vector<uint16_t> key;
+  static thread_local std::vector<int> nslot_of;
+  cost.resize(static_cast<size_t>(nstrips) * nchunks);
   double total = 0.0;
   uint64_t entries = 0;
-  for (int st = 0; st < nstrips; ++st)
-    for (int k = 0; k < nchunks; ++k) {
-      int c = 0;
-      for (int w = 0; w < SL_NW; ++w) {
-        const int cg = st * SL_NW + w;
-        if (cg >= ncg) break;
-        const uint32_t v = L[static_cast<size_t>(cg) * nchunks + k];
-        c = std::max(c, static_cast<int>(v & 255u));
+  for (int st = 0; st < nstrips; ++st) {
+    int* crow = cost.data() + static_cast<size_t>(st) * nchunks;
+    const int w1 = std::min(SL_NW, ncg - st * SL_NW);
+    for (int k = 0; k < nchunks; ++k) crow[k] = 0;
+    for (int w = 0; w < w1; ++w) {
+      const uint32_t* lrow = L + static_cast<size_t>(st * SL_NW + w) * nchunks;
+      for (int k = 0; k < nchunks; ++k) {
+        const uint32_t v = lrow[k];
+        crow[k] = std::max(crow[k], static_cast<int>(v & 255u));
         entries += v >> 8;
       }
-      cost[static_cast<size_t>(st) * nchunks + k] = c;
-      total += c + C0;
     }
+    for (int k = 0; k < nchunks; ++k) total += crow[k] + C0;
+  }
   s.s_entries = entries;
   const double T = std::max(8.0, total / target);
-  struct Item {
-    double cost;
-    SliceWork w;
+  constexpr int KEYS = 1024;  // cost in eighths of a step, clamped
+  auto push = [&](double c, const SliceWork& w) {
+    items.push_back(w);
+    key.push_back(static_cast<uint16_t>(std::min<double>(KEYS - 1, c * 8.0)));
   };
-  std::vector<Item> items;
-  std::vector<int> nslot_of(static_cast<size_t>(nstrips), 0);
+  items.clear();
+  key.clear();
+  nslot_of.assign(static_cast<size_t>(nstrips), 0);
   int nslots = 1;
   for (int st = 0; st < nstrips; ++st) {
     int slot = 0, start = 0;
     double acc = 0.0;
     auto flush = [&](int end) {
-      if (end > start) items.push_back({acc, SliceWork{st, slot++, start, end, 0, 1 << 30, 0, 0}});
+      if (end > start) push(acc, SliceWork{st, slot++, start, end, 0, 1 << 30, 0, 0});
       start = end;
       acc = 0.0;
     };
+    const int* crow = cost.data() + static_cast<size_t>(st) * nchunks;
     for (int k = 0; k < nchunks; ++k) {
-      const int mq = cost[static_cast<size_t>(st) * nchunks + k];
+      const int mq = crow[k];
       const double c = mq + C0;
       if (c > 1.5 * T && mq >= 2 * SL_SO) {
         flush(k);
         const int parts = std::min(static_cast<int>(std::ceil(c / T)), static_cast<int>(ceil_div(mq, SL_SO)));
         const int per = static_cast<int>(round_up(ceil_div(mq, parts), SL_SO));
         for (int q0 = 0; q0 < mq; q0 += per)
-          items.push_back({std::min(per, mq - q0) + C0,
-                           SliceWork{st, slot++, k, k + 1, q0, std::min(q0 + per, mq), 0, 0}});
+          push(std::min(per, mq - q0) + C0, SliceWork{st, slot++, k, k + 1, q0, std::min(q0 + per, mq), 0, 0});
         start = k + 1;
       } else {
         acc += c;
@@ -337,22 +367,41 @@ int slices_plan(Ctx* h, Shard& s) {
   }
   for (int st = 0; st < nstrips; ++st)  // every (strip, slot) is written by some workgroup
     for (int slot = nslot_of[static_cast<size_t>(st)]; slot < nslots; ++slot)
-      items.push_back({0.0, SliceWork{st, slot, 0, 0, 0, 0, 0, 0}});
-  std::stable_sort(items.begin(), items.end(),
-                   [](const Item& a, const Item& b) { return a.cost > b.cost; });
+      push(0.0, SliceWork{st, slot, 0, 0, 0, 0, 0, 0});
   const size_t nw = items.size();
   if (nw > h->csc_hcap_work) {
     if (h->csc_hwork) hipHostFree(h->csc_hwork);
     h->csc_hwork = nullptr;
     h->csc_hcap_work = 0;
-    HIPCHK(hipHostMalloc(&h->csc_hwork, nw * sizeof(SliceWork), hipHostMallocDefault));
-    h->csc_hcap_work = nw;
+    HIPCHK(hipHostMalloc(&h->csc_hwork, (nw + 1024) * sizeof(SliceWork), hipHostMallocDefault));
+    h->csc_hcap_work = nw + 1024;
   }
-  for (size_t i = 0; i < nw; ++i) h->csc_hwork[i] = items[i].w;
+  {  // most expensive first, stable: counting sort by key, straight into the pinned staging buffer
+    int count[KEYS + 1] = {0};
+    for (size_t i = 0; i < nw; ++i) ++count[KEYS - 1 - key[i]];
+    int run = 0;
+    for (int b = 0; b < KEYS; ++b) {
+      const int c = count[b];
+      count[b] = run;
+      run += c;
+    }
+    for (size_t i = 0; i < nw; ++i) h->csc_hwork[count[KEYS - 1 - key[i]]++] = items[i];
+  }
   HIPCHK(hipSetDevice(s.device));
   int rc = grow_dev(s.swork, s.scap_work, nw);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(s.swork, h->csc_hwork, nw * sizeof(SliceWork), hipMemcpyHostToDevice, s.stream));
+  {
+    void* wdev = nullptr;
+    const size_t bytes = nw * sizeof(SliceWork);  // 32 bytes each
+    if (bytes <= (1u << 20) && hipHostGetDevicePointer(&wdev, h->csc_hwork, 0) == hipSuccess && wdev) {
+      hipLaunchKernelGGL(k_copy_words, dim3(static_cast<unsigned>(std::min<size_t>(ceil_div(bytes / 16, 256), 64))),
+                         dim3(256), 0, s.stream, reinterpret_cast<const uint4*>(wdev),
+                         reinterpret_cast<uint4*>(s.swork), static_cast<int64_t>(bytes / 16));
+    } else {
+      (void)hipGetLastError();
+      HIPCHK(hipMemcpyAsync(s.swork, h->csc_hwork, bytes, hipMemcpyHostToDevice, s.stream));
+    }
+  }
   const size_t NSLOT = static_cast<size_t>(nslot(h->V));
   if (static_cast<size_t>(nslots) > s.part_tiles) {
     HIPCHK(hipFree(s.part));
@@ -497,8 +546,10 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
     }
     HIPCHK(hipSetDevice(s0.device));
     HIPCHK(hipEventRecord(e1, s0.stream));
+    const auto th0 = std::chrono::high_resolution_clock::now();
     rc = sync_all(h);
     if (rc) return rc;
+    const auto th1 = std::chrono::high_resolution_clock::now();
     if (!emit) {
       // dense slices (column shards, the other fill kernels, fp64 storage): slices from them
       const auto t0 = std::chrono::high_resolution_clock::now();
@@ -511,6 +562,14 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
     bool again = false;
     rc = emit_check(h, s0, again);
     if (rc) return rc;
+    if (std::getenv("CLIPPER_HIP_HOST_TIMING")) {
+      const auto th2 = std::chrono::high_resolution_clock::now();
+      float kms = 0.f;
+      (void)hipEventElapsedTime(&kms, e0, e1);
+      std::fprintf(stderr, "[affinity] enqueue->synced %.1f us (events %.1f us), check+plan %.1f us\n",
+                   std::chrono::duration<double, std::micro>(th1 - th0).count(), kms * 1e3,
+                   std::chrono::duration<double, std::micro>(th2 - th1).count());
+    }
     if (!again) {
       h->csc_valid = true;
       break;

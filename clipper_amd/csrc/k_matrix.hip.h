@@ -76,4 +76,14 @@ __global__ __launch_bounds__(256) void k_from_csc(T* __restrict__ S, int64_t ld,
     }
 }
 
+// k_copy_words — a few KB of device memory into mapped host memory by the CUs themselves: the
+// read-back of a build's directory. A DMA copy of the same bytes costs ~15 us of engine start-up
+// behind the fill kernel; this launch ~4.
+__global__ __launch_bounds__(256) void k_copy_words(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                    int64_t n16) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n16;
+       i += static_cast<int64_t>(gridDim.x) * 256)
+    dst[i] = src[i];
+}
+
 }  // namespace clipper_hip
