@@ -307,7 +307,7 @@ int slices_plan(Ctx* h, Shard& s) {
   // a counting sort)
   static thread_local std::vector<int> cost;
   static thread_local std::vector<SliceWork> items;
-  static thread_local std::vector<uint16_t> key;
+  static thread_local std::vector<double> key;
   static thread_local std::vector<int> nslot_of;
   cost.resize(static_cast<size_t>(nstrips) * nchunks);
   double total = 0.0;
@@ -328,10 +328,10 @@ int slices_plan(Ctx* h, Shard& s) {
   }
   s.s_entries = entries;
   const double T = std::max(8.0, total / target);
-  constexpr int KEYS = 1024;  // cost in eighths of a step, clamped
+  constexpr int KEYS = 1024;  // sort keys: the cost relative to the most expensive item
   auto push = [&](double c, const SliceWork& w) {
     items.push_back(w);
-    key.push_back(static_cast<uint16_t>(std::min<double>(KEYS - 1, c * 8.0)));
+    key.push_back(c);
   };
   items.clear();
   key.clear();
@@ -377,15 +377,18 @@ int slices_plan(Ctx* h, Shard& s) {
     h->csc_hcap_work = nw + 1024;
   }
   {  // most expensive first, stable: counting sort by key, straight into the pinned staging buffer
+    double cmax = 1e-9;
+    for (size_t i = 0; i < nw; ++i) cmax = std::max(cmax, key[i]);
+    const double scale = (KEYS - 1) / cmax;
     int count[KEYS + 1] = {0};
-    for (size_t i = 0; i < nw; ++i) ++count[KEYS - 1 - key[i]];
+    for (size_t i = 0; i < nw; ++i) ++count[KEYS - 1 - static_cast<int>(key[i] * scale)];
     int run = 0;
     for (int b = 0; b < KEYS; ++b) {
       const int c = count[b];
       count[b] = run;
       run += c;
     }
-    for (size_t i = 0; i < nw; ++i) h->csc_hwork[count[KEYS - 1 - key[i]]++] = items[i];
+    for (size_t i = 0; i < nw; ++i) h->csc_hwork[count[KEYS - 1 - static_cast<int>(key[i] * scale)]++] = items[i];
   }
   HIPCHK(hipSetDevice(s.device));
   int rc = grow_dev(s.swork, s.scap_work, nw);
