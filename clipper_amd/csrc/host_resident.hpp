@@ -159,8 +159,9 @@ template <typename VT, int V, int E>
 int resident_launch_t(Ctx* h, Shard& s, const ResidentArgs& a) {
   Resident& r = h->res;
   auto kern = k_solve_resident<VT, V, E>;
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
+  static bool attr_set[64] = {};  // per instantiation and device
+  const int dv = (s.device >= 0 && s.device < 64) ? s.device : 0;
+  if (!attr_set[dv]) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(RS_LDS_MAX));
@@ -175,11 +176,15 @@ int resident_launch_t(Ctx* h, Shard& s, const ResidentArgs& a) {
         std::fprintf(stderr, "[resident] hipFuncSetAttribute: %s (static LDS %zu, max dynamic %d, device per block %d, optin %d)\n",
                      hipGetErrorString(e), fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes, perblk, optin);
       }
-      return 1;  // this device does not give a workgroup 160 KB of LDS: not an error, no resident solver
+      return 1;  // this device does not give a workgroup 159 KB of LDS: not an error, no resident solver
     }
-    attr_set = true;
+    attr_set[dv] = true;
   }
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(r.nunits)), dim3(RS_NT), r.lds_total, s.stream, a);
+  if (const hipError_t e = hipGetLastError(); e != hipSuccess) {  // refused: the streaming launches take over
+    if (rs_debug()) std::fprintf(stderr, "[resident] launch failed: %s\n", hipGetErrorString(e));
+    return 1;
+  }
   return 0;
 }
 
@@ -242,7 +247,6 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
     r.failed = true;
     return 0;
   }
-  HIPCHK(hipGetLastError());
   volatile HostMirror* hm = h->mirror;
   uint64_t spins = 0;
   bool finished = true;
