@@ -130,12 +130,13 @@ int resident_plan(Ctx* h, Shard& s) {
   std::memcpy(r.host_plan, units.data(), units.size() * sizeof(ResidentUnit));
   std::memcpy(r.host_plan + units.size() * sizeof(ResidentUnit), nsl.data(), static_cast<size_t>(ncg));
   std::atomic_thread_fence(std::memory_order_seq_cst);
-  const size_t xb_bytes = 2ull * maxslots * (V + 1) * static_cast<size_t>(mp) * sizeof(double);
+  const size_t xb_bytes = 2ull * maxslots * (V + 1) * static_cast<size_t>(mp) * 2 * sizeof(unsigned long long);
   if (xb_bytes > r.xb_cap) {
     if (r.xb) HIPCHK(hipFree(r.xb));
     r.xb = nullptr;
     HIPCHK(hipMalloc(&r.xb, xb_bytes));
     r.xb_cap = xb_bytes;
+    HIPCHK(hipMemsetAsync(r.xb, 0, xb_bytes, s.stream));  // no granule may carry a future epoch
   }
   if (units.size() + 1 > r.flags_cap) {
     if (r.flags) HIPCHK(hipFree(r.flags));
@@ -143,7 +144,6 @@ int resident_plan(Ctx* h, Shard& s) {
     r.flags_cap = units.size() + 64;
     HIPCHK(hipMalloc(&r.flags, (r.flags_cap + 1) * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(r.flags, 0, (r.flags_cap + 1) * sizeof(unsigned long long), s.stream));
-    r.epoch = 0;
   }
   r.V = V;
   r.E = E;
@@ -266,9 +266,10 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
     HIPCHK(hipMemcpy(&err, a.err, sizeof(err), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(a.err, 0, sizeof(uint32_t)));
     r.failed = true;  // until the next build
+    HIPCHK(hipMemset(r.xb, 0, r.xb_cap));  // granules of the abandoned solve
     r.last_error = static_cast<int>(err);
     if (rs_debug()) std::fprintf(stderr, "[resident] gave up: error %u\n", err);
-    r.epoch += 1ull << 32;
+    r.epoch += 1ull << 20;
     return 0;
   }
   std::atomic_thread_fence(std::memory_order_acquire);

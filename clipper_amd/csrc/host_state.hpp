@@ -150,7 +150,7 @@ struct Resident {
   uint8_t* host_plan = nullptr;      // pinned + mapped: units, then slots per column group
   uint8_t* host_plan_dev = nullptr;
   size_t host_plan_cap = 0;
-  double* xb = nullptr;              // exchange buffer [2][maxslots][V+1][mp]
+  unsigned long long* xb = nullptr;  // exchange buffer [2][maxslots][V+1][mp][2] (granules)
   size_t xb_cap = 0;
   unsigned long long* flags = nullptr;  // [flags_cap] epochs, then the error word
   size_t flags_cap = 0;

@@ -22,11 +22,13 @@ namespace clipper_hip {
 //     redundantly: same code on the same bits => the same decisions everywhere, no scalar
 //     ever crosses a workgroup. (The column-shard protocol of the multi-GPU driver, with
 //     workgroups as ranks.)
-//   * The only exchange is the pass's all-gather: a workgroup publishes the (V+1) raw sums of its
-//     columns write-through (sc1) into xb[parity][slot], raises its flag to the iteration's
-//     epoch, polls the P flags (one wave, relaxed agent-scope loads) and reads everybody's sums
-//     with sc1 loads. Spins are bounded by the wall clock; a time-out sets `err` and every
-//     workgroup leaves (the host then runs the streaming solver).
+//   * The only exchange is the pass's all-gather, and the data IS the flag: a workgroup publishes
+//     every raw sum of its columns as two 8-byte granules {epoch, half of the fp64 value} with
+//     write-through (sc1) atomic stores into xb[parity][slot]; every thread of every workgroup
+//     sweeps the granules of ITS elements (relaxed agent-scope loads) until both carry the pass's
+//     epoch. No drain, no flag, no fence, no barrier on the hand-off, and nothing that depends
+//     on where a workgroup runs. Spins are bounded by the wall clock; a time-out sets `err`
+//     and every workgroup leaves (the host then runs the streaming solver).
 //   * One workgroup (P = 1: everything fits one LDS) exchanges nothing at all.
 //
 // The line-search WINDOW is kept (V candidates per pass, walked in the reference's order): here it
@@ -56,9 +58,9 @@ struct ResidentArgs {
   SolverParams prm;
   int rescale;
   const double* u0;
-  double* xb;                    // [2][maxslots][V+1][mp]
-  unsigned long long* flags;     // [nunits], zero at allocation, monotonic
-  unsigned long long epoch0;     // this solve's epochs are epoch0 + 1, epoch0 + 2, ...
+  unsigned long long* xb;        // [2][maxslots][V+1][mp][2] granules {epoch << 32 | half of a sum}, zero at allocation
+  unsigned long long* flags;     // (the error word lives behind it)
+  unsigned long long epoch0;     // this solve's epochs are epoch0 + 1, epoch0 + 2, ... (low 32 bits = the tags)
   uint32_t* err;                 // 0 | RS_ERR_*
   uint32_t lds_slices;           // bytes of LDS the slices of a unit may take
   double* u_dev;                 // [mp] final u (device)
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
     __syncthreads();
     ++epoch;
     const int par = static_cast<int>(epoch & 1ull);
+    const unsigned long long tag = (epoch & 0xffffffffull) << 32;
     // sums over the waves of a column group, in wave order; one (column, v) per thread and step
     const int nout = U.ncgs * 64 * NS;
     for (int o = tid; o < nout; o += RS_NT) {
@@ -290,8 +293,14 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
       for (int w = 1; w < U.wpg; ++w) sum += scr[((gl * U.wpg + w) * NS + v) * 64 + c];
       const int64_t col = static_cast<int64_t>(U.cg0 + gl) * 64 + c;
       if (col < mp) {
-        if (single) ylds[v * mp + col] = sum;
-        else rs_st_sc1(A.xb + ((static_cast<int64_t>(par) * A.maxslots + U.slot) * NS + v) * mp + col, sum);
+        if (single) {
+          ylds[v * mp + col] = sum;
+        } else {  // two self-describing granules {epoch, half of the value}: the data IS the flag
+          const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(sum));
+          unsigned long long* gq = A.xb + ((((static_cast<int64_t>(par) * A.maxslots + U.slot) * NS + v) * mp + col) << 1);
+          __hip_atomic_store(gq, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(gq + 1, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     if (single) {
@@ -308,32 +317,57 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
       stamp(5);
       return true;
     }
-    // publish: every storing wave drains its write-through stores, then ONE lane raises the flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-      __hip_atomic_store(A.flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamp(3);
-    // gather: one wave polls everybody's flag
-    int ok_all = 1;
-    if (wave == 0) {
-      const long long t_poll = wall_clock64();
+    // gather: every thread sweeps the granules of ITS elements until they carry this pass's epoch —
+    // no drain, no flag, no acquire (cdna_hip_programming.md 6 G16, form R2); slot by slot, in order
+    int fail = 0;
+    const unsigned long long* xb = A.xb + ((static_cast<int64_t>(par) * A.maxslots * NS * mp) << 1);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+#pragma unroll
+      for (int v = 0; v < NS; ++v) y[e][v] = 0.0;
+    }
+    const long long t_poll = wall_clock64();
+    for (int sl_ = 0; sl_ < A.maxslots && !fail; ++sl_) {
+      double tv[E][NS];
       for (unsigned spins = 0;; ++spins) {
         bool ok = true;
-        for (int f = lane; f < A.nunits; f += 64) ok = ok && rs_ld_flag(A.flags + f) >= epoch;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int64_t i = tid + static_cast<int64_t>(e) * RS_NT;
+          if (sl_ < nslots_e[e]) {
+#pragma unroll
+            for (int v = 0; v < NS; ++v) {
+              const unsigned long long* gq = xb + (((static_cast<int64_t>(sl_) * NS + v) * mp + i) << 1);
+              const unsigned long long g0 = rs_ld_flag(gq), g1 = rs_ld_flag(gq + 1);
+              ok = ok && ((g0 ^ tag) >> 32) == 0 && ((g1 ^ tag) >> 32) == 0;
+              tv[e][v] = __longlong_as_double(static_cast<long long>((g0 << 32) | (g1 & 0xffffffffull)));
+            }
+          }
+        }
         if (__all(ok)) break;
         if ((spins & 63u) == 63u) {
           const bool late = wall_clock64() - t_poll > A.timeout_ticks;
           const uint32_t e2 = __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (late || e2 != 0) {
-            ok_all = 0;
+            fail = 1;
             break;
           }
         }
         __builtin_amdgcn_s_sleep(1);
       }
+      if (!fail) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if (sl_ < nslots_e[e]) {
+#pragma unroll
+            for (int v = 0; v < NS; ++v) y[e][v] += tv[e][v];
+          }
+        }
+      }
     }
-    if (!__syncthreads_and(ok_all)) {
+    // (also the barrier between this pass's reads of the reduce scratch and the next X table)
+    if (__syncthreads_or(fail)) {
       if (tid == 0) {
         uint32_t expect = 0;
         __hip_atomic_compare_exchange_strong(A.err, &expect, static_cast<uint32_t>(RS_ERR_TIMEOUT),
@@ -343,20 +377,6 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
       return false;
     }
     stamp(4);
-    const double* xb = A.xb + static_cast<int64_t>(par) * A.maxslots * NS * mp;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int64_t i = tid + static_cast<int64_t>(e) * RS_NT;
-#pragma unroll
-      for (int v = 0; v < NS; ++v) y[e][v] = 0.0;
-      for (int s = 0; s < nslots_e[e]; ++s) {
-        double t[NS];
-#pragma unroll
-        for (int v = 0; v < NS; ++v) t[v] = rs_ld_sc1(xb + (static_cast<int64_t>(s) * NS + v) * mp + i);
-#pragma unroll
-        for (int v = 0; v < NS; ++v) y[e][v] += t[v];
-      }
-    }
     if (A.stamps && blockIdx.x == 0 && tid == 0 && stamp_row < 500)
       A.stamps[stamp_row * 8 + 5] = wall_clock64() + (y[0][0] > 1e300 ? 1 : 0);
     return true;
