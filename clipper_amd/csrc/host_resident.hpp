@@ -19,8 +19,10 @@ void resident_free(Ctx* h) {
   if (r.xb) hipFree(r.xb);
   if (r.flags) hipFree(r.flags);
   const int vf = r.V_forced;
+  const bool xo = r.xcd_off;
   r = Resident{};
   r.V_forced = vf;
+  r.xcd_off = xo;
 }
 
 // upper bound of the bytes of a slice from its directory word (maxq | entries << 8)
@@ -52,11 +54,6 @@ int resident_plan(Ctx* h, Shard& s) {
   }
   int vmax = 1;  // at these sizes the line search rarely rejects: a window only adds arithmetic
   if (r.V_forced) vmax = r.V_forced;
-  auto pow2 = [](int x) {
-    int p = 1;
-    while (p < x) p *= 2;
-    return p;
-  };
   std::vector<ResidentUnit> units;
   std::vector<uint8_t> nsl(static_cast<size_t>(ncg), 0);
   int V = 0;
@@ -67,10 +64,9 @@ int resident_plan(Ctx* h, Shard& s) {
     // everything in ONE workgroup: no exchange at all
     if (ncg <= RS_NWV) {
       const uint32_t fixed1 = fixed + rs_y_bytes(v, mp, true);
-      const int wpg = RS_NWV / pow2(ncg);
       if (fixed1 + RS_SLICE_PAD < RS_LDS_MAX && total <= RS_LDS_MAX - fixed1 - RS_SLICE_PAD &&
-          ceil_div(nchunks, wpg) <= RS_SMAX) {
-        units.push_back(ResidentUnit{0, ncg, 0, nchunks, 0, wpg, 0, 0});
+          ncg * nchunks <= RS_TMAX) {
+        units.push_back(ResidentUnit{0, ncg, 0, nchunks, 0, 0, 0, 0});
         std::fill(nsl.begin(), nsl.end(), static_cast<uint8_t>(1));
         V = v;
         lds_slices = RS_LDS_MAX - fixed1;
@@ -90,14 +86,14 @@ int resident_plan(Ctx* h, Shard& s) {
           ok = false;
           break;
         }
-        if (acc + b > cap || k - k0 >= RS_NWV * RS_SMAX) {
-          units.push_back(ResidentUnit{cg, 1, k0, k, slot++, RS_NWV, 0, 0});
+        if (acc + b > cap || k - k0 >= RS_TMAX) {
+          units.push_back(ResidentUnit{cg, 1, k0, k, slot++, 0, 0, 0});
           k0 = k;
           acc = 0;
         }
         acc += b;
       }
-      units.push_back(ResidentUnit{cg, 1, k0, nchunks, slot++, RS_NWV, 0, 0});
+      units.push_back(ResidentUnit{cg, 1, k0, nchunks, slot++, 0, 0, 0});
       nsl[static_cast<size_t>(cg)] = static_cast<uint8_t>(slot);
     }
     if (ok && static_cast<int>(units.size()) <= std::min(RS_MAX_UNITS, h->cus - 8)) {
@@ -115,9 +111,63 @@ int resident_plan(Ctx* h, Shard& s) {
   int maxslots = 1;
   for (uint8_t x : nsl) maxslots = std::max<int>(maxslots, x);
 
+  // pieces: the steps of a column group's slices dealt out to its waves in equal shares (the dense
+  // slices of an inlier block are chains ten times as long as the others: cut, they end together)
+  std::vector<uint32_t> pieces(units.size() * RS_NWV * RS_PMAX, 0u);
+  std::vector<uint8_t> npieces(units.size() * RS_NWV, 0), wave_cg(units.size() * RS_NWV, 255);
+  for (size_t ui = 0; ui < units.size(); ++ui) {
+    const ResidentUnit& U = units[ui];
+    // waves to column groups in proportion to their steps (every group at least one)
+    int T[RS_NWV] = {0}, nw[RS_NWV] = {0};
+    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
+      const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
+      for (int k = U.k0; k < U.k1; ++k) T[cgl] += static_cast<int>(lrow[k] & 255u);
+      nw[cgl] = 1;
+    }
+    for (int spare = RS_NWV - U.ncgs; spare > 0; --spare) {
+      int best = 0;
+      for (int cgl = 1; cgl < U.ncgs; ++cgl)
+        if (static_cast<int64_t>(T[cgl]) * nw[best] > static_cast<int64_t>(T[best]) * nw[cgl]) best = cgl;
+      ++nw[best];
+    }
+    int wave = 0;
+    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
+      const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
+      const int target = std::max(1, static_cast<int>(ceil_div(T[cgl], nw[cgl])));
+      int kcur = U.k0, qcur = 0;
+      for (int sub = 0; sub < nw[cgl]; ++sub, ++wave) {
+        const size_t wv = ui * RS_NWV + static_cast<size_t>(wave);
+        wave_cg[wv] = static_cast<uint8_t>(cgl);
+        int rem = (sub == nw[cgl] - 1) ? (1 << 30) : target, n = 0;
+        while (rem > 0 && kcur < U.k1) {
+          const int mq = static_cast<int>(lrow[kcur] & 255u);
+          if (qcur >= mq) {
+            ++kcur;
+            qcur = 0;
+            continue;
+          }
+          if (n == RS_PMAX) {
+            if (sub == nw[cgl] - 1) return 0;  // does not fit the piece lists: streaming launches
+            break;
+          }
+          const int take = std::min(rem, mq - qcur);
+          pieces[wv * RS_PMAX + n++] = static_cast<uint32_t>(kcur - U.k0) | (static_cast<uint32_t>(qcur) << 8) |
+                                       (static_cast<uint32_t>(qcur + take) << 16);
+          qcur += take;
+          rem -= take;
+        }
+        npieces[wv] = static_cast<uint8_t>(n);
+      }
+    }
+  }
+
   HIPCHK(hipSetDevice(s.device));
   // plan in mapped pinned memory: the kernel reads it through the bus once, nothing is copied
-  const size_t plan_bytes = units.size() * sizeof(ResidentUnit) + static_cast<size_t>(ncg) + 64;
+  const size_t off_nsl = units.size() * sizeof(ResidentUnit);
+  const size_t off_np = off_nsl + static_cast<size_t>(round_up(ncg, 16));
+  const size_t off_wc = off_np + static_cast<size_t>(round_up(static_cast<int64_t>(npieces.size()), 16));
+  const size_t off_pc = off_wc + static_cast<size_t>(round_up(static_cast<int64_t>(wave_cg.size()), 16));
+  const size_t plan_bytes = off_pc + pieces.size() * sizeof(uint32_t) + 64;
   if (plan_bytes > r.host_plan_cap) {
     if (r.host_plan) hipHostFree(r.host_plan);
     r.host_plan = nullptr;
@@ -128,7 +178,13 @@ int resident_plan(Ctx* h, Shard& s) {
     r.host_plan_cap = plan_bytes + 4096;
   }
   std::memcpy(r.host_plan, units.data(), units.size() * sizeof(ResidentUnit));
-  std::memcpy(r.host_plan + units.size() * sizeof(ResidentUnit), nsl.data(), static_cast<size_t>(ncg));
+  std::memcpy(r.host_plan + off_nsl, nsl.data(), static_cast<size_t>(ncg));
+  std::memcpy(r.host_plan + off_np, npieces.data(), npieces.size());
+  std::memcpy(r.host_plan + off_wc, wave_cg.data(), wave_cg.size());
+  r.off_wc = off_wc;
+  std::memcpy(r.host_plan + off_pc, pieces.data(), pieces.size() * sizeof(uint32_t));
+  r.off_np = off_np;
+  r.off_pc = off_pc;
   std::atomic_thread_fence(std::memory_order_seq_cst);
   const size_t xb_bytes = 2ull * maxslots * (V + 1) * static_cast<size_t>(mp) * 2 * sizeof(unsigned long long);
   if (xb_bytes > r.xb_cap) {
@@ -142,8 +198,8 @@ int resident_plan(Ctx* h, Shard& s) {
     if (r.flags) HIPCHK(hipFree(r.flags));
     r.flags = nullptr;
     r.flags_cap = units.size() + 64;
-    HIPCHK(hipMalloc(&r.flags, (r.flags_cap + 1) * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(r.flags, 0, (r.flags_cap + 1) * sizeof(unsigned long long), s.stream));
+    HIPCHK(hipMalloc(&r.flags, (r.flags_cap + 4) * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(r.flags, 0, (r.flags_cap + 4) * sizeof(unsigned long long), s.stream));
   }
   r.V = V;
   r.E = E;
@@ -157,6 +213,7 @@ int resident_plan(Ctx* h, Shard& s) {
 
 template <typename VT, int V, int E>
 int resident_launch_t(Ctx* h, Shard& s, const ResidentArgs& a) {
+  const unsigned grid = static_cast<unsigned>(a.xcd_mode ? 8 * a.nunits : a.nunits);
   Resident& r = h->res;
   auto kern = k_solve_resident<VT, V, E>;
   static bool attr_set[64] = {};  // per instantiation and device
@@ -180,7 +237,7 @@ int resident_launch_t(Ctx* h, Shard& s, const ResidentArgs& a) {
     }
     attr_set[dv] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(r.nunits)), dim3(RS_NT), r.lds_total, s.stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(RS_NT), r.lds_total, s.stream, a);
   if (const hipError_t e = hipGetLastError(); e != hipSuccess) {  // refused: the streaming launches take over
     if (rs_debug()) std::fprintf(stderr, "[resident] launch failed: %s\n", hipGetErrorString(e));
     return 1;
@@ -218,6 +275,9 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   a.units = reinterpret_cast<const ResidentUnit*>(r.host_plan_dev);
   a.nunits = r.nunits;
   a.nslots_of_cg = r.host_plan_dev + static_cast<size_t>(r.nunits) * sizeof(ResidentUnit);
+  a.npieces = r.host_plan_dev + r.off_np;
+  a.wave_cg = r.host_plan_dev + r.off_wc;
+  a.pieces = reinterpret_cast<const uint32_t*>(r.host_plan_dev + r.off_pc);
   a.maxslots = r.maxslots;
   a.m = h->m;
   a.mp = h->mp;
@@ -235,41 +295,57 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   a.shared = s.shared;
   a.stamps = h->stamps_dev;
   a.timeout_ticks = 50000000ll;  // 0.5 s on the 100 MHz wall clock
-  std::memset(h->mirror, 0, sizeof(HostMirror));
-  std::atomic_thread_fence(std::memory_order_seq_cst);
-  int lr = 1;
-  dispatch_vt(h, [&](auto tag) {
-    using VT = decltype(tag);
-    lr = resident_launch_v<VT>(h, s, a);
-  });
-  if (lr != 0) {
-    if (rs_debug()) std::fprintf(stderr, "[resident] launch refused (V=%d E=%d)\n", r.V, r.E);
-    r.failed = true;
-    return 0;
-  }
+  a.ctrs = r.flags + r.flags_cap + 1;
+  a.home = 0;
+  // One-XCD mode: with at most 28 units (an XCD has 32 CUs) the launch is 8 x units workgroups and the
+  // ones on XCD 0 do the work, exchanging through their common L2 (per pass ~2.5 us less). Refused
+  // once (the hardware did not put enough workgroups there), it is not tried again.
+  static const bool xcd_env_off = [] {
+    const char* e = std::getenv("CLIPPER_HIP_RESIDENT_XCD");
+    return e && std::atoi(e) == 0;
+  }();
   volatile HostMirror* hm = h->mirror;
-  uint64_t spins = 0;
-  bool finished = true;
-  while (!hm->done) {
-    if ((++spins & 0x3fff) == 0) {
-      hipError_t q = hipStreamQuery(s.stream);
-      if (q != hipSuccess && q != hipErrorNotReady)
-        return fail(CLIPPER_HIP_E_HIP, "resident solver failed: %s", hipGetErrorString(q));
-      if (q == hipSuccess && !hm->done) {  // the launch is over and did not finish the solve
-        finished = false;
-        break;
+  for (int attempt = 0;; ++attempt) {
+    a.xcd_mode = (!r.xcd_off && !xcd_env_off && r.nunits >= 2 && r.nunits <= 28) ? 1 : 0;
+    a.epoch0 = r.epoch;
+    std::memset(h->mirror, 0, sizeof(HostMirror));
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    int lr = 1;
+    dispatch_vt(h, [&](auto tag) {
+      using VT = decltype(tag);
+      lr = resident_launch_v<VT>(h, s, a);
+    });
+    if (lr != 0) {
+      if (rs_debug()) std::fprintf(stderr, "[resident] launch refused (V=%d E=%d)\n", r.V, r.E);
+      r.failed = true;
+      return 0;
+    }
+    uint64_t spins = 0;
+    bool finished = true;
+    while (!hm->done) {
+      if ((++spins & 0x3fff) == 0) {
+        hipError_t q = hipStreamQuery(s.stream);
+        if (q != hipSuccess && q != hipErrorNotReady)
+          return fail(CLIPPER_HIP_E_HIP, "resident solver failed: %s", hipGetErrorString(q));
+        if (q == hipSuccess && !hm->done) {  // the launch is over and did not finish the solve
+          finished = false;
+          break;
+        }
       }
     }
-  }
-  if (!finished) {
+    if (finished) break;
     uint32_t err = 0;
     HIPCHK(hipMemcpy(&err, a.err, sizeof(err), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(a.err, 0, sizeof(uint32_t)));
-    r.failed = true;  // until the next build
+    HIPCHK(hipMemset(r.flags + r.flags_cap, 0, 4 * sizeof(unsigned long long)));  // error word, counters
     HIPCHK(hipMemset(r.xb, 0, r.xb_cap));  // granules of the abandoned solve
-    r.last_error = static_cast<int>(err);
-    if (rs_debug()) std::fprintf(stderr, "[resident] gave up: error %u\n", err);
     r.epoch += 1ull << 20;
+    r.last_error = static_cast<int>(err);
+    if (rs_debug()) std::fprintf(stderr, "[resident] gave up: error %u (one-XCD mode %d)\n", err, a.xcd_mode);
+    if (err == RS_ERR_PLAN && a.xcd_mode && attempt == 0) {
+      r.xcd_off = true;  // placement-free mode from now on
+      continue;
+    }
+    r.failed = true;  // until the next build
     return 0;
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -281,6 +357,8 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   fin.ubp = 0;
   fin.ubv = 0;
   r.epoch += static_cast<unsigned long long>(hm->iters) + 8ull;
+  if (rs_debug()) std::fprintf(stderr, "[resident] solved: units=%d one-XCD mode=%d passes=%lld\n", r.nunits, a.xcd_mode,
+                               static_cast<long long>(fin.n_passes));
   ran = true;
   return 0;
 }

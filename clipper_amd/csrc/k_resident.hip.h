@@ -37,14 +37,15 @@ namespace clipper_hip {
 // ------------------------------------------------------------------------------------------
 constexpr int RS_NT = 512;           // threads per workgroup (8 waves, two per SIMD: 256 VGPRs each)
 constexpr int RS_NWV = RS_NT / 64;   // waves
-constexpr int RS_SMAX = 8;           // slices a wave holds at most
+constexpr int RS_TMAX = 64;          // slices a unit holds at most
+constexpr int RS_PMAX = 12;          // pieces (slice, step range) a wave works on at most
 constexpr int RS_MAXE = 4;           // elements per thread at most (m <= 2048)
 
 struct ResidentUnit {
   int cg0, ncgs;  // column groups [cg0, cg0 + ncgs)
   int k0, k1;     // chunks [k0, k1)
   int slot;       // which of the partial-sum slots of its columns this unit fills
-  int wpg;        // waves per column group (power of two, wpg * pow2(ncgs) = RS_NWV)
+  int wpg;        // (unused: the waves of a column group are listed in ResidentArgs::wave_cg)
   int pad0, pad1;
 };
 
@@ -53,6 +54,12 @@ struct ResidentArgs {
   const ResidentUnit* units;
   int nunits;
   const uint8_t* nslots_of_cg;  // [ncg] slots to add for a column of the group
+  // what every wave works on: pieces[(unit * RS_NWV + wave) * RS_PMAX + j] = chunk - k0 | q0 << 8 | q1 << 16
+  // (steps [q0, q1) of that slice of the wave's column group), npieces[unit * RS_NWV + wave] of them —
+  // the planner cuts the long step chains of dense slices so that the waves of a group end together
+  const uint32_t* pieces;
+  const uint8_t* npieces;
+  const uint8_t* wave_cg;       // [unit * RS_NWV + wave] which column group of the unit the wave works for (255: none)
   int maxslots;
   int64_t m, mp;
   SolverParams prm;
@@ -67,6 +74,12 @@ struct ResidentArgs {
   double* host_u;                // pinned (may be null)
   HostMirror* host;              // pinned (may be null)
   SolveShared* shared;
+  // one-XCD mode (speed only, verified at run time): the launch is 8 x nunits workgroups, the ones
+  // the hardware put on XCD `home` claim the units (ctrs[0]) and exchange through THEIR L2 — plain
+  // stores, L1-bypassing loads, no trip to memory; ctrs[1] counts arrivals, the last one checks that
+  // every unit was claimed (else RS_ERR_PLAN: the host launches again in the placement-free mode)
+  int xcd_mode, home;
+  unsigned long long* ctrs;      // [2], zero between launches
   long long* stamps;             // measurement only (may be null): unit 0, [pass][8] wall-clock stamps
   long long timeout_ticks;       // longest wait for the other workgroups' flags, 100 MHz wall clock
 };
@@ -83,7 +96,7 @@ __host__ __device__ constexpr uint32_t rs_y_bytes(int V, int64_t mp, bool single
   return single ? static_cast<uint32_t>(mp) * (V + 1) * 8u : 0u;
 }
 constexpr uint32_t RS_RED_BYTES = 2 * RS_NWV * 16 * 8;       // block_reduce scratch (N <= 16), twice
-constexpr uint32_t RS_TAB_BYTES = RS_NWV * RS_SMAX * 4 + 64; // slice offsets + a few words
+constexpr uint32_t RS_TAB_BYTES = RS_TMAX * 4 + 64;          // slice offsets + a few words
 constexpr uint32_t RS_SLICE_PAD = 2048;                       // a load front may run past the last slice
 
 __device__ __forceinline__ unsigned long long rs_ld_flag(const unsigned long long* p) {
@@ -96,23 +109,30 @@ __device__ __forceinline__ void rs_st_sc1(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// The slices of this wave against the X table: acc[0] = a, acc[1..V-1] = g_v, acc[V] = b
-// (clipper.cpp:238-241 with w = M + d C folded per entry, see k_gemv.hip.h).
+// The pieces of this wave against the X table: acc[0] = a, acc[1..V-1] = g_v, acc[V] = b
+// (clipper.cpp:238-241 with w = M + d C folded per entry, see k_gemv.hip.h). `toff` = LDS offsets of
+// the slices of the wave's column group (by chunk - k0), `pc` = this lane's copy of piece `lane`.
 template <typename VT, int V>
-__device__ __forceinline__ void rs_wave_pass(const uint8_t* sl, const uint32_t* soff, int nsl,
-                                             int kfirst, int kstride, const double* Xt, double d,
-                                             double (&acc)[V + 1]) {
+__device__ __forceinline__ void rs_wave_pass(const uint8_t* sl, const uint32_t* toff, uint32_t pc, int np,
+                                             int k0, const double* Xt, double d, double (&acc)[V + 1]) {
   constexpr int QB = 4 * static_cast<int>(sizeof(VT));
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int v = 0; v <= V; ++v) acc[v] = 0.0;
-  for (int j = 0; j < nsl; ++j) {
-    const uint8_t* sp = sl + soff[j];
+  for (int j = 0; j < np; ++j) {
+    const uint32_t piece = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pc), j));
+    const int kl = static_cast<int>(piece & 255u), q0 = static_cast<int>((piece >> 8) & 255u);
+    const uint8_t* sp = sl + toff[kl];
     const int maxq = __builtin_amdgcn_readfirstlane(
         static_cast<int>(reinterpret_cast<const uint32_t*>(sp)[1]));
+    const int q1 = min(static_cast<int>((piece >> 16) & 255u), maxq);
     const int tot = sp[16 + lane];
     const uint8_t* fb = sp + 16 + 64 + sl_so_bytes(maxq);
-    const double* xs = Xt + static_cast<int64_t>(kfirst + j * kstride) * SL_SUB * V;
+    for (int q = 0; q < q0; ++q) {  // where step q0 starts: the steps before it, by their lane counts
+      const int cnt = __builtin_amdgcn_readfirstlane(__popcll(__ballot(q < tot)));
+      fb += cnt * QB + ((cnt * 4 + 15) & ~15);
+    }
+    const double* xs = Xt + static_cast<int64_t>(k0 + kl) * SL_SUB * V;
     // one step ahead: every lane loads (an idle lane the step's first quad, a step past the end the
     // bytes behind the slice), so that the loads of step q + 1 fly while step q is multiplied
     SliceQuad<VT> cur, nxt;
@@ -127,7 +147,7 @@ __device__ __forceinline__ void rs_wave_pass(const uint8_t* sl, const uint32_t* 
       fb += cnt * QB + ((cnt * 4 + 15) & ~15);
     };
     auto mult = [&](int q, const SliceQuad<VT>& vq, uint32_t rq) {
-      if (q < tot) {
+      if (q < tot && q < q1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const VT mf = vq.v[e];
@@ -159,9 +179,9 @@ __device__ __forceinline__ void rs_wave_pass(const uint8_t* sl, const uint32_t* 
     // two steps per turn, the quads of the next two requested before these two are multiplied
     SliceQuad<VT> nx2, nx3;
     uint32_t r2 = 0, r3 = 0;
-    issue(0, cur, rcur);
-    issue(1, nxt, rnxt);
-    for (int q = 0; q < maxq; q += 2) {
+    issue(q0, cur, rcur);
+    issue(q0 + 1, nxt, rnxt);
+    for (int q = q0; q < q1; q += 2) {
       issue(q + 2, nx2, r2);
       issue(q + 3, nx3, r3);
       mult(q, cur, rcur);
@@ -194,53 +214,84 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
   double* red = reinterpret_cast<double*>(rs_lds + off);
   double* red2 = red + RS_NWV * 16;  // the window's norm sums (read after the pass)
   off += RS_RED_BYTES;
-  uint32_t* tab = reinterpret_cast<uint32_t*>(rs_lds + off);  // [16][RS_SMAX] offsets, then words
-  uint32_t* words = tab + RS_NWV * RS_SMAX;                   // [0..15] wave totals
+  uint32_t* tab = reinterpret_cast<uint32_t*>(rs_lds + off);  // [RS_TMAX] slice offsets, then words
+  uint32_t* words = tab + RS_TMAX;                            // [0..15] a few words
   off += RS_TAB_BYTES;
   uint8_t* sl = rs_lds + off;
 
   // ---- this workgroup's unit; its slices -> LDS ----------------------------------------------
   const long long ts0 = A.stamps ? wall_clock64() : 0;
-  const ResidentUnit U = A.units[blockIdx.x];
-  const int cgl = wave / U.wpg, sub = wave - cgl * U.wpg;
-  const int cg = U.cg0 + cgl;
-  const bool has_cg = cgl < U.ncgs && cg < A.M.ncg;
-  int nsl = 0;
-  if (has_cg)
-    for (int k = U.k0 + sub; k < U.k1; k += U.wpg) ++nsl;
-  const uint64_t* pre_row = A.M.Pre + static_cast<int64_t>(has_cg ? cg : 0) * A.M.nchunks;
-  uint32_t mybytes = 0;
-  for (int j = 0; j < nsl; ++j) {
-    const uint8_t* src = A.M.data + 16 * pre_row[U.k0 + sub + j * U.wpg];
-    mybytes += reinterpret_cast<const uint32_t*>(src)[2];
+  int unit = blockIdx.x;
+  if (A.xcd_mode) {
+    if (tid == 0) {
+      // HW_REG_XCC_ID (id 20), bits [3:0]: which XCD this workgroup runs on
+      const int xcc = static_cast<int>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) & 15;
+      long long idx = -1;
+      if (xcc == A.home)
+        idx = static_cast<long long>(__hip_atomic_fetch_add(A.ctrs, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the claim before the arrival
+      const unsigned long long arrived =
+          __hip_atomic_fetch_add(A.ctrs + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+      if (arrived == gridDim.x) {  // everybody has claimed or passed: were all units taken?
+        const unsigned long long claimed = __hip_atomic_load(A.ctrs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (claimed < static_cast<unsigned long long>(A.nunits))
+          __hip_atomic_store(A.err, static_cast<uint32_t>(RS_ERR_PLAN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.ctrs, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.ctrs + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      words[RS_NWV] = (idx >= 0 && idx < A.nunits) ? static_cast<uint32_t>(idx) : 0xffffffffu;
+    }
+    __syncthreads();
+    const uint32_t got = words[RS_NWV];
+    if (got == 0xffffffffu) return;  // not on the home XCD, or more workgroups there than units
+    unit = static_cast<int>(got);
+    __syncthreads();
   }
-  if (lane == 0) words[wave] = mybytes;
-  __syncthreads();
-  uint32_t base = 0, total = 0;
+  const ResidentUnit U = A.units[unit];
+  // the unit's wave -> column group map (8 bytes), kept by every thread for the sums over waves
+  const unsigned long long wcg = *reinterpret_cast<const unsigned long long*>(A.wave_cg + static_cast<int64_t>(unit) * RS_NWV);
+  const int cgl = static_cast<int>((wcg >> (8 * wave)) & 255ull);
+  const bool has_cg = cgl < U.ncgs && U.cg0 + cgl < A.M.ncg;
+  const int S = U.k1 - U.k0;           // slices per column group of the unit
+  const int nslices = U.ncgs * S;      // local slice t = cgl * S + (chunk - k0)
+  // sizes (thread t reads the header of slice t), offsets (one wave scans them), copy (wave w takes
+  // the slices t = w, w + 8, ...)
+  uint32_t bytes_t = 0;
+  if (tid < nslices && nslices <= RS_TMAX) {
+    const int tc = tid / S, tk = tid - tc * S;
+    const uint8_t* src_t = A.M.data + 16 * A.M.Pre[static_cast<int64_t>(U.cg0 + tc) * A.M.nchunks + U.k0 + tk];
+    bytes_t = reinterpret_cast<const uint32_t*>(src_t)[2];
+  }
+  if (wave == 0) {
+    uint32_t inc = bytes_t;
 #pragma unroll
-  for (int w = 0; w < RS_NWV; ++w) {
-    const uint32_t b = words[w];
-    if (w < wave) base += b;
-    total += b;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t2 = __shfl_up(inc, o);
+      if (lane >= o) inc += t2;
+    }
+    tab[lane] = inc - bytes_t;
+    if (lane == 63) words[0] = inc;
   }
-  const bool bad_plan = total + RS_SLICE_PAD > A.lds_slices || nsl > RS_SMAX;
+  __syncthreads();
+  const uint32_t total = words[0];
+  const bool bad_plan = total + RS_SLICE_PAD > A.lds_slices || nslices > RS_TMAX;
   if (__syncthreads_or(bad_plan ? 1 : 0)) {
     if (tid == 0) __hip_atomic_store(A.err, static_cast<uint32_t>(RS_ERR_LDS), __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  {
-    uint32_t o = base;
-    for (int j = 0; j < nsl; ++j) {
-      const uint8_t* src = A.M.data + 16 * pre_row[U.k0 + sub + j * U.wpg];
-      const uint32_t nb = reinterpret_cast<const uint32_t*>(src)[2];
-      if (lane == 0) tab[wave * RS_SMAX + j] = o;
-      for (uint32_t b = lane * 16; b < nb; b += 64 * 16)
-        *reinterpret_cast<uint4*>(sl + o + b) = *reinterpret_cast<const uint4*>(src + b);
-      o += nb;
-    }
+  for (int t = wave; t < nslices; t += RS_NWV) {
+    const int tc = t / S, tk = t - tc * S;
+    const uint8_t* src = A.M.data + 16 * A.M.Pre[static_cast<int64_t>(U.cg0 + tc) * A.M.nchunks + U.k0 + tk];
+    const uint32_t nb = reinterpret_cast<const uint32_t*>(src)[2];
+    const uint32_t o = tab[t];
+    for (uint32_t b = lane * 16; b < nb; b += 64 * 16)
+      *reinterpret_cast<uint4*>(sl + o + b) = *reinterpret_cast<const uint4*>(src + b);
   }
-  const uint32_t* soff = tab + wave * RS_SMAX;
+  const uint32_t* toff = tab + (has_cg ? cgl * S : 0);
+  // this wave's pieces: lane j keeps piece j
+  const int np = has_cg ? A.npieces[unit * RS_NWV + wave] : 0;
+  const uint32_t pc = (lane < RS_PMAX) ? A.pieces[(static_cast<int64_t>(unit) * RS_NWV + wave) * RS_PMAX + lane] : 0u;
 
   // ---- per-thread elements -----------------------------------------------------------------
   bool valid[E];
@@ -259,7 +310,7 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
   unsigned long long epoch = A.epoch0;
   int stamp_row = 0;
   auto stamp = [&](int col) {
-    if (A.stamps && blockIdx.x == 0 && tid == 0 && stamp_row < 500) A.stamps[stamp_row * 8 + col] = wall_clock64();
+    if (A.stamps && unit == 0 && tid == 0 && stamp_row < 500) A.stamps[stamp_row * 8 + col] = wall_clock64();
   };
 
   // One pass: the X table (raw candidates of this thread's elements) -> y[e][0..V] for them.
@@ -276,7 +327,7 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
     }
     __syncthreads();
     double acc[NS];
-    rs_wave_pass<VT, V>(sl, soff, nsl, U.k0 + sub, U.wpg, Xt, d, acc);
+    rs_wave_pass<VT, V>(sl, toff, pc, np, U.k0, Xt, d, acc);
     __syncthreads();  // the X table is dead: its memory becomes the reduce scratch
     stamp(2);
 #pragma unroll
@@ -289,8 +340,10 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
     const int nout = U.ncgs * 64 * NS;
     for (int o = tid; o < nout; o += RS_NT) {
       const int c = o & 63, v = (o >> 6) % NS, gl = o / (64 * NS);
-      double sum = scr[((gl * U.wpg) * NS + v) * 64 + c];
-      for (int w = 1; w < U.wpg; ++w) sum += scr[((gl * U.wpg + w) * NS + v) * 64 + c];
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < RS_NWV; ++w)
+        if (static_cast<int>((wcg >> (8 * w)) & 255ull) == gl) sum += scr[(w * NS + v) * 64 + c];
       const int64_t col = static_cast<int64_t>(U.cg0 + gl) * 64 + c;
       if (col < mp) {
         if (single) {
@@ -298,8 +351,13 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
         } else {  // two self-describing granules {epoch, half of the value}: the data IS the flag
           const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(sum));
           unsigned long long* gq = A.xb + ((((static_cast<int64_t>(par) * A.maxslots + U.slot) * NS + v) * mp + col) << 1);
-          __hip_atomic_store(gq, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(gq + 1, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (A.xcd_mode) {  // every reader sits behind the same L2: the granules stay there
+            __hip_atomic_store(gq, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(gq + 1, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {           // write-through: readers may sit behind another XCD's L2
+            __hip_atomic_store(gq, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gq + 1, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
@@ -377,7 +435,7 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
       return false;
     }
     stamp(4);
-    if (A.stamps && blockIdx.x == 0 && tid == 0 && stamp_row < 500)
+    if (A.stamps && unit == 0 && tid == 0 && stamp_row < 500)
       A.stamps[stamp_row * 8 + 5] = wall_clock64() + (y[0][0] > 1e300 ? 1 : 0);
     return true;
   };
@@ -619,7 +677,7 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
 
   // ---- the end: unit 0 hands the result over ---------------------------------------------------
   const long long ts3 = A.stamps ? wall_clock64() : 0;
-  if (blockIdx.x == 0) {
+  if (unit == 0) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int64_t i = tid + static_cast<int64_t>(e) * RS_NT;
