@@ -30,6 +30,9 @@ namespace clipper_hip {
 //     on where a workgroup runs. Spins are bounded by the wall clock; a time-out sets `err`
 //     and every workgroup leaves (the host then runs the streaming solver).
 //   * One workgroup (P = 1: everything fits one LDS) exchanges nothing at all.
+//   * Inside a unit the steps of a column group's slices are dealt out to its waves in equal
+//     PIECES (slice, step range): the chains of the dense inlier slices end with the others.
+//   * One-XCD mode (speed only): see ResidentArgs::xcd_mode.
 //
 // The line-search WINDOW is kept (V candidates per pass, walked in the reference's order): here it
 // saves exchanges instead of bytes. Trial sequence, per-trial arithmetic and results are those of
