@@ -297,13 +297,15 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   a.timeout_ticks = 50000000ll;  // 0.5 s on the 100 MHz wall clock
   a.ctrs = r.flags + r.flags_cap + 1;
   a.home = 0;
+  // test knobs: a home XCD that does not exist (the one-XCD launch must be refused and repeated in
+  // the placement-free mode), a time-out of a few ticks (the streaming launches must take over)
+  if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT_HOME")) a.home = std::atoi(e);
+  if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT_TIMEOUT_TICKS")) a.timeout_ticks = std::atoll(e);
   // One-XCD mode: with at most 28 units (an XCD has 32 CUs) the launch is 8 x units workgroups and the
   // ones on XCD 0 do the work, exchanging through their common L2 (per pass ~2.5 us less). Refused
   // once (the hardware did not put enough workgroups there), it is not tried again.
-  static const bool xcd_env_off = [] {
-    const char* e = std::getenv("CLIPPER_HIP_RESIDENT_XCD");
-    return e && std::atoi(e) == 0;
-  }();
+  const char* xe = std::getenv("CLIPPER_HIP_RESIDENT_XCD");
+  const bool xcd_env_off = xe && std::atoi(xe) == 0;
   volatile HostMirror* hm = h->mirror;
   for (int attempt = 0;; ++attempt) {
     a.xcd_mode = (!r.xcd_off && !xcd_env_off && r.nunits >= 2 && r.nunits <= 28) ? 1 : 0;

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
           }
         }
         if (__all(ok)) break;
-        if ((spins & 63u) == 63u) {
+        if ((spins & 63u) == 63u || A.timeout_ticks < 0) {  // (negative: a test's way to force the time-out)
           const bool late = wall_clock64() - t_poll > A.timeout_ticks;
           const uint32_t e2 = __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (late || e2 != 0) {

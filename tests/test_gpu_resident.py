@@ -189,3 +189,33 @@ def test_resident_pointnormal_and_sparse_setter():
     for g, _ in res:
         g.close()
     g2.close()
+
+
+def test_resident_fallbacks(monkeypatch):
+    """The two ways out of the resident solver: a one-XCD launch whose units are not all claimed is
+    repeated in the placement-free mode (still one launch), a time-out hands the solve to the
+    streaming launches; the answer is the same every way."""
+    p = synth.make_euclidean_problem(1000, 0.85, seed=31)
+    g0, s0 = _solve(p, abi.STORE_F32_CSC, 1)
+    monkeypatch.setenv("CLIPPER_HIP_RESIDENT_HOME", "11")          # no such XCD
+    g1, s1 = _solve(p, abi.STORE_F32_CSC, 0)
+    assert g1.last_solver == 1
+    s1b = g1.solve(p.u0)                                            # the mode is not tried again
+    monkeypatch.delenv("CLIPPER_HIP_RESIDENT_HOME")
+    monkeypatch.setenv("CLIPPER_HIP_RESIDENT_XCD", "0")             # placement-free from the start
+    g2, s2 = _solve(p, abi.STORE_F32_CSC, 0)
+    assert g2.last_solver == 1
+    monkeypatch.delenv("CLIPPER_HIP_RESIDENT_XCD")
+    monkeypatch.setenv("CLIPPER_HIP_RESIDENT_TIMEOUT_TICKS", "-1")  # every wait is "late"
+    g3, s3 = _solve(p, abi.STORE_F32_CSC, 0)
+    assert g3.last_solver == 0
+    monkeypatch.delenv("CLIPPER_HIP_RESIDENT_TIMEOUT_TICKS")
+    s3b = g3.solve(p.u0)                                            # ... and stays with them for this matrix
+    assert g3.last_solver == 0
+    g3.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV) # a new build: resident again
+    s3c = g3.solve(p.u0)
+    assert g3.last_solver == 1
+    for s in (s1, s1b, s2, s3, s3b, s3c):
+        _assert_same(s, s0)
+    for g in (g0, g1, g2, g3):
+        g.close()
