@@ -17,7 +17,7 @@ void resident_free(Ctx* h) {
   Resident& r = h->res;
   if (r.host_plan) hipHostFree(r.host_plan);
   if (r.xb) hipFree(r.xb);
-  if (r.flags) hipFree(r.flags);
+  if (r.ctl) hipFree(r.ctl);
   const int vf = r.V_forced;
   const bool xo = r.xcd_off;
   r = Resident{};
@@ -194,12 +194,9 @@ int resident_plan(Ctx* h, Shard& s) {
     r.xb_cap = xb_bytes;
     HIPCHK(hipMemsetAsync(r.xb, 0, xb_bytes, s.stream));  // no granule may carry a future epoch
   }
-  if (units.size() + 1 > r.flags_cap) {
-    if (r.flags) HIPCHK(hipFree(r.flags));
-    r.flags = nullptr;
-    r.flags_cap = units.size() + 64;
-    HIPCHK(hipMalloc(&r.flags, (r.flags_cap + 4) * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(r.flags, 0, (r.flags_cap + 4) * sizeof(unsigned long long), s.stream));
+  if (!r.ctl) {  // the error word and the two counters of the one-XCD mode
+    HIPCHK(hipMalloc(&r.ctl, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(r.ctl, 0, 4 * sizeof(unsigned long long), s.stream));
   }
   r.V = V;
   r.E = E;
@@ -285,9 +282,8 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   a.rescale = rescale ? 1 : 0;
   a.u0 = s.u0;
   a.xb = r.xb;
-  a.flags = r.flags;
   a.epoch0 = r.epoch;
-  a.err = reinterpret_cast<uint32_t*>(r.flags + r.flags_cap);
+  a.err = reinterpret_cast<uint32_t*>(r.ctl);
   a.lds_slices = r.lds_slices;
   a.u_dev = s.pt;  // point slot (0, 0), array u
   a.host_u = h->u_pinned_dev;
@@ -295,7 +291,7 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   a.shared = s.shared;
   a.stamps = h->stamps_dev;
   a.timeout_ticks = 50000000ll;  // 0.5 s on the 100 MHz wall clock
-  a.ctrs = r.flags + r.flags_cap + 1;
+  a.ctrs = r.ctl + 1;
   a.home = 0;
   // test knobs: a home XCD that does not exist (the one-XCD launch must be refused and repeated in
   // the placement-free mode), a time-out of a few ticks (the streaming launches must take over)
@@ -338,7 +334,7 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
     if (finished) break;
     uint32_t err = 0;
     HIPCHK(hipMemcpy(&err, a.err, sizeof(err), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(r.flags + r.flags_cap, 0, 4 * sizeof(unsigned long long)));  // error word, counters
+    HIPCHK(hipMemset(r.ctl, 0, 4 * sizeof(unsigned long long)));  // error word, counters
     HIPCHK(hipMemset(r.xb, 0, r.xb_cap));  // granules of the abandoned solve
     r.epoch += 1ull << 20;
     r.last_error = static_cast<int>(err);

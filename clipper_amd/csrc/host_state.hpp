@@ -153,8 +153,7 @@ struct Resident {
   size_t off_np = 0, off_wc = 0, off_pc = 0;  // where the piece counts / the wave map / the pieces start in the plan
   unsigned long long* xb = nullptr;  // exchange buffer [2][maxslots][V+1][mp][2] (granules)
   size_t xb_cap = 0;
-  unsigned long long* flags = nullptr;  // [flags_cap] epochs, then the error word
-  size_t flags_cap = 0;
+  unsigned long long* ctl = nullptr;  // [4]: the error word, the two counters of the one-XCD mode
   unsigned long long epoch = 0;
   int V_forced = 0;                  // CLIPPER_HIP_RESIDENT_V
   bool xcd_off = false;              // the one-XCD mode was refused once (or CLIPPER_HIP_RESIDENT_XCD=0)

@@ -48,8 +48,7 @@ struct ResidentUnit {
   int cg0, ncgs;  // column groups [cg0, cg0 + ncgs)
   int k0, k1;     // chunks [k0, k1)
   int slot;       // which of the partial-sum slots of its columns this unit fills
-  int wpg;        // (unused: the waves of a column group are listed in ResidentArgs::wave_cg)
-  int pad0, pad1;
+  int pad0, pad1, pad2;
 };
 
 struct ResidentArgs {
@@ -69,7 +68,6 @@ struct ResidentArgs {
   int rescale;
   const double* u0;
   unsigned long long* xb;        // [2][maxslots][V+1][mp][2] granules {epoch << 32 | half of a sum}, zero at allocation
-  unsigned long long* flags;     // (the error word lives behind it)
   unsigned long long epoch0;     // this solve's epochs are epoch0 + 1, epoch0 + 2, ... (low 32 bits = the tags)
   uint32_t* err;                 // 0 | RS_ERR_*
   uint32_t lds_slices;           // bytes of LDS the slices of a unit may take
@@ -102,14 +100,9 @@ constexpr uint32_t RS_RED_BYTES = 2 * RS_NWV * 16 * 8;       // block_reduce scr
 constexpr uint32_t RS_TAB_BYTES = RS_TMAX * 4 + 64;          // slice offsets + a few words
 constexpr uint32_t RS_SLICE_PAD = 2048;                       // a load front may run past the last slice
 
-__device__ __forceinline__ unsigned long long rs_ld_flag(const unsigned long long* p) {
+// a granule as every reader must see it: past this CU's L1 (agent scope, relaxed)
+__device__ __forceinline__ unsigned long long rs_ld_granule(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double rs_ld_sc1(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void rs_st_sc1(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The pieces of this wave against the X table: acc[0] = a, acc[1..V-1] = g_v, acc[V] = b
@@ -400,7 +393,7 @@ __global__ __launch_bounds__(RS_NT) void k_solve_resident(ResidentArgs A) {
 #pragma unroll
             for (int v = 0; v < NS; ++v) {
               const unsigned long long* gq = xb + (((static_cast<int64_t>(sl_) * NS + v) * mp + i) << 1);
-              const unsigned long long g0 = rs_ld_flag(gq), g1 = rs_ld_flag(gq + 1);
+              const unsigned long long g0 = rs_ld_granule(gq), g1 = rs_ld_granule(gq + 1);
               ok = ok && ((g0 ^ tag) >> 32) == 0 && ((g1 ^ tag) >> 32) == 0;
               tv[e][v] = __longlong_as_double(static_cast<long long>((g0 << 32) | (g1 & 0xffffffffull)));
             }
