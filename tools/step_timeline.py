@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One affinity+solve step as the GPU saw it: every kernel and copy of the last step of a
 `rocprofv3 --kernel-trace --memory-copy-trace` run of bench.py, with start offsets and gaps.
-  python tools/step_timeline.py <results.db>"""
+  python tools/step_timeline.py <results.db> [index of the step's fill launch]"""
 import sqlite3
 import sys
 
@@ -19,7 +19,8 @@ def main():
     if len(fills) < 2:
         print("need two steps")
         return
-    i0, i1 = fills[-2], fills[-1]
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else len(fills) - 2   # which step (index of its fill)
+    i0, i1 = fills[k], fills[k + 1]
     while i0 > 0 and ev[i0][0] - ev[i0 - 1][1] < 30000 and not ev[i0 - 1][2].startswith("k_tail") and not ev[i0 - 1][2].startswith("k_gemv"):
         i0 -= 1
     t0 = ev[i0][0]
