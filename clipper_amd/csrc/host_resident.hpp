@@ -20,9 +20,11 @@ void resident_free(Ctx* h) {
   if (r.ctl) hipFree(r.ctl);
   const int vf = r.V_forced;
   const bool xo = r.xcd_off;
+  const int hm = r.home;
   r = Resident{};
   r.V_forced = vf;
   r.xcd_off = xo;
+  r.home = hm;
 }
 
 // upper bound of the bytes of a slice from its directory word (maxq | entries << 8)
@@ -290,13 +292,17 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   a.host = h->mirror_dev;
   a.shared = s.shared;
   a.stamps = h->stamps_dev;
-  a.timeout_ticks = 50000000ll;  // 0.5 s on the 100 MHz wall clock
   a.ctrs = r.ctl + 1;
-  a.home = 0;
+  // contexts take their home XCD in turn, so that concurrent solves of several contexts do not
+  // queue for the 32 CUs of one XCD
+  static std::atomic<int> next_home{0};
+  if (r.home < 0) r.home = next_home.fetch_add(1) & 7;
+  a.home = r.home;
+  long long timeout_override = 0;
   // test knobs: a home XCD that does not exist (the one-XCD launch must be refused and repeated in
   // the placement-free mode), a time-out of a few ticks (the streaming launches must take over)
   if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT_HOME")) a.home = std::atoi(e);
-  if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT_TIMEOUT_TICKS")) a.timeout_ticks = std::atoll(e);
+  if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT_TIMEOUT_TICKS")) timeout_override = std::atoll(e);
   // One-XCD mode: with at most 28 units (an XCD has 32 CUs) the launch is 8 x units workgroups and the
   // ones on XCD 0 do the work, exchanging through their common L2 (per pass ~2.5 us less). Refused
   // once (the hardware did not put enough workgroups there), it is not tried again.
@@ -305,6 +311,9 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   volatile HostMirror* hm = h->mirror;
   for (int attempt = 0;; ++attempt) {
     a.xcd_mode = (!r.xcd_off && !xcd_env_off && r.nunits >= 2 && r.nunits <= 28) ? 1 : 0;
+    // longest wait for another unit's sums on the 100 MHz wall clock: 0.5 s; in the one-XCD mode 5 ms
+    // (its units compete for one XCD's CUs with whatever else runs there: rather launch again)
+    a.timeout_ticks = timeout_override ? timeout_override : (a.xcd_mode ? 500000ll : 50000000ll);
     a.epoch0 = r.epoch;
     std::memset(h->mirror, 0, sizeof(HostMirror));
     std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -339,7 +348,7 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
     r.epoch += 1ull << 20;
     r.last_error = static_cast<int>(err);
     if (rs_debug()) std::fprintf(stderr, "[resident] gave up: error %u (one-XCD mode %d)\n", err, a.xcd_mode);
-    if (err == RS_ERR_PLAN && a.xcd_mode && attempt == 0) {
+    if ((err == RS_ERR_PLAN || err == RS_ERR_TIMEOUT) && a.xcd_mode && attempt == 0 && timeout_override == 0) {
       r.xcd_off = true;  // placement-free mode from now on
       continue;
     }

@@ -157,6 +157,7 @@ struct Resident {
   unsigned long long epoch = 0;
   int V_forced = 0;                  // CLIPPER_HIP_RESIDENT_V
   bool xcd_off = false;              // the one-XCD mode was refused once (or CLIPPER_HIP_RESIDENT_XCD=0)
+  int home = -1;                     // this context's home XCD in that mode
 };
 
 }  // namespace

@@ -20,7 +20,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--threads", type=int, default=1, help="concurrent host threads, each with its own contexts")
     a = ap.parse_args()
+    if a.threads > 1:
+        import threading
+        ts = [threading.Thread(target=worker, args=(a.seconds, a.seed + 1000 * t, f"[thread {t}] ")) for t in range(a.threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    else:
+        worker(a.seconds, a.seed, "")
+
+
+def worker(seconds, seed, tag):
+    class A:
+        pass
+    a = A()
+    a.seconds, a.seed = seconds, seed
     rng = np.random.default_rng(a.seed)
     ctx = {st: (abi.HipClipper(storage=st), abi.HipClipper(storage=st)) for st in (abi.STORE_F32_CSC, abi.STORE_F64_CSC)}
     for gr, gs in ctx.values():
@@ -48,13 +65,13 @@ def main():
                 streamed_by_plan += 1 if first == 0 else 0
             elif gr.last_solver != first:
                 fallbacks += 1
-                print(f"fallback: m={m} rho={rho} storage={st} rep={rep}", flush=True)
+                print(f"{tag}fallback: m={m} rho={rho} storage={st} rep={rep}", flush=True)
             # the bar of the path: the same selected SET, the objective to 1e-6 relative
             ok = (sorted(sr.nodes.tolist()) == sorted(ss.nodes.tolist()) and sr.ifinal == ss.ifinal
                   and abs(sr.score - ss.score) <= 1e-6 * max(1.0, abs(ss.score)))
             if not ok:
                 mismatches += 1
-                print(f"MISMATCH: m={m} rho={rho} storage={st} resident {sr.score!r}/{sr.n_trials}/{len(sr.nodes)} "
+                print(f"{tag}MISMATCH: m={m} rho={rho} storage={st} resident {sr.score!r}/{sr.n_trials}/{len(sr.nodes)} "
                       f"streaming {ss.score!r}/{ss.n_trials}/{len(ss.nodes)}", flush=True)
             # softer observations: the order of the list (near-equal entries of u), the trial count
             order_diff += 0 if sr.nodes.tolist() == ss.nodes.tolist() else 1
@@ -63,7 +80,7 @@ def main():
             max_trial_diff = max(max_trial_diff, dt)
             max_rel = max(max_rel, abs(sr.score - ss.score) / max(1.0, abs(ss.score)))
         n += 1
-    print(f"{n} problems, {solves} solves in {time.time() - t0:.0f} s: {mismatches} mismatches, {fallbacks} fall-backs after a "
+    print(f"{tag}{n} problems, {solves} solves in {time.time() - t0:.0f} s: {mismatches} mismatches, {fallbacks} fall-backs after a "
           f"resident solve, {streamed_by_plan} problems left to the streaming launches by the planner; "
           f"list order differs in {order_diff} solves, trial count in {trial_diff} (by at most {max_trial_diff}), "
           f"largest relative difference of the objective {max_rel:.1e}")
