@@ -378,7 +378,10 @@ __device__ __forceinline__ void slices_by_plan(const SliceView& M, const SliceJo
   }
 }
 
-constexpr int SL_NW = 4;  // waves (= column groups) per workgroup
+#ifndef CLIPPER_SL_NW
+#define CLIPPER_SL_NW 4
+#endif
+constexpr int SL_NW = CLIPPER_SL_NW;  // waves (= column groups) per workgroup
 #ifndef CLIPPER_SL_D
 #define CLIPPER_SL_D 4
 #endif
