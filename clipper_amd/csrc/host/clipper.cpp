@@ -162,12 +162,20 @@ void CLIPPER::setStorage(Storage storage) {
   storage_ = storage;
 }
 
+void CLIPPER::setResidentSolver(bool on) {
+  resident_ = on;
+  if (h_) check(clipper_hip_set_resident(h_, on ? 0 : 1), "set_resident");
+}
+
+bool CLIPPER::lastSolveWasResident() const { return h_ != nullptr && clipper_hip_last_solver(h_) == 1; }
+
 clipper_hip_ctx* CLIPPER::handle() {
   if (!h_) {
     h_ = clipper_hip_create(device_, static_cast<int>(storage_));
     if (!h_)
       throw std::runtime_error(std::string("clipper: cannot create the GPU context: ") +
                                clipper_hip_last_error());
+    if (!resident_) check(clipper_hip_set_resident(h_, 1), "set_resident");
   }
   return h_;
 }

@@ -305,6 +305,8 @@ PYBIND11_MODULE(clipperpy, m) {
       // additions of this build
       .def("set_device", &clipper::CLIPPER::setDevice, "device"_a)
       .def("set_storage", &clipper::CLIPPER::setStorage, "storage"_a)
+      .def("set_resident_solver", &clipper::CLIPPER::setResidentSolver, "on"_a)
+      .def("last_solve_was_resident", &clipper::CLIPPER::lastSolveWasResident)
       .def("get_path_stats", [](const clipper::CLIPPER& c) {
         const auto s = c.getPathStats();
         return py::dict("n_passes"_a = s.n_passes, "n_trials"_a = s.n_trials,

@@ -117,6 +117,10 @@ class CLIPPER {
   // ---- additions of this build -----------------------------------------------------------
   void setDevice(int device);        ///< HIP device ordinal (default 0); before the first call
   void setStorage(Storage storage);  ///< default F32_CSC (compressed; dense fp32 where it does not apply); before the first call
+  /// Problems of up to 2048 associations are solved by ONE launch that keeps M on chip (the resident
+  /// solver); false = always the streaming launches. Same result either way. Any time.
+  void setResidentSolver(bool on);
+  bool lastSolveWasResident() const;  ///< which of the two the last solve() ran on
   struct PathStats {
     long long n_passes = 0, n_trials = 0;
     double affinity_kernel_ms = 0, d = 0;
@@ -132,6 +136,7 @@ class CLIPPER {
   PathStats stats_;
   int device_ = 0;
   Storage storage_ = Storage::F32_CSC;
+  bool resident_ = true;
   clipper_hip_ctx* h_ = nullptr;
 
   clipper_hip_ctx* handle();

@@ -76,6 +76,24 @@ def test_clipperpy_matches_oracle_on_synthetic_problem(clipperpy):
         assert st["n_passes"] <= st["n_trials"] + 3 + s.ifinal
 
 
+def test_clipperpy_resident_solver_switch(clipperpy):
+    """The default storage solves a problem of this size with the resident (one-launch) solver;
+    set_resident_solver(False) sends it to the streaming launches: the same answer."""
+    p = synth.make_euclidean_problem(600, 0.9, seed=8)
+    ip = clipperpy.invariants.EuclideanDistanceParams()
+    ip.sigma, ip.epsilon = 0.015, 0.05
+    res = []
+    for on in (True, False):
+        c = clipperpy.CLIPPER(clipperpy.invariants.EuclideanDistance(ip), clipperpy.Params())
+        c.set_resident_solver(on)
+        c.score_pairwise_consistency(p.D1, p.D2, p.A)
+        c.solve(p.u0)
+        assert c.last_solve_was_resident() == on
+        res.append(c.get_solution())
+    assert list(res[0].nodes) == list(res[1].nodes)
+    assert abs(res[0].score - res[1].score) <= 1e-9 * res[1].score
+
+
 def test_python_custom_invariant_is_scored_on_host_and_solved_on_gpu(clipperpy):
     # the notebook's use case (examples/python/ex4_bunny.ipynb cell 12): a Python subclass
     class PyEuclid(clipperpy.invariants.PairwiseInvariant):
