@@ -774,8 +774,12 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     volatile HostMirror* hm = h->mirror;
     int64_t queued = 0;
     uint64_t spins = 0;
+    static const int run_ahead = [] {  // (measurement knob)
+      const char* e = std::getenv("CLIPPER_HIP_RUN_AHEAD");
+      return e ? std::max(1, std::atoi(e)) : RUN_AHEAD;
+    }();
     while (!hm->done) {
-      if (queued - hm->iters < RUN_AHEAD) {
+      if (queued - hm->iters < run_ahead) {
         if ((rc = enqueue_iteration(h, prm))) return rc;
         ++queued;
         spins = 0;
@@ -784,7 +788,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         hipError_t q = hipStreamQuery(s0.stream);
         if (q != hipSuccess && q != hipErrorNotReady)
           return fail(CLIPPER_HIP_E_HIP, "solver stream failed: %s", hipGetErrorString(q));
-        if (q == hipSuccess && !hm->done && queued - hm->iters >= RUN_AHEAD)
+        if (q == hipSuccess && !hm->done && queued - hm->iters >= run_ahead)
           return fail(CLIPPER_HIP_E_HIP, "solver made no progress (iters %lld of %lld queued)",
                       static_cast<long long>(hm->iters), static_cast<long long>(queued));
       }
