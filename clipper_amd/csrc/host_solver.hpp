@@ -115,7 +115,8 @@ int ensure_problem(Ctx* h, int64_t m) {
   h->m = m;
   h->W = W;
   h->mp = P * W;
-  const int V = h->V_forced ? h->V_forced : (m >= WINDOW_MIN_M ? 6 : (m >= WINDOW4_MIN_M ? 4 : 1));
+  const int64_t six_from = h->compressed ? WINDOW_MIN_M_CSC : WINDOW_MIN_M;
+  const int V = h->V_forced ? h->V_forced : (m >= six_from ? 6 : (m >= WINDOW4_MIN_M ? 4 : 1));
   const bool same = (h->alloc_m == m && h->alloc_W == W && h->V == V);
   h->V = V;
   plan_tiles(h);

@@ -44,7 +44,8 @@ constexpr int gemv_unr(int V, int esize, bool hasc) {
 // line-search candidates per pass: 6 from m = 6000 on, 4 from m = 2000 on, else 1 (an iteration
 // is latency-bound there: at m = 100 and 1k the 10 % fewer passes of a window of 4 cost 10 %
 // more per iteration; at m = 5k it is 20 % fewer for 15 %); CLIPPER_HIP_WINDOW = 1|4|6|8 overrides
-constexpr int64_t WINDOW_MIN_M = 6000;
+constexpr int64_t WINDOW_MIN_M = 6000;       // dense storages: a window of 6 from here on
+constexpr int64_t WINDOW_MIN_M_CSC = 8500;   // slices: measured crossover of the windows of 4 and 6 (profiles/r02e_window_sweep.txt)
 constexpr int64_t WINDOW4_MIN_M = 2000;
 // multi-process: iterations queued between two state snapshots. Up to two batches of no-op
 // iterations (each still holds its all-gather) run past convergence: keep them short. 16 -> 4

@@ -224,7 +224,8 @@ int64_t clipper_hip_distance_based_correspondences(int device, const double* P0,
 /* Line-search window: how many consecutive step sizes alpha, alpha*beta, ... of the
  * backtracking line search (clipper.cpp:234-251) one pass over M evaluates at once. The
  * trial sequence, the accepted trial and the result are those of the reference for every
- * window; only the number of passes over M changes. 0 = automatic (6 for m >= 6000, 4 for m >= 2000, else 1);
+ * window; only the number of passes over M changes. 0 = automatic (6 for m >= 8500 on slices,
+ * m >= 6000 on a dense store; 4 for m >= 2000; else 1);
  * 1, 4, 6 or 8 forces a size (also: environment CLIPPER_HIP_WINDOW). Takes effect at the next
  * affinity build / set_matrix. clipper_hip_window returns the size in use. */
 int clipper_hip_set_window(clipper_hip_t* h, int window);

@@ -185,12 +185,14 @@ def test_column_shards_keep_a_compressed_copy_each(monkeypatch):
 
 @pytest.mark.parametrize("m,rho,seed", [(6500, 0.95, 2)])
 def test_column_shards_window_mode(m, rho, seed):
-    """m >= 6000: the automatic window of 6 candidates per pass on sharded compressed copies."""
+    """The window of 6 candidates per pass (automatic from m = 8500 on the slices) on sharded compressed copies."""
     p = synth.make_euclidean_problem(m, rho, seed=seed)
     one = abi.HipClipper(storage=abi.STORE_F32_CSC)
     one.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    assert one.window == 4   # the automatic choice at this size
     s1 = one.solve(p.u0)
     grp = abi.HipClipper(storage=abi.STORE_F32_CSC, group=[0] * 4)
+    grp.set_window(6)
     grp.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
     assert grp.window == 6 and grp.storage_in_use == abi.STORE_F32_CSC
     s4 = grp.solve(p.u0)
