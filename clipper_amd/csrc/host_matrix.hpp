@@ -301,7 +301,15 @@ int slices_plan(Ctx* h, Shard& s) {
   const uint32_t* L = h->csc_hLq;
   static const double target_env = std::getenv("CLIPPER_HIP_CSC_WGS") ? std::max(1.0, std::atof(std::getenv("CLIPPER_HIP_CSC_WGS"))) : 0.0;
   static const double c0_env = std::getenv("CLIPPER_HIP_CSC_C0") ? std::max(0.0, std::atof(std::getenv("CLIPPER_HIP_CSC_C0"))) : -1.0;
-  const double target = target_env > 0.0 ? target_env : static_cast<double>(h->cus) * 4.0;
+  // workgroups of a pass: four per CU; for small matrices a quarter of the slices — fewer partial-sum
+  // slots for the tail to add — and exactly one per CU when that is close (a second short workgroup on
+  // a few CUs doubles those CUs' time): per iteration 20.4 instead of 22.3 us at m = 3000, 23.0 instead
+  // of 24.4 at m = 4000 (profiles/r02e_window_sweep.txt)
+  double target = target_env;
+  if (target <= 0.0) {
+    const double quarter = static_cast<double>(ncg) * nchunks / 4.0;
+    target = quarter < 1.5 * h->cus ? h->cus : std::min<double>(quarter, 4.0 * h->cus);
+  }
   const double C0 = c0_env >= 0.0 ? c0_env : 2.0;  // what a chunk costs besides its steps (staging, barrier, header), in steps
   // (this runs between the fill and the first pass of every build: buffers are kept, the order is
   // a counting sort)
