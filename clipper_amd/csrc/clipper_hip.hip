@@ -39,6 +39,7 @@
 #include "kernels.hip.h"
 #include "dsd_host.h"
 #include "host_batch.hpp"
+#include "host_plan.hpp"
 
 using namespace clipper_hip;
 

@@ -296,87 +296,15 @@ GroupSource<VT> group_source(const Ctx* h, const Shard& s) {
 // slice — the waves of a workgroup meet at every chunk — plus a constant for the staging); a
 // chunk that alone exceeds the target is split by step range. Most expensive first.
 int slices_plan(Ctx* h, Shard& s) {
-  const int ncg = s.s_ncg, nchunks = s.s_nchunks;
-  const int nstrips = static_cast<int>(ceil_div(ncg, SL_NW));
-  const uint32_t* L = h->csc_hLq;
   static const double target_env = std::getenv("CLIPPER_HIP_CSC_WGS") ? std::max(1.0, std::atof(std::getenv("CLIPPER_HIP_CSC_WGS"))) : 0.0;
   static const double c0_env = std::getenv("CLIPPER_HIP_CSC_C0") ? std::max(0.0, std::atof(std::getenv("CLIPPER_HIP_CSC_C0"))) : -1.0;
-  // workgroups of a pass: four per CU; for small matrices a quarter of the slices — fewer partial-sum
-  // slots for the tail to add — and exactly one per CU when that is close (a second short workgroup on
-  // a few CUs doubles those CUs' time): per iteration 20.4 instead of 22.3 us at m = 3000, 23.0 instead
-  // of 24.4 at m = 4000 (profiles/r02e_window_sweep.txt)
-  double target = target_env;
-  if (target <= 0.0) {
-    const double quarter = static_cast<double>(ncg) * nchunks / 4.0;
-    target = quarter < 1.5 * h->cus ? h->cus : std::min<double>(quarter, 4.0 * h->cus);
-  }
-  const double C0 = c0_env >= 0.0 ? c0_env : 2.0;  // what a chunk costs besides its steps (staging, barrier, header), in steps
-  // (this runs between the fill and the first pass of every build: buffers are kept, the order is
-  // a counting sort)
-  static thread_local std::vector<int> cost;
-  static thread_local std::vector<SliceWork> items;
-  static thread_local std::vector<double> key;
-  static thread_local std::vector<int> nslot_of;
-  cost.resize(static_cast<size_t>(nstrips) * nchunks);
-  double total = 0.0;
-  uint64_t entries = 0;
-  for (int st = 0; st < nstrips; ++st) {
-    int* crow = cost.data() + static_cast<size_t>(st) * nchunks;
-    const int w1 = std::min(SL_NW, ncg - st * SL_NW);
-    for (int k = 0; k < nchunks; ++k) crow[k] = 0;
-    for (int w = 0; w < w1; ++w) {
-      const uint32_t* lrow = L + static_cast<size_t>(st * SL_NW + w) * nchunks;
-      for (int k = 0; k < nchunks; ++k) {
-        const uint32_t v = lrow[k];
-        crow[k] = std::max(crow[k], static_cast<int>(v & 255u));
-        entries += v >> 8;
-      }
-    }
-    for (int k = 0; k < nchunks; ++k) total += crow[k] + C0;
-  }
-  s.s_entries = entries;
-  const double T = std::max(8.0, total / target);
-  constexpr int KEYS = 1024;  // sort keys: the cost relative to the most expensive item
-  auto push = [&](double c, const SliceWork& w) {
-    items.push_back(w);
-    key.push_back(c);
-  };
-  items.clear();
-  key.clear();
-  nslot_of.assign(static_cast<size_t>(nstrips), 0);
-  int nslots = 1;
-  for (int st = 0; st < nstrips; ++st) {
-    int slot = 0, start = 0;
-    double acc = 0.0;
-    auto flush = [&](int end) {
-      if (end > start) push(acc, SliceWork{st, slot++, start, end, 0, 1 << 30, 0, 0});
-      start = end;
-      acc = 0.0;
-    };
-    const int* crow = cost.data() + static_cast<size_t>(st) * nchunks;
-    for (int k = 0; k < nchunks; ++k) {
-      const int mq = crow[k];
-      const double c = mq + C0;
-      if (c > 1.5 * T && mq >= 2 * SL_SO) {
-        flush(k);
-        const int parts = std::min(static_cast<int>(std::ceil(c / T)), static_cast<int>(ceil_div(mq, SL_SO)));
-        const int per = static_cast<int>(round_up(ceil_div(mq, parts), SL_SO));
-        for (int q0 = 0; q0 < mq; q0 += per)
-          push(std::min(per, mq - q0) + C0, SliceWork{st, slot++, k, k + 1, q0, std::min(q0 + per, mq), 0, 0});
-        start = k + 1;
-      } else {
-        acc += c;
-        if (acc >= T) flush(k + 1);
-      }
-    }
-    flush(nchunks);
-    nslot_of[static_cast<size_t>(st)] = slot;
-    nslots = std::max(nslots, slot);
-  }
-  for (int st = 0; st < nstrips; ++st)  // every (strip, slot) is written by some workgroup
-    for (int slot = nslot_of[static_cast<size_t>(st)]; slot < nslots; ++slot)
-      push(0.0, SliceWork{st, slot, 0, 0, 0, 0, 0, 0});
-  const size_t nw = items.size();
+  static_assert(sizeof(clipper_plan::Work) == sizeof(SliceWork), "the planner's work item is the kernel's");
+  static thread_local clipper_plan::PassPlan plan;  // (buffers kept from build to build)
+  clipper_plan::plan_pass(h->csc_hLq, s.s_ncg, s.s_nchunks, clipper_plan::PassConsts{SL_NW, SL_SO}, h->cus,
+                          target_env, c0_env >= 0.0 ? c0_env : 2.0, plan);
+  s.s_entries = plan.entries;
+  const int nslots = plan.nslots;
+  const size_t nw = plan.work.size();
   if (nw > h->csc_hcap_work) {
     if (h->csc_hwork) hipHostFree(h->csc_hwork);
     h->csc_hwork = nullptr;
@@ -384,20 +312,7 @@ int slices_plan(Ctx* h, Shard& s) {
     HIPCHK(hipHostMalloc(&h->csc_hwork, (nw + 1024) * sizeof(SliceWork), hipHostMallocDefault));
     h->csc_hcap_work = nw + 1024;
   }
-  {  // most expensive first, stable: counting sort by key, straight into the pinned staging buffer
-    double cmax = 1e-9;
-    for (size_t i = 0; i < nw; ++i) cmax = std::max(cmax, key[i]);
-    const double scale = (KEYS - 1) / cmax;
-    int count[KEYS + 1] = {0};
-    for (size_t i = 0; i < nw; ++i) ++count[KEYS - 1 - static_cast<int>(key[i] * scale)];
-    int run = 0;
-    for (int b = 0; b < KEYS; ++b) {
-      const int c = count[b];
-      count[b] = run;
-      run += c;
-    }
-    for (size_t i = 0; i < nw; ++i) h->csc_hwork[count[KEYS - 1 - static_cast<int>(key[i] * scale)]++] = items[i];
-  }
+  std::memcpy(h->csc_hwork, plan.work.data(), nw * sizeof(SliceWork));
   HIPCHK(hipSetDevice(s.device));
   int rc = grow_dev(s.swork, s.scap_work, nw);
   if (rc) return rc;

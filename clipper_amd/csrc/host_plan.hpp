@@ -1,0 +1,298 @@
+// host_plan.hpp — the two planners that run on the host between a build and its first pass, as pure
+// functions of the slice directory (no HIP, no context): plan_pass (the work list of the streaming
+// pass on the slices) and plan_resident (units, pieces and wave map of the resident solver).
+// Included by clipper_hip.hip (host_matrix.hpp / host_resident.hpp) and by tests/cpp/test_planners.cpp,
+// which checks on the CPU that every plan covers every step of every slice exactly once.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace clipper_plan {
+
+// what the streaming pass's workgroup does: layout of clipper_hip::SliceWork (k_slices.hip.h)
+struct Work {
+  int strip, slot, t0, t1;
+  int q0, q1, pad0, pad1;
+};
+
+struct PassConsts {
+  int nw;   // column groups (waves) per workgroup     SL_NW
+  int so;   // steps between two recorded step offsets  SL_SO
+};
+
+struct PassPlan {
+  std::vector<Work> work;  // most expensive first
+  int nslots = 1;          // partial-sum slots per column the tail adds
+  uint64_t entries = 0;    // stored entries of the matrix
+};
+
+// L[cg * nchunks + k] = maxq | entries << 8 of slice (cg, k). target <= 0: the default number of
+// workgroups — four per CU; for small matrices a quarter of the slices (fewer partial-sum slots for
+// the tail to add) and exactly one per CU when that is close (a second short workgroup on a few CUs
+// doubles those CUs' time): profiles/r02e_window_sweep.txt.
+inline void plan_pass(const uint32_t* L, int ncg, int nchunks, const PassConsts& K, int cus, double target,
+                      double C0 /* cost of a chunk besides its steps, in steps */, PassPlan& out) {
+  const int nstrips = (ncg + K.nw - 1) / K.nw;
+  if (target <= 0.0) {
+    const double quarter = static_cast<double>(ncg) * nchunks / 4.0;
+    target = quarter < 1.5 * cus ? cus : std::min<double>(quarter, 4.0 * cus);
+  }
+  // (this runs between the fill and the first pass of every build: buffers are kept, the order is a
+  // counting sort)
+  static thread_local std::vector<int> cost;
+  static thread_local std::vector<Work> items;
+  static thread_local std::vector<double> key;
+  static thread_local std::vector<int> nslot_of;
+  cost.resize(static_cast<size_t>(nstrips) * nchunks);
+  double total = 0.0;
+  uint64_t entries = 0;
+  for (int st = 0; st < nstrips; ++st) {
+    int* crow = cost.data() + static_cast<size_t>(st) * nchunks;
+    const int w1 = std::min(K.nw, ncg - st * K.nw);
+    for (int k = 0; k < nchunks; ++k) crow[k] = 0;
+    for (int w = 0; w < w1; ++w) {
+      const uint32_t* lrow = L + static_cast<size_t>(st * K.nw + w) * nchunks;
+      for (int k = 0; k < nchunks; ++k) {
+        const uint32_t v = lrow[k];
+        crow[k] = std::max(crow[k], static_cast<int>(v & 255u));
+        entries += v >> 8;
+      }
+    }
+    for (int k = 0; k < nchunks; ++k) total += crow[k] + C0;
+  }
+  out.entries = entries;
+  const double T = std::max(8.0, total / target);
+  auto push = [&](double c, const Work& w) {
+    items.push_back(w);
+    key.push_back(c);
+  };
+  items.clear();
+  key.clear();
+  nslot_of.assign(static_cast<size_t>(nstrips), 0);
+  int nslots = 1;
+  for (int st = 0; st < nstrips; ++st) {
+    int slot = 0, start = 0;
+    double acc = 0.0;
+    auto flush = [&](int end) {
+      if (end > start) push(acc, Work{st, slot++, start, end, 0, 1 << 30, 0, 0});
+      start = end;
+      acc = 0.0;
+    };
+    const int* crow = cost.data() + static_cast<size_t>(st) * nchunks;
+    for (int k = 0; k < nchunks; ++k) {
+      const int mq = crow[k];
+      const double c = mq + C0;
+      if (c > 1.5 * T && mq >= 2 * K.so) {
+        // a dense block's chunk: a chain of steps several times the average — cut by step range
+        flush(k);
+        const int parts = std::min(static_cast<int>(std::ceil(c / T)), (mq + K.so - 1) / K.so);
+        const int per = ((mq + parts - 1) / parts + K.so - 1) / K.so * K.so;
+        for (int q0 = 0; q0 < mq; q0 += per)
+          push(std::min(per, mq - q0) + C0, Work{st, slot++, k, k + 1, q0, std::min(q0 + per, mq), 0, 0});
+        start = k + 1;
+      } else {
+        acc += c;
+        if (acc >= T) flush(k + 1);
+      }
+    }
+    flush(nchunks);
+    nslot_of[static_cast<size_t>(st)] = slot;
+    nslots = std::max(nslots, slot);
+  }
+  for (int st = 0; st < nstrips; ++st)  // every (strip, slot) is written by some workgroup
+    for (int slot = nslot_of[static_cast<size_t>(st)]; slot < nslots; ++slot)
+      push(0.0, Work{st, slot, 0, 0, 0, 0, 0, 0});
+  out.nslots = nslots;
+  // most expensive first, stable: counting sort by the cost relative to the most expensive item
+  constexpr int KEYS = 1024;
+  const size_t nw = items.size();
+  out.work.resize(nw);
+  double cmax = 1e-9;
+  for (size_t i = 0; i < nw; ++i) cmax = std::max(cmax, key[i]);
+  const double scale = (KEYS - 1) / cmax;
+  int count[KEYS + 1] = {0};
+  for (size_t i = 0; i < nw; ++i) ++count[KEYS - 1 - static_cast<int>(key[i] * scale)];
+  int run = 0;
+  for (int b = 0; b < KEYS; ++b) {
+    const int c = count[b];
+    count[b] = run;
+    run += c;
+  }
+  for (size_t i = 0; i < nw; ++i) out.work[static_cast<size_t>(count[KEYS - 1 - static_cast<int>(key[i] * scale)]++)] = items[i];
+}
+
+// ---- the resident solver (k_resident.hip.h) -----------------------------------------------------
+
+struct Unit {  // layout of clipper_hip::ResidentUnit
+  int cg0, ncgs;  // column groups [cg0, cg0 + ncgs)
+  int k0, k1;     // chunks [k0, k1)
+  int slot;       // which of the partial-sum slots of its columns this unit fills
+  int pad0, pad1, pad2;
+};
+
+struct ResidentConsts {
+  int nt;              // threads per workgroup                         RS_NT
+  int nwv;             // waves per workgroup                           RS_NWV
+  int tmax;            // slices a unit holds at most                   RS_TMAX
+  int pmax;            // pieces a wave works on at most                RS_PMAX
+  int maxe;            // elements per thread at most                   RS_MAXE
+  uint32_t lds_max;    // dynamic LDS of a workgroup                    RS_LDS_MAX
+  uint32_t red_bytes, tab_bytes, slice_pad;  //                         RS_RED_BYTES, RS_TAB_BYTES, RS_SLICE_PAD
+  int so;              //                                               SL_SO
+};
+
+constexpr uint32_t so_bytes(int maxq, int so) { return static_cast<uint32_t>(((maxq + so - 1) / so * 4 + 15) & ~15); }
+inline uint32_t xt_bytes(int V, int64_t mp, int nwv) {
+  const uint32_t xt = static_cast<uint32_t>(mp) * V * 8u, sc = static_cast<uint32_t>(nwv) * (V + 1) * 64u * 8u;
+  return xt > sc ? xt : sc;
+}
+// upper bound of the bytes of a slice from its directory word (maxq | entries << 8)
+inline uint32_t slice_bound(uint32_t lq, uint32_t quad_bytes, int so) {
+  const uint32_t maxq = lq & 255u, entries = lq >> 8;
+  if (maxq == 0) return 16 + 64 + so_bytes(0, so);
+  const uint32_t nquads = std::min<uint32_t>((entries + 3u * 64u) / 4u, 64u * maxq);
+  return 16 + 64 + so_bytes(static_cast<int>(maxq), so) + nquads * (quad_bytes + 4u) + maxq * 12u;
+}
+
+struct ResidentPlan {
+  bool ok = false;
+  int V = 0, E = 0, maxslots = 1;
+  uint32_t lds_slices = 0;
+  uint64_t total_bound = 0;
+  std::vector<Unit> units;
+  std::vector<uint8_t> nsl;       // [ncg] slots to add for a column of the group
+  std::vector<uint8_t> npieces;   // [unit * nwv + wave]
+  std::vector<uint8_t> wave_cg;   // [unit * nwv + wave] column group of the unit the wave works for (255: none)
+  std::vector<uint32_t> pieces;   // [(unit * nwv + wave) * pmax + j] = chunk - k0 | q0 << 8 | q1 << 16
+};
+
+// Decides whether the slices fit the resident solver and lays out its units: a column group x a range
+// of chunks sized by slice_bound() so that a unit fits the LDS beside the x table; one unit when
+// everything fits one workgroup. Then the pieces: the steps of a column group's slices dealt out to
+// its waves in equal shares (the dense slices of an inlier block are chains ten times as long as the
+// others: cut, they end together), waves to column groups in proportion to their steps.
+inline void plan_resident(const uint32_t* L, int ncg, int nchunks, int64_t m, int64_t mp, int esize,
+                          int max_units, int v_forced, const ResidentConsts& K, ResidentPlan& out) {
+  out = ResidentPlan{};
+  if (m > static_cast<int64_t>(K.maxe) * K.nt || mp > static_cast<int64_t>(K.maxe) * K.nt) return;  // above: the streaming launches win
+  const int E = (mp <= K.nt) ? 1 : (mp <= 2 * K.nt ? 2 : 4);
+  const uint32_t QBY = 4u * static_cast<uint32_t>(esize);
+  std::vector<uint32_t> ub(static_cast<size_t>(ncg) * nchunks);
+  uint64_t total = 0;
+  for (size_t i = 0; i < ub.size(); ++i) {
+    ub[i] = slice_bound(L[i], QBY, K.so);
+    total += ub[i];
+  }
+  out.total_bound = total;
+  int vmax = 1;  // at these sizes the line search rarely rejects: a window only adds arithmetic
+  if (v_forced) vmax = v_forced;
+  std::vector<Unit>& units = out.units;
+  out.nsl.assign(static_cast<size_t>(ncg), 0);
+  int V = 0;
+  for (int v = vmax; v >= 1; v = (v_forced ? 0 : v / 2)) {
+    units.clear();
+    const uint32_t fixed = xt_bytes(v, mp, K.nwv) + K.red_bytes + K.tab_bytes;
+    // everything in ONE workgroup: no exchange at all
+    if (ncg <= K.nwv) {
+      const uint32_t fixed1 = fixed + static_cast<uint32_t>(mp) * (v + 1) * 8u;
+      if (fixed1 + K.slice_pad < K.lds_max && total <= K.lds_max - fixed1 - K.slice_pad && ncg * nchunks <= K.tmax) {
+        units.push_back(Unit{0, ncg, 0, nchunks, 0, 0, 0, 0});
+        std::fill(out.nsl.begin(), out.nsl.end(), static_cast<uint8_t>(1));
+        V = v;
+        out.lds_slices = K.lds_max - fixed1;
+        break;
+      }
+    }
+    if (fixed + K.slice_pad + 4096 >= K.lds_max) continue;
+    const uint32_t cap = K.lds_max - fixed - K.slice_pad;
+    bool ok = true;
+    for (int cg = 0; cg < ncg && ok; ++cg) {
+      int slot = 0, k0 = 0;
+      uint32_t acc = 0;
+      for (int k = 0; k < nchunks; ++k) {
+        const uint32_t b = ub[static_cast<size_t>(cg) * nchunks + k];
+        if (b > cap) {
+          ok = false;
+          break;
+        }
+        if (acc + b > cap || k - k0 >= K.tmax) {
+          units.push_back(Unit{cg, 1, k0, k, slot++, 0, 0, 0});
+          k0 = k;
+          acc = 0;
+        }
+        acc += b;
+      }
+      units.push_back(Unit{cg, 1, k0, nchunks, slot++, 0, 0, 0});
+      out.nsl[static_cast<size_t>(cg)] = static_cast<uint8_t>(slot);
+    }
+    if (ok && static_cast<int>(units.size()) <= max_units) {
+      V = v;
+      out.lds_slices = K.lds_max - fixed;
+      break;
+    }
+  }
+  if (V == 0) return;
+  out.V = V;
+  out.E = E;
+  out.maxslots = 1;
+  for (uint8_t x : out.nsl) out.maxslots = std::max<int>(out.maxslots, x);
+
+  const size_t NWV = static_cast<size_t>(K.nwv), PM = static_cast<size_t>(K.pmax);
+  out.pieces.assign(units.size() * NWV * PM, 0u);
+  out.npieces.assign(units.size() * NWV, 0);
+  out.wave_cg.assign(units.size() * NWV, 255);
+  std::vector<int> T(NWV), nw(NWV);
+  for (size_t ui = 0; ui < units.size(); ++ui) {
+    const Unit& U = units[ui];
+    // waves to column groups in proportion to their steps (every group at least one)
+    std::fill(T.begin(), T.end(), 0);
+    std::fill(nw.begin(), nw.end(), 0);
+    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
+      const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
+      for (int k = U.k0; k < U.k1; ++k) T[cgl] += static_cast<int>(lrow[k] & 255u);
+      nw[cgl] = 1;
+    }
+    for (int spare = K.nwv - U.ncgs; spare > 0; --spare) {
+      int best = 0;
+      for (int cgl = 1; cgl < U.ncgs; ++cgl)
+        if (static_cast<int64_t>(T[cgl]) * nw[best] > static_cast<int64_t>(T[best]) * nw[cgl]) best = cgl;
+      ++nw[best];
+    }
+    int wave = 0;
+    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
+      const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
+      const int target = std::max(1, (T[cgl] + nw[cgl] - 1) / nw[cgl]);
+      int kcur = U.k0, qcur = 0;
+      for (int sub = 0; sub < nw[cgl]; ++sub, ++wave) {
+        const size_t wv = ui * NWV + static_cast<size_t>(wave);
+        out.wave_cg[wv] = static_cast<uint8_t>(cgl);
+        int rem = (sub == nw[cgl] - 1) ? (1 << 30) : target, n = 0;
+        while (rem > 0 && kcur < U.k1) {
+          const int mq = static_cast<int>(lrow[kcur] & 255u);
+          if (qcur >= mq) {
+            ++kcur;
+            qcur = 0;
+            continue;
+          }
+          if (n == K.pmax) {
+            if (sub == nw[cgl] - 1) return;  // does not fit the piece lists: streaming launches (ok stays false)
+            break;
+          }
+          const int take = std::min(rem, mq - qcur);
+          out.pieces[wv * PM + static_cast<size_t>(n++)] = static_cast<uint32_t>(kcur - U.k0) |
+                                                           (static_cast<uint32_t>(qcur) << 8) |
+                                                           (static_cast<uint32_t>(qcur + take) << 16);
+          qcur += take;
+          rem -= take;
+        }
+        out.npieces[wv] = static_cast<uint8_t>(n);
+      }
+    }
+  }
+  out.ok = true;
+}
+
+}  // namespace clipper_plan

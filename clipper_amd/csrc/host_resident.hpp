@@ -27,141 +27,35 @@ void resident_free(Ctx* h) {
   r.home = hm;
 }
 
-// upper bound of the bytes of a slice from its directory word (maxq | entries << 8)
-uint32_t rs_slice_bound(uint32_t lq, uint32_t quad_bytes) {
-  const uint32_t maxq = lq & 255u, entries = lq >> 8;
-  if (maxq == 0) return 16 + 64 + sl_so_bytes(0);
-  const uint32_t nquads = std::min<uint32_t>((entries + 3u * 64u) / 4u, 64u * maxq);
-  return 16 + 64 + sl_so_bytes(static_cast<int>(maxq)) + nquads * (quad_bytes + 4u) + maxq * 12u;
-}
-
-// Decide whether the current slices fit the resident solver and lay out its units. Called when a
-// build's directory (csc_hLq) is on the host. Leaves r.ready = false when the problem does not fit.
+// Decide whether the current slices fit the resident solver and lay out its units (host_plan.hpp).
+// Called when a build's directory (csc_hLq) is on the host. Leaves r.ready = false when the problem
+// does not fit.
 int resident_plan(Ctx* h, Shard& s) {
   Resident& r = h->res;
   r.ready = false;
   r.failed = false;
   if (h->resident_mode == 1 || h->V_forced != 0 || h->world != 1 || h->multiproc || h->explicitC) return 0;
-  const int64_t m = h->m, mp = h->mp;
-  if (m > RS_MAXE * RS_NT || mp > RS_MAXE * RS_NT) return 0;  // above: the streaming launches win
-  const int E = (mp <= RS_NT) ? 1 : (mp <= 2 * RS_NT ? 2 : 4);
+  static_assert(sizeof(clipper_plan::Unit) == sizeof(ResidentUnit), "the planner's unit is the kernel's");
+  static_assert(clipper_plan::so_bytes(17, SL_SO) == sl_so_bytes(17) && clipper_plan::so_bytes(32, SL_SO) == sl_so_bytes(32) &&
+                    clipper_plan::so_bytes(0, SL_SO) == sl_so_bytes(0),
+                "the planner sizes the step-offset table as the format does");
+  const clipper_plan::ResidentConsts K{RS_NT, RS_NWV, RS_TMAX, RS_PMAX, RS_MAXE, RS_LDS_MAX,
+                                       RS_RED_BYTES, RS_TAB_BYTES, RS_SLICE_PAD, SL_SO};
+  static thread_local clipper_plan::ResidentPlan plan;
   const int ncg = s.s_ncg, nchunks = s.s_nchunks;
-  const uint32_t* L = h->csc_hLq;
-  const uint32_t QBY = 4u * static_cast<uint32_t>(h->esize());
-  std::vector<uint32_t> ub(static_cast<size_t>(ncg) * nchunks);
-  uint64_t total = 0;
-  for (size_t i = 0; i < ub.size(); ++i) {
-    ub[i] = rs_slice_bound(L[i], QBY);
-    total += ub[i];
-  }
-  int vmax = 1;  // at these sizes the line search rarely rejects: a window only adds arithmetic
-  if (r.V_forced) vmax = r.V_forced;
-  std::vector<ResidentUnit> units;
-  std::vector<uint8_t> nsl(static_cast<size_t>(ncg), 0);
-  int V = 0;
-  uint32_t lds_slices = 0, lds_total = 0;
-  for (int v = vmax; v >= 1; v = (r.V_forced ? 0 : v / 2)) {
-    units.clear();
-    const uint32_t fixed = rs_xt_bytes(v, mp) + RS_RED_BYTES + RS_TAB_BYTES;
-    // everything in ONE workgroup: no exchange at all
-    if (ncg <= RS_NWV) {
-      const uint32_t fixed1 = fixed + rs_y_bytes(v, mp, true);
-      if (fixed1 + RS_SLICE_PAD < RS_LDS_MAX && total <= RS_LDS_MAX - fixed1 - RS_SLICE_PAD &&
-          ncg * nchunks <= RS_TMAX) {
-        units.push_back(ResidentUnit{0, ncg, 0, nchunks, 0, 0, 0, 0});
-        std::fill(nsl.begin(), nsl.end(), static_cast<uint8_t>(1));
-        V = v;
-        lds_slices = RS_LDS_MAX - fixed1;
-        lds_total = RS_LDS_MAX;
-        break;
-      }
-    }
-    if (fixed + RS_SLICE_PAD + 4096 >= RS_LDS_MAX) continue;
-    const uint32_t cap = RS_LDS_MAX - fixed - RS_SLICE_PAD;
-    bool ok = true;
-    for (int cg = 0; cg < ncg && ok; ++cg) {
-      int slot = 0, k0 = 0;
-      uint32_t acc = 0;
-      for (int k = 0; k < nchunks; ++k) {
-        const uint32_t b = ub[static_cast<size_t>(cg) * nchunks + k];
-        if (b > cap) {
-          ok = false;
-          break;
-        }
-        if (acc + b > cap || k - k0 >= RS_TMAX) {
-          units.push_back(ResidentUnit{cg, 1, k0, k, slot++, 0, 0, 0});
-          k0 = k;
-          acc = 0;
-        }
-        acc += b;
-      }
-      units.push_back(ResidentUnit{cg, 1, k0, nchunks, slot++, 0, 0, 0});
-      nsl[static_cast<size_t>(cg)] = static_cast<uint8_t>(slot);
-    }
-    if (ok && static_cast<int>(units.size()) <= std::min(RS_MAX_UNITS, h->cus - 8)) {
-      V = v;
-      lds_slices = RS_LDS_MAX - fixed;
-      lds_total = RS_LDS_MAX;
-      break;
-    }
-  }
+  clipper_plan::plan_resident(h->csc_hLq, ncg, nchunks, h->m, h->mp, static_cast<int>(h->esize()),
+                              std::min(RS_MAX_UNITS, h->cus - 8), r.V_forced, K, plan);
   if (rs_debug())
-    std::fprintf(stderr, "[resident] plan m=%lld ncg=%d nchunks=%d total_ub=%llu -> V=%d E=%d units=%zu\n",
-                 static_cast<long long>(m), ncg, nchunks, static_cast<unsigned long long>(total), V, E,
-                 units.size());
-  if (V == 0) return 0;
-  int maxslots = 1;
-  for (uint8_t x : nsl) maxslots = std::max<int>(maxslots, x);
-
-  // pieces: the steps of a column group's slices dealt out to its waves in equal shares (the dense
-  // slices of an inlier block are chains ten times as long as the others: cut, they end together)
-  std::vector<uint32_t> pieces(units.size() * RS_NWV * RS_PMAX, 0u);
-  std::vector<uint8_t> npieces(units.size() * RS_NWV, 0), wave_cg(units.size() * RS_NWV, 255);
-  for (size_t ui = 0; ui < units.size(); ++ui) {
-    const ResidentUnit& U = units[ui];
-    // waves to column groups in proportion to their steps (every group at least one)
-    int T[RS_NWV] = {0}, nw[RS_NWV] = {0};
-    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
-      const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
-      for (int k = U.k0; k < U.k1; ++k) T[cgl] += static_cast<int>(lrow[k] & 255u);
-      nw[cgl] = 1;
-    }
-    for (int spare = RS_NWV - U.ncgs; spare > 0; --spare) {
-      int best = 0;
-      for (int cgl = 1; cgl < U.ncgs; ++cgl)
-        if (static_cast<int64_t>(T[cgl]) * nw[best] > static_cast<int64_t>(T[best]) * nw[cgl]) best = cgl;
-      ++nw[best];
-    }
-    int wave = 0;
-    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
-      const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
-      const int target = std::max(1, static_cast<int>(ceil_div(T[cgl], nw[cgl])));
-      int kcur = U.k0, qcur = 0;
-      for (int sub = 0; sub < nw[cgl]; ++sub, ++wave) {
-        const size_t wv = ui * RS_NWV + static_cast<size_t>(wave);
-        wave_cg[wv] = static_cast<uint8_t>(cgl);
-        int rem = (sub == nw[cgl] - 1) ? (1 << 30) : target, n = 0;
-        while (rem > 0 && kcur < U.k1) {
-          const int mq = static_cast<int>(lrow[kcur] & 255u);
-          if (qcur >= mq) {
-            ++kcur;
-            qcur = 0;
-            continue;
-          }
-          if (n == RS_PMAX) {
-            if (sub == nw[cgl] - 1) return 0;  // does not fit the piece lists: streaming launches
-            break;
-          }
-          const int take = std::min(rem, mq - qcur);
-          pieces[wv * RS_PMAX + n++] = static_cast<uint32_t>(kcur - U.k0) | (static_cast<uint32_t>(qcur) << 8) |
-                                       (static_cast<uint32_t>(qcur + take) << 16);
-          qcur += take;
-          rem -= take;
-        }
-        npieces[wv] = static_cast<uint8_t>(n);
-      }
-    }
-  }
+    std::fprintf(stderr, "[resident] plan m=%lld ncg=%d nchunks=%d total_ub=%llu -> V=%d E=%d units=%zu ok=%d\n",
+                 static_cast<long long>(h->m), ncg, nchunks, static_cast<unsigned long long>(plan.total_bound),
+                 plan.V, plan.E, plan.units.size(), plan.ok ? 1 : 0);
+  if (!plan.ok) return 0;
+  const int V = plan.V, E = plan.E, maxslots = plan.maxslots;
+  const int64_t mp = h->mp;
+  const std::vector<clipper_plan::Unit>& units = plan.units;
+  const std::vector<uint8_t>&nsl = plan.nsl, &npieces = plan.npieces, &wave_cg = plan.wave_cg;
+  const std::vector<uint32_t>& pieces = plan.pieces;
+  const uint32_t lds_slices = plan.lds_slices, lds_total = RS_LDS_MAX;
 
   HIPCHK(hipSetDevice(s.device));
   // plan in mapped pinned memory: the kernel reads it through the bus once, nothing is copied
