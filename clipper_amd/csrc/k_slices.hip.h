@@ -383,13 +383,13 @@ __device__ __forceinline__ void slices_by_plan(const SliceView& M, const SliceJo
 #endif
 constexpr int SL_NW = CLIPPER_SL_NW;  // waves (= column groups) per workgroup
 #ifndef CLIPPER_SL_D
-#define CLIPPER_SL_D 4
+#define CLIPPER_SL_D 3
 #endif
-constexpr int SL_D = CLIPPER_SL_D;   // steps in flight per lane
+constexpr int SL_D = CLIPPER_SL_D;   // steps in flight per lane (2 / 3 / 4 / 6 / 8 measured: profiles/r02e_window_sweep.txt)
 #ifndef CLIPPER_SL_OCC
-#define CLIPPER_SL_OCC 5
+#define CLIPPER_SL_OCC 6
 #endif
-constexpr int SL_OCC = CLIPPER_SL_OCC;  // waves per SIMD the pass kernel is compiled for (5 workgroups per CU)
+constexpr int SL_OCC = CLIPPER_SL_OCC;  // waves per SIMD the pass kernel is compiled for (= workgroups per CU)
 
 // G of a solver iteration on the slices (one shard): decision, then the pass
 template <typename VT, int H, int V>
