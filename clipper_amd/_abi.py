@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_get_selected_associations", "clipper_hip_matvec", "clipper_hip_set_profiling",
     "clipper_hip_set_window", "clipper_hip_window", "clipper_hip_densest_subgraph",
     "clipper_hip_set_resident", "clipper_hip_last_solver",
+    "clipper_hip_set_row_view", "clipper_hip_get_view_stats",
     "clipper_hip_storage_in_use", "clipper_hip_knn", "clipper_hip_distance_based_correspondences",
     "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
@@ -87,6 +88,16 @@ class Timings(C.Structure):
         ("solve_total_ms", C.c_double), ("gemv_avg_us", C.c_double),
         ("gemv_min_us", C.c_double), ("gemv_launches", C.c_int64), ("gemv_bytes", C.c_double),
         ("gemv_useful_bytes", C.c_double), ("affinity_bytes", C.c_double),
+    ]
+
+
+class ViewStats(C.Structure):
+    """clipper_hip_view_stats_t (include/clipper_hip.h): the row views of the last solve."""
+
+    _fields_ = [
+        ("builds", C.c_int64), ("rows", C.c_int64), ("bytes", C.c_int64),
+        ("view_passes", C.c_int64), ("passes", C.c_int64), ("build_ms", C.c_double),
+        ("view_pass_avg_us", C.c_double), ("view_pass_samples", C.c_int64),
     ]
 
 
@@ -157,6 +168,8 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_set_resident.argtypes = [vp, C.c_int]
     L.clipper_hip_last_solver.argtypes = [vp]
     L.clipper_hip_storage_in_use.argtypes = [vp]
+    L.clipper_hip_set_row_view.argtypes = [vp, C.c_int]
+    L.clipper_hip_get_view_stats.argtypes = [vp, C.POINTER(ViewStats)]
     L.clipper_hip_knn.argtypes = [C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_int, C.c_int, ip, dp]
     L.clipper_hip_distance_based_correspondences.argtypes = [
         C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, ip, C.c_int64]
@@ -412,6 +425,15 @@ class HipClipper:
     def last_solver(self) -> int:
         """What the last solve ran on: 0 = streaming launches, 1 = resident."""
         return int(self.L.clipper_hip_last_solver(self.h))
+
+    def set_row_view(self, mode: int):
+        """0 = build row views of M[live rows, :] during a solve where that pays, 1 = never."""
+        self._check(self.L.clipper_hip_set_row_view(self.h, int(mode)))
+
+    def view_stats(self) -> ViewStats:
+        t = ViewStats()
+        self._check(self.L.clipper_hip_get_view_stats(self.h, C.byref(t)))
+        return t
 
     @property
     def storage_in_use(self) -> int:

@@ -46,6 +46,7 @@ using namespace clipper_hip;
 #include "host_state.hpp"
 #include "host_solver.hpp"
 #include "host_matrix.hpp"
+#include "host_rowview.hpp"
 #include "host_resident.hpp"
 #include "host_registration.hpp"
 
@@ -168,6 +169,7 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   if (h->csc_htotal) hipHostFree(h->csc_htotal);
   resident_free(h);
   if (h->csc_hwork) hipHostFree(h->csc_hwork);
+  if (h->rv_count) hipHostFree(h->rv_count);
   delete h;
 }
 
@@ -185,6 +187,10 @@ int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double
   const EuclidParams prm{sigma, epsilon, mindist, affinityeps};
   const int64_t mm = h->m, W = h->W, pstride = h->staged_pstride;
   const int d = h->staged_d;
+  h->fill_kind = 1;  // what a row view of this matrix is filled with later (host_rowview.hpp)
+  h->fill_e = prm;
+  h->fill_n = PointNormalParams{};
+  h->fill_E2 = guarded_threshold_sq(guarded_threshold(epsilon, h->staged_maxabs, d));
   return run_affinity(h, use_sym_fill(h) && (d == 2 || d == 3), [&](Shard& s) {
     dim3 grid(static_cast<unsigned>(ceil_div(W, 1024)),
               static_cast<unsigned>(ceil_div(mm, AFF_ROWS_PER_BLK))),
@@ -241,6 +247,10 @@ int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, doubl
     return fail(CLIPPER_HIP_E_STATE, "PointNormalDistance needs staged inputs with d == 6");
   const PointNormalParams prm{sigp, epsp, sign, epsn, affinityeps};
   const int64_t mm = h->m, W = h->W, pstride = h->staged_pstride;
+  h->fill_kind = 2;
+  h->fill_e = EuclidParams{};
+  h->fill_n = prm;
+  h->fill_E2 = guarded_threshold_sq(guarded_threshold(epsp, h->staged_maxabs, 3));
   return run_affinity(h, use_sym_fill(h), [&](Shard& s) {
     dim3 grid(static_cast<unsigned>(ceil_div(W, 1024)),
               static_cast<unsigned>(ceil_div(mm, AFF_ROWS_PER_BLK))),
@@ -327,6 +337,8 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
   h->nodes.clear();
   h->has_matrix = false;  // until the new matrix is complete
   h->csc_valid = false;
+  h->fill_kind = 0;  // no points behind this matrix: no row view
+  rowview_drop(h);
   int rc = ensure_problem(h, m);
   if (rc) return rc;
   h->has_matrix = false;
@@ -449,6 +461,8 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
   h->nodes.clear();
   h->has_matrix = false;
   h->csc_valid = false;
+  h->fill_kind = 0;  // no points behind this matrix: no row view
+  rowview_drop(h);
   if ((rc = ensure_problem(h, m))) return rc;
   h->has_matrix = false;
   h->csc_valid = false;
@@ -661,6 +675,7 @@ int clipper_hip_get_matrix(clipper_hip_t* h, double* M_out, double* C_out) {
       if (rc) return rc;
     }
   }
+  if (h->csc_valid) drop_dense(h);  // the copy was materialised for this call only: M lives in the slices
   return 0;
 }
 
@@ -713,6 +728,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   const int64_t m = h->m;
   const size_t vbytes = static_cast<size_t>(m) * sizeof(double);
 
+  h->rv_stats = clipper_hip_view_stats_t{};
   h->ev_used = 0;
   if (h->profiling)  // marks of the previous solve
   {
@@ -736,6 +752,10 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   std::memset(&init, 0, sizeof(init));
   init.alpha = 1.0;
   for (int l = 0; l < VS; ++l) init.nrm[l] = 1.0;
+  init.nlive = init.nout = static_cast<int32_t>(std::min<int64_t>(m, 0x7fffffff));  // unknown until a tail counts
+  init.rv_last = -100;
+  rowview_drop(h);  // a solve starts without a view: what it builds is a function of this solve alone
+  h->rvp = (!h->multiproc && h->world == 1) ? rowview_policy(h) : ViewPolicy{};
   // with rescaling the first iteration runs the pair pass on u0; without, it only normalises
   init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
   init.stage = P->rescale_u0 ? ST_PASS : ST_RESULTS;
@@ -775,11 +795,26 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     volatile HostMirror* hm = h->mirror;
     int64_t queued = 0;
     uint64_t spins = 0;
+    h->rv_fresh = false;
     static const int run_ahead = [] {  // (measurement knob)
       const char* e = std::getenv("CLIPPER_HIP_RUN_AHEAD");
       return e ? std::max(1, std::atoi(e)) : RUN_AHEAD;
     }();
     while (!hm->done) {
+      if (hm->hold) {
+        // The decision asked for a row view (k_solver.hip.h, LIVE ROWS) and put the solve on hold:
+        // whatever was queued behind it does nothing. Drain, build the view from exactly the state
+        // that asked, lift the hold, go on.
+        HIPCHK(hipStreamSynchronize(s0.stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        hm->hold = 0;
+        queued = hm->iters;              // the iterations that did nothing never counted
+        h->launch_counter = hm->iters;   // (profiling: launch index = the device's iteration count)
+        bool built = false;
+        if ((rc = rowview_build(h, built))) return rc;
+        h->rv_fresh = built;
+        continue;
+      }
       if (queued - hm->iters < run_ahead) {
         if ((rc = enqueue_iteration(h, prm))) return rc;
         ++queued;
@@ -802,6 +837,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     fin.ifinal = hm->ifinal;
     fin.ubp = hm->ubp;
     fin.ubv = hm->ubv;
+    h->rv_stats.view_passes = hm->n_view_passes;
   } else {
     // Multi-process: every rank must queue the same number of iterations (each holds a
     // collective), so the decision to stop rests on state snapshots only, which are
@@ -881,6 +917,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     info->n_passes = fin.n_passes;
     info->n_trials = fin.n_trials;
   }
+  h->rv_stats.passes = fin.n_passes;
 
   // mat-vec timings from the event pairs
   h->tm.gemv_avg_us = h->tm.gemv_min_us = 0.0;
@@ -892,16 +929,25 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     // transition (0); launches queued past convergence have no mark
     const uint8_t* kind = h->kind;
     const int64_t iters_run = std::min<int64_t>(h->launch_counter, KIND_CAP);
-    double sum = 0.0, mn = 1e30;
-    int64_t nreal = 0;
+    double sum = 0.0, mn = 1e30, vsum = 0.0;
+    int64_t nreal = 0, nview = 0;
     for (int k = 0; k < h->ev_used; ++k) {
       const int64_t li = h->ev_launch_index[static_cast<size_t>(k)];
       if (li >= iters_run || !kind[static_cast<size_t>(li)]) continue;
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, h->ev_pairs[2 * k], h->ev_pairs[2 * k + 1]));
+      if (kind[static_cast<size_t>(li)] == 2) {  // the launch streamed the row view, not M
+        vsum += ms;
+        ++nview;
+        continue;
+      }
       sum += ms;
       mn = std::min<double>(mn, ms);
       ++nreal;
+    }
+    if (nview > 0) {
+      h->rv_stats.view_pass_avg_us = vsum / static_cast<double>(nview) * 1e3;
+      h->rv_stats.view_pass_samples = nview;
     }
     if (nreal > 0) {
       h->tm.gemv_avg_us = sum / static_cast<double>(nreal) * 1e3;
@@ -1091,6 +1137,20 @@ int clipper_hip_set_resident(clipper_hip_t* h, int mode) {
 }
 
 int clipper_hip_last_solver(const clipper_hip_t* h) { return h ? h->last_solver : -1; }
+
+int clipper_hip_set_row_view(clipper_hip_t* h, int mode) {
+  if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (mode != 0 && mode != 1) return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic) or 1 (never)");
+  h->rv_mode = mode;
+  if (mode == 1) rowview_drop(h);
+  return 0;
+}
+
+int clipper_hip_get_view_stats(const clipper_hip_t* h, clipper_hip_view_stats_t* out) {
+  if (!h || !out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  *out = h->rv_stats;
+  return 0;
+}
 
 int clipper_hip_storage_in_use(const clipper_hip_t* h) {
   if (!h) return -1;

@@ -15,7 +15,25 @@ SliceView slice_view(const Ctx* h, const Shard& s) {
   M.work = s.swork;
   M.nchunks = s.s_nchunks;
   M.ncg = s.s_ncg;
+  M.nwork = s.s_nwork;
+  M.rowmap = nullptr;
+  M.nrows = h->m;
   return M;
+}
+
+// the row view of this shard's columns (data == null: none in use)
+SliceView row_view(const Ctx* h, const Shard& s) {
+  SliceView R{};
+  if (!s.rv.valid || !h->csc_valid) return R;
+  R.data = s.rv.st.sdata;
+  R.Pre = s.rv.st.sPre;
+  R.work = s.rv.st.swork;
+  R.nchunks = s.rv.st.s_nchunks;
+  R.ncg = s.rv.st.s_ncg;
+  R.nwork = s.rv.st.s_nwork;
+  R.rowmap = s.rv.rowmap[s.rv.cur];
+  R.nrows = s.rv.nrows;
+  return R;
 }
 
 // calls f(value type tag) for the storage's element type
@@ -71,12 +89,13 @@ int grow_dev(T*& p, size_t& cap, size_t need, size_t elem = sizeof(T)) {
   return 0;
 }
 
-// the per-slice arrays (directory, sizes, costs) and the pinned staging of this build
-int slices_arrays(Ctx* h, Shard& s) {
-  HIPCHK(hipSetDevice(s.device));
-  if (!s.cctl) HIPCHK(hipMalloc(&s.cctl, CSC_ARENAS * sizeof(CscBuildCtl)));
+// the per-slice arrays (directory, sizes, costs) of the store `st` (this shard's columns x `nrows`
+// rows) and the pinned staging of this build
+int slices_arrays(Ctx* h, Shard& sh, SliceStore& s, int64_t nrows) {
+  HIPCHK(hipSetDevice(sh.device));
+  if (!sh.cctl) HIPCHK(hipMalloc(&sh.cctl, CSC_ARENAS * sizeof(CscBuildCtl)));
   s.s_ncg = static_cast<int>(h->W / SL_W);
-  s.s_nchunks = static_cast<int>(ceil_div(h->m, SL_SUB * SL_H));
+  s.s_nchunks = static_cast<int>(ceil_div(nrows, SL_SUB * SL_H));
   const size_t nsl = static_cast<size_t>(s.s_ncg) * s.s_nchunks;
   if (nsl > s.scap_slices) {
     for (void** p : {reinterpret_cast<void**>(&s.sSizes), reinterpret_cast<void**>(&s.sLq),
@@ -105,15 +124,14 @@ int slices_arrays(Ctx* h, Shard& s) {
   if (!h->csc_htotal) HIPCHK(hipHostMalloc(&h->csc_htotal, 2 * sizeof(uint64_t), hipHostMallocDefault));
   return 0;
 }
+int slices_arrays(Ctx* h, Shard& s) { return slices_arrays(h, s, s, h->m); }
 
 // Before a fill that writes the slices itself (k_affinity_sym): the arenas of the slice store
 // reset. out.Pre == null: compressed storage not in use.
-int emit_prepare(Ctx* h, Shard& s, SliceOut& out) {
+int emit_prepare(Ctx* h, Shard& sh, SliceStore& s, int64_t nrows, SliceOut& out) {
   out = SliceOut{};
-  h->csc_valid = false;
-  h->csc_emitted = false;
   if (!csc_applies(h)) return 0;
-  if (int rc = slices_arrays(h, s)) return rc;
+  if (int rc = slices_arrays(h, sh, s, nrows)) return rc;
   const size_t units = s.scap_bytes >= SL_TAILPAD ? (s.scap_bytes - SL_TAILPAD) / 16 : 0;
   CscBuildCtl* init = h->csc_hctl + CSC_ARENAS;  // second half: what the device starts from
   for (int k = 0; k < CSC_ARENAS; ++k) {
@@ -127,11 +145,11 @@ int emit_prepare(Ctx* h, Shard& s, SliceOut& out) {
       s.sLq + round_up(static_cast<int64_t>(s.s_ncg) * s.s_nchunks, 32));
   void* idev = nullptr;
   if (hipHostGetDevicePointer(&idev, init, 0) == hipSuccess && idev) {  // 2 KB: a launch beats a DMA copy
-    hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(256), 0, s.stream, reinterpret_cast<const uint4*>(idev),
+    hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(256), 0, sh.stream, reinterpret_cast<const uint4*>(idev),
                        reinterpret_cast<uint4*>(ectl), static_cast<int64_t>(CSC_ARENAS * sizeof(CscBuildCtl) / 16));
   } else {
     (void)hipGetLastError();
-    HIPCHK(hipMemcpyAsync(ectl, init, CSC_ARENAS * sizeof(CscBuildCtl), hipMemcpyHostToDevice, s.stream));
+    HIPCHK(hipMemcpyAsync(ectl, init, CSC_ARENAS * sizeof(CscBuildCtl), hipMemcpyHostToDevice, sh.stream));
   }
   out.Pre = s.sPre;
   out.Lq = s.sLq;
@@ -142,32 +160,39 @@ int emit_prepare(Ctx* h, Shard& s, SliceOut& out) {
   out.stamps = h->stamps_dev ? h->stamps_dev + 8192 : nullptr;
   return 0;
 }
+int emit_prepare(Ctx* h, Shard& s, SliceOut& out) {
+  h->csc_valid = false;
+  h->csc_emitted = false;
+  return emit_prepare(h, s, s, h->m, out);
+}
 
 // After such a fill: the counters to pinned host memory; emit_check() reads them once the stream
 // was synchronised, grows the arena if a slice did not fit (`again`), else plans the passes.
-int emit_enqueue(Ctx* h, Shard& s) {
-  HIPCHK(hipSetDevice(s.device));
+int emit_enqueue(Ctx* h, Shard& sh, SliceStore& s) {
+  HIPCHK(hipSetDevice(sh.device));
   const size_t nsl8 = static_cast<size_t>(round_up(static_cast<int64_t>(s.s_ncg) * s.s_nchunks, 32));
   const size_t bytes = nsl8 * sizeof(uint32_t) + CSC_ARENAS * sizeof(CscBuildCtl);
   void* hdev = nullptr;
   if (bytes <= (1u << 20) && hipHostGetDevicePointer(&hdev, h->csc_hLq, 0) == hipSuccess && hdev) {
     const int64_t n16 = static_cast<int64_t>(bytes / 16);  // (both terms are multiples of 32 bytes)
     hipLaunchKernelGGL(k_copy_words, dim3(static_cast<unsigned>(std::min<int64_t>(ceil_div(n16, 256), 64))),
-                       dim3(256), 0, s.stream, reinterpret_cast<const uint4*>(s.sLq),
+                       dim3(256), 0, sh.stream, reinterpret_cast<const uint4*>(s.sLq),
                        reinterpret_cast<uint4*>(hdev), n16);
   } else {
     (void)hipGetLastError();
-    HIPCHK(hipMemcpyAsync(h->csc_hLq, s.sLq, bytes, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipMemcpyAsync(h->csc_hLq, s.sLq, bytes, hipMemcpyDeviceToHost, sh.stream));
   }
   return 0;
 }
+int emit_enqueue(Ctx* h, Shard& s) { return emit_enqueue(h, s, s); }
 
-int slices_plan(Ctx* h, Shard& s);
+int slices_plan(Ctx* h, Shard& sh, SliceStore& s, bool whole);
+int slices_plan(Ctx* h, Shard& s) { return slices_plan(h, s, s, true); }
 int resident_plan(Ctx* h, Shard& s);
 
-int emit_check(Ctx* h, Shard& s, bool& again) {
+int emit_check(Ctx* h, Shard& sh, SliceStore& s, bool whole, bool& again) {
   again = false;
-  HIPCHK(hipSetDevice(s.device));
+  HIPCHK(hipSetDevice(sh.device));
   bool over = false;
   size_t worst = 0;
   uint64_t sum = 0;
@@ -186,14 +211,15 @@ int emit_check(Ctx* h, Shard& s, bool& again) {
     const size_t units = (need + need / 8 + 256 * CSC_ARENAS) / CSC_ARENAS * CSC_ARENAS;
     const size_t cap = units * 16 + SL_TAILPAD;
     HIPCHK(hipMalloc(&s.sdata, cap));
-    HIPCHK(hipMemsetAsync(s.sdata + units * 16, 0, SL_TAILPAD, s.stream));
+    HIPCHK(hipMemsetAsync(s.sdata + units * 16, 0, SL_TAILPAD, sh.stream));
     s.scap_bytes = cap;
     again = true;
     return 0;
   }
   s.s_bytes = sum * 16;
-  return slices_plan(h, s);
+  return slices_plan(h, sh, s, whole);
 }
+int emit_check(Ctx* h, Shard& s, bool& again) { return emit_check(h, s, s, true, again); }
 
 // Before a build through groups: the group directory, the arenas' cursors reset, the per-slice arrays. Returns
 // what a kernel that emits groups needs; out.Goff == null: compressed storage not in use.
@@ -295,7 +321,7 @@ GroupSource<VT> group_source(const Ctx* h, const Shard& s) {
 // of SL_NW column groups, runs of chunks of about equal cost (cost of a chunk: its slowest
 // slice — the waves of a workgroup meet at every chunk — plus a constant for the staging); a
 // chunk that alone exceeds the target is split by step range. Most expensive first.
-int slices_plan(Ctx* h, Shard& s) {
+int slices_plan(Ctx* h, Shard& sh, SliceStore& s, bool whole) {
   static const double target_env = std::getenv("CLIPPER_HIP_CSC_WGS") ? std::max(1.0, std::atof(std::getenv("CLIPPER_HIP_CSC_WGS"))) : 0.0;
   static const double c0_env = std::getenv("CLIPPER_HIP_CSC_C0") ? std::max(0.0, std::atof(std::getenv("CLIPPER_HIP_CSC_C0"))) : -1.0;
   static_assert(sizeof(clipper_plan::Work) == sizeof(SliceWork), "the planner's work item is the kernel's");
@@ -313,7 +339,7 @@ int slices_plan(Ctx* h, Shard& s) {
     h->csc_hcap_work = nw + 1024;
   }
   std::memcpy(h->csc_hwork, plan.work.data(), nw * sizeof(SliceWork));
-  HIPCHK(hipSetDevice(s.device));
+  HIPCHK(hipSetDevice(sh.device));
   int rc = grow_dev(s.swork, s.scap_work, nw);
   if (rc) return rc;
   {
@@ -321,23 +347,28 @@ int slices_plan(Ctx* h, Shard& s) {
     const size_t bytes = nw * sizeof(SliceWork);  // 32 bytes each
     if (bytes <= (1u << 20) && hipHostGetDevicePointer(&wdev, h->csc_hwork, 0) == hipSuccess && wdev) {
       hipLaunchKernelGGL(k_copy_words, dim3(static_cast<unsigned>(std::min<size_t>(ceil_div(bytes / 16, 256), 64))),
-                         dim3(256), 0, s.stream, reinterpret_cast<const uint4*>(wdev),
+                         dim3(256), 0, sh.stream, reinterpret_cast<const uint4*>(wdev),
                          reinterpret_cast<uint4*>(s.swork), static_cast<int64_t>(bytes / 16));
     } else {
       (void)hipGetLastError();
-      HIPCHK(hipMemcpyAsync(s.swork, h->csc_hwork, bytes, hipMemcpyHostToDevice, s.stream));
+      HIPCHK(hipMemcpyAsync(s.swork, h->csc_hwork, bytes, hipMemcpyHostToDevice, sh.stream));
     }
+    // the pinned staging is shared by every store and shard of the context: the copy has to be
+    // through before the next plan overwrites it (one shard's own builds are ordered by its stream
+    // and by the wait that precedes every plan)
+    if (h->sh.size() > 1) HIPCHK(hipStreamSynchronize(sh.stream));
   }
   const size_t NSLOT = static_cast<size_t>(nslot(h->V));
-  if (static_cast<size_t>(nslots) > s.part_tiles) {
-    HIPCHK(hipFree(s.part));
-    s.part = nullptr;
-    s.part_tiles = static_cast<size_t>(nslots) + 8;
-    HIPCHK(hipMalloc(&s.part, s.part_tiles * NSLOT * static_cast<size_t>(h->W) * sizeof(double)));
+  if (static_cast<size_t>(nslots) > sh.part_tiles) {
+    HIPCHK(hipStreamSynchronize(sh.stream));
+    HIPCHK(hipFree(sh.part));
+    sh.part = nullptr;
+    sh.part_tiles = static_cast<size_t>(nslots) + 8;
+    HIPCHK(hipMalloc(&sh.part, sh.part_tiles * NSLOT * static_cast<size_t>(h->W) * sizeof(double)));
   }
   s.s_nwork = static_cast<int>(nw);
   s.s_nslots = nslots;
-  return resident_plan(h, s);  // small problems: the whole solve as one launch
+  return whole ? resident_plan(h, sh) : 0;  // small problems: the whole solve as one launch
 }
 
 // After the stream was synchronised: did everything fit? If not (always the case for the first
@@ -421,12 +452,69 @@ int csc_rebuild(Ctx* h) {
   return sync_all(h);
 }
 
+bool rect_fill_possible(const Ctx* h);
+int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O);
+
+// Every compressed build the symmetric kernel cannot serve (fp64 values, column shards): the
+// rectangular tile kernel writes each shard's slices straight from its LDS images — no dense store, no
+// groups, no packers, whatever the size. The shards fill concurrently; their directories come back one
+// after the other (the pinned staging is the context's).
+int run_affinity_rect(Ctx* h, double& kernel_ms) {
+  drop_dense(h);
+  Shard& s0 = h->sh[0];
+  HIPCHK(hipSetDevice(s0.device));
+  if (!h->ev_aff[0]) {
+    HIPCHK(hipEventCreate(&h->ev_aff[0]));
+    HIPCHK(hipEventCreate(&h->ev_aff[1]));
+  }
+  std::vector<char> pending(h->sh.size(), 1);
+  kernel_ms = 0.0;
+  for (int attempt = 0;; ++attempt) {
+    if (attempt >= 3) return fail(CLIPPER_HIP_E_HIP, "compressed storage: the build keeps overflowing");
+    HIPCHK(hipSetDevice(s0.device));
+    HIPCHK(hipEventRecord(h->ev_aff[0], s0.stream));
+    std::vector<SliceOut> outs(h->sh.size());
+    for (size_t k = 0; k < h->sh.size(); ++k) {
+      if (!pending[k]) continue;
+      Shard& s = h->sh[k];
+      HIPCHK(hipSetDevice(s.device));
+      int rc = emit_prepare(h, s, s, h->m, outs[k]);
+      if (rc) return rc;
+      // (emit_prepare stages the arenas' start values in pinned memory shared by all shards)
+      if (h->sh.size() > 1) HIPCHK(hipStreamSynchronize(s.stream));
+      if ((rc = launch_rect(h, s, nullptr, h->m, outs[k]))) return rc;
+    }
+    HIPCHK(hipSetDevice(s0.device));
+    HIPCHK(hipEventRecord(h->ev_aff[1], s0.stream));
+    bool any = false;
+    for (size_t k = 0; k < h->sh.size(); ++k) {
+      if (!pending[k]) continue;
+      Shard& s = h->sh[k];
+      int rc = emit_enqueue(h, s, s);
+      if (rc) return rc;
+      HIPCHK(hipStreamSynchronize(s.stream));
+      HIPCHK(hipGetLastError());
+      bool again = false;
+      if ((rc = emit_check(h, s, s, csc_single(h), again))) return rc;
+      pending[k] = again ? 1 : 0;
+      any = any || again;
+    }
+    float ms = 0.f;
+    HIPCHK(hipSetDevice(s0.device));
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_aff[0], h->ev_aff[1]));
+    kernel_ms = ms;  // the last round of fills (the first of a problem size only sizes the arenas)
+    if (!any) break;
+  }
+  return sync_all(h);
+}
+
 // `emits`: the fill kernel `launch` starts writes the slices itself when asked to
 // (k_affinity_sym, fp32) — then neither a dense store nor groups are needed
 template <typename Launch>
 int run_affinity(Ctx* h, bool emits, Launch launch) {
   h->has_matrix = false;  // until the build has succeeded (a failed rebuild leaves no matrix)
   h->csc_valid = false;
+  for (auto& s : h->sh) s.rv.valid = false;  // a row view of the previous matrix
   h->nodes.clear();
   // explicit constraint storage is not needed on this path: C == pattern(M)
   for (auto& s : h->sh) {
@@ -440,6 +528,17 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
   plan_tiles(h);
   int rc = 0;
   const bool emit = csc_applies(h) && csc_single(h) && emits && h->storage == CLIPPER_HIP_STORE_F32;
+  static const bool rect_off = std::getenv("CLIPPER_HIP_RECT_FILL") && std::atoi(std::getenv("CLIPPER_HIP_RECT_FILL")) == 0;
+  if (!emit && csc_applies(h) && rect_fill_possible(h) && !h->plain_affinity && !h->strip_affinity && !rect_off) {
+    double kms = 0.0;
+    if ((rc = run_affinity_rect(h, kms))) return rc;
+    h->csc_valid = true;
+    h->csc_emitted = true;
+    h->tm.affinity_kernel_ms = kms;
+    h->tm.affinity_bytes = static_cast<double>(h->sh[0].s_bytes);
+    h->has_matrix = true;
+    return 0;
+  }
   if (emit) drop_dense(h);  // a materialised copy would be stale
   else if ((rc = ensure_dense(h, false))) return rc;
   Shard& s0 = h->sh[0];
@@ -559,6 +658,7 @@ int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32
     hipFree(dout);
     for (size_t e = 0; e < tmp.size(); ++e) Wsub[e] += tmp[e];  // disjoint column sets
   }
+  if (h->csc_valid) drop_dense(h);  // the copy was materialised for this gather only: M lives in the slices
   for (int32_t a : dsd::densest_subgraph(Wsub, k, h->m)) nodes.push_back(S[static_cast<size_t>(a)]);
   return 0;
 }

@@ -1,0 +1,217 @@
+// host_rowview.hpp — the rectangular fill's launcher, and the ROW VIEW of the solver: when it pays to
+// build one, how it is built between two iterations, what the launches are told about it.
+// Part of clipper_hip.hip (one translation unit; included there, in order).
+//
+// Why: row r of every line-search candidate max(u + alpha g, 0) (clipper.cpp:235-236) is exactly zero
+// unless u[r] > 0 or g[r] > 0 ("live", k_solver.hip.h), and the reference's iteration drives the
+// outliers' rows out of the live set within a few steps (m = 10k, 95 % outliers: 36 % live during
+// the first outer iteration, 5 % from the second on — 52 of 66 trials). A pass then needs
+// M[live rows, :] only. The view is the slices of exactly that sub-matrix, written by the same tile
+// kernel that serves column shards and fp64 values (k_affinity_rect); the device decides per pass
+// whether the view may stand in for M (no live row outside it), so a view that is out of date costs
+// time, never correctness.
+#pragma once
+
+namespace {
+
+// ---- k_affinity_rect for the invariant the current matrix was scored with -------------------------
+template <typename K>
+void launch_rect_kernel(K kernel, int lds_bytes, dim3 grid, hipStream_t stream, const RectGeom& G,
+                        const Shard& s, int64_t pstride, const int32_t* A0, const int32_t* A1,
+                        const EuclidParams& e, const PointNormalParams& n, float E2, const SliceOut& O) {
+  static std::vector<const void*> raised;  // once per kernel instantiation
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  if (std::find(raised.begin(), raised.end(), fn) == raised.end()) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    raised.push_back(fn);
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(AT_WAVES * 64), lds_bytes, stream, G, s.P1, s.P2, s.P1f, s.P2f,
+                     pstride, A0, A1, e, n, E2, O);
+}
+
+bool rect_fill_possible(const Ctx* h) {
+  return (h->fill_kind == 1 && (h->staged_d == 2 || h->staged_d == 3)) ||
+         (h->fill_kind == 2 && h->staged_d == 6);
+}
+
+// The slices of M[rows, this shard's columns] into the store O describes. rowmap == null: all rows.
+int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O) {
+  if (!rect_fill_possible(h)) return fail(CLIPPER_HIP_E_STATE, "no built-in invariant is staged");
+  RectGeom G;
+  G.m = h->m;
+  G.nrows = nrows;
+  G.rowmap = rowmap;
+  G.col0 = static_cast<int64_t>(s.slot) * h->W;
+  G.ncols = std::max<int64_t>(0, std::min<int64_t>(h->W, h->m - G.col0));
+  const int64_t nTr = ceil_div(nrows, AT);
+  const int32_t* A0 = s.Adev;
+  const int32_t* A1 = s.Adev + h->m;
+  const int64_t ps = h->staged_pstride;
+  dispatch_vt(h, [&](auto t) {
+    using VT = decltype(t);
+    constexpr int TW = rect_tw<VT>();
+    G.nTc = static_cast<int>(ceil_div(h->W, TW));
+    const dim3 grid(static_cast<unsigned>(nTr * G.nTc));
+    constexpr int L = rect_lds_bytes<VT>();
+    if (h->fill_kind == 2)
+      launch_rect_kernel(k_affinity_rect<3, true, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+    else if (h->staged_d == 3)
+      launch_rect_kernel(k_affinity_rect<3, false, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+    else
+      launch_rect_kernel(k_affinity_rect<2, false, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+  });
+  return 0;
+}
+
+// ---- the row view -----------------------------------------------------------------------------------
+
+void rowview_drop(Ctx* h) {
+  for (auto& s : h->sh) s.rv.valid = false;
+}
+
+void rowview_free(Shard& s) {
+  auto fr = [](auto*& p) {
+    if (p) hipFree(p);
+    p = nullptr;
+  };
+  RowView& v = s.rv;
+  fr(v.st.sSizes);
+  fr(v.st.sLq);
+  fr(v.st.sPre);
+  fr(v.st.sBlk);
+  fr(v.st.sdata);
+  fr(v.st.swork);
+  v.st = SliceStore{};
+  fr(v.rowmap[0]);
+  fr(v.rowmap[1]);
+  fr(v.in_view[0]);
+  fr(v.in_view[1]);
+  fr(v.blk);
+  v.cap_rows = v.cap_flags = v.cap_blk = 0;
+  v.valid = false;
+  v.nrows = 0;
+}
+
+// a view can exist at all: one device, slices with C == pattern(M), scored from staged points
+bool rowview_possible(const Ctx* h) {
+  static const bool env_off = [] {
+    const char* e = std::getenv("CLIPPER_HIP_ROW_VIEW");
+    return e && std::atoi(e) == 0;
+  }();
+  return !env_off && h->rv_mode == 0 && h->csc_valid && csc_single(h) && !h->explicitC &&
+         rect_fill_possible(h) && h->m >= RV_MIN_M;
+}
+
+// The cost model the device-side policy (view_wanted, k_solver.hip.h) works with, for the matrix at
+// hand. A pass that streams r of the m rows: what the launch costs besides the bytes (decision,
+// prologue, the slowest workgroup's tail) + r rows' share of the slices at the rate the pass sustains.
+// Building a view of r rows: drain + compaction + directory round trip + planning, and the rectangular
+// fill (r * m pairs at the rate of the tile kernels, which have no mirror image to share).
+ViewPolicy rowview_policy(const Ctx* h) {
+  static const double scale_env = std::getenv("CLIPPER_HIP_RV_BUILD_SCALE") ? std::atof(std::getenv("CLIPPER_HIP_RV_BUILD_SCALE")) : 1.0;
+  ViewPolicy p{};
+  p.on = rowview_possible(h) ? 1 : 0;
+  p.max_builds = RV_MAX_BUILDS;
+  p.pass_fixed = 8e-6;
+  p.pass_per_row = static_cast<double>(h->sh[0].s_bytes) / static_cast<double>(h->m) / 3.3e12;
+  p.build_fixed = 60e-6 * scale_env;
+  p.build_per_row = static_cast<double>(h->m) * 4.5e-12 * scale_env;
+  return p;
+}
+
+template <typename T>
+int rv_grow(T*& p, size_t& cap, size_t need) {
+  if (need <= cap && p) return 0;
+  if (p) hipFree(p);
+  p = nullptr;
+  cap = 0;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(need, 1) * sizeof(T)));
+  cap = need;
+  return 0;
+}
+
+// Builds the view from the state the NEXT iteration decides from (state copy h->par). The stream is
+// idle (the caller drained it). built = false: the live rows were too many to be worth it — the view
+// in use, if any, stays as it is.
+template <int V>
+int rowview_build_v(Ctx* h, bool& built) {
+  built = false;
+  Shard& s = h->sh[0];
+  RowView& v = s.rv;
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  HIPCHK(hipSetDevice(s.device));
+  const int64_t m = h->m, mp = h->mp;
+  const int nblk = static_cast<int>(ceil_div(m, RV_BLK));
+  int rc;
+  {
+    size_t c0 = v.cap_flags, c1 = v.cap_flags;
+    if ((rc = rv_grow(v.in_view[0], c0, static_cast<size_t>(mp)))) return rc;
+    if ((rc = rv_grow(v.in_view[1], c1, static_cast<size_t>(mp)))) return rc;
+    v.cap_flags = static_cast<size_t>(mp);
+    size_t r0 = v.cap_rows, r1 = v.cap_rows;
+    if ((rc = rv_grow(v.rowmap[0], r0, static_cast<size_t>(mp)))) return rc;
+    if ((rc = rv_grow(v.rowmap[1], r1, static_cast<size_t>(mp)))) return rc;
+    v.cap_rows = static_cast<size_t>(mp);
+    if ((rc = rv_grow(v.blk, v.cap_blk, static_cast<size_t>(nblk) + 2))) return rc;
+  }
+  if (!h->rv_count) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->rv_count), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->rv_count_dev), h->rv_count, 0));
+  }
+  const int next = v.cur ^ 1;
+  *h->rv_count = -1;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  hipLaunchKernelGGL((k_rv_flags<V>), dim3(static_cast<unsigned>(nblk)), dim3(256), 0, s.stream,
+                     s.st + h->par, s.pt, mp, m, v.in_view[next], v.blk);
+  hipLaunchKernelGGL(k_rv_scan, dim3(1), dim3(1024), 0, s.stream, v.blk, nblk, h->rv_count_dev);
+  hipLaunchKernelGGL(k_rv_scatter, dim3(static_cast<unsigned>(nblk)), dim3(256), 0, s.stream,
+                     v.in_view[next], m, v.blk, v.rowmap[next], static_cast<int64_t>(v.cap_rows));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  const int64_t nrows = *h->rv_count;
+  if (nrows < 0) return fail(CLIPPER_HIP_E_HIP, "row view: the row count did not arrive");
+  const double rows_now = v.valid ? static_cast<double>(v.nrows) : static_cast<double>(m);
+  // the union over the pending outcomes may be larger than the live count the decision asked with:
+  // the same cost model, now with the rows the view would really have (a function of the state alone)
+  const ViewPolicy pol = rowview_policy(h);
+  const double horizon = std::max<double>(12.0, static_cast<double>(h->mirror->iters));
+  if (nrows == 0 || static_cast<double>(nrows) > 0.85 * rows_now ||
+      pol.build_fixed + pol.build_per_row * static_cast<double>(nrows) >
+          horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row) {
+    hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, static_cast<int>(nrows));
+    h->rv_stats.build_ms +=
+        std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    return 0;
+  }
+  v.valid = false;  // its store is about to be overwritten
+  for (int attempt = 0;; ++attempt) {
+    SliceOut O{};
+    if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
+    if ((rc = launch_rect(h, s, v.rowmap[next], nrows, O))) return rc;
+    if ((rc = emit_enqueue(h, s, v.st))) return rc;
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipGetLastError());
+    bool again = false;
+    if ((rc = emit_check(h, s, v.st, false, again))) return rc;
+    if (!again) break;
+    if (attempt >= 2) return fail(CLIPPER_HIP_E_HIP, "row view: the build keeps overflowing");
+  }
+  v.cur = next;
+  v.nrows = nrows;
+  v.valid = true;
+  built = true;
+  hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, 0);
+  h->rv_stats.builds += 1;
+  h->rv_stats.rows = nrows;
+  h->rv_stats.bytes = static_cast<int64_t>(v.st.s_bytes);
+  h->rv_stats.build_ms +=
+      std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+  return 0;
+}
+
+int rowview_build(Ctx* h, bool& built) {
+  int rc = 0;
+  dispatch_window(h, [&](auto v) { rc = rowview_build_v<decltype(v)::value>(h, built); });
+  return rc;
+}
+
+}  // namespace

@@ -6,6 +6,8 @@ namespace {
 
 using Ctx = clipper_hip_ctx;
 
+void rowview_free(Shard& s);
+
 int free_shard_buffers(Shard& s) {
   hipSetDevice(s.device);
   auto fr = [](auto*& p) {
@@ -38,6 +40,7 @@ int free_shard_buffers(Shard& s) {
   fr(s.sdata);
   fr(s.swork);
   s.scap_slices = s.scap_bytes = s.scap_work = 0;
+  rowview_free(s);
   s.part_tiles = 0;
   fr(s.P1);
   fr(s.P2);
@@ -128,7 +131,7 @@ int ensure_problem(Ctx* h, int64_t m) {
     s.bytes_S = bytesS;
     // CLIPPER_HIP_STORE_F32_CSC keeps M compressed: the dense store exists only while a path
     // that needs it is in use (ensure_dense)
-    if (!csc_single(h)) HIPCHK(hipMalloc(&s.S, bytesS));
+    if (!h->compressed) HIPCHK(hipMalloc(&s.S, bytesS));
     const size_t nvec = static_cast<size_t>(P * W) * sizeof(double);
     const size_t V = static_cast<size_t>(h->V);
     HIPCHK(hipMalloc(&s.u0, nvec));
@@ -139,7 +142,7 @@ int ensure_problem(Ctx* h, int64_t m) {
       HIPCHK(hipMalloc(&s.X[k], (V + 1) * VS * nvec));
       HIPCHK(hipMemsetAsync(s.X[k], 0, (V + 1) * VS * nvec, s.stream));
     }
-    const size_t Q = V * (2 + 2 * V) + 2 * V + 2;
+    const size_t Q = static_cast<size_t>(tail_q(h->V));
     const size_t nwg = static_cast<size_t>(ceil_div(m, TAIL_THREADS));
     HIPCHK(hipMalloc(&s.scal, (nwg + ceil_div(nwg, SCAL_FOLD) + 1) * Q * sizeof(double)));
     HIPCHK(hipMalloc(&s.ab, NSLOT * nvec));
@@ -203,6 +206,7 @@ void launch_pass(Ctx* h, Shard& s, const SolveArgs& a) {
 }
 
 SliceView slice_view(const Ctx* h, const Shard& s);
+SliceView row_view(const Ctx* h, const Shard& s);
 
 // the pair-mode mat-vec alone on table X (matvec API, micro-benchmark)
 void launch_plain(Ctx* h, Shard& s, const double* X) {
@@ -225,12 +229,13 @@ SliceView slice_view(const Ctx* h, const Shard& s);
 
 template <int V>
 void launch_pass_csc(Ctx* h, Shard& s, const SolveArgs& a) {
-  const SliceView M = slice_view(h, s);
-  dim3 grid(static_cast<unsigned>(s.s_nwork)), block(SL_NW * 64);
+  const SliceView M = slice_view(h, s), R = row_view(h, s);
+  // (the LAST workgroup records the decided state: on M it is the one with the least to stream)
+  dim3 grid(static_cast<unsigned>(std::max(M.nwork, R.nwork))), block(SL_NW * 64);
   if (h->storage == CLIPPER_HIP_STORE_F64)
-    hipLaunchKernelGGL((k_gemv_slices<double, 1, V>), grid, block, 0, s.stream, M, a);
+    hipLaunchKernelGGL((k_gemv_slices<double, 1, V>), grid, block, 0, s.stream, M, R, a);
   else
-    hipLaunchKernelGGL((k_gemv_slices<float, 1, V>), grid, block, 0, s.stream, M, a);
+    hipLaunchKernelGGL((k_gemv_slices<float, 1, V>), grid, block, 0, s.stream, M, R, a);
 }
 
 // calls f(integral_constant<V>) for the context's window size
@@ -351,13 +356,21 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.scal_in = s.scal;
   a.nwg_in = a.nwg;
   if (a.nwg > SCAL_FOLD_MIN) {  // folded copy behind the partials themselves
-    a.scal_in = s.scal + static_cast<int64_t>(a.nwg) * (h->V * (2 + 2 * h->V) + 2 * h->V + 2);
+    a.scal_in = s.scal + static_cast<int64_t>(a.nwg) * tail_q(h->V);
     a.nwg_in = static_cast<int>(ceil_div(a.nwg, SCAL_FOLD));
   }
   a.marks = (h->profiling && &s == &h->sh[0]) ? s.marks : nullptr;
   a.kind = (a.marks && !h->multiproc) ? h->kind_dev : nullptr;
   a.host_u = (!h->multiproc && &s == &h->sh[0]) ? h->u_pinned_dev : nullptr;
   a.stamps = (&s == &h->sh[0]) ? h->stamps_dev : nullptr;
+  // the row view, while one is in use (one shard)
+  const bool view = h->csc_valid && s.rv.valid;
+  a.in_view = view ? s.rv.in_view[s.rv.cur] : nullptr;
+  a.rv_nslots = view ? s.rv.st.s_nslots : 0;
+  a.rv_nwork = view ? s.rv.st.s_nwork : 0;
+  a.rv_fresh = (view && h->rv_fresh) ? 1 : 0;
+  a.rv_rows = view ? static_cast<int>(s.rv.nrows) : 0;
+  a.rvp = h->rvp;
   return a;
 }
 
@@ -392,6 +405,7 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
     }
   }
   ++h->launch_counter;
+  const bool fresh_used = h->rv_fresh;
   if (sharded) {
     for (auto& s : h->sh) {  // the tile partials of the pass -> this shard's block of `ab`
       HIPCHK(hipSetDevice(s.device));
@@ -418,9 +432,10 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
     }
     if (a.nwg_in != a.nwg)
       hipLaunchKernelGGL(k_scal_fold, dim3(static_cast<unsigned>(a.nwg_in)), dim3(128), 0, s.stream,
-                         a.scal, a.nwg, V * (2 + 2 * V) + 2 * V + 2,
+                         a.scal, a.nwg, tail_q(V),
                          const_cast<double*>(a.scal_in), a.shared);
   }
+  if (fresh_used) h->rv_fresh = false;  // only the first iteration after a build decides from the state it saw
   return 0;
 }
 

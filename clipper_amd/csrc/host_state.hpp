@@ -50,6 +50,9 @@ constexpr int64_t WINDOW4_MIN_M = 2000;
 // multi-process: iterations queued between two state snapshots. Up to two batches of no-op
 // iterations (each still holds its all-gather) run past convergence: keep them short. 16 -> 4
 // changes nothing on a 1-rank world (tools/rank1_probe.py).
+// the row view (host_rowview.hpp): problems the resident solver does not take anyway; views per solve
+constexpr int64_t RV_MIN_M = 3000;
+constexpr int RV_MAX_BUILDS = 6;
 constexpr int SOLVE_BATCH = 4;
 constexpr int RUN_AHEAD = 4;     // one process: iterations kept queued ahead of the device
 constexpr int MAX_EVENT_PAIRS = 256;  // per solve; created when profiling is switched on
@@ -91,8 +94,36 @@ int load_rccl() {
   return 0;
 }
 
+// ---- one set of slices (k_slices.hip.h): the data, its directory, the work list of a pass ----
+struct SliceStore {
+  uint32_t* sSizes = nullptr;   // [nslices] size / 16
+  uint32_t* sLq = nullptr;      // [nslices] maxq | entries << 8
+  uint64_t* sPre = nullptr;     // [nslices]
+  uint64_t* sBlk = nullptr;     // scan block sums [nblk + 1]; the last one = total units
+  uint8_t* sdata = nullptr;
+  SliceWork* swork = nullptr;
+  size_t scap_slices = 0, scap_bytes = 0, scap_work = 0;
+  int s_ncg = 0, s_nchunks = 0;
+  int s_nwork = 0;        // workgroups of a pass
+  int s_nslots = 0;       // partial-sum slots per column (what the tail adds)
+  uint64_t s_bytes = 0;   // bytes of the slices
+  uint64_t s_entries = 0; // stored entries (both triangles)
+};
+
+// ---- the row view of M (k_solver.hip.h, LIVE ROWS; host_rowview.hpp) ---------------------------
+struct RowView {
+  SliceStore st;               // the slices of M[rows, :] (this shard's columns)
+  int32_t* rowmap[2] = {nullptr, nullptr};  // [cap_rows] association of view row r': in use / being built
+  uint8_t* in_view[2] = {nullptr, nullptr};  // [mp] row flags: of the view in use / of the one being built
+  int cur = 0;                 // which of the two the view in use owns
+  uint32_t* blk = nullptr;     // [nblk + 2] per-block live counts, then their offsets
+  size_t cap_rows = 0, cap_flags = 0, cap_blk = 0;
+  int64_t nrows = 0;
+  bool valid = false;
+};
+
 // ---- one column slice of M on one device ------------------------------------------------
-struct Shard {
+struct Shard : SliceStore {
   int device = 0;
   int slot = 0;  // global shard index: owns columns [slot*W, slot*W + W)
   hipStream_t stream = nullptr;
@@ -126,19 +157,8 @@ struct Shard {
   uint8_t* grows = nullptr;     // [4 * gcap_units]
   CscBuildCtl* cctl = nullptr;  // [CSC_ARENAS]
   size_t gcap_units = 0, gcap_groups = 0;
-  // -- slices: what the passes stream
-  uint32_t* sSizes = nullptr;   // [nslices] size / 16
-  uint32_t* sLq = nullptr;      // [nslices] maxq | entries << 8
-  uint64_t* sPre = nullptr;     // [nslices]
-  uint64_t* sBlk = nullptr;     // scan block sums [nblk + 1]; the last one = total units
-  uint8_t* sdata = nullptr;
-  SliceWork* swork = nullptr;
-  size_t scap_slices = 0, scap_bytes = 0, scap_work = 0;
-  int s_ncg = 0, s_nchunks = 0;
-  int s_nwork = 0;        // workgroups of a pass
-  int s_nslots = 0;       // partial-sum slots per column (what the tail adds)
-  uint64_t s_bytes = 0;   // bytes of the slices
-  uint64_t s_entries = 0; // stored entries (both triangles)
+  // -- slices: what the passes stream: the SliceStore this shard IS (all rows), and the row view
+  RowView rv;
 };
 
 // the resident solver (k_resident.hip.h): plan of the current slices and its buffers
@@ -221,6 +241,20 @@ struct clipper_hip_ctx {
   Resident res;
   int resident_mode = 0;   // 0 = use the resident solver where the slices fit, 1 = never
   int last_solver = 0;     // what the last solve ran on: 0 = streaming launches, 1 = resident
+
+  // what built the matrix, kept so that a row view can be filled from the same points later:
+  // 0 = nothing (setMatrixData: no view), 1 = EuclideanDistance, 2 = PointNormalDistance
+  int fill_kind = 0;
+  EuclidParams fill_e{};
+  PointNormalParams fill_n{};
+  float fill_E2 = 0.f;
+  // row-view policy (host_rowview.hpp)
+  ViewPolicy rvp{};           // the cost model the device-side policy works with (host_rowview.hpp)
+  bool rv_fresh = false;      // the next iteration is the first after a view was built
+  int rv_mode = 0;            // 0 = automatic, 1 = never (clipper_hip_set_row_view / CLIPPER_HIP_ROW_VIEW=0)
+  int32_t* rv_count = nullptr;      // pinned + mapped: rows of the view being built
+  int32_t* rv_count_dev = nullptr;
+  clipper_hip_view_stats_t rv_stats{};
 
   long long* stamps_dev = nullptr;  // CLIPPER_HIP_STAMPS=1: [4096][4], see SolveArgs::stamps
   bool profiling = false;

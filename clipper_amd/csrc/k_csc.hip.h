@@ -127,12 +127,13 @@ __device__ __forceinline__ void gr_emit(const VT (&v)[GR_RB], int64_t g, const G
 // only records its size and maxq (the host grows the arena and repeats the fill).
 // Contains ONE __syncthreads (every wave of the workgroup must call it). `base_s`: LDS, one
 // unsigned long long per slice of the workgroup, this slice's at index `sl`.
-__device__ __forceinline__ void slice_emit_lds(const float* col, int stride, uint64_t mlo,
+template <typename VT>
+__device__ __forceinline__ void slice_emit_lds(const VT* col, int stride, uint64_t mlo,
                                                uint64_t mhi, int64_t s, int sl, int half,
                                                const SliceOut& O, unsigned long long* base_s,
                                                long long* tstamp) {
-  static_assert(SL_SUB == 128, "a slice is as tall as a tile of k_affinity_sym");
-  constexpr int QB = 16;
+  static_assert(SL_SUB == 128, "a slice is as tall as a tile of the fill kernels");
+  constexpr int QB = 4 * static_cast<int>(sizeof(VT));
   const int lane = threadIdx.x & 63;
   const int n = __popcll(mlo) + __popcll(mhi);
   const int tot = (n + 3) >> 2;
@@ -183,7 +184,8 @@ __device__ __forceinline__ void slice_emit_lds(const float* col, int stride, uin
     const bool own = (q & 1) == half;  // uniform
     if (own && (q % SL_SO) == 0 && lane == 0) so[q / SL_SO] = off;
     if (active) {
-      float v4[4] = {0.f, 0.f, 0.f, 0.f};
+      SliceQuad<VT> vq;
+      vq.v[0] = vq.v[1] = vq.v[2] = vq.v[3] = VT(0);
       uint32_t rq = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -196,13 +198,13 @@ __device__ __forceinline__ void slice_emit_lds(const float* col, int stride, uin
           mhi &= mhi - 1;
         }
         if (own && row >= 0) {
-          v4[e] = col[row * stride];
+          vq.v[e] = col[row * stride];
           rq |= static_cast<uint32_t>(row) << (8 * e);
         }
       }
       if (own) {
         const uint32_t rank = sl_lane_rank(mask);
-        *reinterpret_cast<float4*>(sp + off + rank * QB) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        vq.store(sp + off + rank * QB);
         *reinterpret_cast<uint32_t*>(sp + off + cnt * QB + rank * 4) = rq;
       }
     }

@@ -72,6 +72,12 @@ struct SliceView {
   const SliceWork* work;
   int nchunks;  // chunks of R rows
   int ncg;      // column groups
+  int nwork;    // workgroups of a pass (entries of `work`)
+  // A ROW VIEW (k_solver.hip.h, LIVE ROWS): the slices of M[rows, :] for a row list — row r' of the
+  // view is row rowmap[r'] of M, the x rows of a chunk are gathered through the map when they are
+  // staged. The matrix itself: rowmap == null, nrows == m.
+  const int32_t* rowmap;
+  int64_t nrows;
 };
 
 // Window mode stages candidates 0 .. sl_xload(V)-1 of a table row at a pitch of sl_xpitch(V)
@@ -139,12 +145,13 @@ struct SliceXStage {
   double wu[WINDOW ? PER : 1], wg[WINDOW ? PER : 1];
   double s[WINDOW ? 1 : PER];
   __device__ __forceinline__ void load(const WindowSource& W, const double* __restrict__ X, int xstride,
-                                       int64_t r0, int64_t m) {
+                                       int64_t r0, int64_t nrows, const int32_t* __restrict__ rowmap) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int p = threadIdx.x + i * NT;
-      const int64_t r = r0 + p;
-      const bool in = p < PIECES && r < m;
+      const int64_t rv = r0 + p;
+      const bool in = p < PIECES && rv < nrows;
+      const int64_t r = (in && rowmap != nullptr) ? rowmap[rv] : rv;  // (uniform branch: one view per launch)
       if constexpr (WINDOW) {
         wu[i] = in ? W.U[r] : 0.0;
         wg[i] = in ? W.G[r] : 0.0;
@@ -202,7 +209,7 @@ struct SliceJob {
 template <int H, int NW>
 __device__ __forceinline__ void slice_begin(const SliceView& M, SliceJob<H, NW>& J) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const SliceWork w = M.work[blockIdx.x];
+  const SliceWork w = M.work[static_cast<int>(blockIdx.x) < M.nwork ? blockIdx.x : 0];
   J.strip = w.strip;
   J.slot = w.slot;
   J.cg = J.strip * NW + wave;
@@ -215,6 +222,16 @@ __device__ __forceinline__ void slice_begin(const SliceView& M, SliceJob<H, NW>&
   J.pre1 = 0;
 #pragma unroll
   for (int h = 0; h < H; ++h) J.first.nq[h] = 0;
+  if (static_cast<int>(blockIdx.x) >= M.nwork) {  // no item of this view for this workgroup
+    J.strip = J.slot = J.t0 = J.t1 = J.q0 = J.q1 = 0;
+    J.cg = M.ncg;
+    J.first.maxq = 0;
+    J.first.sp = M.data;
+    J.pre1 = 0;
+#pragma unroll
+    for (int h = 0; h < H; ++h) J.first.nq[h] = 0;
+    return;
+  }
   if (J.cg < M.ncg && J.t0 < J.t1) {
     const uint64_t* pre = M.Pre + static_cast<int64_t>(J.cg) * M.nchunks + J.t0;
     J.first.load(M.data + 16 * pre[0], threadIdx.x & 63);
@@ -249,7 +266,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
   SliceXStage<WINDOW, XL, XP, R, NT> xst;
   __syncthreads();  // the decision at the head of the launch used the same LDS
   if (t0 < t1) {
-    xst.load(WS, X, xstride, static_cast<int64_t>(t0) * R, m);
+    xst.load(WS, X, xstride, static_cast<int64_t>(t0) * R, M.nrows, M.rowmap);
     xst.store(WS, lds);
   }
   __syncthreads();
@@ -263,7 +280,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
     SliceHead<H> nxt = cur;
     uint64_t pre_next2 = 0;
     if (more) {
-      xst.load(WS, X, xstride, static_cast<int64_t>(k + 1) * R, m);
+      xst.load(WS, X, xstride, static_cast<int64_t>(k + 1) * R, M.nrows, M.rowmap);
       if (mine) nxt.load(M.data + 16 * pre_next, lane);
       if (k + 2 < t1) pre_next2 = pre_row[k + 2];
     }
@@ -348,7 +365,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
   }
 
   const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
-  if (c < ld) {
+  if (c < ld && static_cast<int>(blockIdx.x) < M.nwork) {
 #pragma unroll
     for (int v = 0; v < NS; ++v) {
       const int slot = (v == NS - 1) ? NSLOT - 1 : v;
@@ -392,8 +409,10 @@ constexpr int SL_D = CLIPPER_SL_D;   // steps in flight per lane (2 / 3 / 4 / 6 
 constexpr int SL_OCC = CLIPPER_SL_OCC;  // waves per SIMD the pass kernel is compiled for (= workgroups per CU)
 
 // G of a solver iteration on the slices (one shard): decision, then the pass
+// `RV`: the row view of M (RV.data == null: none). The grid covers the larger of the two work lists;
+// which one a launch streams is decided at its head (PassPlan::view).
 template <typename VT, int H, int V>
-__global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M, SolveArgs A) {
+__global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M, SliceView RV, SolveArgs A) {
   __shared__ __attribute__((aligned(16))) double lds[sl_lds_doubles(V, H, SL_NW)];
   __shared__ __attribute__((aligned(16))) SolverState stash;
   const long long c0 = A.stamps ? wall_clock64() : 0;
@@ -402,6 +421,12 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   PassPlan plan;
   if (!iteration_head<V, SL_NW * 64>(A, lds, &stash, plan)) return;
   const long long c1 = A.stamps ? wall_clock64() : 0;
+  if (plan.view) {
+    // (the view's slices are few and hot in L2: its first header is requested here, not ahead of the
+    // decision; one call site of the streaming loop for both — M is only a name from here on)
+    M = RV;
+    slice_begin<H, SL_NW>(M, J);
+  }
   slices_by_plan<VT, H, V, SL_NW, SL_D>(M, J, A, plan, lds);
   flush_state(A, &stash);
   if (A.stamps && threadIdx.x == 0 && blockIdx.x < 1536) {

@@ -44,6 +44,48 @@ constexpr int VS = 8;       // doubles per table row; window sizes V <= VS
 // partial-sum slots per row tile: slot 0 = a = M_off x_0, slots 1..V-1 = g_v of the other
 // candidates, slot V = b = C_off x_0 (a pair-mode pass fills slots 0 and V only)
 constexpr int nslot(int V) { return V + 1; }
+// what a tail workgroup sums per candidate: Fnew, ||x - u||^2, the V (z, sum) pairs of the next
+// window's norms, and the LIVE CODE of the point the candidate would become (below)
+constexpr int tail_nr(int V) { return 3 + 2 * V; }
+// ... and per launch: V of those, the V pairs of the "all rejected" window, the two penalty sums
+constexpr int tail_q(int V) { return V * tail_nr(V) + 2 * V + 2; }
+
+// ------------------------------------------------------------------------------------------
+// LIVE ROWS and the ROW VIEW (what lets a pass skip the rows that cannot contribute)
+//
+// A window is built from a point (u', g') = (u, gradF): candidate l = max(u' + alpha_l g', 0)
+// (clipper.cpp:235-236). u' >= 0 always, so row r of EVERY candidate is exactly 0 unless
+//     live(r) :=  u'[r] > 0  or  g'[r] > 0,
+// and a row of zeros adds exact zeros to every sum of the pass: it can be skipped without
+// changing a bit of any partial sum it is skipped from. The projected gradient ascent of
+// clipper.cpp:226-262 drives the outliers' entries of u to zero within a few iterations and the
+// penalty keeps their gradient negative: at the headline problem (m = 10k, 95 % outliers) 45 %
+// of the rows are live after the first step, 36 % for the rest of the first outer iteration and
+// 5 % from the second outer iteration on (52 of 66 trials).
+// The host therefore builds, when the live rows have become few, a ROW VIEW of M: the slices of
+// M[R, :] for a row list R (host_rowview.hpp, k_affinity_rect) — and a pass streams the view
+// instead of M whenever the view is known to cover the live rows of the window it multiplies:
+//   * the tail counts, for the point every candidate v would become, its live rows and those of
+//     them that lie outside the view (one double: live + 2^26 * outside — exact integer sums);
+//   * the decision keeps the code of the accepted candidate in the state (nlive, nout) and
+//     plans the pass on the view iff nout == 0 (PassPlan::view); otherwise the pass runs on M
+//     itself, which is always correct;
+//   * WHEN a view is built is decided on the device too, as a function of the solver state alone
+//     (view_wanted below: a cost model of the passes to come against the fill): the decision then
+//     puts the solve on HOLD — this and every later iteration already queued do nothing — and tells
+//     the host, which drains the stream, builds the view from exactly the state that asked for it,
+//     lifts the hold and goes on queueing. Nothing depends on how far ahead the host was: a solve is
+//     bit-reproducible from run to run, views included.
+// ------------------------------------------------------------------------------------------
+constexpr double LIVE_OUT = 67108864.0;  // 2^26: the "outside the view" digit of a live code
+
+// cost model of the view policy (seconds; set by the host from the matrix at hand, see host_rowview.hpp)
+struct ViewPolicy {
+  int32_t on;           // 0: no views for this matrix
+  int32_t max_builds;
+  double pass_fixed, pass_per_row;    // a pass that streams r rows: pass_fixed + r * pass_per_row
+  double build_fixed, build_per_row;  // building a view of r rows
+};
 
 enum Phase : int32_t {
   PH_NORMALIZE = 0,  // no rescale: u = u0/||u0||, no pass consumed       (clipper.cpp:196-198)
@@ -82,6 +124,17 @@ struct SolverState {
   int64_t n_trials;  // trials the reference would have evaluated (window slots past the
                      // accepted candidate do not count)
   int64_t n_iters;   // iterations (G, T) the device has started
+  int32_t nlive;     // live rows of the current point (u, gradF), see LIVE ROWS above
+  int32_t nout;      // ... of which outside the row view the tail counted against
+  int32_t view;      // the pass of this iteration ran on the row view (1) or on M (0): which
+                     // partial-sum slots the tail adds
+  int32_t hold;      // the decision wants a row view built before it goes on: nothing runs until the
+                     // host has built it (or refused) and cleared this
+  int64_t n_view_passes;  // passes that ran on the row view
+  int32_t rv_builds;   // views asked for so far
+  int32_t rv_last;     // n_iters when the last one was asked for
+  int32_t rv_backoff;  // the host refused a view of this many rows (0: none): ask again only well below
+  int32_t pad1;
 };
 
 // What outlives the alternating state: the end of the solve. Kernels launched after
@@ -102,6 +155,10 @@ struct HostMirror {
   int64_t iters;
   int32_t ifinal, ubp, ubv;
   int32_t done;
+  int32_t nlive, nout;    // live rows of the current point / of them outside the view (reporting)
+  int64_t n_view_passes;
+  int32_t hold;           // the solve waits for the host to build a row view (SolverState::hold)
+  int32_t pad;
 };
 
 struct SolverParams {
@@ -150,6 +207,14 @@ struct SolveArgs {
   double* host_u; // pinned host memory [m] (may be null): the final u, written before `done`
   long long* stamps;  // measurement only (may be null): per workgroup {start, head done, end} of the
                       // last pass launch, 100 MHz wall clock (clipper_hip_debug_stamps)
+  // the row view (null / 0: none), see LIVE ROWS
+  const uint8_t* in_view;  // [m] 1 = the row is in the view
+  int rv_nslots;           // partial-sum slots of a pass on the view (ntiles: of a pass on M)
+  int rv_nwork;            // workgroups of a pass on the view
+  int rv_fresh;            // the view was built from exactly the state this iteration decides from:
+                           // it covers the live rows of every outcome, whatever the tail counted
+  int rv_rows;             // rows of the view
+  ViewPolicy rvp;
 };
 constexpr int KIND_CAP = 1 << 16;
 
@@ -256,7 +321,24 @@ __device__ __forceinline__ bool is_writer_block() {
   return blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1;
 }
 
+// The view policy: build a view of the `nlive` live rows now? Rows a pass streams today: the view's
+// while it covers the live rows, else all of M's; as many passes to come as there have been
+// iterations (at least 12: the penalty homotopy's later outer iterations are the long ones).
+__device__ __forceinline__ bool view_wanted(const SolveArgs& A, int nlive, int nout, int64_t n_iters,
+                                            int builds, int last, int backoff) {
+  if (builds >= A.rvp.max_builds || n_iters < 2 || n_iters - last < 3) return false;
+  if (nlive <= 0 || nlive >= A.m) return false;
+  const double rows_now = (A.in_view != nullptr && nout == 0) ? static_cast<double>(A.rv_rows) : static_cast<double>(A.m);
+  const double r = static_cast<double>(nlive);
+  if (r > 0.8 * rows_now) return false;
+  if (backoff > 0 && r > 0.8 * static_cast<double>(backoff)) return false;  // nothing much changed since a refusal
+  const double horizon = n_iters > 12 ? static_cast<double>(n_iters) : 12.0;
+  const double gain = horizon * ((rows_now - r) * A.rvp.pass_per_row);
+  return gain > A.rvp.build_fixed + r * A.rvp.build_per_row;
+}
+
 struct PassPlan {
+  int view;    // 1: stream the row view instead of M
   int phase;
   int sel;     // table of Xin that holds the pending window, or
   int from_u;  // -1, or (p*V + v): pair-mode pass straight on the u array of point slot (p, v)
@@ -280,14 +362,14 @@ struct HeadLoads {
   int done, stage, phase;
   double d, F, alpha, s;
   int i, j, k, ubp, ubv, sel;
-  int64_t n_passes, n_trials, n_iters;
+  int64_t n_passes, n_trials, n_iters, n_view_passes;
+  int nlive, nout, hold, rv_builds, rv_last, rv_backoff;
   double chain;  // this thread's share of sum_w scal[w][q]
 };
 
 template <int V, int NT>
 __device__ __forceinline__ void head_loads(const SolveArgs& A, HeadLoads& L) {
-  constexpr int NR = 2 + 2 * V;
-  constexpr int Q = V * NR + 2 * V + 2;
+  constexpr int Q = tail_q(V);
   constexpr int QPAD = pow2_at_least(Q);
   constexpr int NCH = NT / QPAD;
   const SolverState* st = A.st_cur;
@@ -307,6 +389,13 @@ __device__ __forceinline__ void head_loads(const SolveArgs& A, HeadLoads& L) {
   L.n_passes = st->n_passes;
   L.n_trials = st->n_trials;
   L.n_iters = st->n_iters;
+  L.n_view_passes = st->n_view_passes;
+  L.nlive = st->nlive;
+  L.nout = st->nout;
+  L.hold = st->hold;
+  L.rv_builds = st->rv_builds;
+  L.rv_last = st->rv_last;
+  L.rv_backoff = st->rv_backoff;
   // sums[q] = sum over the tail workgroups w of scal[w][q]: NCH interleaved chains per
   // quantity (w = c, c + NCH, ...), added in chain order
   const int tid = threadIdx.x;
@@ -331,9 +420,9 @@ __device__ __forceinline__ void head_loads(const SolveArgs& A, HeadLoads& L) {
 template <int V, int NT>
 __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, double* red,
                                        SolverState* stash, PassPlan& plan) {
-  constexpr int NR = 2 + 2 * V;
+  constexpr int NR = tail_nr(V);
   constexpr int PEN = V * NR + 2 * V;  // speculative penalty sums of candidate 0
-  constexpr int Q = PEN + 2;
+  constexpr int Q = tail_q(V);
   constexpr int QPAD = pow2_at_least(Q);
   constexpr int NCH = NT / QPAD;  // interleaved summation chains per quantity
   constexpr int NWV = NT / 64;
@@ -350,6 +439,13 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   int i_ = L.i, j_ = L.j, k_ = L.k, ubp = L.ubp, ubv = L.ubv, sel = L.sel;
   int64_t n_passes = L.n_passes, n_trials = L.n_trials;
   const int64_t n_iters = L.n_iters + 1;
+  // live rows of the current point / of them outside the row view: unchanged while the point is
+  int nlive = L.nlive, nout = L.nout;
+  auto live_code = [&](double code) {  // live + 2^26 * outside, summed exactly
+    const double o = floor(code * (1.0 / LIVE_OUT));
+    nout = static_cast<int>(o);
+    nlive = static_cast<int>(code - o * LIVE_OUT);
+  };
   double nrm[V], sx[V];
 #pragma unroll
   for (int l = 0; l < V; ++l) {
@@ -412,6 +508,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         }
       } else {
         const double deltau = sqrt(sums[jstar * NR + 1]);
+        live_code(sums[jstar * NR + NR - 1]);  // the point becomes candidate jstar
         s = st->sx[jstar];
         F = Fnew;  // :256-258 — u <- x, gradF <- gradFnew: the point slot the tail filled
         ubp ^= 1;
@@ -452,6 +549,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       }
     } else {  // PH_BUILD: the tail formed gradF, F and the first window of an outer iteration
       F = sums[0];  // :220
+      live_code(sums[NR - 1]);  // the gradient changed with the penalty
       j_ = 0;
       if (P.maxiniters <= 0) {
         action = ACT_SLOW;  // empty inner loop: u unchanged, its (a, b) in cab are still valid
@@ -475,6 +573,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   if (action == ACT_SLOW) {
     // ---- sweeps over whole vectors: workgroup (0,0) alone -----------------------------------
     if (!writer) return false;
+    nlive = nout = static_cast<int>(m < 0x7fffffff ? m : 0x7fffffff);  // unknown until a tail counts again
     const double* ca_ = A.cab;         // a = M_off x of the last pair-mode pass / of candidate 0
     const double* cb_ = A.cab + A.mp;  // b = C_off x
     if (phase == PH_NORMALIZE || phase == PH_RESCALE) {
@@ -587,6 +686,26 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
     __syncthreads();
   }
 
+  // The pass of this iteration runs on the row view when the view covers every live row of what it
+  // multiplies: a window built from the decided point, or (pair mode) that point's u itself.
+  // (a view built from exactly this state covers every outcome by construction — whatever the tail,
+  // which ran before the view existed, counted)
+  if (A.rv_fresh != 0 && action != ACT_SLOW) nout = 0;
+  // Is it time to build a (smaller) row view? A function of the state alone; see LIVE ROWS.
+  if (action == ACT_PASS && next_phase == PH_TRIAL && A.rvp.on != 0 && A.rv_fresh == 0 &&
+      view_wanted(A, nlive, nout, n_iters, L.rv_builds, L.rv_last, L.rv_backoff)) {
+    // HOLD: this iteration decides nothing — the state it read goes on unchanged, marked
+    if (writer && tid == 0) {
+      SolverState t = *st;
+      t.hold = 1;
+      *A.st_next = t;
+      if (A.host != nullptr)
+        __hip_atomic_store(&A.host->hold, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return false;
+  }
+  const bool on_view = A.in_view != nullptr && nout == 0 && action == ACT_PASS &&
+                       (next_phase == PH_TRIAL || need_pair);
   // ---- record the decided state (workgroup (0,0), one thread) ------------------------------
   // A pass iteration parks it in LDS and writes it out AFTER the streaming loop (flush_state):
   // a global store ahead of the loop would make the compiler treat the table rows as possibly
@@ -617,6 +736,15 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       o->n_passes = n_passes + (action == ACT_PASS ? 1 : 0);
       o->n_trials = n_trials;
       o->n_iters = n_iters;
+      o->nlive = nlive;
+      o->nout = nout;
+      o->view = (action == ACT_PASS && on_view) ? 1 : 0;
+      o->hold = 0;
+      o->n_view_passes = L.n_view_passes + ((action == ACT_PASS && on_view) ? 1 : 0);
+      o->rv_builds = L.rv_builds;
+      o->rv_last = L.rv_last;
+      o->rv_backoff = L.rv_backoff;
+      o->pad1 = 0;
     };
     if (action == ACT_PASS) record(stash);
     else record(A.st_next);
@@ -644,12 +772,16 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         // every store above (and the vectors this workgroup wrote) before the flag
         __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      if (action != ACT_PASS)
-        __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (action != ACT_PASS) {
+        __hip_atomic_store(&hm->nlive, nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->nout, nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   // the decision came out of LDS reads: tell the compiler it is wave-uniform, so that the
   // multipliers of the streaming loop stay scalar loads
+  plan.view = __builtin_amdgcn_readfirstlane(on_view ? 1 : 0);
   plan.phase = __builtin_amdgcn_readfirstlane(next_phase);
   plan.sel = __builtin_amdgcn_readfirstlane(sel);
   plan.from_u = __builtin_amdgcn_readfirstlane(need_pair ? ubp * V + ubv : -1);
@@ -674,8 +806,13 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
   HeadLoads L;
   head_loads<V, NT>(A, L);
   if (L.done) return false;
+  if (L.hold) {  // waiting for the host to build a row view: the state goes on as it is
+    if (is_writer_block() && threadIdx.x == 0) *A.st_next = *st;
+    return false;
+  }
   if (L.stage == ST_RESULTS) return decide<V, NT>(A, L, lds, stash, plan);
   // the pass was prepared by a transition iteration (or by k_init): run it as it stands
+  plan.view = 0;  // (pair-mode passes on a whole vector: u0, the normalised u)
   plan.phase = st->phase;
   plan.sel = st->sel;
   plan.from_u = -1;
@@ -687,6 +824,7 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
     stash->stage = ST_RESULTS;
     stash->n_passes = st->n_passes + 1;
     stash->n_iters = st->n_iters + 1;
+    stash->view = 0;
   }
   return true;
 }
@@ -697,9 +835,13 @@ __device__ __forceinline__ void flush_state(const SolveArgs& A, const SolverStat
   if (is_writer_block() && threadIdx.x == 0) {
     *A.st_next = *stash;
     const int64_t n_iters = stash->n_iters;
-    if (A.marks != nullptr && n_iters <= KIND_CAP) A.marks[n_iters - 1] = 1;
-    if (A.host != nullptr)
-      __hip_atomic_store(&A.host->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (A.marks != nullptr && n_iters <= KIND_CAP) A.marks[n_iters - 1] = stash->view ? 2 : 1;
+    if (A.host != nullptr) {
+      __hip_atomic_store(&A.host->nlive, stash->nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&A.host->nout, stash->nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&A.host->n_view_passes, stash->n_view_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&A.host->iters, n_iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -751,9 +893,8 @@ __global__ __launch_bounds__(128) void k_scal_fold(const double* __restrict__ sc
 //           store per element and outcome, and nothing for the kernel boundary to write back.
 template <int V, bool FUSED_REDUCE, bool TABLES = true>
 __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) void k_tail(SolveArgs A) {
-  constexpr int NR = 2 + 2 * V;
-  constexpr int PEN = V * NR + 2 * V;
-  constexpr int Q = PEN + 2;
+  constexpr int NR = tail_nr(V);
+  constexpr int Q = tail_q(V);
   constexpr int NRED = NR + 2 * V + 2;  // what a v = 0 workgroup reduces
   constexpr int NSLOT = nslot(V);
   constexpr int NTW = TAIL_WAVES * (FUSED_REDUCE ? TAIL_SPLIT : 1);  // waves of the workgroup
@@ -772,14 +913,18 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   const int ubp = st->ubp, ubv = st->ubv, sel = st->sel;
   const double d = st->d, alpha = st->alpha, s_cur = st->s;
   const double nrmv = st->nrm[v], sxv = st->sx[v];
+  // the pass streamed the row view: its own (fewer) partial-sum slots
+  const int nslots_pass = st->view ? A.rv_nslots : A.ntiles;
+  // "live and outside the view" weighs 1 + 2^26 in the live code
+  const double live_w = (valid && A.in_view != nullptr && A.in_view[i] == 0) ? 1.0 + LIVE_OUT : 1.0;
 
   // raw sums of slot v (and of slot V, the b of candidate 0, for the v = 0 workgroups): these
   // loads do not depend on the solver state
   double p0 = 0.0, p1 = 0.0;
   if (FUSED_REDUCE) {  // single shard: W >= m; this group's quarter of the slots, in slot order
     const int64_t o1 = (v == 0) ? static_cast<int64_t>(V) * A.W : 0;  // slot V relative to slot 0
-    const int per = (A.ntiles + TAIL_SPLIT - 1) / TAIL_SPLIT;
-    const int t0 = grp * per, t1 = (t0 + per < A.ntiles) ? t0 + per : A.ntiles;
+    const int per = (nslots_pass + TAIL_SPLIT - 1) / TAIL_SPLIT;
+    const int t0 = grp * per, t1 = (t0 + per < nslots_pass) ? t0 + per : nslots_pass;
     if (i < A.m) {
       const double* p = A.part + static_cast<int64_t>(v) * A.W + i;
       const int64_t ts = static_cast<int64_t>(NSLOT) * A.W;
@@ -824,6 +969,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
     p1 = blk[o1 + off];
   }
   if (done) return;
+  if (st->hold) return;             // the solve waits for a row view: nothing was decided, nothing ran
   if (stage != ST_RESULTS) return;  // a pass was only prepared: nothing to evaluate
   const long long c1 = A.stamps ? wall_clock64() + (p0 > 1e300 ? 1 : 0) : 0;
 
@@ -849,6 +995,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
       const double gi = (1 + d) * ui - d * s_cur + A.cab[i] + A.cab[A.mp + i] * d;  // :219
       pt_arr(A, V, ubp, ubv, 1)[i] = gi;
       r[0] = ui * gi;  // :220
+      r[NR - 1] = (ui > 0.0 || gi > 0.0) ? live_w : 0.0;
       double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       double al = 1.0;
 #pragma unroll
@@ -897,6 +1044,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
       r[0] = xi * gn;  // :242
       const double du = xi - ui;
       r[1] = du * du;  // :253
+      r[NR - 1] = (xi > 0.0 || gn > 0.0) ? live_w : 0.0;  // live rows of the point it would become
       // next window if candidate v is accepted: alpha = 1, beta, beta^2, ... (:227, :235-236)
       double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       double al = 1.0;

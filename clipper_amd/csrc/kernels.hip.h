@@ -32,6 +32,7 @@
 //   k_resident.hip.h  the resident solver: findDenseClique as one launch for problems that fit on chip
 //   k_affinity.hip.h  k_gather_points, k_affinity_* (plain, compacting strips, symmetric tiles + emission)
 //   k_matrix.hip.h    k_from_dense_upper, k_from_csc, k_gather_sub
+//   k_rowview.hip.h   the row list of a row view of M (the live rows of the solver's current points)
 //   k_knn.hip.h       brute-force k-nearest neighbours (putative associations)
 #pragma once
 
@@ -41,4 +42,5 @@
 #include "k_resident.hip.h"
 #include "k_affinity.hip.h"
 #include "k_matrix.hip.h"
+#include "k_rowview.hip.h"
 #include "k_knn.hip.h"

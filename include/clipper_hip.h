@@ -85,6 +85,19 @@ typedef struct clipper_hip_timings_t {
   double affinity_bytes;     /* bytes of M the last affinity build wrote (dense store or slices) */
 } clipper_hip_timings_t;
 
+/* The row view of the last solve (clipper_hip_set_row_view below). */
+typedef struct clipper_hip_view_stats_t {
+  int64_t builds;        /* row views built during the last solve                           */
+  int64_t rows;          /* rows of the last one built (0: none)                            */
+  int64_t bytes;         /* bytes its slices hold                                           */
+  int64_t view_passes;   /* passes of the last solve that streamed a view instead of M      */
+  int64_t passes;        /* all passes of the last solve                                    */
+  double build_ms;       /* host wall clock spent building views (drain + compaction + fill + plan) */
+  double view_pass_avg_us; /* mean duration of the sampled pass launches that streamed a view
+                              (profiling on; 0 = none sampled)                               */
+  int64_t view_pass_samples;
+} clipper_hip_view_stats_t;
+
 /* ---- life cycle --------------------------------------------------------------------- */
 
 int clipper_hip_device_count(void);
@@ -239,6 +252,17 @@ int clipper_hip_window(const clipper_hip_t* h);
  * clipper_hip_last_solver: what the last solve ran on, 0 = streaming launches, 1 = resident. */
 int clipper_hip_set_resident(clipper_hip_t* h, int mode);
 int clipper_hip_last_solver(const clipper_hip_t* h);
+
+/* The row view. Row r of every line-search candidate max(u + alpha g, 0) (clipper.cpp:235-236) is
+ * exactly zero unless u[r] > 0 or g[r] > 0, and such a row adds exact zeros to M x: once the
+ * projected gradient ascent has driven most of u to zero (a few iterations on registration data)
+ * a pass needs only the rows that are still live. On the scorePairwiseConsistency path (one
+ * device, slices, built-in invariant) the solver then builds the slices of M[live rows, :] from the
+ * staged points and streams THOSE while the device-side check "no live row outside the view" holds;
+ * any pass for which it does not hold streams M itself. Same trial sequence, same sums up to the
+ * order of the partial sums. mode 0 = automatic, 1 = never (also: CLIPPER_HIP_ROW_VIEW=0). */
+int clipper_hip_set_row_view(clipper_hip_t* h, int mode);
+int clipper_hip_get_view_stats(const clipper_hip_t* h, clipper_hip_view_stats_t* out);
 
 /* How the current matrix is stored: CLIPPER_HIP_STORE_F32_CSC only while the compressed copy is
  * in use (one shard, C == pattern(M)); a context created with it otherwise reports _F32. */
