@@ -170,6 +170,7 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   resident_free(h);
   if (h->csc_hwork) hipHostFree(h->csc_hwork);
   if (h->rv_count) hipHostFree(h->rv_count);
+  if (h->rv_desc_host) hipHostFree(h->rv_desc_host);
   delete h;
 }
 
@@ -1184,6 +1185,76 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
     const int64_t p = i / W, off = i - p * W;
     if (yM) yM[i] = ab[static_cast<size_t>(p * 2 * W + off)];
     if (yC) yC[i] = ab[static_cast<size_t>(p * 2 * W + W + off)];
+  }
+  return 0;
+}
+
+// The products of clipper_hip_matvec through a ROW VIEW of the given rows: yM = M_off[:, rows] x[rows],
+// yC likewise — what a pass of the solver computes when it streams the view instead of M. Builds the
+// slices of M[rows, :] with the rectangular fill kernel from the staged points (the view of a later
+// solve is built anew). For tests: equal to clipper_hip_matvec of x with every other entry zeroed, up
+// to the order of the partial sums.
+int clipper_hip_view_matvec(clipper_hip_t* h, const int32_t* rows, int64_t nrows, const double* x,
+                            double* yM, double* yC) {
+  if (!h || !rows || !x || nrows < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (!h->has_matrix || !h->csc_valid || !csc_single(h) || !rect_fill_possible(h))
+    return fail(CLIPPER_HIP_E_STATE, "a row view needs slices of a matrix scored from staged points on one device");
+  const int64_t m = h->m, W = h->W;
+  for (int64_t r = 0; r < nrows; ++r)
+    if (rows[r] < 0 || rows[r] >= m || (r > 0 && rows[r] <= rows[r - 1]))
+      return fail(CLIPPER_HIP_E_INVALID, "rows must be ascending association indices");
+  Shard& s = h->sh[0];
+  RowView& v = s.rv;
+  HIPCHK(hipSetDevice(s.device));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  v.valid = false;
+  int rc;
+  {
+    size_t r0 = v.cap_rows, r1 = v.cap_rows;
+    if ((rc = rv_grow(v.rowmap[0], r0, static_cast<size_t>(h->mp)))) return rc;
+    if ((rc = rv_grow(v.rowmap[1], r1, static_cast<size_t>(h->mp)))) return rc;
+    v.cap_rows = static_cast<size_t>(h->mp);
+  }
+  HIPCHK(hipMemcpyAsync(v.rowmap[0], rows, static_cast<size_t>(nrows) * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
+  for (int attempt = 0;; ++attempt) {
+    SliceOut O{};
+    if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
+    if ((rc = launch_rect(h, s, v.rowmap[0], nrows, O))) return rc;
+    if ((rc = emit_enqueue(h, s, v.st))) return rc;
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipGetLastError());
+    bool again = false;
+    if ((rc = emit_check(h, s, v.st, false, again))) return rc;
+    if (!again) break;
+    if (attempt >= 2) return fail(CLIPPER_HIP_E_HIP, "row view: the build keeps overflowing");
+  }
+  HIPCHK(hipMemcpyAsync(s.u0, x, static_cast<size_t>(m) * sizeof(double), hipMemcpyHostToDevice, s.stream));
+  hipLaunchKernelGGL(k_spread, dim3(static_cast<unsigned>(ceil_div(m, 256))), dim3(256), 0, s.stream, s.u0, m, s.X[0]);
+  h->u0_staged = false;
+  SliceView R{};
+  R.data = v.st.sdata;
+  R.Pre = v.st.sPre;
+  R.work = v.st.swork;
+  R.nchunks = v.st.s_nchunks;
+  R.ncg = v.st.s_ncg;
+  R.nwork = v.st.s_nwork;
+  R.rowmap = v.rowmap[0];
+  R.nrows = nrows;
+  R.pad = 0;
+  dim3 grid(static_cast<unsigned>(R.nwork)), block(SL_NW * 64);
+  if (h->storage == CLIPPER_HIP_STORE_F64)
+    hipLaunchKernelGGL((k_gemv_slices_plain<double, 1>), grid, block, 0, s.stream, R, W, m, s.X[0], s.part);
+  else
+    hipLaunchKernelGGL((k_gemv_slices_plain<float, 1>), grid, block, 0, s.stream, R, W, m, s.X[0], s.part);
+  hipLaunchKernelGGL(k_reduce, dim3(static_cast<unsigned>(ceil_div(2 * W, 256))), dim3(256), 0, s.stream, s.part,
+                     v.st.s_nslots, 2, W, s.ab);
+  std::vector<double> ab(static_cast<size_t>(2 * W));
+  HIPCHK(hipMemcpyAsync(ab.data(), s.ab, ab.size() * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  HIPCHK(hipGetLastError());
+  for (int64_t i = 0; i < m; ++i) {
+    if (yM) yM[i] = ab[static_cast<size_t>(i)];
+    if (yC) yC[i] = ab[static_cast<size_t>(W + i)];
   }
   return 0;
 }

@@ -18,6 +18,7 @@ SliceView slice_view(const Ctx* h, const Shard& s) {
   M.nwork = s.s_nwork;
   M.rowmap = nullptr;
   M.nrows = h->m;
+  M.pad = 0;
   return M;
 }
 

@@ -87,6 +87,7 @@ void rowview_free(Shard& s) {
   fr(v.in_view[0]);
   fr(v.in_view[1]);
   fr(v.blk);
+  fr(v.desc);
   v.cap_rows = v.cap_flags = v.cap_blk = 0;
   v.valid = false;
   v.nrows = 0;
@@ -199,6 +200,17 @@ int rowview_build_v(Ctx* h, bool& built) {
   v.nrows = nrows;
   v.valid = true;
   built = true;
+  {  // the descriptor a pass on the view reads, to the device
+    if (!v.desc) HIPCHK(hipMalloc(reinterpret_cast<void**>(&v.desc), sizeof(SliceView)));
+    if (!h->rv_desc_host) {
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->rv_desc_host), sizeof(SliceView), hipHostMallocMapped | hipHostMallocCoherent));
+      HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->rv_desc_host_dev), h->rv_desc_host, 0));
+    }
+    *h->rv_desc_host = row_view(h, s);
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(64), 0, s.stream, reinterpret_cast<const uint4*>(h->rv_desc_host_dev),
+                       reinterpret_cast<uint4*>(v.desc), static_cast<int64_t>(sizeof(SliceView) / 16));
+  }
   hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, 0);
   h->rv_stats.builds += 1;
   h->rv_stats.rows = nrows;

@@ -232,10 +232,11 @@ void launch_pass_csc(Ctx* h, Shard& s, const SolveArgs& a) {
   const SliceView M = slice_view(h, s), R = row_view(h, s);
   // (the LAST workgroup records the decided state: on M it is the one with the least to stream)
   dim3 grid(static_cast<unsigned>(std::max(M.nwork, R.nwork))), block(SL_NW * 64);
+  const SliceView* rdev = s.rv.desc;  // (read only while a.in_view says there is a view)
   if (h->storage == CLIPPER_HIP_STORE_F64)
-    hipLaunchKernelGGL((k_gemv_slices<double, 1, V>), grid, block, 0, s.stream, M, R, a);
+    hipLaunchKernelGGL((k_gemv_slices<double, 1, V>), grid, block, 0, s.stream, M, rdev, a);
   else
-    hipLaunchKernelGGL((k_gemv_slices<float, 1, V>), grid, block, 0, s.stream, M, R, a);
+    hipLaunchKernelGGL((k_gemv_slices<float, 1, V>), grid, block, 0, s.stream, M, rdev, a);
 }
 
 // calls f(integral_constant<V>) for the context's window size

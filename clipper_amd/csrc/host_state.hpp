@@ -116,6 +116,7 @@ struct RowView {
   int32_t* rowmap[2] = {nullptr, nullptr};  // [cap_rows] association of view row r': in use / being built
   uint8_t* in_view[2] = {nullptr, nullptr};  // [mp] row flags: of the view in use / of the one being built
   int cur = 0;                 // which of the two the view in use owns
+  SliceView* desc = nullptr;   // device copy of the view's descriptor (what a pass on the view reads)
   uint32_t* blk = nullptr;     // [nblk + 2] per-block live counts, then their offsets
   size_t cap_rows = 0, cap_flags = 0, cap_blk = 0;
   int64_t nrows = 0;
@@ -252,6 +253,8 @@ struct clipper_hip_ctx {
   ViewPolicy rvp{};           // the cost model the device-side policy works with (host_rowview.hpp)
   bool rv_fresh = false;      // the next iteration is the first after a view was built
   int rv_mode = 0;            // 0 = automatic, 1 = never (clipper_hip_set_row_view / CLIPPER_HIP_ROW_VIEW=0)
+  SliceView* rv_desc_host = nullptr;     // pinned + mapped staging of a view's descriptor
+  SliceView* rv_desc_host_dev = nullptr;
   int32_t* rv_count = nullptr;      // pinned + mapped: rows of the view being built
   int32_t* rv_count_dev = nullptr;
   clipper_hip_view_stats_t rv_stats{};

@@ -78,7 +78,9 @@ struct SliceView {
   // staged. The matrix itself: rowmap == null, nrows == m.
   const int32_t* rowmap;
   int64_t nrows;
+  int64_t pad;  // (64 bytes: the row view's descriptor is copied to the device in 16-byte words)
 };
+static_assert(sizeof(SliceView) == 64, "SliceView is copied in 16-byte words");
 
 // Window mode stages candidates 0 .. sl_xload(V)-1 of a table row at a pitch of sl_xpitch(V)
 // doubles: an ODD number of 16-byte units (1, 3, 5), so that the rows of a sub-block spread over
@@ -144,14 +146,27 @@ struct SliceXStage {
   static constexpr int PER = (PIECES + NT - 1) / NT;
   double wu[WINDOW ? PER : 1], wg[WINDOW ? PER : 1];
   double s[WINDOW ? 1 : PER];
-  __device__ __forceinline__ void load(const WindowSource& W, const double* __restrict__ X, int xstride,
-                                       int64_t r0, int64_t nrows, const int32_t* __restrict__ rowmap) {
+  int64_t ridx[PER];  // rows of M the pieces of the chunk AFTER the one being loaded stand for
+  // A row view gathers its x rows through the row list: the list entries of a chunk are requested
+  // one chunk ahead of the values (index(k + 2) beside values(k + 1)), so that no load of the
+  // prefetch waits for another one in front of the streaming loop.
+  __device__ __forceinline__ void index(int64_t r0, int64_t nrows, const int32_t* __restrict__ rowmap) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int p = threadIdx.x + i * NT;
       const int64_t rv = r0 + p;
       const bool in = p < PIECES && rv < nrows;
-      const int64_t r = (in && rowmap != nullptr) ? rowmap[rv] : rv;  // (uniform branch: one view per launch)
+      ridx[i] = (in && rowmap != nullptr) ? rowmap[rv] : rv;  // (uniform branch: one view per launch)
+    }
+  }
+  __device__ __forceinline__ void load(const WindowSource& W, const double* __restrict__ X, int xstride,
+                                       int64_t r0, int64_t nrows) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int p = threadIdx.x + i * NT;
+      const int64_t rv = r0 + p;
+      const bool in = p < PIECES && rv < nrows;
+      const int64_t r = ridx[i];
       if constexpr (WINDOW) {
         wu[i] = in ? W.U[r] : 0.0;
         wg[i] = in ? W.G[r] : 0.0;
@@ -266,8 +281,10 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
   SliceXStage<WINDOW, XL, XP, R, NT> xst;
   __syncthreads();  // the decision at the head of the launch used the same LDS
   if (t0 < t1) {
-    xst.load(WS, X, xstride, static_cast<int64_t>(t0) * R, M.nrows, M.rowmap);
+    xst.index(static_cast<int64_t>(t0) * R, M.nrows, M.rowmap);
+    xst.load(WS, X, xstride, static_cast<int64_t>(t0) * R, M.nrows);
     xst.store(WS, lds);
+    xst.index(static_cast<int64_t>(t0 + 1) * R, M.nrows, M.rowmap);
   }
   __syncthreads();
   SliceHead<H> cur = J.first;
@@ -280,7 +297,8 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
     SliceHead<H> nxt = cur;
     uint64_t pre_next2 = 0;
     if (more) {
-      xst.load(WS, X, xstride, static_cast<int64_t>(k + 1) * R, M.nrows, M.rowmap);
+      xst.load(WS, X, xstride, static_cast<int64_t>(k + 1) * R, M.nrows);
+      xst.index(static_cast<int64_t>(k + 2) * R, M.nrows, M.rowmap);
       if (mine) nxt.load(M.data + 16 * pre_next, lane);
       if (k + 2 < t1) pre_next2 = pre_row[k + 2];
     }
@@ -409,10 +427,11 @@ constexpr int SL_D = CLIPPER_SL_D;   // steps in flight per lane (2 / 3 / 4 / 6 
 constexpr int SL_OCC = CLIPPER_SL_OCC;  // waves per SIMD the pass kernel is compiled for (= workgroups per CU)
 
 // G of a solver iteration on the slices (one shard): decision, then the pass
-// `RV`: the row view of M (RV.data == null: none). The grid covers the larger of the two work lists;
-// which one a launch streams is decided at its head (PassPlan::view).
+// `RV`: the descriptor of the row view of M, in device memory (read only by a launch whose decision
+// chose the view: PassPlan::view — as a second by-value argument it cost 130 registers spilled to
+// scratch, some of them inside the streaming loop). The grid covers the larger of the two work lists.
 template <typename VT, int H, int V>
-__global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M, SliceView RV, SolveArgs A) {
+__global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M, const SliceView* __restrict__ RV, SolveArgs A) {
   __shared__ __attribute__((aligned(16))) double lds[sl_lds_doubles(V, H, SL_NW)];
   __shared__ __attribute__((aligned(16))) SolverState stash;
   const long long c0 = A.stamps ? wall_clock64() : 0;
@@ -422,9 +441,11 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   if (!iteration_head<V, SL_NW * 64>(A, lds, &stash, plan)) return;
   const long long c1 = A.stamps ? wall_clock64() : 0;
   if (plan.view) {
-    // (the view's slices are few and hot in L2: its first header is requested here, not ahead of the
-    // decision; one call site of the streaming loop for both — M is only a name from here on)
-    M = RV;
+    // (The view's slices are few and hot in L2: its first header is requested here, not ahead of the
+    // decision. Holding a second job across the decision — even its wave-uniform words alone — costs
+    // 170-220 registers spilled to scratch: the kernel is SGPR-bound with two views and the solver's
+    // arguments. One call site of the streaming loop for both: M is only a name from here on.)
+    M = *RV;
     slice_begin<H, SL_NW>(M, J);
   }
   slices_by_plan<VT, H, V, SL_NW, SL_D>(M, J, A, plan, lds);

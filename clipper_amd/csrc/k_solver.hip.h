@@ -337,6 +337,14 @@ __device__ __forceinline__ bool view_wanted(const SolveArgs& A, int nlive, int n
   return gain > A.rvp.build_fixed + r * A.rvp.build_per_row;
 }
 
+// dst = *src by the threads of a workgroup, 8 bytes each
+__device__ __forceinline__ void copy_state(SolverState* dst, const SolverState* src, int tid, int nt) {
+  static_assert(sizeof(SolverState) % 8 == 0, "copied in 8-byte words");
+  const unsigned long long* s8 = reinterpret_cast<const unsigned long long*>(src);
+  unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
+  for (int k = tid; k < static_cast<int>(sizeof(SolverState) / 8); k += nt) d8[k] = s8[k];
+}
+
 struct PassPlan {
   int view;    // 1: stream the row view instead of M
   int phase;
@@ -417,8 +425,11 @@ __device__ __forceinline__ void head_loads(const SolveArgs& A, HeadLoads& L) {
   L.chain = acc;
 }
 
+// NOT inlined: as part of the pass kernels' bodies it pushed the register allocator of the slices'
+// streaming loop (80 registers at 6 workgroups per CU) into spilling inside that loop
+// (tools/spill_report.py); as a call it spills around the head only.
 template <int V, int NT>
-__device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, double* red,
+__device__ __noinline__ bool decide(const SolveArgs& A, const HeadLoads& L, double* red,
                                        SolverState* stash, PassPlan& plan) {
   constexpr int NR = tail_nr(V);
   constexpr int PEN = V * NR + 2 * V;  // speculative penalty sums of candidate 0
@@ -695,12 +706,14 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   if (action == ACT_PASS && next_phase == PH_TRIAL && A.rvp.on != 0 && A.rv_fresh == 0 &&
       view_wanted(A, nlive, nout, n_iters, L.rv_builds, L.rv_last, L.rv_backoff)) {
     // HOLD: this iteration decides nothing — the state it read goes on unchanged, marked
-    if (writer && tid == 0) {
-      SolverState t = *st;
-      t.hold = 1;
-      *A.st_next = t;
-      if (A.host != nullptr)
-        __hip_atomic_store(&A.host->hold, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (writer) {  // (block-uniform; word by word: a struct copy by one thread is 66 registers)
+      copy_state(A.st_next, st, tid, NT);
+      __syncthreads();
+      if (tid == 0) {
+        A.st_next->hold = 1;
+        if (A.host != nullptr)
+          __hip_atomic_store(&A.host->hold, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     return false;
   }
@@ -807,7 +820,7 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
   head_loads<V, NT>(A, L);
   if (L.done) return false;
   if (L.hold) {  // waiting for the host to build a row view: the state goes on as it is
-    if (is_writer_block() && threadIdx.x == 0) *A.st_next = *st;
+    if (is_writer_block()) copy_state(A.st_next, st, threadIdx.x, NT);
     return false;
   }
   if (L.stage == ST_RESULTS) return decide<V, NT>(A, L, lds, stash, plan);
@@ -819,12 +832,15 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
   plan.d = st->d;
   plan.src = 0;  // (pair-mode passes only: never read)
   plan.alpha0 = 1.0;
-  if (is_writer_block() && threadIdx.x == 0) {
-    *stash = *st;
-    stash->stage = ST_RESULTS;
-    stash->n_passes = st->n_passes + 1;
-    stash->n_iters = st->n_iters + 1;
-    stash->view = 0;
+  if (is_writer_block()) {  // (word by word by the whole workgroup: one thread's struct copy is 70 registers)
+    copy_state(stash, st, threadIdx.x, NT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      stash->stage = ST_RESULTS;
+      stash->n_passes = L.n_passes + 1;
+      stash->n_iters = L.n_iters + 1;
+      stash->view = 0;
+    }
   }
   return true;
 }
@@ -832,8 +848,9 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
 // End of a pass iteration: workgroup (0,0) writes the state it decided on where the tail and
 // the next iteration read it, marks the iteration as a pass and reports progress to the host.
 __device__ __forceinline__ void flush_state(const SolveArgs& A, const SolverState* stash) {
-  if (is_writer_block() && threadIdx.x == 0) {
-    *A.st_next = *stash;
+  if (!is_writer_block()) return;
+  copy_state(A.st_next, stash, threadIdx.x, blockDim.x);
+  if (threadIdx.x == 0) {
     const int64_t n_iters = stash->n_iters;
     if (A.marks != nullptr && n_iters <= KIND_CAP) A.marks[n_iters - 1] = stash->view ? 2 : 1;
     if (A.host != nullptr) {

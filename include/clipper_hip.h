@@ -264,6 +264,12 @@ int clipper_hip_last_solver(const clipper_hip_t* h);
 int clipper_hip_set_row_view(clipper_hip_t* h, int mode);
 int clipper_hip_get_view_stats(const clipper_hip_t* h, clipper_hip_view_stats_t* out);
 
+/* The products of clipper_hip_matvec through a row view built for the given rows (ascending association
+ * indices): yM = M_off[:, rows] x[rows], yC likewise — what a pass of the solver computes when it
+ * streams the view. For tests of the view's storage and of the rectangular fill kernel that writes it. */
+int clipper_hip_view_matvec(clipper_hip_t* h, const int32_t* rows, int64_t nrows, const double* x,
+                            double* yM, double* yC);
+
 /* How the current matrix is stored: CLIPPER_HIP_STORE_F32_CSC only while the compressed copy is
  * in use (one shard, C == pattern(M)); a context created with it otherwise reports _F32. */
 int clipper_hip_storage_in_use(const clipper_hip_t* h);

@@ -49,10 +49,12 @@ def test_views_do_not_change_the_result(storage, m, rho):
         assert s.nodes.tolist() == sr.nodes.tolist()
         assert abs(s.score - sr.score) <= 1e-6 * abs(sr.score)
         assert s.ifinal == sr.ifinal
-    # the same trials either way: a view only re-associates partial sums (1e-16 relative)
-    assert abs(s1.score - s0.score) <= 1e-12 * abs(s0.score)
-    assert abs(s1.n_trials - s0.n_trials) <= max(2, s0.n_trials // 50)
-    assert np.allclose(s1.u, s0.u, rtol=0, atol=1e-10)
+    # A view only re-associates partial sums (1e-16 relative). At an outlier ratio of 0.5 line searches
+    # run to over a hundred trials whose accept / stop tests (|dF| < 1e-9 at F ~ 2000: 5e-13 relative)
+    # sit on exactly such rounding errors: a handful of trials more or less, the same point to 1e-9.
+    assert abs(s1.score - s0.score) <= 1e-10 * abs(s0.score)
+    assert abs(s1.n_trials - s0.n_trials) <= max(2, s0.n_trials // 20)
+    assert np.allclose(s1.u, s0.u, rtol=0, atol=1e-8)
     print(f"m={m} rho={rho} storage={storage}: views {st1}, trials {s1.n_trials}/{s0.n_trials} (oracle {sr.n_trials})")
     g0.close()
     g1.close()
@@ -103,9 +105,50 @@ def test_a_view_that_stops_covering_falls_back_to_the_matrix():
     g.close()
 
 
+@pytest.mark.parametrize("storage", [abi.STORE_F32_CSC, abi.STORE_F64_CSC])
+@pytest.mark.parametrize("m,nrows,pointnormal", [(3000, 1, False), (3000, 129, False), (4097, 700, False),
+                                                 (3500, 3500, False), (3200, 260, True)])
+def test_view_product_equals_the_matrix_product_on_the_same_rows(storage, m, nrows, pointnormal):
+    """The view's storage (k_affinity_rect: rows gathered through a row list, no mirror image) and the
+    pass on it (x rows gathered through the same list) against the pass on M itself — whose storage
+    comes from the symmetric fill kernel (fp32) or from the rectangular one with all rows (fp64) — and
+    against the oracle's product."""
+    p = synth.make_pointnormal_problem(m, 0.9, seed=5) if pointnormal else synth.make_euclidean_problem(m, 0.9, seed=m)
+    g = abi.HipClipper(storage=storage)
+    r = ref.RefClipper()
+    if pointnormal:
+        g.score_pairwise_consistency_pointnormal(p.D1, p.D2, p.A)
+        r.score_pairwise_consistency_pointnormal(p.D1, p.D2, p.A)
+    else:
+        g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+        r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    rng = np.random.default_rng(m + nrows)
+    rows = np.sort(rng.choice(m, size=nrows, replace=False)).astype(np.int32)
+    x = rng.random(m)
+    xm = np.zeros(m)
+    xm[rows] = x[rows]
+    yM, yC = g.view_matvec(rows, x)       # x outside `rows` must not matter
+    zM, zC = g.matvec(xm)
+    oM, oC = r.matvec(xm)
+    scale = max(1.0, float(np.max(np.abs(zM))))
+    assert np.max(np.abs(yM - zM)) <= 1e-13 * scale
+    assert np.max(np.abs(yC - zC)) <= 1e-13 * max(1.0, float(np.max(np.abs(zC))))
+    # against the oracle: fp32 storage rounds the values (6e-8 relative each), fp64 does not
+    tol = 1e-12 if storage == abi.STORE_F64_CSC else 2e-7
+    assert np.max(np.abs(yM - oM)) <= tol * scale
+    assert np.max(np.abs(yC - oC)) <= 1e-12 * max(1.0, float(np.max(np.abs(oC))))
+    # ... and a solve afterwards builds its own views
+    sg = g.solve(p.u0)
+    sr = r.solve(p.u0)
+    assert sg.nodes.tolist() == sr.nodes.tolist()
+    g.close()
+
+
 def test_solver_parameter_variants_with_views():
-    p = synth.make_euclidean_problem(5000, 0.9, seed=31)
-    for kw in (dict(beta=0.5), dict(maxlsiters=3), dict(maxiniters=5), dict(rescale_u0=0),
+    # (maxlsiters = 3 is not here: the reference's iteration then never converges — 400 000 trials
+    # and eight minutes of oracle; the line-search limits are covered at small m in test_gpu_parity.py)
+    p = synth.make_euclidean_problem(3200, 0.9, seed=31)
+    for kw in (dict(beta=0.5), dict(maxiniters=5), dict(rescale_u0=0),
                dict(tol_u=1e-5, tol_F=1e-6), dict(rounding=0), dict(maxoliters=2)):
         prm = ref.Params(**kw)
         r = ref.RefClipper(prm)

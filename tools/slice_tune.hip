@@ -350,7 +350,7 @@ void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const 
   CK(hipMemset(dpart, 0, npart * 8));
   CK(hipMemcpy(ddata, P.data.data(), P.data.size(), hipMemcpyHostToDevice));
   CK(hipMemcpy(dPre, P.Pre.data(), P.Pre.size() * 8, hipMemcpyHostToDevice));
-  SliceView M{ddata, dPre, dwork, P.nchunks, P.ncg, static_cast<int>(work.size()), nullptr, c.m};
+  SliceView M{ddata, dPre, dwork, P.nchunks, P.ncg, static_cast<int>(work.size()), nullptr, c.m, 0};
   auto kern = k_pass<VT, H, (V > 0), VV, NW, D, OCC>;
   const size_t lds_bytes = static_cast<size_t>(2) * SL_SUB * H * ((V > 0) ? sl_xpitch(VV) : 1) * 8;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
