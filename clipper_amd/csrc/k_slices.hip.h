@@ -82,6 +82,34 @@ struct SliceView {
 };
 static_assert(sizeof(SliceView) == 64, "SliceView is copied in 16-byte words");
 
+// The same descriptor as the device code uses it: every pointer typed as a GLOBAL-memory pointer. A
+// descriptor that a kernel LOADS (the row view's) carries generic pointers as far as the compiler
+// can tell, and every load of the streaming loop through one becomes a flat load, which waits on the
+// LDS counter too: +35 % per pass at every size, measured (profiles/r03_variants.txt). The type says
+// what inference cannot.
+#define CLIPPER_GLOBAL __attribute__((address_space(1)))
+typedef const CLIPPER_GLOBAL uint8_t* gbytes_t;
+struct SliceViewG {
+  gbytes_t data;
+  const CLIPPER_GLOBAL uint64_t* Pre;
+  const CLIPPER_GLOBAL SliceWork* work;
+  int nchunks, ncg, nwork;
+  const CLIPPER_GLOBAL int32_t* rowmap;
+  int64_t nrows;
+};
+__device__ __forceinline__ SliceViewG to_global(const SliceView& M) {
+  SliceViewG G;
+  G.data = (gbytes_t)M.data;
+  G.Pre = (const CLIPPER_GLOBAL uint64_t*)M.Pre;
+  G.work = (const CLIPPER_GLOBAL SliceWork*)M.work;
+  G.nchunks = M.nchunks;
+  G.ncg = M.ncg;
+  G.nwork = M.nwork;
+  G.rowmap = (const CLIPPER_GLOBAL int32_t*)M.rowmap;
+  G.nrows = M.nrows;
+  return G;
+}
+
 // Window mode stages candidates 0 .. sl_xload(V)-1 of a table row at a pitch of sl_xpitch(V)
 // doubles: an ODD number of 16-byte units (1, 3, 5), so that the rows of a sub-block spread over
 // all 16 slots a ds_read_b128 lane group can serve in one LDS cycle (pitch 32 B would use 8
@@ -106,6 +134,11 @@ struct SliceQuad<float> {
     const float4 t = *reinterpret_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
+  __device__ __forceinline__ void load(const __attribute__((address_space(1))) uint8_t* p) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 t = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
   __device__ __forceinline__ void store(uint8_t* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -116,6 +149,12 @@ struct SliceQuad<double> {
   __device__ __forceinline__ void load(const uint8_t* p) {
     const double2 t0 = reinterpret_cast<const double2*>(p)[0];
     const double2 t1 = reinterpret_cast<const double2*>(p)[1];
+    v[0] = t0.x; v[1] = t0.y; v[2] = t1.x; v[3] = t1.y;
+  }
+  __device__ __forceinline__ void load(const __attribute__((address_space(1))) uint8_t* p) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const f64x2 t0 = reinterpret_cast<const __attribute__((address_space(1))) f64x2*>(p)[0];
+    const f64x2 t1 = reinterpret_cast<const __attribute__((address_space(1))) f64x2*>(p)[1];
     v[0] = t0.x; v[1] = t0.y; v[2] = t1.x; v[3] = t1.y;
   }
   __device__ __forceinline__ void store(uint8_t* p) const {
@@ -146,17 +185,17 @@ struct SliceXStage {
   static constexpr int PER = (PIECES + NT - 1) / NT;
   double wu[WINDOW ? PER : 1], wg[WINDOW ? PER : 1];
   double s[WINDOW ? 1 : PER];
-  int64_t ridx[PER];  // rows of M the pieces of the chunk AFTER the one being loaded stand for
+  int32_t ridx[PER];  // rows of M the pieces of the chunk AFTER the one being loaded stand for
   // A row view gathers its x rows through the row list: the list entries of a chunk are requested
   // one chunk ahead of the values (index(k + 2) beside values(k + 1)), so that no load of the
   // prefetch waits for another one in front of the streaming loop.
-  __device__ __forceinline__ void index(int64_t r0, int64_t nrows, const int32_t* __restrict__ rowmap) {
+  __device__ __forceinline__ void index(int64_t r0, int64_t nrows, const CLIPPER_GLOBAL int32_t* rowmap) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int p = threadIdx.x + i * NT;
       const int64_t rv = r0 + p;
       const bool in = p < PIECES && rv < nrows;
-      ridx[i] = (in && rowmap != nullptr) ? rowmap[rv] : rv;  // (uniform branch: one view per launch)
+      ridx[i] = (in && rowmap != nullptr) ? rowmap[rv] : static_cast<int32_t>(rv);  // (uniform branch: one view per launch)
     }
   }
   __device__ __forceinline__ void load(const WindowSource& W, const double* __restrict__ X, int xstride,
@@ -201,12 +240,12 @@ struct SliceXStage {
 // what a wave needs of a slice before it can address the steps
 template <int H>
 struct SliceHead {
-  const uint8_t* sp;
+  gbytes_t sp;
   int maxq;
   int nq[H];
-  __device__ __forceinline__ void load(const uint8_t* p, int lane) {
+  __device__ __forceinline__ void load(gbytes_t p, int lane) {
     sp = p;
-    maxq = static_cast<int>(reinterpret_cast<const uint32_t*>(p)[1]);
+    maxq = static_cast<int>(reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(p)[1]);
 #pragma unroll
     for (int h = 0; h < H; ++h) nq[h] = p[16 + h * 64 + lane];
   }
@@ -222,16 +261,18 @@ struct SliceJob {
 };
 
 template <int H, int NW>
-__device__ __forceinline__ void slice_begin(const SliceView& M, SliceJob<H, NW>& J) {
+__device__ __forceinline__ void slice_begin(const SliceViewG& M, SliceJob<H, NW>& J) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const SliceWork w = M.work[static_cast<int>(blockIdx.x) < M.nwork ? blockIdx.x : 0];
-  J.strip = w.strip;
-  J.slot = w.slot;
+  // (a struct cannot be copied out of an address space: the work item as its six ints)
+  const CLIPPER_GLOBAL int* w = reinterpret_cast<const CLIPPER_GLOBAL int*>(
+      M.work + (static_cast<int>(blockIdx.x) < M.nwork ? blockIdx.x : 0));
+  J.strip = w[0];
+  J.slot = w[1];
   J.cg = J.strip * NW + wave;
-  J.t0 = w.t0;
-  J.t1 = w.t1;
-  J.q0 = w.q0;
-  J.q1 = w.q1;
+  J.t0 = w[2];
+  J.t1 = w[3];
+  J.q0 = w[4];
+  J.q1 = w[5];
   J.first.maxq = 0;
   J.first.sp = M.data;
   J.pre1 = 0;
@@ -248,7 +289,7 @@ __device__ __forceinline__ void slice_begin(const SliceView& M, SliceJob<H, NW>&
     return;
   }
   if (J.cg < M.ncg && J.t0 < J.t1) {
-    const uint64_t* pre = M.Pre + static_cast<int64_t>(J.cg) * M.nchunks + J.t0;
+    const CLIPPER_GLOBAL uint64_t* pre = M.Pre + static_cast<int64_t>(J.cg) * M.nchunks + J.t0;
     J.first.load(M.data + 16 * pre[0], threadIdx.x & 63);
     if (J.t0 + 1 < J.t1) J.pre1 = pre[1];
   }
@@ -260,7 +301,7 @@ __device__ __forceinline__ void slice_begin(const SliceView& M, SliceJob<H, NW>&
 // workgroup (double buffered). WINDOW / pair mode and the slots as in gemv_core (k_gemv.hip.h).
 // D = steps of a slice kept in flight per lane.
 template <typename VT, int H, bool WINDOW, int V, int NSLOT, int NW, int D>
-__device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H, NW>& J, int64_t ld,
+__device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H, NW>& J, int64_t ld,
                                            int64_t m, double d, const WindowSource& WS,
                                            const double* __restrict__ X, int xstride,
                                            double* __restrict__ part, double* lds) {
@@ -289,7 +330,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
   __syncthreads();
   SliceHead<H> cur = J.first;
   uint64_t pre_next = J.pre1;  // Pre of slice k + 1, requested a chunk ago
-  const uint64_t* pre_row = M.Pre + static_cast<int64_t>(mine ? cg : 0) * M.nchunks;
+  const CLIPPER_GLOBAL uint64_t* pre_row = M.Pre + static_cast<int64_t>(mine ? cg : 0) * M.nchunks;
   for (int k = t0; k < t1; ++k) {
     const double* xs = lds + ((k - t0) & 1) * (R * XP);
     double* xnext = lds + (((k - t0) & 1) ^ 1) * (R * XP);
@@ -309,9 +350,9 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
 #pragma unroll
       for (int h = 0; h < H; ++h) tot += cur.nq[h];
       // load front (wave-uniform): step q0 of the slice
-      const uint8_t* fbase = cur.sp + 16 + H * 64 + sl_so_bytes(maxq);
+      gbytes_t fbase = cur.sp + 16 + H * 64 + sl_so_bytes(maxq);
       if (J.q0 > 0 && J.q0 < maxq)
-        fbase = cur.sp + reinterpret_cast<const uint32_t*>(cur.sp + 16 + H * 64)[J.q0 / SL_SO];
+        fbase = cur.sp + reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(cur.sp + 16 + H * 64)[J.q0 / SL_SO];
       SliceQuad<VT> mv[D];
       uint32_t rw[D];
       // Every lane issues every load of every step (an idle lane re-reads the step's first quad,
@@ -324,7 +365,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
         const int cnt = __builtin_amdgcn_readfirstlane(__popcll(mask));
         const uint32_t rank = active ? sl_lane_rank(mask) : 0u;
         vq.load(fbase + rank * QB);
-        rq = *reinterpret_cast<const uint32_t*>(fbase + cnt * QB + rank * 4);
+        rq = *reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(fbase + cnt * QB + rank * 4);
         fbase += cnt * QB + ((cnt * 4 + 15) & ~15);
       };
 #pragma unroll
@@ -397,7 +438,7 @@ __device__ __forceinline__ void slice_core(const SliceView& M, const SliceJob<H,
 
 // window or pair mode by the plan of this iteration
 template <typename VT, int H, int V, int NW, int D>
-__device__ __forceinline__ void slices_by_plan(const SliceView& M, const SliceJob<H, NW>& J,
+__device__ __forceinline__ void slices_by_plan(const SliceViewG& M, const SliceJob<H, NW>& J,
                                                const SolveArgs& A, const PassPlan& plan,
                                                double* lds) {
   if (plan.phase == PH_TRIAL) {
@@ -435,20 +476,20 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   __shared__ __attribute__((aligned(16))) double lds[sl_lds_doubles(V, H, SL_NW)];
   __shared__ __attribute__((aligned(16))) SolverState stash;
   const long long c0 = A.stamps ? wall_clock64() : 0;
+  SliceViewG G = to_global(M);
   SliceJob<H, SL_NW> J;
-  slice_begin<H, SL_NW>(M, J);
+  slice_begin<H, SL_NW>(G, J);
   PassPlan plan;
   if (!iteration_head<V, SL_NW * 64>(A, lds, &stash, plan)) return;
   const long long c1 = A.stamps ? wall_clock64() : 0;
   if (plan.view) {
     // (The view's slices are few and hot in L2: its first header is requested here, not ahead of the
     // decision. Holding a second job across the decision — even its wave-uniform words alone — costs
-    // 170-220 registers spilled to scratch: the kernel is SGPR-bound with two views and the solver's
-    // arguments. One call site of the streaming loop for both: M is only a name from here on.)
-    M = *RV;
-    slice_begin<H, SL_NW>(M, J);
+    // 170-220 registers spilled to scratch. One call site of the streaming loop for both.)
+    G = to_global(*RV);
+    slice_begin<H, SL_NW>(G, J);
   }
-  slices_by_plan<VT, H, V, SL_NW, SL_D>(M, J, A, plan, lds);
+  slices_by_plan<VT, H, V, SL_NW, SL_D>(G, J, A, plan, lds);
   flush_state(A, &stash);
   if (A.stamps && threadIdx.x == 0 && blockIdx.x < 1536) {
     A.stamps[blockIdx.x * 4 + 0] = c0;
@@ -465,9 +506,10 @@ __global__ __launch_bounds__(SL_NW * 64, 2) void k_gemv_slices_plain(SliceView M
                                                                       const double* __restrict__ X,
                                                                       double* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) double lds[2 * SL_SUB * H];
+  const SliceViewG G = to_global(M);
   SliceJob<H, SL_NW> J;
-  slice_begin<H, SL_NW>(M, J);
-  slice_core<VT, H, false, 1, 2, SL_NW, SL_D>(M, J, ld, m, 0.0, WindowSource{}, X, VS, part, lds);
+  slice_begin<H, SL_NW>(G, J);
+  slice_core<VT, H, false, 1, 2, SL_NW, SL_D>(G, J, ld, m, 0.0, WindowSource{}, X, VS, part, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -998,12 +1040,12 @@ __global__ __launch_bounds__(256) void k_slice_expand(SliceView M, ST* __restric
     for (int q = 0; q < R; ++q)
       if (r0 + q < m) S[(r0 + q) * ld + c] = ST(0);
   SliceHead<H> hd;
-  hd.load(M.data + 16 * M.Pre[s], lane);
+  hd.load(static_cast<gbytes_t>((gbytes_t)M.data + 16 * M.Pre[s]), lane);
   const int maxq = __builtin_amdgcn_readfirstlane(hd.maxq);
   int tot = 0;
 #pragma unroll
   for (int h = 0; h < H; ++h) tot += hd.nq[h];
-  const uint8_t* fbase = hd.sp + 16 + H * 64 + sl_so_bytes(maxq);
+  gbytes_t fbase = hd.sp + 16 + H * 64 + sl_so_bytes(maxq);
   for (int q = 0; q < maxq; ++q) {
     const bool active = q < tot;
     const uint64_t mask = __ballot(active);
@@ -1012,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_slice_expand(SliceView M, ST* __restric
       const uint32_t rank = sl_lane_rank(mask);
       SliceQuad<VT> vq;
       vq.load(fbase + rank * QB);
-      const uint32_t rq = *reinterpret_cast<const uint32_t*>(fbase + cnt * QB + rank * 4);
+      const uint32_t rq = *reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(fbase + cnt * QB + rank * 4);
       int rowbase = 0, edge = hd.nq[0];
 #pragma unroll
       for (int h = 1; h < H; ++h) {

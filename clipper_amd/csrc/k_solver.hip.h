@@ -425,11 +425,8 @@ __device__ __forceinline__ void head_loads(const SolveArgs& A, HeadLoads& L) {
   L.chain = acc;
 }
 
-// NOT inlined: as part of the pass kernels' bodies it pushed the register allocator of the slices'
-// streaming loop (80 registers at 6 workgroups per CU) into spilling inside that loop
-// (tools/spill_report.py); as a call it spills around the head only.
 template <int V, int NT>
-__device__ __noinline__ bool decide(const SolveArgs& A, const HeadLoads& L, double* red,
+__device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, double* red,
                                        SolverState* stash, PassPlan& plan) {
   constexpr int NR = tail_nr(V);
   constexpr int PEN = V * NR + 2 * V;  // speculative penalty sums of candidate 0
@@ -457,11 +454,16 @@ __device__ __noinline__ bool decide(const SolveArgs& A, const HeadLoads& L, doub
     nout = static_cast<int>(o);
     nlive = static_cast<int>(code - o * LIVE_OUT);
   };
-  double nrm[V], sx[V];
+  // The norms of the window a pass iteration leaves pending go straight into the LDS copy of the state
+  // it records (`stash`: a pass iteration parks its state there, see below) — 4 V registers held from
+  // here to the record were what tipped the streaming loop's allocation into scratch. Every other
+  // outcome records the defaults (1, 0).
+  if (writer && tid == 0) {
 #pragma unroll
-  for (int l = 0; l < V; ++l) {
-    nrm[l] = 1.0;
-    sx[l] = 0.0;
+    for (int l = 0; l < V; ++l) {
+      stash->nrm[l] = 1.0;
+      stash->sx[l] = 0.0;
+    }
   }
   // what this iteration does next
   enum { ACT_PASS, ACT_BUILD, ACT_SLOW, ACT_DONE };
@@ -509,12 +511,13 @@ __device__ __noinline__ bool decide(const SolveArgs& A, const HeadLoads& L, doub
         // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
         sel = V;
         action = ACT_PASS;
-        if (writer) {  // the norms are only recorded (for the tail): no other workgroup needs them
+        if (writer && tid == 0) {  // the norms are only recorded (for the tail): no other workgroup needs them
 #pragma unroll
           for (int l = 0; l < V; ++l) {
             const double z = sums[V * NR + 2 * l];
-            nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
-            sx[l] = sums[V * NR + 2 * l + 1] / nrm[l];
+            const double nl = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
+            stash->nrm[l] = nl;
+            stash->sx[l] = sums[V * NR + 2 * l + 1] / nl;
           }
         }
       } else {
@@ -548,12 +551,13 @@ __device__ __noinline__ bool decide(const SolveArgs& A, const HeadLoads& L, doub
           k_ = 0;
           sel = jstar;  // the tail already built max(x + beta^l gradFnew, 0) in table jstar
           action = ACT_PASS;
-          if (writer) {
+          if (writer && tid == 0) {
 #pragma unroll
             for (int l = 0; l < V; ++l) {
               const double z = sums[jstar * NR + 2 + 2 * l];
-              nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
-              sx[l] = sums[jstar * NR + 3 + 2 * l] / nrm[l];
+              const double nl = (z > 0.0) ? sqrt(z) : 1.0;
+              stash->nrm[l] = nl;
+              stash->sx[l] = sums[jstar * NR + 3 + 2 * l] / nl;
             }
           }
         }
@@ -569,12 +573,13 @@ __device__ __noinline__ bool decide(const SolveArgs& A, const HeadLoads& L, doub
         k_ = 0;
         sel = 0;
         action = ACT_PASS;
-        if (writer) {
+        if (writer && tid == 0) {
 #pragma unroll
           for (int l = 0; l < V; ++l) {
             const double z = sums[2 + 2 * l];
-            nrm[l] = (z > 0.0) ? sqrt(z) : 1.0;
-            sx[l] = sums[3 + 2 * l] / nrm[l];
+            const double nl = (z > 0.0) ? sqrt(z) : 1.0;
+            stash->nrm[l] = nl;
+            stash->sx[l] = sums[3 + 2 * l] / nl;
           }
         }
       }
@@ -725,15 +730,17 @@ __device__ __noinline__ bool decide(const SolveArgs& A, const HeadLoads& L, doub
   // clobbered and turn their scalar loads into per-lane vector loads.
   if (writer && tid == 0) {
     // (two call sites so that each store keeps its address space: LDS or global, never flat)
-    auto record = [&](SolverState* o) {
+    auto record = [&](SolverState* o, bool norms_in_place) {
       o->d = d;
       o->F = F;
       o->alpha = alpha;
       o->s = s;
+      if (!norms_in_place) {
 #pragma unroll
-      for (int l = 0; l < V; ++l) {
-        o->nrm[l] = nrm[l];
-        o->sx[l] = sx[l];
+        for (int l = 0; l < V; ++l) {
+          o->nrm[l] = 1.0;
+          o->sx[l] = 0.0;
+        }
       }
       o->sel = sel;
       o->ubp = ubp;
@@ -759,8 +766,8 @@ __device__ __noinline__ bool decide(const SolveArgs& A, const HeadLoads& L, doub
       o->rv_backoff = L.rv_backoff;
       o->pad1 = 0;
     };
-    if (action == ACT_PASS) record(stash);
-    else record(A.st_next);
+    if (action == ACT_PASS) record(stash, true);
+    else record(A.st_next, false);
     if (action == ACT_DONE) {
       SolveShared* sh = A.shared;
       sh->F = F;

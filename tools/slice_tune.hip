@@ -291,12 +291,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_pass(SliceView M, int64_t ld, 
                                                        long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const long long c0 = stamps ? wall_clock64() : 0;
+  const SliceViewG G = to_global(M);
   SliceJob<H, NW> J;
-  slice_begin<H, NW>(M, J);
+  slice_begin<H, NW>(G, J);
   // window mode: candidate l = max(U + 0.5^l G, 0); U, G lie behind the table (main())
   const int64_t mp = (m + 63) / 64 * 64;
   const WindowSource WS{X + mp * VS, X + mp * VS + mp, 1.0, 0.5};
-  slice_core<VT, H, WINDOW, V, nslot(V), NW, D>(M, J, ld, m, d, WS, X, VS, part, lds);
+  slice_core<VT, H, WINDOW, V, nslot(V), NW, D>(G, J, ld, m, d, WS, X, VS, part, lds);
   if (stamps && (threadIdx.x & 63) == 0) {
     stamps[(blockIdx.x * NW + (threadIdx.x >> 6)) * 2] = c0;
     stamps[(blockIdx.x * NW + (threadIdx.x >> 6)) * 2 + 1] = wall_clock64();
