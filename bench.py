@@ -13,9 +13,11 @@ u0) are staged into HBM before the timed region; every step re-runs the affinity
 the full solver. With N > 1 the SAME problem is column-sharded over the N GPUs (one process
 per GPU, per-pass RCCL all-gather of the (M_off x, C_off x) slices): strong scaling.
 
-`value` is the step with the inputs resident in HBM (the measurement contract); the same step
-with host buffers handed to the drop-in entry points (H2D of D1, D2, A, u0 and D2H of u inside,
-SURVEY 8d's wording) is timed over the same number of warmed steps as `ms_per_step_host_buffers`.
+`value` is the step with the inputs resident in HBM when the timed region starts — the measurement
+contract of this build ("if the boundary hands over host buffers, note the PCIe-inclusive rate ...
+it is never `value`"); the same step with host buffers handed to the drop-in entry points (H2D of
+D1, D2, A, u0 and D2H of u inside: SURVEY 8d's wording of the metric) is timed over the same number
+of warmed steps and reported beside it as `ms_per_step_host_buffers`.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement), extended with
   "roofline"     achieved GB/s of the dominant kernel (the pass: one sweep over M for a whole
@@ -64,6 +66,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not bracket mat-vec launches with HIP events (roofline fields become 0)")
+    ap.add_argument("--probe-m", type=int, default=100000,
+                    help="size of the `scaling_probe` object: the same step at the size whose pass is "
+                         "HBM-bound and whose shards scale (0 = no probe)")
+    ap.add_argument("--probe-steps", type=int, default=3)
     return ap.parse_args()
 
 
@@ -145,43 +151,49 @@ def main():
         g = abi.HipClipper(device=local_rank, storage=storage)
 
     inv = synth.EUCLID_BENCH_PARAMS
-    # inputs resident in HBM before the timed region
-    g.stage_inputs(problem.D1, problem.D2, problem.A)
-    g.affinity_euclidean_staged(**inv)
-    g.stage_u0(problem.u0)
 
-    def step():
+    def timed_steps(prob, steps, warmup, profile):
+        """W untimed + K timed steps (affinity build + solve) on `prob`, inputs resident in HBM first."""
+        g.stage_inputs(prob.D1, prob.D2, prob.A)
         g.affinity_euclidean_staged(**inv)
-        return g.solve_staged()
+        g.stage_u0(prob.u0)
+        for _ in range(warmup):
+            g.affinity_euclidean_staged(**inv)
+            g.solve_staged()
+        g.set_profiling(profile)
+        r = dict(aff_ms=[], solve_ms=[], gemv_us=0.0, gemv_n=0, view_us=0.0, view_n=0, xchg_us=0.0, xchg_n=0)
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ta = time.perf_counter()
+            g.affinity_euclidean_staged(**inv)
+            tb = time.perf_counter()
+            r["sol"] = g.solve_staged()
+            tc = time.perf_counter()
+            r["aff_ms"].append((tb - ta) * 1e3)
+            r["solve_ms"].append((tc - tb) * 1e3)
+            tm = g.timings()
+            vs = g.view_stats()
+            r["gemv_us"] += tm.gemv_avg_us * tm.gemv_launches
+            r["gemv_n"] += tm.gemv_launches
+            r["view_us"] += vs.view_pass_avg_us * vs.view_pass_samples
+            r["view_n"] += vs.view_pass_samples
+            r["xchg_us"] += tm.exchange_avg_us * tm.exchange_samples
+            r["xchg_n"] += tm.exchange_samples
+        barrier_sync()
+        elapsed = time.perf_counter() - t0
+        g.set_profiling(False)
+        if N > 1:
+            elapsed = cdist.max_over_ranks(elapsed)
+        r["ms_per_step"] = elapsed * 1e3 / steps
+        r["tm"], r["vs"] = g.timings(), g.view_stats()
+        return r
 
-    for _ in range(args.warmup):
-        step()
-
-    g.set_profiling(not args.no_profile)
-    aff_ms, solve_ms, gemv_us, gemv_n = [], [], [], []
-    barrier_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ta = time.perf_counter()
-        g.affinity_euclidean_staged(**inv)
-        tb = time.perf_counter()
-        sol = g.solve_staged()
-        tc = time.perf_counter()
-        aff_ms.append((tb - ta) * 1e3)
-        solve_ms.append((tc - tb) * 1e3)
-        tm = g.timings()
-        gemv_us.append(tm.gemv_avg_us * tm.gemv_launches)
-        gemv_n.append(tm.gemv_launches)
-    barrier_sync()
-    elapsed = time.perf_counter() - t0
-    g.set_profiling(False)
-
-    if N > 1:
-        elapsed = cdist.max_over_ranks(elapsed)
-
-    tm = g.timings()
-    ms_per_step = elapsed * 1e3 / args.steps
-    gemv_avg_us = sum(gemv_us) / max(1, sum(gemv_n))
+    R = timed_steps(problem, args.steps, args.warmup, not args.no_profile)
+    sol, tm, vstats = R["sol"], R["tm"], R["vs"]
+    aff_ms, solve_ms = R["aff_ms"], R["solve_ms"]
+    ms_per_step = R["ms_per_step"]
+    gemv_avg_us = R["gemv_us"] / max(1, R["gemv_n"])
     gemv_bytes = tm.gemv_bytes  # s * m * W_local: algorithmic bytes of ONE launch on THIS rank
     achieved = gemv_bytes / (gemv_avg_us * 1e-6) / 1e9 if gemv_avg_us > 0 else 0.0
 
@@ -199,25 +211,61 @@ def main():
     if N > 1:
         host_ms = cdist.max_over_ranks(host_ms)
 
+    # The same step at the size whose pass is HBM-bound and whose column shards scale:
+    # recorded beside the headline for every N, so that a scaling run shows a curve that CAN scale
+    probe = None
+    if args.probe_m and args.probe_m != args.m:
+        pp = synth.make_euclidean_problem(args.probe_m, 0.95, seed=args.seed)
+        P = timed_steps(pp, args.probe_steps, 1, not args.no_profile)
+        ptm, pvs = P["tm"], P["vs"]
+        pass_us = P["gemv_us"] / max(1, P["gemv_n"])
+        probe = {
+            "m": args.probe_m, "rho": 0.95, "steps": args.probe_steps, "n_gpus": N,
+            "ms_per_step": round(P["ms_per_step"], 3),
+            "affinity_ms": round(sum(P["aff_ms"]) / len(P["aff_ms"]), 3),
+            "solve_ms": round(sum(P["solve_ms"]) / len(P["solve_ms"]), 3),
+            "passes": int(P["sol"].n_passes), "trials": int(P["sol"].n_trials),
+            "pass_on_M_us": round(pass_us, 1), "bytes_per_pass_on_M_this_rank": ptm.gemv_bytes,
+            "pass_on_M_GBps": round(ptm.gemv_bytes / (pass_us * 1e-6) / 1e9, 1) if pass_us > 0 else 0.0,
+            "pass_on_M_frac_of_hbm_peak": round(ptm.gemv_bytes / (pass_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if pass_us > 0 else 0.0,
+            "passes_on_a_row_view": int(pvs.view_passes), "view_rows": int(pvs.rows), "view_bytes": int(pvs.bytes),
+            "pass_on_view_us": round(P["view_us"] / max(1, P["view_n"]), 1),
+            "exchange_us": round(P["xchg_us"] / max(1, P["xchg_n"]), 1) if N > 1 else None,
+            "exchange_bytes_per_rank": ptm.exchange_bytes if N > 1 else None,
+            "nodes": int(len(P["sol"].nodes)), "score": P["sol"].score,
+        }
+
     out = None
     if rank == 0:
         name, cus, hbm = g.device_info()
         in_use = {abi.STORE_F32: "f32", abi.STORE_F64: "f64", abi.STORE_F32_CSC: "csc",
                   abi.STORE_F64_CSC: "csc64"}[g.storage_in_use]
         compressed = in_use in ("csc", "csc64")
-        traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "gemv_traffic.json")
+        # PMC figures cannot be collected inside this process (rocprofv3 wraps a command): they come
+        # from profiles/pmc_r03.json, written by tools/pmc_summary.py from a rocprofv3 --pmc run of this
+        # same command, with the commit and the kernel's byte count at that time. A record taken on
+        # other bytes than today's is NOT quoted.
+        traffic, traffic_source, issue = None, None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_r03.json")
         if os.path.exists(pmc):
             try:
-                rec = json.load(open(pmc))
-                key = f"r02_m{args.m}_{in_use}_bytes_per_launch"
-                traffic = rec.get(key)
-                if traffic is not None:
-                    traffic_source = {"file": "profiles/gemv_traffic.json", "key": key,
-                                      "measured_at_commit": rec.get("r02_commit"),
-                                      "kernel_bytes_then": rec.get(f"r02_m{args.m}_{in_use}_algorithmic_bytes")}
+                rec = json.load(open(pmc)).get(f"m{args.m}_{in_use}")
             except Exception:
-                traffic, traffic_source = None, None
+                rec = None
+            if rec:
+                then = rec.get("pass_bytes_per_launch")
+                if then is not None and abs(then - tm.gemv_bytes) > 1e-6 * max(1.0, tm.gemv_bytes):
+                    print(f"bench.py: profiles/pmc_r03.json was measured on {then} bytes per pass, the kernel "
+                          f"reads {tm.gemv_bytes} today: STALE, not quoted — re-run tools/gpu_pmc_r03.sh",
+                          file=sys.stderr, flush=True)
+                    traffic_source = {"file": "profiles/pmc_r03.json", "stale": True, "kernel_bytes_then": then}
+                else:
+                    traffic = rec.get("pass_hbm_bytes_per_launch")
+                    traffic_source = {"file": "profiles/pmc_r03.json", "key": f"m{args.m}_{in_use}",
+                                      "measured_at_commit": rec.get("commit"), "kernel_bytes_then": then,
+                                      "read_bytes": rec.get("pass_read_bytes"), "written_bytes": rec.get("pass_written_bytes"),
+                                      "how": rec.get("how")}
+                    issue = rec.get("affinity_issue")
         useful = tm.gemv_useful_bytes
         achieved_useful = useful / (gemv_avg_us * 1e-6) / 1e9 if gemv_avg_us > 0 else 0.0
         regime = ("Infinity-Cache-resident: %.0f MB per pass < 256 MiB, re-read every pass — served "
@@ -270,13 +318,24 @@ def main():
                 if (compressed and gemv_avg_us > 0) else None,
             },
             "roofline_affinity": {
-                "bound": "hbm", "achieved": round(aff_achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(aff_achieved / HBM_PEAK_GBPS, 4),
-                "kernel": "k_affinity_sym (writes the slices itself)" if compressed else "affinity fill",
-                "bytes_per_launch": tm.affinity_bytes, "kernel_ms": round(aff_kernel_ms, 4),
-                "note": "store floor only: the fill is bound by fp64 VALU issue and dependent latency "
-                        "(prefilter + exact scores of the survivors), see profiles/ and DESIGN.md",
+                "bound": "valu-issue", "kernel": "k_affinity_sym (writes the slices itself)" if compressed else "affinity fill",
+                "kernel_ms": round(aff_kernel_ms, 4),
+                # VALU instructions the launch issued (SQ_INSTS_VALU) x 4 cycles per wave64 instruction on a
+                # 16-lane fp64 / 32-lane fp32 SIMD-cycle budget = kernel time x SIMDs x clock: PMC record
+                "issue": issue,
+                "store_stream": {"bound": "hbm", "achieved": round(aff_achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": round(aff_achieved / HBM_PEAK_GBPS, 4), "bytes_per_launch": tm.affinity_bytes,
+                                 "note": "what the fill writes, as a store floor only: it is bound by VALU issue "
+                                         "(prefilter + exact fp64 scores of the survivors), see `issue`"},
             },
+            "row_view": {
+                "what": "passes that streamed the slices of M[live rows, :] instead of M (rows with u = 0 and "
+                        "g <= 0 are exact zeros in every line-search candidate; DESIGN.md 3c)",
+                "passes_on_view": int(vstats.view_passes), "passes": int(sol.n_passes), "views_built": int(vstats.builds),
+                "rows": int(vstats.rows), "bytes": int(vstats.bytes), "build_ms": round(vstats.build_ms, 4),
+                "pass_on_view_us": round(R["view_us"] / max(1, R["view_n"]), 2),
+            },
+            "scaling_probe": probe,
         }
         if N == 1 and not args.no_cpu_baseline:
             cb, sref = cpu_baseline(problem, args)

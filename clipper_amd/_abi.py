@@ -88,6 +88,7 @@ class Timings(C.Structure):
         ("solve_total_ms", C.c_double), ("gemv_avg_us", C.c_double),
         ("gemv_min_us", C.c_double), ("gemv_launches", C.c_int64), ("gemv_bytes", C.c_double),
         ("gemv_useful_bytes", C.c_double), ("affinity_bytes", C.c_double),
+        ("exchange_avg_us", C.c_double), ("exchange_samples", C.c_int64), ("exchange_bytes", C.c_double),
     ]
 
 

@@ -153,6 +153,7 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   }
   if (!h->sh.empty()) hipSetDevice(h->sh[0].device);
   for (hipEvent_t e : h->ev_pairs) hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_xchg) hipEventDestroy(e);
   if (h->ev_poll[0]) hipEventDestroy(h->ev_poll[0]);
   if (h->ev_poll[1]) hipEventDestroy(h->ev_poll[1]);
   if (h->host_state) hipHostFree(h->host_state);
@@ -731,6 +732,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
 
   h->rv_stats = clipper_hip_view_stats_t{};
   h->ev_used = 0;
+  std::fill(h->ev_xchg_used.begin(), h->ev_xchg_used.end(), 0);
   if (h->profiling)  // marks of the previous solve
   {
     const size_t n = static_cast<size_t>(std::min<int64_t>(h->launch_counter + 1, KIND_CAP));
@@ -945,6 +947,26 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
       sum += ms;
       mn = std::min<double>(mn, ms);
       ++nreal;
+    }
+    // the exchanges of the same iterations (column shards)
+    h->tm.exchange_avg_us = 0.0;
+    h->tm.exchange_samples = 0;
+    h->tm.exchange_bytes = static_cast<double>(nslot(h->V)) * static_cast<double>(h->W) * sizeof(double);
+    {
+      double xs = 0.0;
+      int64_t nx = 0;
+      for (int k = 0; k < h->ev_used; ++k) {
+        const int64_t li = h->ev_launch_index[static_cast<size_t>(k)];
+        if (!h->ev_xchg_used[static_cast<size_t>(k)] || li >= iters_run || !kind[static_cast<size_t>(li)]) continue;
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_xchg[2 * k], h->ev_xchg[2 * k + 1]));
+        xs += ms;
+        ++nx;
+      }
+      if (nx > 0) {
+        h->tm.exchange_avg_us = xs / static_cast<double>(nx) * 1e3;
+        h->tm.exchange_samples = nx;
+      }
     }
     if (nview > 0) {
       h->rv_stats.view_pass_avg_us = vsum / static_cast<double>(nview) * 1e3;
@@ -1269,6 +1291,9 @@ int clipper_hip_set_profiling(clipper_hip_t* h, int on) {
     h->ev_pairs.resize(2 * MAX_EVENT_PAIRS);
     h->ev_launch_index.assign(MAX_EVENT_PAIRS, 0);
     for (auto& e : h->ev_pairs) HIPCHK(hipEventCreate(&e));
+    h->ev_xchg.resize(2 * MAX_EVENT_PAIRS);
+    h->ev_xchg_used.assign(MAX_EVENT_PAIRS, 0);
+    for (auto& e : h->ev_xchg) HIPCHK(hipEventCreate(&e));
   }
   return 0;
 }

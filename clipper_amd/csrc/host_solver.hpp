@@ -407,6 +407,8 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   }
   ++h->launch_counter;
   const bool fresh_used = h->rv_fresh;
+  const int xk = (prof && sharded) ? h->ev_used - 1 : -1;  // this iteration's exchange is timed too
+  if (xk >= 0) HIPCHK(hipEventRecord(h->ev_xchg[2 * xk], s0.stream));
   if (sharded) {
     for (auto& s : h->sh) {  // the tile partials of the pass -> this shard's block of `ab`
       HIPCHK(hipSetDevice(s.device));
@@ -417,6 +419,11 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
     }
     int rc = exchange(h, nslot(V));
     if (rc) return rc;
+    if (xk >= 0) {
+      HIPCHK(hipSetDevice(s0.device));
+      HIPCHK(hipEventRecord(h->ev_xchg[2 * xk + 1], s0.stream));
+      h->ev_xchg_used[static_cast<size_t>(xk)] = 1;
+    }
   }
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));

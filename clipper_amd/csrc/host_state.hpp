@@ -263,6 +263,8 @@ struct clipper_hip_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created by clipper_hip_set_profiling
   std::vector<int64_t> ev_launch_index;  // which mat-vec launch of the solve each pair timed
+  std::vector<hipEvent_t> ev_xchg;       // 2*MAX_EVENT_PAIRS: around the exchange of the same iterations
+  std::vector<char> ev_xchg_used;
   int ev_used = 0;
   int64_t launch_counter = 0;
   clipper_hip_timings_t tm{};

@@ -477,17 +477,22 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   __shared__ __attribute__((aligned(16))) SolverState stash;
   const long long c0 = A.stamps ? wall_clock64() : 0;
   SliceViewG G = to_global(M);
-  SliceJob<H, SL_NW> J;
+  SliceJob<H, SL_NW> J, JV;
   slice_begin<H, SL_NW>(G, J);
+  // Both jobs are requested ahead of the decision, which hides them: a pass on a small view is a chain
+  // of latencies (work item -> directory -> header), not a stream. (Also requesting this thread's
+  // row-list entry for the first chunk here tips the register allocation into scratch: not done.)
+  SliceViewG GV = G;
+  if (A.in_view != nullptr) {
+    GV = to_global(*RV);
+    slice_begin<H, SL_NW>(GV, JV);
+  }
   PassPlan plan;
   if (!iteration_head<V, SL_NW * 64>(A, lds, &stash, plan)) return;
   const long long c1 = A.stamps ? wall_clock64() : 0;
-  if (plan.view) {
-    // (The view's slices are few and hot in L2: its first header is requested here, not ahead of the
-    // decision. Holding a second job across the decision — even its wave-uniform words alone — costs
-    // 170-220 registers spilled to scratch. One call site of the streaming loop for both.)
-    G = to_global(*RV);
-    slice_begin<H, SL_NW>(G, J);
+  if (plan.view) {  // (one call site of the streaming loop for both)
+    G = GV;
+    J = JV;
   }
   slices_by_plan<VT, H, V, SL_NW, SL_D>(G, J, A, plan, lds);
   flush_state(A, &stash);

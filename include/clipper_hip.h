@@ -83,6 +83,11 @@ typedef struct clipper_hip_timings_t {
   double gemv_useful_bytes;  /* compressed storage: stored entries (both triangles, no quad
                                 padding) x (value + row byte); dense store: = gemv_bytes     */
   double affinity_bytes;     /* bytes of M the last affinity build wrote (dense store or slices) */
+  double exchange_avg_us;    /* column shards: mean duration of the sampled per-pass exchanges (reduce
+                                launch + all-gather) of the last solve, HIP events on the solver
+                                stream (profiling on; 0: none sampled / one shard)            */
+  int64_t exchange_samples;
+  double exchange_bytes;     /* bytes this rank contributes to one exchange                   */
 } clipper_hip_timings_t;
 
 /* The row view of the last solve (clipper_hip_set_row_view below). */

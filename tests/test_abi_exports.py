@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(abi.Params) == 72
     assert abi.Params.rounding.offset == 68 and abi.Params.beta.offset == 32
     assert ctypes.sizeof(abi.SolveInfo) == 48
-    assert ctypes.sizeof(abi.Timings) == 72
+    assert ctypes.sizeof(abi.Timings) == 96
     p = abi.Params()
     assert (p.tol_u, p.tol_F, p.maxiniters, p.maxoliters, p.beta, p.maxlsiters, p.eps,
             p.affinityeps, p.rescale_u0, p.rounding) == (

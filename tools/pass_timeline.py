@@ -25,9 +25,15 @@ t0 = st[:, 0].min()
 pc = lambda v, f: float(np.sort(v)[int(f * (len(v) - 1))])
 start, head, end = (st[:, 0] - t0) * 0.01, (st[:, 1] - st[:, 0]) * 0.01, (st[:, 2] - t0) * 0.01
 body = (st[:, 2] - st[:, 1]) * 0.01
-print(f"m={m} workgroups stamped {len(st)} passes {s.n_passes}")
+vs = g.view_stats()
+print(f"m={m} workgroups stamped {len(st)} passes {s.n_passes} (on a row view: {vs.view_passes}; last view {vs.rows} rows, {vs.bytes} bytes)")
 for name, v in (("start", start), ("head (launch -> decision done)", head), ("body", body), ("end", end)):
     print(f"  {name:32s} p10 {pc(v,.1):6.2f} p50 {pc(v,.5):6.2f} p90 {pc(v,.9):6.2f} p99 {pc(v,.99):6.2f} max {v.max():6.2f} us")
+work = (st[:, 3] >> 32) > 0   # workgroups that had chunks to stream (a pass on a view leaves most of the grid idle)
+if work.sum() and work.sum() < len(st):
+    print(f"  workgroups with chunks to stream: {int(work.sum())}")
+    for name, v in (("head", head[work]), ("body", body[work]), ("end", end[work])):
+        print(f"    {name:30s} p10 {pc(v,.1):6.2f} p50 {pc(v,.5):6.2f} p90 {pc(v,.9):6.2f} p99 {pc(v,.99):6.2f} max {v.max():6.2f} us")
 tl = allst[1536:2048]
 tl = tl[tl[:, 2] > 0]
 if len(tl):

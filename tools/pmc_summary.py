@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""PMC counters of a rocprofv3 --pmc run of bench.py, per kernel, and the record bench.py quotes
+(profiles/pmc_r03.json). The pass kernel is launched for passes on M, for passes on a row view
+(far fewer bytes) and for iterations that do nothing: a launch counts as a PASS ON M when it runs at
+least 0.6 x the longest launch of that kernel in the run.
+  tools/pmc_summary.py --key m10000_csc --bytes <bytes per pass> --commit <sha> --json profiles/pmc_r03.json <db> [...]"""
+import argparse
+import json
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dbs", nargs="+")
+    ap.add_argument("--key")
+    ap.add_argument("--bytes", type=float, default=None)
+    ap.add_argument("--commit", default="")
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    per = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [(value, duration)]
+    for db in a.dbs:
+        con = sqlite3.connect(db)
+        for name, cname, val, dur in con.execute(
+                "select kernel_name, counter_name, value, duration from counters_collection"):
+            short = name.split("(")[0].replace("void clipper_hip::", "").replace("clipper_hip::", "")
+            per[short][cname].append((val, dur))
+    summary = {}
+    for k in sorted(per):
+        for c in sorted(per[k]):
+            rows = per[k][c]
+            dmax = max(d for _, d in rows)
+            sel = [v for v, d in rows if d >= 0.6 * dmax] if k.startswith(("k_gemv", "k_tail")) else [v for v, _ in rows]
+            sel.sort()
+            med = sel[len(sel) // 2]
+            summary.setdefault(k, {})[c] = dict(n=len(sel), of=len(rows), median=med, mean=sum(sel) / len(sel),
+                                                median_duration_us=sorted(d for _, d in rows if d >= 0.6 * dmax)[len(sel) // 2] / 1e3)
+            print(f"{k[:46]:46s} {c:24s} n={len(sel):4d}/{len(rows):4d} median {med:16.1f} mean {sum(sel)/len(sel):16.1f}")
+    if not (a.json and a.key):
+        return
+    rec = {}
+    if os.path.exists(a.json):
+        rec = json.load(open(a.json))
+    e = rec.setdefault(a.key, {})
+    e["commit"] = a.commit
+    if a.bytes is not None:
+        e["pass_bytes_per_launch"] = a.bytes
+    pk = next((k for k in summary if k.startswith("k_gemv_slices")), None) or next((k for k in summary if k.startswith("k_gemv")), None)
+    if pk:
+        s = summary[pk]
+        if "FETCH_SIZE" in s:   # KB; a wide coalesced read is tallied at half its bytes on gfx950 (MI355X_MICROARCH.md, HBM)
+            e["pass_read_bytes"] = 2.0 * 1024.0 * s["FETCH_SIZE"]["median"]
+        if "WRITE_SIZE" in s:
+            e["pass_written_bytes"] = 1024.0 * s["WRITE_SIZE"]["median"]
+        if "pass_read_bytes" in e and "pass_written_bytes" in e:
+            e["pass_hbm_bytes_per_launch"] = e["pass_read_bytes"] + e["pass_written_bytes"]
+        e["how"] = ("median over the pass-on-M launches of %s in separate rocprofv3 --pmc runs of bench.py; read = 2 x FETCH_SIZE "
+                    "(the gfx950 tally of 128-byte requests at 64 bytes), written = WRITE_SIZE (uncalibrated)" % pk)
+        for c in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU",
+                  "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"):
+            if c in s:
+                e.setdefault("pass_counters", {})[c] = s[c]["median"]
+        if "SQ_LDS_BANK_CONFLICT" in s and "SQ_LDS_IDX_ACTIVE" in s and s["SQ_LDS_IDX_ACTIVE"]["median"] > 0:
+            e["pass_lds_conflict_share"] = s["SQ_LDS_BANK_CONFLICT"]["median"] / s["SQ_LDS_IDX_ACTIVE"]["median"]
+    ak = next((k for k in summary if k.startswith("k_affinity_sym")), None) or next((k for k in summary if k.startswith("k_affinity")), None)
+    if ak and "SQ_INSTS_VALU" in summary[ak]:
+        s = summary[ak]
+        insts = s["SQ_INSTS_VALU"]["median"]
+        dur_us = s["SQ_INSTS_VALU"]["median_duration_us"]
+        simd_cycles = dur_us * 1e-6 * 2.4e9 * 1024.0   # 256 CUs x 4 SIMDs at 2.4 GHz
+        e["affinity_issue"] = {
+            "kernel": ak, "valu_wave_instructions": insts, "kernel_us_under_the_profiler": dur_us,
+            "simd_cycles_available": simd_cycles,
+            "frac_at_2_cycles_per_instruction": insts * 2.0 / simd_cycles,   # all of them fp32 (SIMD-32: 2 cycles per wave64)
+            "frac_at_4_cycles_per_instruction": insts * 4.0 / simd_cycles,   # all of them fp64 / transcendental-free (16 lanes)
+            "note": "SQ_INSTS_VALU x cycles a wave64 VALU instruction holds its SIMD (2: fp32, 4: fp64) / (kernel time x "
+                    "1024 SIMDs x 2.4 GHz); the fill mixes an fp32 prefilter with exact fp64 scores, the truth lies between",
+        }
+        for c in ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+            if c in s:
+                e["affinity_issue"][c] = s[c]["median"]
+    json.dump(rec, open(a.json, "w"), indent=1, sort_keys=True)
+    print("wrote", a.json, "key", a.key)
+
+
+if __name__ == "__main__":
+    main()
