@@ -1,5 +1,5 @@
-// k_rowview.hip.h — the row list of a row view (k_solver.hip.h, LIVE ROWS): which rows can be non-zero
-// in any candidate the NEXT decision may leave pending, in ascending order.
+// k_rowview.hip.h — the row list of a row view (k_solver.hip.h, LIVE ROWS): the rows that can be non-zero
+// in the window the next pass multiplies, in ascending order.
 // Part of kernels.hip.h (include that one): hand-written gfx950 device code of the CLIPPER hot path.
 #pragma once
 
@@ -10,30 +10,19 @@
 
 namespace clipper_hip {
 
-// The view is built between two iterations, from the state `st` the next iteration will decide from:
-//   * its current point (u, gradF) = point slot (ubp, ubv) — what stays if every pending candidate is
-//     rejected, and what a build iteration formed the new gradient into;
-//   * if the results of a window pass are pending (phase PH_TRIAL, stage ST_RESULTS): the points the
-//     tail stored into slots (ubp ^ 1, v), v < V — what the point becomes if candidate v is accepted.
-// A row is kept when it is live (u > 0 or g > 0) in ANY of them: whatever the decision turns out to
-// be, the window (or the pair-mode vector) it leaves pending has no non-zero row outside the list.
+// The view is built while the solve is on HOLD (k_solver.hip.h): the decision that asked for it has
+// worked out — deterministically, it will work it out again when the hold is lifted — which point the
+// solve continues from (hold_slot: the accepted candidate's point slot, or the unchanged point's). The
+// window the next pass multiplies is built from that point, so its rows are exactly the live rows of
+// that point: u > 0 or g > 0.
 constexpr int RV_BLK = 1024;  // rows per workgroup (256 threads x 4)
 
 template <int V>
 __device__ __forceinline__ bool rv_live(const SolverState* st, const double* pt, int64_t mp, int64_t i) {
-  const int ubp = st->ubp, ubv = st->ubv;
-  const double* u = pt + ((static_cast<int64_t>(ubp) * V + ubv) * 2 + 0) * mp;
-  const double* g = pt + ((static_cast<int64_t>(ubp) * V + ubv) * 2 + 1) * mp;
-  bool live = u[i] > 0.0 || g[i] > 0.0;
-  if (st->phase == PH_TRIAL && st->stage == ST_RESULTS) {
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const double* uv = pt + ((static_cast<int64_t>(ubp ^ 1) * V + v) * 2 + 0) * mp;
-      const double* gv = pt + ((static_cast<int64_t>(ubp ^ 1) * V + v) * 2 + 1) * mp;
-      live = live || uv[i] > 0.0 || gv[i] > 0.0;
-    }
-  }
-  return live;
+  const int64_t slot = st->hold_slot;
+  const double* u = pt + (slot * 2 + 0) * mp;
+  const double* g = pt + (slot * 2 + 1) * mp;
+  return u[i] > 0.0 || g[i] > 0.0;
 }
 
 // flags[i] = live(i); blk[b] = live rows of block b

@@ -134,7 +134,8 @@ struct SolverState {
   int32_t rv_builds;   // views asked for so far
   int32_t rv_last;     // n_iters when the last one was asked for
   int32_t rv_backoff;  // the host refused a view of this many rows (0: none): ask again only well below
-  int32_t pad1;
+  int32_t hold_slot;   // while on hold: the point slot p * V + v the decision ends on — the window it
+                       // will leave pending is built from that point, the view must cover ITS live rows
 };
 
 // What outlives the alternating state: the end of the solve. Kernels launched after
@@ -716,6 +717,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       __syncthreads();
       if (tid == 0) {
         A.st_next->hold = 1;
+        A.st_next->hold_slot = ubp * V + ubv;  // (after the decision: the accepted candidate's slot, or the unchanged point's)
         if (A.host != nullptr)
           __hip_atomic_store(&A.host->hold, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -764,7 +766,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       o->rv_builds = L.rv_builds;
       o->rv_last = L.rv_last;
       o->rv_backoff = L.rv_backoff;
-      o->pad1 = 0;
+      o->hold_slot = 0;
     };
     if (action == ACT_PASS) record(stash, true);
     else record(A.st_next, false);

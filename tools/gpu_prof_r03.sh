@@ -14,7 +14,7 @@ for m in $SIZES; do
   ( cd /tmp && CLIPPER_HIP_ROW_VIEW=0 timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/trace_noview_m$m -o trace -- $B > $ROOT/$OUT/trace_noview_m$m.log 2>&1 )
   DB=$(find $OUT/trace_noview_m$m -name '*.db' | head -1)
   [ -n "$DB" ] && python tools/rocpd_stats.py $DB --json $OUT/kernel_stats_noview_m$m.json > $OUT/kernel_stats_noview_m$m.txt 2>&1
-  bytes=$(tail -1 $OUT/trace_m$m.log | python -c "import sys,json; print(json.loads(sys.stdin.readline())['roofline']['bytes_per_launch'])")
+  bytes=$(grep '^{"metric"' $OUT/trace_m$m.log | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.readline())['roofline']['bytes_per_launch'])")
   B2="python $ROOT/bench.py --m $m --steps 2 --warmup 1 --no-cpu-baseline --probe-m 0 --no-profile"
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
     name=$(echo $set | tr ' ' '_')
