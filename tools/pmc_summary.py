@@ -32,11 +32,12 @@ def main():
         for c in sorted(per[k]):
             rows = per[k][c]
             dmax = max(d for _, d in rows)
-            sel = [v for v, d in rows if d >= 0.6 * dmax] if k.startswith(("k_gemv", "k_tail")) else [v for v, _ in rows]
-            sel.sort()
+            keep = [(v, d) for v, d in rows if d >= 0.6 * dmax] if k.startswith(("k_gemv", "k_tail")) else rows
+            sel = sorted(v for v, _ in keep)
+            durs = sorted(d for _, d in keep)
             med = sel[len(sel) // 2]
             summary.setdefault(k, {})[c] = dict(n=len(sel), of=len(rows), median=med, mean=sum(sel) / len(sel),
-                                                median_duration_us=sorted(d for _, d in rows if d >= 0.6 * dmax)[len(sel) // 2] / 1e3)
+                                                median_duration_us=durs[len(durs) // 2] / 1e3)
             print(f"{k[:46]:46s} {c:24s} n={len(sel):4d}/{len(rows):4d} median {med:16.1f} mean {sum(sel)/len(sel):16.1f}")
     if not (a.json and a.key):
         return
