@@ -458,6 +458,47 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
   int rc;
   if ((rc = check_csc("M", Mcolptr, Mrow, Mval))) return rc;
   if ((rc = check_csc("C", Ccolptr, Crow, Cval))) return rc;
+  // The reference reads M_.selfadjointView<Upper>() (clipper.cpp:194-271): of a matrix handed over with
+  // BOTH triangles stored (a full symmetric SpAffinity) only the upper entries count. Here every stored
+  // off-diagonal entry stands for the symmetric pair, so a pair stored in both triangles is taken once
+  // — the upper copy, as the reference would — for every storage mode alike; a pair stored only below
+  // the diagonal keeps counting (the reference would ignore it).
+  struct Csc {
+    std::vector<int64_t> cp;
+    std::vector<int32_t> ri;
+    std::vector<double> va;
+  } Mn, Cn;
+  auto upper_wins = [&](const int64_t*& cp, const int32_t*& ri, const double*& va, Csc& out) {
+    bool lower = false;
+    for (int64_t j = 0; j < m && !lower; ++j)
+      for (int64_t p = cp[j]; p < cp[j + 1]; ++p)
+        if (ri[p] > j) {
+          lower = true;
+          break;
+        }
+    if (!lower) return;
+    std::vector<uint64_t> up;  // (row << 32 | column) of the upper entries
+    for (int64_t j = 0; j < m; ++j)
+      for (int64_t p = cp[j]; p < cp[j + 1]; ++p)
+        if (ri[p] < j) up.push_back((static_cast<uint64_t>(ri[p]) << 32) | static_cast<uint64_t>(j));
+    std::sort(up.begin(), up.end());
+    out.cp.assign(static_cast<size_t>(m) + 1, 0);
+    for (int64_t j = 0; j < m; ++j) {
+      for (int64_t p = cp[j]; p < cp[j + 1]; ++p) {
+        const int64_t i = ri[p];
+        if (i > j && std::binary_search(up.begin(), up.end(), (static_cast<uint64_t>(j) << 32) | static_cast<uint64_t>(i)))
+          continue;  // (i, j) below the diagonal, (j, i) stored above it: the upper copy stands for the pair
+        out.ri.push_back(static_cast<int32_t>(i));
+        out.va.push_back(va[p]);
+      }
+      out.cp[static_cast<size_t>(j) + 1] = static_cast<int64_t>(out.ri.size());
+    }
+    cp = out.cp.data();
+    ri = out.ri.data();
+    va = out.va.data();
+  };
+  upper_wins(Mcolptr, Mrow, Mval, Mn);
+  upper_wins(Ccolptr, Crow, Cval, Cn);
   const int64_t nnzM = Mcolptr[m], nnzC = Ccolptr[m];
   if (h->A.size() != static_cast<size_t>(2 * m)) h->A.clear();
   h->nodes.clear();

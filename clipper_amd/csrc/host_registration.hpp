@@ -99,6 +99,20 @@ int read_ply_vertices(const char* path, std::vector<double>& pts, int64_t& n) {
       if (props[i].name == std::string(1, "xyz"[k])) ix[k] = static_cast<int>(i);
   if (ix[0] < 0 || ix[1] < 0 || ix[2] < 0) return fail(CLIPPER_HIP_E_INVALID, "vertex element has no x, y, z");
   if (n < 0) return fail(CLIPPER_HIP_E_INVALID, "negative vertex count");
+  {
+    // the header's count is not trusted: every vertex takes at least one byte per property of the body
+    // (ascii: a digit and a separator each), so a count the rest of the file cannot hold is refused
+    // before anything is allocated for it
+    const std::streampos body = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streamoff left = f.tellg() - body;
+    f.seekg(body);
+    size_t per = 0;
+    for (const PlyProp& pp : props) per += (fmt == "ascii") ? 2u : static_cast<size_t>(pp.bytes);
+    if (left < 0 || static_cast<unsigned long long>(n) * std::max<size_t>(per, 1) > static_cast<unsigned long long>(left) + 1ull)
+      return fail(CLIPPER_HIP_E_INVALID, "PLY header declares %lld vertices, the file holds %lld more bytes",
+                  static_cast<long long>(n), static_cast<long long>(left));
+  }
   pts.assign(static_cast<size_t>(n) * 3, 0.0);
   if (fmt == "ascii") {
     std::vector<double> row(props.size());
@@ -209,7 +223,11 @@ int64_t clipper_hip_read_ply_xyz(const char* path, double* pts_out, int64_t capa
   if (!path) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   std::vector<double> pts;
   int64_t n = 0;
-  if (int rc = read_ply_vertices(path, pts, n)) return rc;
+  try {  // (no exception may cross the C boundary: a file too large for this host's memory is an error code)
+    if (int rc = read_ply_vertices(path, pts, n)) return rc;
+  } catch (const std::exception& e) {
+    return fail(CLIPPER_HIP_E_NOMEM, "reading %s: %s", path, e.what());
+  }
   if (pts_out == nullptr) return n;  // size query
   if (capacity < n) return fail(CLIPPER_HIP_E_INVALID, "capacity %lld < %lld vertices", static_cast<long long>(capacity), static_cast<long long>(n));
   // column-major 3 x n (clipper::invariants::Data): datum i = pts_out[3 i .. 3 i + 2]

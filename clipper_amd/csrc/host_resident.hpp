@@ -109,7 +109,7 @@ int resident_launch_t(Ctx* h, Shard& s, const ResidentArgs& a) {
   const unsigned grid = static_cast<unsigned>(a.xcd_mode ? 8 * a.nunits : a.nunits);
   Resident& r = h->res;
   auto kern = k_solve_resident<VT, V, E>;
-  static bool attr_set[64] = {};  // per instantiation and device
+  static std::atomic<bool> attr_set[64] = {};  // per instantiation and device (contexts may solve concurrently)
   const int dv = (s.device >= 0 && s.device < 64) ? s.device : 0;
   if (!attr_set[dv]) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -258,6 +258,11 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   fin.ubp = 0;
   fin.ubv = 0;
   r.epoch += static_cast<unsigned long long>(hm->iters) + 8ull;
+  // the granules carry the low 32 bits of the epoch: long before they wrap, start over on a clean buffer
+  if ((r.epoch & 0xffffffffull) > 0xf0000000ull) {
+    HIPCHK(hipMemset(r.xb, 0, r.xb_cap));
+    r.epoch = (r.epoch & ~0xffffffffull) + (1ull << 32);
+  }
   if (rs_debug()) std::fprintf(stderr, "[resident] solved: units=%d one-XCD mode=%d passes=%lld\n", r.nunits, a.xcd_mode,
                                static_cast<long long>(fin.n_passes));
   ran = true;

@@ -118,7 +118,8 @@ class CLIPPER {
   void setDevice(int device);        ///< HIP device ordinal (default 0); before the first call
   void setStorage(Storage storage);  ///< default F32_CSC (compressed; dense fp32 where it does not apply); before the first call
   /// Problems of up to 2048 associations are solved by ONE launch that keeps M on chip (the resident
-  /// solver); false = always the streaming launches. Same result either way. Any time.
+  /// solver); false = always the streaming launches. Same result either way. Switching
+  /// it off takes effect at the next solve(), switching it back on at the next build of M.
   void setResidentSolver(bool on);
   bool lastSolveWasResident() const;  ///< which of the two the last solve() ran on
   struct PathStats {

@@ -178,8 +178,12 @@ int clipper_hip_get_associations(const clipper_hip_t* h, int32_t* A_out /* col-m
  * length is m (so getSelectedAssociations keeps working), else clears it. */
 int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, int64_t m);
 
-/* CLIPPER::setSparseMatrixData (clipper.cpp:162-166): strictly-upper CSC, int64 column
- * pointers, int32 row indices. */
+/* CLIPPER::setSparseMatrixData (clipper.cpp:162-166): CSC, int64 column pointers, int32 row
+ * indices. The reference reads the upper triangle of what it is given (selfadjointView<Upper>).
+ * Here every stored off-diagonal entry stands for the symmetric pair; a pair stored in BOTH
+ * triangles (a full symmetric matrix) counts once, with the upper copy's value — the same matrix
+ * the reference would see, in every storage mode. The same (row, column) stored twice is an error
+ * with the compressed storage. The diagonal is implicit: stored diagonal entries are ignored. */
 int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
                            const int32_t* Mrow, const double* Mval, const int64_t* Ccolptr,
                            const int32_t* Crow, const double* Cval);
@@ -253,7 +257,8 @@ int clipper_hip_window(const clipper_hip_t* h);
  * share them (m up to a few thousand, one device, C == pattern(M), automatic window), the whole of
  * findDenseClique (clipper.cpp:172-323) runs as ONE launch that keeps M on chip; otherwise — and
  * always with mode 1, or CLIPPER_HIP_RESIDENT=0 in the environment — as the streaming launches
- * (decision + pass, tail) per iteration. Same trial sequence and result either way.
+ * (decision + pass, tail) per iteration. Same trial sequence and result either way. Mode 1 takes
+ * effect at the next solve; back to 0 at the next affinity build / set_matrix (the plan is made there).
  * clipper_hip_last_solver: what the last solve ran on, 0 = streaming launches, 1 = resident. */
 int clipper_hip_set_resident(clipper_hip_t* h, int mode);
 int clipper_hip_last_solver(const clipper_hip_t* h);

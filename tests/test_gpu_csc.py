@@ -281,6 +281,34 @@ def test_set_sparse_equals_set_matrix(m, storage):
     assert np.array_equal(a.get_affinity_matrix(), c.get_affinity_matrix())
 
 
+@pytest.mark.parametrize("storage", [abi.STORE_F32, abi.STORE_F64, abi.STORE_F32_CSC, abi.STORE_F64_CSC])
+def test_set_sparse_full_symmetric_input_counts_every_pair_once(storage):
+    """A SpAffinity with BOTH triangles stored — which the reference accepts and reads the upper
+    half of (selfadjointView<Upper>, clipper.cpp:194-271) — is the same matrix in every storage mode;
+    where the two copies of a pair differ, the upper one counts."""
+    import scipy.sparse as sp
+    m = 300
+    M, C = _random_symmetric(m, 0.1, seed=9)
+    U = _upper_csc(M)
+    P = sp.csc_matrix((np.ones_like(U.data), U.indices, U.indptr), shape=U.shape)
+    a = abi.HipClipper(storage=storage)
+    a.set_sparse_matrix_data(m, U.indptr, U.indices, U.data, P.indptr, P.indices, P.data)
+    Ma, Ca = a.get_affinity_matrix(), a.get_constraint_matrix()
+    F = sp.csc_matrix(M - np.diag(np.diag(M)))          # both triangles
+    low = sp.csc_matrix(np.tril(M, -1) * 0.5)            # ... the lower copies carry other values
+    F = sp.csc_matrix(sp.triu(F, 1) + low)
+    F.sort_indices()
+    PF = sp.csc_matrix((np.ones_like(F.data), F.indices, F.indptr), shape=F.shape)
+    b = abi.HipClipper(storage=storage)
+    b.set_sparse_matrix_data(m, F.indptr, F.indices, F.data, PF.indptr, PF.indices, PF.data)
+    assert b.storage_in_use == storage
+    assert np.array_equal(b.get_affinity_matrix(), Ma)
+    assert np.array_equal(b.get_constraint_matrix(), Ca)
+    u0 = np.random.default_rng(1).random(m)
+    sa, sb = a.solve(u0), b.solve(u0)
+    assert sa.nodes.tolist() == sb.nodes.tolist() and sa.score == sb.score
+
+
 def test_set_sparse_rejects_malformed_input():
     m = 50
     M, C = _random_symmetric(m, 0.2, seed=2)
@@ -306,12 +334,16 @@ def test_set_sparse_rejects_malformed_input():
             g.set_sparse_matrix_data(*args)
         s1 = g.solve(np.ones(m))       # rejected before anything was touched: the old matrix is intact
         assert s1.nodes.tolist() == s0.nodes.tolist() and s1.score == s0.score
-    # the same entry in both triangles (found while the lists are merged: no matrix afterwards)
+    # the same (row, column) stored twice (found while the lists are merged: no matrix afterwards)
     import scipy.sparse as sp
-    B = sp.csc_matrix(M - np.eye(m))
-    B.sort_indices()
+    dup_ptr = U.indptr.copy()
+    col = int(np.argmax(np.diff(U.indptr) >= 1))
+    at = int(U.indptr[col])
+    dup_rows = np.insert(U.indices, at, U.indices[at])
+    dup_vals = np.insert(U.data, at, U.data[at])
+    dup_ptr[col + 1:] += 1
     with pytest.raises(abi.ClipperError):
-        g.set_sparse_matrix_data(m, B.indptr, B.indices, B.data, B.indptr, B.indices, np.ones_like(B.data))
+        g.set_sparse_matrix_data(m, dup_ptr, dup_rows, dup_vals, dup_ptr, dup_rows, np.ones_like(dup_vals))
     with pytest.raises(abi.ClipperError):
         g.solve(np.ones(m))
     g.set_sparse_matrix_data(*ok)                       # and the context is still usable

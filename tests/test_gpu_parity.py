@@ -203,7 +203,10 @@ def test_euclidean_any_dimension(d):
     _check_affinity(c, r, abi.STORE_F64)
     u0 = rng.random(300)
     # random repeated endpoints + mindist make this a long (~3000 passes, d ~ 1e9) homotopy
-    _check_solution(c.solve(u0), r.solve(u0), ordered=False, rel=1e-5, same_ifinal=False)
+    sg, sr = c.solve(u0), r.solve(u0)
+    print(f"d={d}: rel dscore {abs(sg.score - sr.score) / max(1.0, abs(sr.score)):.2e}, ifinal {sg.ifinal}/{sr.ifinal}, "
+          f"trials {sg.n_trials}/{sr.n_trials}")
+    _check_solution(sg, sr, ordered=False, rel=REL_SCORE, same_ifinal=False)
 
 
 def test_duplicate_and_repeated_associations():
@@ -220,7 +223,10 @@ def test_duplicate_and_repeated_associations():
     assert M[0, 1] == 0 and M[3, 4] == 0 and M[5, 6] == 0
     u0 = np.full(7, 1 / np.sqrt(7))
     # u has exact structural ties, and the repeated endpoints make the homotopy long (d ~ 1e9)
-    _check_solution(c.solve(u0), r.solve(u0), ordered=False, rel=1e-5, same_ifinal=False)
+    sg, sr = c.solve(u0), r.solve(u0)
+    print(f"rel dscore {abs(sg.score - sr.score) / max(1.0, abs(sr.score)):.2e}, ifinal {sg.ifinal}/{sr.ifinal}, "
+          f"trials {sg.n_trials}/{sr.n_trials}")
+    _check_solution(sg, sr, ordered=False, rel=REL_SCORE, same_ifinal=False)
 
 
 @pytest.mark.parametrize("storage", STORAGES)
