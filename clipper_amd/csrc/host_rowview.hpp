@@ -51,15 +51,21 @@ int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const Sl
     using VT = decltype(t);
     constexpr int TW = rect_tw<VT>();
     G.nTc = static_cast<int>(ceil_div(h->W, TW));
-    const dim3 grid(static_cast<unsigned>(nTr * G.nTc));
+    const int64_t ntiles = nTr * G.nTc;
+    constexpr int64_t PER_LAUNCH = int64_t(1) << 22;  // x 512 threads < 2^32 work-items per dispatch
     constexpr int L = rect_lds_bytes<VT>();
-    if (h->fill_kind == 2)
-      launch_rect_kernel(k_affinity_rect<3, true, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
-    else if (h->staged_d == 3)
-      launch_rect_kernel(k_affinity_rect<3, false, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
-    else
-      launch_rect_kernel(k_affinity_rect<2, false, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+    for (int64_t t0 = 0; t0 < ntiles; t0 += PER_LAUNCH) {
+      G.tile0 = t0;
+      const dim3 grid(static_cast<unsigned>(std::min<int64_t>(PER_LAUNCH, ntiles - t0)));
+      if (h->fill_kind == 2)
+        launch_rect_kernel(k_affinity_rect<3, true, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+      else if (h->staged_d == 3)
+        launch_rect_kernel(k_affinity_rect<3, false, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+      else
+        launch_rect_kernel(k_affinity_rect<2, false, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+    }
   });
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

@@ -749,6 +749,8 @@ struct RectGeom {
   const int32_t* rowmap; // [nrows] association of view row r' (null: r' itself)
   int64_t col0, ncols;   // the view's columns are associations [col0, col0 + ncols)
   int nTc;               // column tiles (tile t = row tile t / nTc, column tile t % nTc)
+  int64_t tile0;         // first tile of this launch (a dispatch holds at most 2^32 work-items: the 11 M
+                         // tiles of m = 300 000 with fp64 values take three launches)
 };
 
 template <typename VT>
@@ -779,8 +781,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_rect(
   int32_t* rowidx = reinterpret_cast<int32_t*>(colmask + TW * 4);
   // heaviest tiles first where that is known: the consistent associations sit at the end of the
   // list in the reference's benchmark layout (bm_utils.cpp:311-314), so the column tiles run backwards
-  const int I = static_cast<int>(blockIdx.x) / G.nTc;
-  const int J = G.nTc - 1 - static_cast<int>(blockIdx.x) % G.nTc;
+  const int64_t tile = G.tile0 + blockIdx.x;
+  const int I = static_cast<int>(tile / G.nTc);
+  const int J = G.nTc - 1 - static_cast<int>(tile % G.nTc);
   const int64_t r0 = static_cast<int64_t>(I) * AT;          // first view row of the tile
   const int64_t cl0 = static_cast<int64_t>(J) * TW;          // first view column of the tile
   const double affinityeps = POINTNORMAL ? nprm.affinityeps : eprm.affinityeps;
