@@ -114,8 +114,19 @@ __device__ __forceinline__ SliceViewG to_global(const SliceView& M) {
 // doubles: an ODD number of 16-byte units (1, 3, 5), so that the rows of a sub-block spread over
 // all 16 slots a ds_read_b128 lane group can serve in one LDS cycle (pitch 32 B would use 8
 // of them, 64 B only 4).
+// CLIPPER_SL_XMODE (tools/slice_tune.hip only; the product is mode 0): what a window pass stages per x row
+// and what it computes per entry instead —
+//   0  all V candidates staged (48 bytes at V = 6: three ds_read_b128 per entry)
+//   1  (u', g') staged (16 bytes: one ds_read_b128 per entry), the V candidates formed in registers per
+//      entry with the tail's own expression
+//   2  (u', g', candidate 0, candidate 1) staged (two ds_read_b128), candidates 2 .. V-1 in registers
+// Measured: profiles/r03_slice_tune_xmode.txt.
+#ifndef CLIPPER_SL_XMODE
+#define CLIPPER_SL_XMODE 0
+#endif
+constexpr int SL_XMODE = CLIPPER_SL_XMODE;
 constexpr int sl_xload(int V) { return V <= 2 ? 2 : (V <= 4 ? 4 : (V <= 6 ? 6 : 8)); }
-constexpr int sl_xpitch(int V) { return V <= 2 ? 2 : (V <= 6 ? 6 : 10); }
+constexpr int sl_xpitch(int V) { return SL_XMODE == 1 ? 2 : (V <= 2 ? 2 : (V <= 6 ? 6 : 10)); }
 constexpr int sl_lds_doubles(int V, int H, int NW) {
   const int a = 2 * SL_SUB * H * sl_xpitch(V);  // two x buffers
   const int b = NW * 64 + NW * 2 * V + 8;       // the decision's scratch
@@ -218,7 +229,19 @@ struct SliceXStage {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int p = threadIdx.x + i * NT;
-      if constexpr (WINDOW) {
+      if constexpr (WINDOW && SL_XMODE != 0) {
+        if (p < PIECES) {
+          *reinterpret_cast<double2*>(xs + p * XP) = make_double2(wu[i], wg[i]);
+          if constexpr (SL_XMODE == 2) {
+            double t0 = wu[i] + W.alpha0 * wg[i];
+            t0 = (t0 > 0.0) ? t0 : 0.0;
+            const double a1 = W.alpha0 * W.beta;
+            double t1 = wu[i] + a1 * wg[i];
+            t1 = (t1 > 0.0) ? t1 : 0.0;
+            *reinterpret_cast<double2*>(xs + p * XP + 2) = make_double2(t0, t1);
+          }
+        }
+      } else if constexpr (WINDOW) {
         double al = W.alpha0;
 #pragma unroll
         for (int l = 0; l < XL; l += 2) {
@@ -390,7 +413,35 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
               const double mm = static_cast<double>(mf);
               const double ii = mf != VT(0) ? 1.0 : 0.0;
               const uint32_t row = rowbase + ((rw[j] >> (8 * e)) & 255u);
-              if constexpr (WINDOW) {
+              if constexpr (WINDOW && SL_XMODE != 0) {
+                const double* xr = xs + row * XP;
+                const double2 ug = *reinterpret_cast<const double2*>(xr);
+                double xv[V > 2 ? V : 2];
+                double al = WS.alpha0;
+                int l0 = 0;
+                if constexpr (SL_XMODE == 2) {
+                  const double2 t2 = *reinterpret_cast<const double2*>(xr + 2);
+                  xv[0] = t2.x;
+                  xv[1] = t2.y;
+                  al = (al * WS.beta) * WS.beta;
+                  l0 = 2;
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                  if (v >= l0) {
+                    double t = ug.x + al * ug.y;
+                    xv[v] = (t > 0.0) ? t : 0.0;
+                    al = al * WS.beta;
+                  }
+                }
+                acc[0] = fma(mm, xv[0], acc[0]);
+                acc[V] = fma(ii, xv[0], acc[V]);
+                if (V > 1) {
+                  const double w = fma(d, ii, mm);
+#pragma unroll
+                  for (int v = 1; v < V; ++v) acc[v] = fma(w, xv[v], acc[v]);
+                }
+              } else if constexpr (WINDOW) {
                 const double* xr = xs + row * XP;
                 double xv[XP];
 #pragma unroll

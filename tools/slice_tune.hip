@@ -428,7 +428,8 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   c.cus = prop.multiProcessorCount;
-  printf("device %s, %d CUs; m=%lld density=%.3f inliers=%.3f\n", prop.gcnArchName, c.cus, (long long)m, density, inl);
+  printf("device %s, %d CUs; m=%lld density=%.3f inliers=%.3f; CLIPPER_SL_XMODE=%d (x row pitch %d bytes)\n", prop.gcnArchName, c.cus,
+         (long long)m, density, inl, SL_XMODE, sl_xpitch(6) * 8);
   // matrix
   c.cols.assign(static_cast<size_t>(m), {});
   const int64_t i0 = m - static_cast<int64_t>(inl * m);
@@ -480,7 +481,8 @@ int main(int argc, char** argv) {
     Packed<float> Q = pack<float>(c.cols, m, 1, order);
     printf("%s: model %.2f LDS cycles per lane group and gather (1.0 = conflict-free)\n", names[order],
            g_sim_cycles / g_sim_instr);
-    for (int rep = 0; rep < 2; ++rep) run_variant<float, 1, 6, 4, 4, 2>(c, Q, 4.0 * cu, reps, ref6, true, names[order]);
+    // the product's geometry: 4 waves, 3 steps in flight, compiled for 6 workgroups per CU
+    for (int rep = 0; rep < 3; ++rep) run_variant<float, 1, 6, 4, 3, 6>(c, Q, 4.0 * cu, reps, ref6, true, names[order]);
   }
   return 0;
 }
