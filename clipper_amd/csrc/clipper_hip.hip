@@ -799,7 +799,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   init.nlive = init.nout = static_cast<int32_t>(std::min<int64_t>(m, 0x7fffffff));  // unknown until a tail counts
   init.rv_last = -100;
   rowview_drop(h);  // a solve starts without a view: what it builds is a function of this solve alone
-  h->rvp = (!h->multiproc && h->world == 1) ? rowview_policy(h) : ViewPolicy{};
+  h->rvp = rowview_policy(h);
   // with rescaling the first iteration runs the pair pass on u0; without, it only normalises
   init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
   init.stage = P->rescale_u0 ? ST_PASS : ST_RESULTS;
@@ -849,7 +849,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         // The decision asked for a row view (k_solver.hip.h, LIVE ROWS) and put the solve on hold:
         // whatever was queued behind it does nothing. Drain, build the view from exactly the state
         // that asked, lift the hold, go on.
-        HIPCHK(hipStreamSynchronize(s0.stream));
+        if ((rc = sync_all(h))) return rc;  // (every local shard: an in-process group holds on all of them)
         std::atomic_thread_fence(std::memory_order_acquire);
         hm->hold = 0;
         queued = hm->iters;              // the iterations that did nothing never counted
@@ -889,7 +889,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     int batch = SOLVE_BATCH;
     if (const char* e = std::getenv("CLIPPER_HIP_SOLVE_BATCH")) batch = std::max(1, std::atoi(e));  // tuning knob, same on every rank
     HIPCHK(hipSetDevice(s0.device));
-    rc = run_batched_until_done(
+    h->rv_fresh = false;
+    rc = run_batched_with_holds(
         batch, [&]() { return enqueue_iteration(h, prm); },
         [&](int slot) -> int {
           HIPCHK(hipSetDevice(s0.device));
@@ -898,9 +899,20 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
           HIPCHK(hipEventRecord(h->ev_poll[slot], s0.stream));
           return 0;
         },
-        [&](int slot, bool& d) -> int {
+        [&](int slot, int& st) -> int {
           HIPCHK(hipEventSynchronize(h->ev_poll[slot]));
-          d = h->host_state[slot].done != 0;
+          st = h->host_state[slot].done != 0 ? 1 : (h->host_state[slot].hold != 0 ? 2 : 0);
+          return 0;
+        },
+        [&]() -> int {
+          // every rank reads the hold from the same snapshot: all of them have queued the same
+          // iterations, so draining cannot wait for a peer; then each builds its columns of the view
+          if (int r2 = sync_all(h)) return r2;
+          h->mirror->hold = 0;
+          h->launch_counter = h->mirror->iters;
+          bool built = false;
+          if (int r2 = rowview_build(h, built)) return r2;
+          h->rv_fresh = built;
           return 0;
         },
         nullptr);
@@ -908,6 +920,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     if ((rc = sync_all(h))) return rc;
     HIPCHK(hipSetDevice(s0.device));
     HIPCHK(hipMemcpy(&fin, s0.shared, sizeof(fin), hipMemcpyDeviceToHost));
+    h->rv_stats.view_passes = h->mirror->n_view_passes;
   }
 
   }  // !resident

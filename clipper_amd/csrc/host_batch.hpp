@@ -46,4 +46,40 @@ int run_batched_until_done(int batch, Enqueue&& enqueue, Snapshot&& snapshot, Wa
   return 0;
 }
 
+// The same loop for a solve that may go on HOLD (k_solver.hip.h, LIVE ROWS): wait_state(slot, st) reports
+// 0 = running, 1 = done, 2 = on hold — from the same snapshot index on every rank. On hold every rank has
+// queued the same iterations (the ones behind the hold do nothing but still perform their exchange), so
+// every rank can drain its stream without waiting for a peer that queued less; on_hold() does that, builds
+// the view and lifts the hold; the snapshots taken before are stale and the loop primes itself again.
+template <class Enqueue, class Snapshot, class WaitState, class OnHold>
+int run_batched_with_holds(int batch, Enqueue&& enqueue, Snapshot&& snapshot, WaitState&& wait_state,
+                           OnHold&& on_hold, int64_t* iterations) {
+  int slot = 0;
+  bool have_prev = false, done = false;
+  int64_t n = 0;
+  if (batch < 1) batch = 1;
+  while (!done) {
+    for (int it = 0; it < batch; ++it) {
+      if (int rc = enqueue()) return rc;
+      ++n;
+    }
+    if (int rc = snapshot(slot)) return rc;
+    if (have_prev) {
+      int st = 0;
+      if (int rc = wait_state(slot ^ 1, st)) return rc;
+      if (st == 2) {
+        if (int rc = on_hold()) return rc;
+        have_prev = false;
+        slot ^= 1;
+        continue;
+      }
+      done = (st == 1);
+    }
+    have_prev = true;
+    slot ^= 1;
+  }
+  if (iterations) *iterations = n;
+  return 0;
+}
+
 }  // namespace clipper_hip

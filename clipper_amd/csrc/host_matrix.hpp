@@ -454,6 +454,7 @@ int csc_rebuild(Ctx* h) {
 }
 
 bool rect_fill_possible(const Ctx* h);
+int gather_slice_bytes(Ctx* h);
 int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O);
 
 // Every compressed build the symmetric kernel cannot serve (fp64 values, column shards): the
@@ -535,6 +536,7 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
     if ((rc = run_affinity_rect(h, kms))) return rc;
     h->csc_valid = true;
     h->csc_emitted = true;
+    if ((rc = gather_slice_bytes(h))) return rc;
     h->tm.affinity_kernel_ms = kms;
     h->tm.affinity_bytes = static_cast<double>(h->sh[0].s_bytes);
     h->has_matrix = true;

@@ -99,14 +99,41 @@ void rowview_free(Shard& s) {
   v.nrows = 0;
 }
 
-// a view can exist at all: one device, slices with C == pattern(M), scored from staged points
+// a view can exist at all: slices with C == pattern(M), scored from staged points; column shards: the
+// bytes of all shards are known (the policy's cost model must be the same on every rank)
 bool rowview_possible(const Ctx* h) {
   static const bool env_off = [] {
     const char* e = std::getenv("CLIPPER_HIP_ROW_VIEW");
     return e && std::atoi(e) == 0;
   }();
-  return !env_off && h->rv_mode == 0 && h->csc_valid && csc_single(h) && !h->explicitC &&
-         rect_fill_possible(h) && h->m >= RV_MIN_M;
+  return !env_off && h->rv_mode == 0 && h->csc_valid && !h->explicitC && rect_fill_possible(h) &&
+         h->m >= RV_MIN_M && (csc_single(h) || h->total_slice_bytes > 0.0);
+}
+
+// Column shards: the bytes all shards' slices hold, by one all-gather of a one-slot block at build time
+// (each shard's count rides in the first element of its block) — every rank gets the same sum, so
+// every rank's policy takes the same decisions.
+int gather_slice_bytes(Ctx* h) {
+  h->total_slice_bytes = 0.0;
+  if (csc_single(h) || !h->csc_valid) return 0;
+  if (h->multiproc && !h->comm && !h->xchg_fn) return 0;  // no exchange yet: this matrix is solved without views
+  for (auto& s : h->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    const double v = static_cast<double>(s.s_bytes);
+    HIPCHK(hipMemcpy(s.ab + static_cast<int64_t>(s.slot) * h->W, &v, sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (int rc = exchange(h, 1)) return rc;
+  if (int rc = sync_all(h)) return rc;
+  Shard& s0 = h->sh[0];
+  HIPCHK(hipSetDevice(s0.device));
+  double total = 0.0;
+  for (int p = 0; p < h->world; ++p) {
+    double v = 0.0;
+    HIPCHK(hipMemcpy(&v, s0.ab + static_cast<int64_t>(p) * h->W, sizeof(double), hipMemcpyDeviceToHost));
+    total += v;
+  }
+  h->total_slice_bytes = total;
+  return 0;
 }
 
 // The cost model the device-side policy (view_wanted, k_solver.hip.h) works with, for the matrix at
@@ -120,9 +147,12 @@ ViewPolicy rowview_policy(const Ctx* h) {
   p.on = rowview_possible(h) ? 1 : 0;
   p.max_builds = RV_MAX_BUILDS;
   p.pass_fixed = 8e-6;
-  p.pass_per_row = static_cast<double>(h->sh[0].s_bytes) / static_cast<double>(h->m) / 3.3e12;
+  // (column shards: a shard's share of the bytes all shards hold — the same figure on every rank)
+  const double bytes = csc_single(h) ? static_cast<double>(h->sh[0].s_bytes)
+                                     : h->total_slice_bytes / static_cast<double>(std::max(1, h->world));
+  p.pass_per_row = bytes / static_cast<double>(h->m) / 3.3e12;
   p.build_fixed = 60e-6 * scale_env;
-  p.build_per_row = static_cast<double>(h->m) * 4.5e-12 * scale_env;
+  p.build_per_row = static_cast<double>(h->W) * 4.5e-12 * scale_env;  // (a shard fills its own columns of the rows)
   return p;
 }
 
@@ -141,9 +171,32 @@ int rv_grow(T*& p, size_t& cap, size_t need) {
 // idle (the caller drained it). built = false: the live rows were too many to be worth it — the view
 // in use, if any, stays as it is.
 template <int V>
+int rowview_build_shard(Ctx* h, Shard& s, bool& built);
+
+// every local shard builds its own view (its columns of the same rows: the row list is a function of the
+// solver state, which is identical on every shard and rank)
+template <int V>
 int rowview_build_v(Ctx* h, bool& built) {
   built = false;
-  Shard& s = h->sh[0];
+  bool first = true;
+  for (auto& s : h->sh) {
+    bool b = false;
+    if (int rc = rowview_build_shard<V>(h, s, b)) return rc;
+    if (first) built = b;
+    else if (b != built) return fail(CLIPPER_HIP_E_HIP, "row view: the shards disagree");
+    first = false;
+  }
+  if (built) {
+    h->rv_stats.builds += 1;
+    h->rv_stats.rows = h->sh[0].rv.nrows;
+    h->rv_stats.bytes = static_cast<int64_t>(h->sh[0].rv.st.s_bytes);
+  }
+  return 0;
+}
+
+template <int V>
+int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
+  built = false;
   RowView& v = s.rv;
   const auto t0 = std::chrono::high_resolution_clock::now();
   HIPCHK(hipSetDevice(s.device));
@@ -184,7 +237,7 @@ int rowview_build_v(Ctx* h, bool& built) {
   if (nrows == 0 || static_cast<double>(nrows) > 0.85 * rows_now ||
       pol.build_fixed + pol.build_per_row * static_cast<double>(nrows) >
           horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row) {
-    hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, static_cast<int>(nrows));
+    hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows));
     h->rv_stats.build_ms +=
         std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
     return 0;
@@ -217,10 +270,7 @@ int rowview_build_v(Ctx* h, bool& built) {
     hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(64), 0, s.stream, reinterpret_cast<const uint4*>(h->rv_desc_host_dev),
                        reinterpret_cast<uint4*>(v.desc), static_cast<int64_t>(sizeof(SliceView) / 16));
   }
-  hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, 0);
-  h->rv_stats.builds += 1;
-  h->rv_stats.rows = nrows;
-  h->rv_stats.bytes = static_cast<int64_t>(v.st.s_bytes);
+  hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0);
   h->rv_stats.build_ms +=
       std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
   return 0;

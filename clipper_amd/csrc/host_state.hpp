@@ -250,6 +250,7 @@ struct clipper_hip_ctx {
   PointNormalParams fill_n{};
   float fill_E2 = 0.f;
   // row-view policy (host_rowview.hpp)
+  double total_slice_bytes = 0.0;  // column shards: bytes of all shards' slices (gather_slice_bytes)
   ViewPolicy rvp{};           // the cost model the device-side policy works with (host_rowview.hpp)
   bool rv_fresh = false;      // the next iteration is the first after a view was built
   int rv_mode = 0;            // 0 = automatic, 1 = never (clipper_hip_set_row_view / CLIPPER_HIP_ROW_VIEW=0)

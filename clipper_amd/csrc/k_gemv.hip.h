@@ -300,16 +300,17 @@ __global__ __launch_bounds__(256) void k_reduce_pass(SolveArgs A, int nslots) {
   const int64_t tstride = static_cast<int64_t>(nslots) * ld;
   if (e >= tstride) return;
   const double* p = A.part + e;
+  const int ntiles = A.st_next->view ? A.rv_nslots : A.ntiles;  // a pass on the row view wrote its own (fewer) slots
   double acc = 0.0;
   int t = 0;
-  for (; t + 8 <= A.ntiles; t += 8) {
+  for (; t + 8 <= ntiles; t += 8) {
     double v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = p[static_cast<int64_t>(t + q) * tstride];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc += v[q];
   }
-  for (; t < A.ntiles; ++t) acc += p[static_cast<int64_t>(t) * tstride];
+  for (; t < ntiles; ++t) acc += p[static_cast<int64_t>(t) * tstride];
   A.ab[static_cast<int64_t>(A.slot) * tstride + e] = acc;
 }
 

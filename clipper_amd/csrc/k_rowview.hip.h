@@ -114,8 +114,9 @@ __global__ __launch_bounds__(256) void k_rv_scatter(const uint8_t* __restrict__ 
 
 // the host has built the view the state asked for (or refused: too many rows once the pending
 // candidates were counted in): the hold is lifted, the policy's counters move on
-__global__ void k_rv_resume(SolverState* st, int refused_rows) {
+__global__ void k_rv_resume(SolverState* st, SolveShared* shared, int refused_rows) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    shared->hold = 0;
     st->hold = 0;
     st->rv_builds += 1;
     st->rv_last = static_cast<int32_t>(st->n_iters);

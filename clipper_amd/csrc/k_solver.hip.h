@@ -145,6 +145,8 @@ struct SolveShared {
   int64_t n_passes, n_trials;
   int32_t ifinal, ubp, ubv;
   int32_t done;
+  int32_t hold;  // the solve waits for a row view (SolverState::hold): what a multi-process host reads in
+  int32_t pad;   // its state snapshots — bit-identical on every rank, like `done`
 };
 
 // Host-visible progress record in pinned, coherent host memory. Workgroup (0,0) of G writes it
@@ -718,6 +720,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       if (tid == 0) {
         A.st_next->hold = 1;
         A.st_next->hold_slot = ubp * V + ubv;  // (after the decision: the accepted candidate's slot, or the unchanged point's)
+        A.shared->hold = 1;
         if (A.host != nullptr)
           __hip_atomic_store(&A.host->hold, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -884,6 +887,7 @@ __global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, Sol
     if (threadIdx.x == 0) {
       *st0 = init;
       A.shared->done = 0;
+      A.shared->hold = 0;
     }
   }
 }

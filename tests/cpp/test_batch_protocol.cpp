@@ -121,8 +121,77 @@ static int drive_template(int batch, int64_t converge_at) {
   return (rc == -7 && calls == 3) ? 0 : 1;
 }
 
+// The hold-aware loop with R simulated ranks: the device goes on hold at iteration `hold_at` (every
+// iteration behind it does nothing but still enters its collective), every rank must notice from the
+// same snapshot, drain, "build" and resume; then the solve converges `more` real iterations later.
+static int simulate_holds(int R, int batch, int64_t hold_at, int64_t more) {
+  Collective coll;
+  coll.R = R;
+  std::vector<Rank> ranks(static_cast<size_t>(R));
+  std::vector<int> rcs(static_cast<size_t>(R), 0), holds(static_cast<size_t>(R), 0);
+  std::vector<int64_t> queued(static_cast<size_t>(R), 0), real(static_cast<size_t>(R), 0);
+  std::vector<std::thread> th;
+  for (int k = 0; k < R; ++k)
+    th.emplace_back([&, k]() {
+      Rank& rk = ranks[k];
+      int64_t next = 0;
+      int held = 0;        // device state: 0 running, 1 on hold
+      bool was_held = false;
+      int host_state[2] = {0, 0};
+      rcs[k] = clipper_hip::run_batched_with_holds(
+          batch,
+          [&]() {
+            const int64_t idx = next++;
+            rk.stream.push_back([&, idx]() {
+              if (!coll.enter(idx)) return false;
+              if (rk.done || held) return true;  // nothing runs on hold or past the end
+              ++real[k];
+              if (!was_held && real[k] == hold_at) held = 1;
+              else if (was_held && real[k] >= hold_at + more) rk.done = 1;
+              return true;
+            });
+            return 0;
+          },
+          [&](int slot) {
+            rk.stream.push_back([&, slot]() { host_state[slot] = rk.done ? 1 : (held ? 2 : 0); return true; });
+            return 0;
+          },
+          [&](int slot, int& st) {
+            if (!rk.drain()) return -1;
+            st = host_state[slot];
+            return 0;
+          },
+          [&]() {
+            if (!rk.drain()) return -3;
+            held = 0;
+            was_held = true;
+            ++holds[k];
+            return 0;
+          },
+          &queued[k]);
+      if (rcs[k] == 0 && !rk.drain()) rcs[k] = -2;
+    });
+  for (auto& t : th) t.join();
+  for (int k = 0; k < R; ++k)
+    if (rcs[k] || holds[k] != 1 || real[k] != hold_at + more) {
+      printf("holds R=%d batch=%d hold_at=%lld: rank %d rc %d holds %d real %lld\n", R, batch, (long long)hold_at, k, rcs[k],
+             holds[k], (long long)real[k]);
+      return 1;
+    }
+  for (int k = 1; k < R; ++k)
+    if (queued[k] != queued[0]) { printf("holds: ranks queued %lld vs %lld\n", (long long)queued[0], (long long)queued[k]); return 1; }
+  for (size_t i = 0; i < coll.arrived.size(); ++i)
+    if (coll.arrived[i] != R) { printf("holds: collective %zu entered by %d of %d ranks\n", i, coll.arrived[i], R); return 1; }
+  return 0;
+}
+
 int main() {
   int bad = 0;
+  for (int R : {1, 2, 3, 8})
+    for (int batch = 1; batch <= 5; ++batch)
+      for (int64_t hold_at : {1, 2, 4, 5, 9, 17})
+        for (int64_t more : {1, 3, 8})
+          bad += simulate_holds(R, batch, hold_at, more);
   for (int R : {1, 2, 3, 8})
     for (int batch = 1; batch <= 7; ++batch)
       for (int64_t c : {1, 2, 3, 4, 5, 8, 9, 16, 17, 31, 100})

@@ -53,8 +53,10 @@ def _worker(rank, world, port, m, storage, out_dir):
     s = g.solve(p.u0)
     s2 = g.solve(p.u0)                                       # and once more on the same context
     assert s2.nodes.tolist() == s.nodes.tolist() and np.array_equal(s2.u, s.u)
+    vs = g.view_stats()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u=s.u, score=s.score, nodes=s.nodes,
-             passes=s.n_passes, trials=s.n_trials, calls=calls[0], storage=used, window=g.window)
+             passes=s.n_passes, trials=s.n_trials, calls=calls[0], storage=used, window=g.window,
+             views=vs.builds, view_passes=vs.view_passes)
     g.close()
     tdist.barrier()
     tdist.destroy_process_group()
@@ -88,6 +90,9 @@ def test_two_processes_share_one_gpu(tmp_path, m, storage_name):
     assert np.array_equal(r0["nodes"], r1["nodes"])
     assert r0["calls"] == r1["calls"] and r0["calls"] >= 2 * int(r0["passes"])   # two solves, one exchange per iteration
     assert int(r0["storage"]) == storage
+    if m >= 3000 and storage_name.endswith("CSC"):   # both ranks went on hold together and built their views
+        assert int(r0["views"]) >= 1 and int(r0["views"]) == int(r1["views"])
+        assert int(r0["view_passes"]) == int(r1["view_passes"]) > 0
     # the single-GPU answer
     p = synth.make_euclidean_problem(m, 0.9, seed=77)
     one = abi.HipClipper(device=0, storage=storage)

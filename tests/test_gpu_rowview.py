@@ -161,3 +161,26 @@ def test_solver_parameter_variants_with_views():
         assert abs(sg.score - sr.score) <= 1e-6 * abs(sr.score), kw
         assert sg.ifinal == sr.ifinal, kw
         g.close()
+
+
+@pytest.mark.parametrize("storage", [abi.STORE_F32_CSC, abi.STORE_F64_CSC])
+@pytest.mark.parametrize("nshards", [2, 3])
+def test_column_shards_build_their_own_views(storage, nshards):
+    """Column shards (here: several logical shards on one device, driven by one thread): every shard
+    builds the slices of ITS columns of the same row list, the hold is taken and lifted on all of
+    them together, and the result is the oracle's."""
+    p = synth.make_euclidean_problem(9000, 0.95, seed=21)
+    _, sr = _oracle(p, **synth.EUCLID_BENCH_PARAMS)
+    g = abi.HipClipper(storage=storage, group=[0] * nshards)
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    s = g.solve(p.u0)
+    st = g.view_stats()
+    assert s.nodes.tolist() == sr.nodes.tolist()
+    assert abs(s.score - sr.score) <= 1e-6 * abs(sr.score) and s.ifinal == sr.ifinal
+    assert st.builds >= 1 and st.view_passes > 0, (st.builds, st.view_passes)
+    s2 = g.solve(p.u0)
+    assert np.array_equal(s2.u, s.u)   # bit-reproducible
+    g.set_row_view(1)
+    s0 = g.solve(p.u0)
+    assert s0.nodes.tolist() == sr.nodes.tolist() and g.view_stats().builds == 0
+    g.close()
