@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--m", type=int, default=10000, help="putative associations")
+    ap.add_argument("--m", "--size", dest="m", type=int, default=10000,
+                    help="putative associations (under torch.distributed.run write --size: it reads --m as one of its own options)")
     ap.add_argument("--rho", type=float, default=None, help="outlier ratio (default 0.95; 0.90 at m<=1000)")
     ap.add_argument("--storage", choices=["f32", "f64", "csc", "csc64"], default="csc",
                     help="how M is kept in HBM: csc / csc64 = stored entries only (fp32 / fp64 values; the "

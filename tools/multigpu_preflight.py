@@ -2,7 +2,7 @@
 """First thing to run on a multi-GPU box: does the column-sharded path work here, step by step?
 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port 29511 \
-         tools/multigpu_preflight.py [--m 20000] [--exchange rccl|callback] [--same-device]
+         tools/multigpu_preflight.py [--size 20000] [--exchange rccl|callback] [--same-device]
 
 One rank per GPU (`--same-device`: every rank on device 0 — with `--exchange callback` that is how the
 multi-process driver runs on a ONE-GPU box). Every step prints PASS / FAIL with what it saw; the
@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--m", type=int, default=20000)
+    ap.add_argument("--size", dest="m", type=int, default=20000, help="associations (not --m: torch.distributed.run would read it as one of its own options)")
     ap.add_argument("--exchange", choices=["rccl", "callback"], default="rccl")
     ap.add_argument("--same-device", action="store_true")
     ap.add_argument("--storage", choices=["csc", "csc64", "f32"], default="csc")
