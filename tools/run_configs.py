@@ -25,6 +25,7 @@ CONFIGS = {
     "pn5k": dict(kind="pointnormal", m=5000, rho=0.90),
     "30k": dict(kind="euclid", m=30000, rho=0.95),
     "100k": dict(kind="euclid", m=100000, rho=0.95),
+    "300k": dict(kind="euclid", m=300000, rho=0.95),
 }
 
 
@@ -64,7 +65,7 @@ def run(name, cfg, reps, storage, with_cpu):
     g.stage_u0(p.u0)
     g.solve_staged()
     g.set_profiling(True)
-    ta, ts, gemv = [], [], []
+    ta, ts, gemv, vgemv = [], [], [], []
     for _ in range(reps):
         t0 = time.perf_counter()
         affinity()
@@ -74,7 +75,9 @@ def run(name, cfg, reps, storage, with_cpu):
         ta.append((t1 - t0) * 1e3)
         ts.append((t2 - t1) * 1e3)
         gemv.append(g.timings().gemv_avg_us)
+        vgemv.append(g.view_stats().view_pass_avg_us)
     tm = g.timings()
+    vs = g.view_stats()
     row = dict(config=name, kind=cfg["kind"], m=m, rho=rho,
                storage={abi.STORE_F32: "f32", abi.STORE_F64: "f64", abi.STORE_F32_CSC: "csc",
                         abi.STORE_F64_CSC: "csc64"}[storage],
@@ -85,6 +88,11 @@ def run(name, cfg, reps, storage, with_cpu):
                gemv_us=round(float(np.median(gemv)), 2) if np.median(gemv) > 0 else None,
                gemv_GBps=round(tm.gemv_bytes / float(np.median(gemv)) * 1e-3, 1) if np.median(gemv) > 0 else None,
                frac_of_8TBps=round(tm.gemv_bytes / float(np.median(gemv)) / 8e6, 4) if np.median(gemv) > 0 else None,
+               # the row views of the solve (passes that streamed M[live rows, :] instead of M)
+               passes_on_view=int(vs.view_passes), views_built=int(vs.builds), view_rows=int(vs.rows),
+               view_bytes=int(vs.bytes), view_build_ms=round(vs.build_ms, 4),
+               view_pass_us=round(float(np.median(vgemv)), 2) if np.median(vgemv) > 0 else None,
+               trials=int(sol.n_trials),
                score=sol.score, nodes=int(len(sol.nodes)), ifinal=int(sol.ifinal))
     prec, rec = synth.precision_recall(g.get_selected_associations(), p.Agt)
     row.update(precision=round(prec, 4), recall=round(rec, 4))
