@@ -998,6 +998,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         ++nview;
         continue;
       }
+      if (kind[static_cast<size_t>(li)] == 3) continue;  // a pair-mode pass (one vector): not the window pass the roofline is about
       sum += ms;
       mn = std::min<double>(mn, ms);
       ++nreal;

@@ -864,7 +864,10 @@ __device__ __forceinline__ void flush_state(const SolveArgs& A, const SolverStat
   copy_state(A.st_next, stash, threadIdx.x, blockDim.x);
   if (threadIdx.x == 0) {
     const int64_t n_iters = stash->n_iters;
-    if (A.marks != nullptr && n_iters <= KIND_CAP) A.marks[n_iters - 1] = stash->view ? 2 : 1;
+    // what this launch streamed: 1 = a window pass on M, 2 = a pass on the row view, 3 = a pair-mode pass
+    // on M (one vector: initialisation, penalty update) — the pass timings keep them apart
+    if (A.marks != nullptr && n_iters <= KIND_CAP)
+      A.marks[n_iters - 1] = stash->view ? 2 : (stash->phase == PH_TRIAL ? 1 : 3);
     if (A.host != nullptr) {
       __hip_atomic_store(&A.host->nlive, stash->nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(&A.host->nout, stash->nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
