@@ -854,6 +854,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         hm->hold = 0;
         queued = hm->iters;              // the iterations that did nothing never counted
         h->launch_counter = hm->iters;   // (profiling: launch index = the device's iteration count)
+        while (h->ev_used > 0 && h->ev_launch_index[static_cast<size_t>(h->ev_used - 1)] >= hm->iters)
+          --h->ev_used;                  // event pairs around launches that did nothing
         bool built = false;
         if ((rc = rowview_build(h, built))) return rc;
         h->rv_fresh = built;
@@ -910,6 +912,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
           if (int r2 = sync_all(h)) return r2;
           h->mirror->hold = 0;
           h->launch_counter = h->mirror->iters;
+          while (h->ev_used > 0 && h->ev_launch_index[static_cast<size_t>(h->ev_used - 1)] >= h->mirror->iters)
+            --h->ev_used;  // event pairs around launches that did nothing
           bool built = false;
           if (int r2 = rowview_build(h, built)) return r2;
           h->rv_fresh = built;
