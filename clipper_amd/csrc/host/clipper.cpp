@@ -169,6 +169,17 @@ void CLIPPER::setResidentSolver(bool on) {
 
 bool CLIPPER::lastSolveWasResident() const { return h_ != nullptr && clipper_hip_last_solver(h_) == 1; }
 
+void CLIPPER::setRowViews(bool on) {
+  row_views_ = on;
+  if (h_) check(clipper_hip_set_row_view(h_, on ? 0 : 1), "set_row_view");
+}
+
+long long CLIPPER::lastSolvePassesOnAView() const {
+  clipper_hip_view_stats_t st{};
+  if (h_ == nullptr || clipper_hip_get_view_stats(h_, &st) < 0) return 0;
+  return st.view_passes;
+}
+
 clipper_hip_ctx* CLIPPER::handle() {
   if (!h_) {
     h_ = clipper_hip_create(device_, static_cast<int>(storage_));
@@ -176,6 +187,7 @@ clipper_hip_ctx* CLIPPER::handle() {
       throw std::runtime_error(std::string("clipper: cannot create the GPU context: ") +
                                clipper_hip_last_error());
     if (!resident_) check(clipper_hip_set_resident(h_, 1), "set_resident");
+    if (!row_views_) check(clipper_hip_set_row_view(h_, 1), "set_row_view");
   }
   return h_;
 }

@@ -306,6 +306,8 @@ PYBIND11_MODULE(clipperpy, m) {
       .def("set_device", &clipper::CLIPPER::setDevice, "device"_a)
       .def("set_storage", &clipper::CLIPPER::setStorage, "storage"_a)
       .def("set_resident_solver", &clipper::CLIPPER::setResidentSolver, "on"_a)
+      .def("set_row_views", &clipper::CLIPPER::setRowViews, "on"_a)
+      .def("last_solve_passes_on_a_view", &clipper::CLIPPER::lastSolvePassesOnAView)
       .def("last_solve_was_resident", &clipper::CLIPPER::lastSolveWasResident)
       .def("get_path_stats", [](const clipper::CLIPPER& c) {
         const auto s = c.getPathStats();

@@ -89,6 +89,8 @@ class CLIPPER {
 
   CLIPPER(const invariants::PairwiseInvariantPtr& invariant, const Params& params);
   ~CLIPPER();
+  /// (NOT copyable, unlike the reference's class — clipper.h:82 there is copyable by default: an object
+  /// owns a device context with M in HBM; share it through a pointer, or build a second one)
   CLIPPER(const CLIPPER&) = delete;
   CLIPPER& operator=(const CLIPPER&) = delete;
 
@@ -122,6 +124,10 @@ class CLIPPER {
   /// it off takes effect at the next solve(), switching it back on at the next build of M.
   void setResidentSolver(bool on);
   bool lastSolveWasResident() const;  ///< which of the two the last solve() ran on
+  /// Row views: once most of u is zero a pass streams the slices of M[live rows, :]
+  /// instead of M (same sums up to the order of the partial sums). false = every pass streams M. Any time.
+  void setRowViews(bool on);
+  long long lastSolvePassesOnAView() const;  ///< how many passes of the last solve() streamed a view
   struct PathStats {
     long long n_passes = 0, n_trials = 0;
     double affinity_kernel_ms = 0, d = 0;
@@ -138,6 +144,7 @@ class CLIPPER {
   int device_ = 0;
   Storage storage_ = Storage::F32_CSC;
   bool resident_ = true;
+  bool row_views_ = true;
   clipper_hip_ctx* h_ = nullptr;
 
   clipper_hip_ctx* handle();

@@ -94,6 +94,25 @@ def test_clipperpy_resident_solver_switch(clipperpy):
     assert abs(res[0].score - res[1].score) <= 1e-9 * res[1].score
 
 
+def test_clipperpy_row_views_switch(clipperpy):
+    """m = 9000 through the pybind11 module: with row views (the default) most passes stream the view,
+    set_row_views(False) makes every pass stream M: the same selected list and `ifinal`."""
+    p = synth.make_euclidean_problem(9000, 0.95, seed=21)
+    ip = clipperpy.invariants.EuclideanDistanceParams()
+    ip.sigma, ip.epsilon = 0.015, 0.05
+    res, on_view = [], []
+    for on in (True, False):
+        c = clipperpy.CLIPPER(clipperpy.invariants.EuclideanDistance(ip), clipperpy.Params())
+        c.set_row_views(on)
+        c.score_pairwise_consistency(p.D1, p.D2, p.A)
+        c.solve(p.u0)
+        res.append(c.get_solution())
+        on_view.append(c.last_solve_passes_on_a_view())
+    assert on_view[0] > 0 and on_view[1] == 0
+    assert list(res[0].nodes) == list(res[1].nodes) and res[0].ifinal == res[1].ifinal
+    assert abs(res[0].score - res[1].score) <= 1e-9 * res[1].score
+
+
 def test_python_custom_invariant_is_scored_on_host_and_solved_on_gpu(clipperpy):
     # the notebook's use case (examples/python/ex4_bunny.ipynb cell 12): a Python subclass
     class PyEuclid(clipperpy.invariants.PairwiseInvariant):
