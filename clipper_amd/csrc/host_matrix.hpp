@@ -327,8 +327,8 @@ int slices_plan(Ctx* h, Shard& sh, SliceStore& s, bool whole) {
   static const double c0_env = std::getenv("CLIPPER_HIP_CSC_C0") ? std::max(0.0, std::atof(std::getenv("CLIPPER_HIP_CSC_C0"))) : -1.0;
   static_assert(sizeof(clipper_plan::Work) == sizeof(SliceWork), "the planner's work item is the kernel's");
   static thread_local clipper_plan::PassPlan plan;  // (buffers kept from build to build)
-  clipper_plan::plan_pass(h->csc_hLq, s.s_ncg, s.s_nchunks, clipper_plan::PassConsts{SL_NW, SL_SO}, h->cus,
-                          target_env, c0_env >= 0.0 ? c0_env : 2.0, plan);
+  clipper_plan::plan_pass(h->csc_hLq, s.s_ncg, s.s_nchunks, clipper_plan::PassConsts{SL_NW, SL_SO, SL_OCC, whole ? 12 : 8},
+                          h->cus, target_env, c0_env >= 0.0 ? c0_env : 2.0, plan);
   s.s_entries = plan.entries;
   const int nslots = plan.nslots;
   const size_t nw = plan.work.size();

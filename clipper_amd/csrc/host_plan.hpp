@@ -21,6 +21,8 @@ struct Work {
 struct PassConsts {
   int nw;   // column groups (waves) per workgroup     SL_NW
   int so;   // steps between two recorded step offsets  SL_SO
+  int occ = 6;        // workgroups per CU the pass kernel is compiled for  SL_OCC
+  int per_strip = 12; // work items per strip a large matrix is cut into (12: M itself, 8: a row view)
 };
 
 struct PassPlan {
@@ -32,13 +34,21 @@ struct PassPlan {
 // L[cg * nchunks + k] = maxq | entries << 8 of slice (cg, k). target <= 0: the default number of
 // workgroups — four per CU; for small matrices a quarter of the slices (fewer partial-sum slots for
 // the tail to add) and exactly one per CU when that is close (a second short workgroup on a few CUs
-// doubles those CUs' time): profiles/r02e_window_sweep.txt.
+// doubles those CUs' time): profiles/r02e_window_sweep.txt. LARGE matrices (round 3,
+// profiles/r03_wgs_sweep.txt) get whole ROUNDS of the workgroups the chip holds at once (occ per CU):
+// about per_strip items per strip — 1024 workgroups left a third of the 1536 places empty and every
+// CU's last item uneven; with 3 - 8 rounds the dispatcher evens the items out: m = 100k 1.83 -> 1.57 ms
+// per pass on M, 300k 16.8 -> 13.8 ms, at 8 - 16 partial-sum slots per strip for the tail.
 inline void plan_pass(const uint32_t* L, int ncg, int nchunks, const PassConsts& K, int cus, double target,
                       double C0 /* cost of a chunk besides its steps, in steps */, PassPlan& out) {
   const int nstrips = (ncg + K.nw - 1) / K.nw;
   if (target <= 0.0) {
     const double quarter = static_cast<double>(ncg) * nchunks / 4.0;
     target = quarter < 1.5 * cus ? cus : std::min<double>(quarter, 4.0 * cus);
+    const double places = static_cast<double>(K.occ) * cus;  // workgroups the chip holds at once
+    const double want = static_cast<double>(K.per_strip) * nstrips;
+    if (want >= 0.8 * places && quarter >= places)
+      target = places * std::min(8.0, std::max(1.0, std::floor(want / places + 0.5)));
   }
   // (this runs between the fill and the first pass of every build: buffers are kept, the order is a
   // counting sort)

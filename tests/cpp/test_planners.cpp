@@ -46,8 +46,8 @@ static std::vector<uint32_t> directory(std::mt19937& rng, int ncg, int nchunks, 
   return L;
 }
 
-static void check_pass(const std::vector<uint32_t>& L, int ncg, int nchunks, int cus, double target) {
-  const PassConsts K{4, 16};
+static size_t check_pass(const std::vector<uint32_t>& L, int ncg, int nchunks, int cus, double target,
+                         const PassConsts K = PassConsts{4, 16}) {
   PassPlan P;
   plan_pass(L.data(), ncg, nchunks, K, cus, target, 2.0, P);
   const int nstrips = (ncg + K.nw - 1) / K.nw;
@@ -82,6 +82,7 @@ static void check_pass(const std::vector<uint32_t>& L, int ncg, int nchunks, int
       }
       REQUIRE(at == mq);  // the step ranges partition [0, maxq of the strip's chunk)
     }
+  return P.work.size();
 }
 
 static bool check_resident(const std::vector<uint32_t>& L, int ncg, int nchunks, int64_t m, int esize, int max_units) {
@@ -178,6 +179,16 @@ int main() {
               nres_ok += check_resident(L, ncg, nchunks, m, esize, max_units) ? 1 : 0;
             }
       }
+  // large matrices and their row views: whole rounds of the workgroups the chip holds (6 per CU)
+  for (int nchunks : {782, 41}) {
+    std::snprintf(g_case, sizeof(g_case), "m=100000 nchunks=%d", nchunks);
+    const auto L = directory(rng, 1563, nchunks, 0.11, 0.05);
+    for (int per_strip : {12, 8}) {
+      const size_t nw = check_pass(L, 1563, nchunks, 256, 0.0, PassConsts{4, 16, 6, per_strip});
+      ++npass;
+      REQUIRE(nw >= 1536 && nw <= 8 * 1536 + 391 * 40);  // (+ the fillers of strips with fewer items than the fullest)
+    }
+  }
   REQUIRE(nres_ok > nres / 4);  // (the small and the sparse ones fit)
   std::printf("planners ok: %d pass plans, %d resident plans (%d fit the chip)\n", npass, nres, nres_ok);
   return 0;
