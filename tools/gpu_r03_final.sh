@@ -12,7 +12,7 @@ timeout 300 python tools/run_configs.py --configs 10k,30k,100k,300k --storage cs
 timeout 200 python tools/rowview_probe.py --m 10000 30000 100000 300000 --reps 3 --profile > $out/rowview_probe.jsonl 2>&1; echo "probe rc=$?"
 timeout 60 python tools/pass_timeline.py 10000 > $out/pass_timeline_m10000.txt 2>&1
 CLIPPER_HIP_ROW_VIEW=0 timeout 60 python tools/pass_timeline.py 10000 > $out/pass_timeline_m10000_views_off.txt 2>&1
-timeout 900 bash tools/gpu_prof_r03.sh r03b_prof 660aabe > $out/prof_stdout.txt 2>&1; echo "prof rc=$?"
+timeout 900 bash tools/gpu_prof_r03.sh r03b_prof df33747 > $out/prof_stdout.txt 2>&1; echo "prof rc=$?"
 cp gpurun_out/r03b_prof/*.txt gpurun_out/r03b_prof/*.json $out/ 2>/dev/null
 for m in 10000 100000; do grep '^{"metric"' gpurun_out/r03b_prof/trace_m$m.log | tail -1 > $out/bench_under_rocprof_m$m.jsonl; done
 rm -rf gpurun_out/r03b_prof
