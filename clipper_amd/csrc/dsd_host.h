@@ -9,16 +9,22 @@
 //
 // Written for what this path produces — a COMPLETE weighted graph on k nodes (every pair of S is
 // an edge of the reference's list, zero weights included): no adjacency lists. The pair arcs are
-// one antisymmetric k x k flow matrix X (residual a->b = W[a][b] - X[a][b]); Dinic's BFS levels
-// and DFS with current-arc pointers walk the dense rows. The minimal source side of a minimum cut
-// is unique, so the node set equals the reference's; the strict `flow < cap` tests are its own.
-// This is a serial O(44 * k^2 * phases) host computation on |S| = nnz(u) nodes, by design the
-// same place the reference spends it; the hot path (affinity, passes over M) is on the device.
+// one k x k matrix of residual capacities (R[a][b] = W[a][b] - flow a->b, the flow antisymmetric);
+// Dinic's BFS levels and DFS with current-arc pointers walk the dense rows, from a seeded feasible flow.
+// The minimal source side of a minimum cut is unique, so the node set equals the reference's; the strict
+// `flow < cap` tests are its own.
+// The reference runs one maximum flow per bisection step (~45 at m = 10k); densest_subgraph() below
+// replays the bisection against a candidate density and certifies it with the two flows at its end
+// points (see there). Serial host code on |S| = nnz(u) nodes, O(k^2) memory, the same place the reference
+// spends it; the gather of the sub-matrix is on the device (k_slice_gather_sub / k_gather_sub).
 #pragma once
 
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
 #include <vector>
 
 namespace clipper_hip {
@@ -26,66 +32,118 @@ namespace dsd {
 
 class DenseCut {
  public:
-  DenseCut(const double* W, int k) : W_(W), k_(k), X_(static_cast<size_t>(k) * k, 0.0),
+  // W: k x k symmetric, ZERO diagonal (Problem sees to it)
+  DenseCut(const double* W, int k) : W_(W), k_(k), R_(new double[static_cast<size_t>(k) * k]),
                                      fs_(k, 0.0), ft_(k, 0.0), ct_(k, 0.0), dist_(k + 2, -1),
-                                     it_(k + 2, 0) {}
+                                     it_(k + 2, 0) {}  // (R_ is set by every solve(), not here)
 
   // minimum cut for source capacities `cs` and sink capacities ct[a]; returns the source side
   // (reachable set in the residual graph) over the k inner nodes
   void solve(double cs, const std::vector<double>& ct, std::vector<char>& side) {
     cs_ = cs;
     ct_ = ct;
-    std::fill(X_.begin(), X_.end(), 0.0);
-    std::fill(fs_.begin(), fs_.end(), 0.0);
-    std::fill(ft_.begin(), ft_.end(), 0.0);
+    std::memcpy(R_.get(), W_, static_cast<size_t>(k_) * k_ * sizeof(double));
+    seed();
     while (bfs()) {
       std::fill(it_.begin(), it_.end(), 0);
       while (augment()) {
       }
     }
-    // reachability from the source (node 0); inner node a is index a + 1
+    // reachability from the source: the nodes whose source arc has room, then along residual arcs
     side.assign(static_cast<size_t>(k_), 0);
-    std::vector<int> st;
-    for (int a = 0; a < k_; ++a)
+    q_.clear();
+    un_.clear();
+    for (int a = 0; a < k_; ++a) {
       if (fs_[a] < cs_) {
         side[a] = 1;
-        st.push_back(a);
+        q_.push_back(a);
+      } else {
+        un_.push_back(a);
       }
-    while (!st.empty()) {
-      const int a = st.back();
-      st.pop_back();
-      const double* w = W_ + static_cast<size_t>(a) * k_;
-      const double* x = X_.data() + static_cast<size_t>(a) * k_;
-      for (int b = 0; b < k_; ++b)
-        if (!side[b] && b != a && x[b] < w[b]) {
+    }
+    for (size_t h = 0; h < q_.size() && !un_.empty(); ++h) {
+      const double* r = R_.get() + static_cast<size_t>(q_[h]) * k_;
+      size_t keep = 0;
+      for (int b : un_) {
+        if (r[b] > 0.0) {
           side[b] = 1;
-          st.push_back(b);
+          q_.push_back(b);
+        } else {
+          un_[keep++] = b;
         }
+      }
+      un_.resize(keep);
     }
   }
 
  private:
-  // node ids: 0 = source, 1..k = inner, k+1 = sink
+  // A feasible flow to start from (any maximum flow has the same minimal source side). Every node
+  // forwards what its own sink arc takes: source -> a -> sink, min(cs, ct[a]). What is left is a
+  // transport problem — nodes whose source arc still has room (degree above 2g) against nodes whose sink
+  // arc has (degree below 2g) — and most of it goes over the direct arcs a -> b, row by row; the
+  // phases below find the rest (paths over more than one inner arc).
+  void seed() {
+    un_.clear();  // the nodes whose sink arc has room
+    for (int a = 0; a < k_; ++a) {
+      const double f = std::max(0.0, std::min(cs_, ct_[a]));
+      fs_[a] = f;
+      ft_[a] = f;
+      if (ct_[a] - f > 0.0) un_.push_back(a);
+    }
+    for (int a = 0; a < k_ && !un_.empty(); ++a) {
+      double room = cs_ - fs_[a];
+      if (!(room > 0.0)) continue;
+      double* r = R_.get() + static_cast<size_t>(a) * k_;
+      size_t keep = 0, i = 0;
+      for (; i < un_.size() && room > 0.0; ++i) {
+        const int b = un_[i];
+        const double want = ct_[b] - ft_[b];
+        const double d = std::min(room, std::min(want, r[b]));
+        if (d > 0.0) {
+          r[b] -= d;
+          R_[static_cast<size_t>(b) * k_ + a] += d;
+          ft_[b] += d;
+          room -= d;
+        }
+        if (ct_[b] - ft_[b] > 0.0) un_[keep++] = b;
+      }
+      for (; i < un_.size(); ++i) un_[keep++] = un_[i];
+      un_.resize(keep);
+      fs_[a] = cs_ - room;
+    }
+  }
+
+  // node ids: 0 = source, 1..k = inner, k+1 = sink. Levels by breadth-first search over the residual
+  // arcs; a row is compared against the nodes that have no level yet only (on these nearly complete
+  // graphs the first few rows label everything).
   bool bfs() {
     std::fill(dist_.begin(), dist_.end(), -1);
     dist_[0] = 0;
-    std::vector<int> q;
-    q.reserve(static_cast<size_t>(k_) + 2);
-    for (int a = 0; a < k_; ++a)
+    q_.clear();
+    un_.clear();
+    for (int a = 0; a < k_; ++a) {
       if (fs_[a] < cs_) {
         dist_[a + 1] = 1;
-        q.push_back(a);
+        q_.push_back(a);
+      } else {
+        un_.push_back(a);
       }
-    for (size_t h = 0; h < q.size(); ++h) {
-      const int a = q[h];
+    }
+    for (size_t h = 0; h < q_.size(); ++h) {
+      const int a = q_[h];
       const int da = dist_[a + 1];
-      const double* w = W_ + static_cast<size_t>(a) * k_;
-      const double* x = X_.data() + static_cast<size_t>(a) * k_;
-      for (int b = 0; b < k_; ++b)
-        if (dist_[b + 1] < 0 && b != a && x[b] < w[b]) {
+      if (dist_[k_ + 1] >= 0 && da >= dist_[k_ + 1]) break;  // (deeper levels cannot lie on a shortest path)
+      const double* r = R_.get() + static_cast<size_t>(a) * k_;
+      size_t keep = 0;
+      for (int b : un_) {
+        if (r[b] > 0.0) {
           dist_[b + 1] = da + 1;
-          q.push_back(b);
+          q_.push_back(b);
+        } else {
+          un_[keep++] = b;
         }
+      }
+      un_.resize(keep);
       if (dist_[k_ + 1] < 0 && ft_[a] < ct_[a]) dist_[k_ + 1] = da + 1;
     }
     return dist_[k_ + 1] >= 0;
@@ -113,17 +171,17 @@ class DenseCut {
       const int a = cur;
       int& i = it_[a + 1];
       bool adv = false, at_sink = false;
-      const double* w = W_ + static_cast<size_t>(a) * k_;
-      const double* x = X_.data() + static_cast<size_t>(a) * k_;
-      for (; i <= k_; ++i) {
-        if (i == 0) {
-          if (ft_[a] < ct_[a] && dist_[k_ + 1] == dist_[a + 1] + 1) {
-            at_sink = true;
-            break;
-          }
-        } else {
+      const double* r = R_.get() + static_cast<size_t>(a) * k_;
+      const int next = dist_[a + 1] + 1;
+      if (i == 0) {
+        if (ft_[a] < ct_[a] && dist_[k_ + 1] == next) at_sink = true;
+        else i = 1;
+      }
+      if (!at_sink) {
+        const int* dist1 = dist_.data() + 1;
+        for (; i <= k_; ++i) {
           const int b = i - 1;
-          if (b != a && x[b] < w[b] && dist_[b + 1] == dist_[a + 1] + 1) {
+          if (r[b] > 0.0 && dist1[b] == next) {
             path_.push_back(b);
             cur = b;
             adv = true;
@@ -131,23 +189,25 @@ class DenseCut {
           }
         }
       }
-      if (at_sink) break;
-      if (adv) continue;
-      // dead end: retreat one node and skip the arc that led here
-      path_.pop_back();
-      if (path_.empty()) {
-        cur = -1;
-        ++it_[0];
-      } else {
-        cur = path_.back();
-        ++it_[cur + 1];
+      if (!at_sink) {
+        if (adv) continue;
+        // dead end: retreat one node and skip the arc that led here
+        path_.pop_back();
+        if (path_.empty()) {
+          cur = -1;
+          ++it_[0];
+        } else {
+          cur = path_.back();
+          ++it_[cur + 1];
+        }
+        continue;
       }
+      break;
     }
     // bottleneck and push: source -> path_[0] -> ... -> path_.back() -> sink
     double df = cs_ - fs_[path_[0]];
     for (size_t h = 0; h + 1 < path_.size(); ++h) {
-      const int a = path_[h], b = path_[h + 1];
-      const double r = W_[static_cast<size_t>(a) * k_ + b] - X_[static_cast<size_t>(a) * k_ + b];
+      const double r = R_[static_cast<size_t>(path_[h]) * k_ + path_[h + 1]];
       if (r < df) df = r;
     }
     const int last = path_.back();
@@ -155,8 +215,8 @@ class DenseCut {
     fs_[path_[0]] += df;
     for (size_t h = 0; h + 1 < path_.size(); ++h) {
       const int a = path_[h], b = path_[h + 1];
-      X_[static_cast<size_t>(a) * k_ + b] += df;
-      X_[static_cast<size_t>(b) * k_ + a] -= df;
+      R_[static_cast<size_t>(a) * k_ + b] -= df;
+      R_[static_cast<size_t>(b) * k_ + a] += df;
     }
     ft_[last] += df;
     return df > 0.0;
@@ -165,44 +225,192 @@ class DenseCut {
   const double* W_;
   int k_;
   double cs_ = 0.0;
-  std::vector<double> X_, fs_, ft_, ct_;
-  std::vector<int> dist_, it_, path_;
+  std::unique_ptr<double[]> R_;  // residual capacity of the inner arcs: W - (antisymmetric flow)
+  std::vector<double> fs_, ft_, ct_;
+  std::vector<int> dist_, it_, path_, q_, un_;
 };
+
+// The reference's bisection (dsd.cpp:200-241) with the test "is the minimum cut at density g more than
+// the source alone" left to the caller: returns the last g that passed (L), the last that failed (U)
+// and whether either bound ever moved. n_total: nodes of the WHOLE graph (termination, dsd.cpp:219).
+struct Bisection {
+  double L, U;
+  bool moved_L, moved_U;
+};
+template <typename NonTrivial>
+inline Bisection bisect(double half, int64_t n_total, NonTrivial&& nontrivial) {
+  Bisection b{0.0, half, false, false};  // dsd.cpp:200-201
+  const double nn = static_cast<double>(n_total) * static_cast<double>(n_total - 1);
+  while (nn * (b.U - b.L) >= 1.0) {  // dsd.cpp:219
+    const double g = (b.U + b.L) / 2;
+    if (nontrivial(g)) {
+      b.L = g;  // dsd.cpp:232-234
+      b.moved_L = true;
+    } else {
+      b.U = g;  // dsd.cpp:229-230
+      b.moved_U = true;
+    }
+  }
+  return b;
+}
+
+struct Problem {
+  std::vector<double>& W;
+  int k;
+  int64_t n_total;
+  double half;
+  std::vector<double> degree, ct;
+  DenseCut net;
+  Problem(std::vector<double>& W_, int k_, int64_t n_)
+      : W(W_), k(k_), n_total(n_), half(static_cast<double>((static_cast<int64_t>(k_) * k_ - k_) / 2)),  // dsd.cpp:286, :25
+        degree(static_cast<size_t>(k_), 0.0), ct(static_cast<size_t>(k_)), net(W_.data(), k_) {
+    for (int a = 0; a < k; ++a) {
+      W[static_cast<size_t>(a) * k + a] = 0.0;
+      double s = 0.0;
+      for (int b = 0; b < k; ++b) s += W[static_cast<size_t>(a) * k + b];  // dsd.cpp:190-195
+      degree[static_cast<size_t>(a)] = s;
+    }
+  }
+  // the source side of the minimum cut at density g (empty = only the source)
+  bool cut(double g, std::vector<char>& side) {
+    for (int a = 0; a < k; ++a) ct[static_cast<size_t>(a)] = half + 2 * g - degree[static_cast<size_t>(a)];  // dsd.cpp:33
+    net.solve(half, ct, side);
+    bool any = false;
+    for (char c : side) any = any || c;
+    return any;
+  }
+};
+
+// The reference's procedure as it stands: one maximum flow per bisection step (about
+// log2(k^2 n^2 / 2) of them). The fast path below falls back to it, and the tests hold it against it.
+inline std::vector<char> side_by_bisection(Problem& P) {
+  std::vector<char> side, final_side;
+  bisect(P.half, P.n_total, [&](double g) {
+    if (!P.cut(g, side)) return false;
+    final_side = side;
+    return true;
+  });
+  return final_side;
+}
+
+// Edge weight inside a node set over its size (each pair once), in extended precision.
+inline void weight_and_size(const std::vector<double>& W, int k, const std::vector<char>& in, long double& e,
+                            long double& n) {
+  e = 0.0L;
+  n = 0.0L;
+  for (int a = 0; a < k; ++a) {
+    if (!in[static_cast<size_t>(a)]) continue;
+    n += 1.0L;
+    const double* w = W.data() + static_cast<size_t>(a) * k;
+    long double s = 0.0L;
+    for (int b = a + 1; b < k; ++b)
+      if (in[static_cast<size_t>(b)]) s += w[b];
+    e += s;
+  }
+}
+
+// Greedy peeling (remove the node of least weighted degree, keep the densest prefix seen): a node set
+// whose density is a lower bound of the maximum, and on the graphs this path produces — one dense
+// cluster, a sparse fringe — usually the maximum itself. O(k^2).
+inline std::vector<char> peel(const Problem& P) {
+  const int k = P.k;
+  std::vector<double> deg(P.degree);
+  std::vector<char> alive(static_cast<size_t>(k), 1);
+  std::vector<int> order;
+  order.reserve(static_cast<size_t>(k));
+  long double e = 0.0L;
+  for (double d : deg) e += d;
+  e /= 2;
+  long double best = -1.0L;
+  int best_removed = 0;
+  for (int left = k; left >= 1; --left) {
+    const long double dens = e / left;
+    if (dens > best) {
+      best = dens;
+      best_removed = k - left;
+    }
+    int v = -1;
+    double dv = std::numeric_limits<double>::infinity();
+    for (int a = 0; a < k; ++a)
+      if (alive[static_cast<size_t>(a)] && deg[static_cast<size_t>(a)] < dv) {
+        v = a;
+        dv = deg[static_cast<size_t>(a)];
+      }
+    if (v < 0) break;  // (only NaN degrees left)
+    alive[static_cast<size_t>(v)] = 0;
+    order.push_back(v);
+    e -= dv;
+    const double* w = P.W.data() + static_cast<size_t>(v) * k;
+    for (int b = 0; b < k; ++b) deg[static_cast<size_t>(b)] -= w[b];
+  }
+  std::vector<char> in(static_cast<size_t>(k), 1);
+  for (int i = 0; i < best_removed; ++i) in[static_cast<size_t>(order[static_cast<size_t>(i)])] = 0;
+  return in;
+}
 
 // W: k x k symmetric weights (row-major, diagonal ignored) of the complete graph on the
 // sub-graph's nodes; n_total: number of nodes of the WHOLE graph (it enters the reference's
 // termination test, dsd.cpp:219). Returns the local indices (ascending) of the densest subgraph.
-inline std::vector<int32_t> densest_subgraph(std::vector<double>& W, int k, int64_t n_total) {
+//
+// The minimum cut at density g is more than the source alone exactly when g < d* = the maximum density
+// (Goldberg): every step of the reference's bisection only compares its midpoint with d*. Given a
+// candidate set of density d the whole bisection is replayed with "g < d" in place of a flow — it ends at
+// some (L, U) — and then CERTIFIED by the two flows the reference would have run there: the cut at U must
+// be the source alone (no set is denser than U: every step that lowered U was right, monotonicity), the
+// cut at L must not be (every step that raised L was right), and that cut is the answer, the same set
+// the reference remembers at its last successful step. If the cut at U finds a set, it is denser than
+// the candidate: it becomes the candidate (Dinkelbach's step) and the replay is repeated. Two flows
+// instead of ~45 when the peeling finds the optimum; anything unexpected falls back to the plain
+// procedure.
+inline std::vector<int32_t> densest_subgraph(std::vector<double>& W, int k, int64_t n_total,
+                                             int* flows_out = nullptr) {
   std::vector<int32_t> out;
   if (k < 2) return out;
-  for (int a = 0; a < k; ++a) W[static_cast<size_t>(a) * k + a] = 0.0;
-  const int64_t m = static_cast<int64_t>(k) * k - k;  // dsd.cpp:286
-  const double half = static_cast<double>(m / 2);     // dsd.cpp:25 (`m / 2` on int64)
-  std::vector<double> degree(static_cast<size_t>(k), 0.0), ct(static_cast<size_t>(k));
-  for (int a = 0; a < k; ++a) {
-    double s = 0.0;
-    for (int b = 0; b < k; ++b) s += W[static_cast<size_t>(a) * k + b];  // dsd.cpp:190-195
-    degree[a] = s;
-  }
-  double L = 0.0, U = half;  // dsd.cpp:200-201
-  std::vector<char> side, final_side;
-  DenseCut net(W.data(), k);
-  const double nn = static_cast<double>(n_total) * static_cast<double>(n_total - 1);
-  while (nn * (U - L) >= 1.0) {  // dsd.cpp:219
-    const double g = (U + L) / 2;
-    for (int a = 0; a < k; ++a) ct[a] = half + 2 * g - degree[a];  // dsd.cpp:33
-    net.solve(half, ct, side);
-    bool any = false;
-    for (char c : side) any = any || c;
-    if (!any) {
-      U = g;  // dsd.cpp:229-230
-    } else {
-      L = g;
-      final_side = side;
+  Problem P(W, k, n_total);
+  std::vector<char> final_side, side, cand = peel(P);
+  int flows = 0;
+  bool done = false;
+  for (int round = 0; round < 16 && !done; ++round) {
+    long double e, n;
+    weight_and_size(W, k, cand, e, n);
+    if (n < 1.0L) break;
+    const Bisection b = bisect(P.half, n_total, [&](double g) { return static_cast<long double>(g) * n < e; });
+    if (b.moved_U) {
+      ++flows;
+      if (P.cut(b.U, side)) {  // a set denser than U exists: the candidate was not the optimum
+        long double e2, n2;
+        weight_and_size(W, k, side, e2, n2);
+        if (!(e2 * n > e * n2)) break;  // (not denser than the candidate: numerical noise — plain procedure)
+        cand = side;
+        continue;
+      }
     }
+    if (b.moved_L) {
+      ++flows;
+      if (!P.cut(b.L, final_side)) break;  // (the candidate's own density refuted: noise — plain procedure)
+    } else {
+      final_side.assign(static_cast<size_t>(k), 0);  // no step ever succeeded: the reference returns nothing
+    }
+    done = true;
   }
+  if (!done) {
+    final_side = side_by_bisection(P);
+    flows = -1;
+  }
+  if (flows_out) *flows_out = flows;
   for (int a = 0; a < static_cast<int>(final_side.size()); ++a)
-    if (final_side[a]) out.push_back(a);
+    if (final_side[static_cast<size_t>(a)]) out.push_back(a);
+  return out;
+}
+
+// the plain procedure (tests, fall-back)
+inline std::vector<int32_t> densest_subgraph_by_bisection(std::vector<double>& W, int k, int64_t n_total) {
+  std::vector<int32_t> out;
+  if (k < 2) return out;
+  Problem P(W, k, n_total);
+  const std::vector<char> final_side = side_by_bisection(P);
+  for (int a = 0; a < static_cast<int>(final_side.size()); ++a)
+    if (final_side[static_cast<size_t>(a)]) out.push_back(a);
   return out;
 }
 

@@ -629,31 +629,55 @@ double algorithmic_gemv_bytes(const Ctx* h, bool dense = false) {
          static_cast<double>(valid) * (h->explicitC ? 2.0 : 1.0);
 }
 
-// dsd::solve(M_, S) (dsd.cpp:274-320): gathers the sub-matrix induced by S from the device
-// slices and runs Goldberg's algorithm on the host (dsd_host.h). Nodes come back ascending.
+// dsd::solve(M_, S) (dsd.cpp:274-320): gathers the sub-matrix induced by S from the device and runs
+// Goldberg's algorithm on the host (dsd_host.h). Nodes come back ascending. With M in slices the gather
+// walks the slices themselves (k_slice_gather_sub: one read of M, no dense copy — at m = 300 000 there
+// could not be one); a dense store is gathered by index (k_gather_sub).
 int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32_t>& nodes) {
   nodes.clear();
   const int k = static_cast<int>(S.size());
   if (k < 2) return 0;
   std::vector<double> Wsub(static_cast<size_t>(k) * k, 0.0), tmp(static_cast<size_t>(k) * k);
-  if (int rc = ensure_dense(h, true)) return rc;
+  // position of every node in the list; a list that names a node twice is gathered by index
+  std::vector<int32_t> pos(static_cast<size_t>(h->m), -1);
+  bool listed_once = true;
+  for (int a = 0; a < k; ++a) {
+    int32_t& p = pos[static_cast<size_t>(S[static_cast<size_t>(a)])];
+    listed_once = listed_once && p < 0;
+    p = a;
+  }
+  const bool from_slices = h->csc_valid && listed_once;
+  if (!from_slices)
+    if (int rc = ensure_dense(h, true)) return rc;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     int32_t* didx = nullptr;
     double* dout = nullptr;
-    HIPCHK(hipMalloc(&didx, static_cast<size_t>(k) * sizeof(int32_t)));
+    const size_t nidx = from_slices ? pos.size() : static_cast<size_t>(k);
+    HIPCHK(hipMalloc(&didx, nidx * sizeof(int32_t)));
     HIPCHK(hipMalloc(&dout, tmp.size() * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(didx, S.data(), static_cast<size_t>(k) * sizeof(int32_t),
+    HIPCHK(hipMemcpyAsync(didx, from_slices ? pos.data() : S.data(), nidx * sizeof(int32_t),
                           hipMemcpyHostToDevice, s.stream));
     HIPCHK(hipMemsetAsync(dout, 0, tmp.size() * sizeof(double), s.stream));
-    dim3 grid(static_cast<unsigned>(ceil_div(static_cast<int64_t>(k) * k, 256))), block(256);
     const int64_t c0 = static_cast<int64_t>(s.slot) * h->W;
-    if (h->storage == CLIPPER_HIP_STORE_F64)
-      hipLaunchKernelGGL((k_gather_sub<double>), grid, block, 0, s.stream,
-                         static_cast<const double*>(s.S), h->W, c0, h->W, didx, k, dout);
-    else
-      hipLaunchKernelGGL((k_gather_sub<float>), grid, block, 0, s.stream,
-                         static_cast<const float*>(s.S), h->W, c0, h->W, didx, k, dout);
+    if (from_slices) {
+      const int64_t nsl = static_cast<int64_t>(s.s_ncg) * s.s_nchunks;
+      dim3 grid(static_cast<unsigned>(ceil_div(nsl, 4))), block(256);
+      dispatch_vt(h, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((k_slice_gather_sub<T, SL_H>), grid, block, 0, s.stream, slice_view(h, s), didx,
+                           c0, h->m, k, dout);
+      });
+    } else {
+      dim3 grid(static_cast<unsigned>(ceil_div(static_cast<int64_t>(k) * k, 256))), block(256);
+      if (h->storage == CLIPPER_HIP_STORE_F64)
+        hipLaunchKernelGGL((k_gather_sub<double>), grid, block, 0, s.stream,
+                           static_cast<const double*>(s.S), h->W, c0, h->W, didx, k, dout);
+      else
+        hipLaunchKernelGGL((k_gather_sub<float>), grid, block, 0, s.stream,
+                           static_cast<const float*>(s.S), h->W, c0, h->W, didx, k, dout);
+    }
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(tmp.data(), dout, tmp.size() * sizeof(double), hipMemcpyDeviceToHost,
                           s.stream));
     HIPCHK(hipStreamSynchronize(s.stream));
@@ -661,7 +685,7 @@ int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32
     hipFree(dout);
     for (size_t e = 0; e < tmp.size(); ++e) Wsub[e] += tmp[e];  // disjoint column sets
   }
-  if (h->csc_valid) drop_dense(h);  // the copy was materialised for this gather only: M lives in the slices
+  if (h->csc_valid) drop_dense(h);  // a copy materialised for this gather only: M lives in the slices
   for (int32_t a : dsd::densest_subgraph(Wsub, k, h->m)) nodes.push_back(S[static_cast<size_t>(a)]);
   return 0;
 }

@@ -1,6 +1,6 @@
 // k_slices.hip.h — the compressed storage of M that the solver's passes stream: the layout
 // ("slices"), the pass (slice_core, k_gemv_slices), the packers (k_slice_count, k_slice_scan*,
-// k_slice_pack) and k_slice_expand.
+// k_slice_pack), k_slice_expand and k_slice_gather_sub.
 // Part of kernels.hip.h (include that one): hand-written gfx950 device code of the CLIPPER hot path.
 #pragma once
 
@@ -1121,6 +1121,60 @@ __global__ __launch_bounds__(256) void k_slice_expand(SliceView M, ST* __restric
       for (int e = 0; e < 4; ++e)
         if (vq.v[e] != VT(0) && c < ld)
           S[(r0 + rowbase + ((rq >> (8 * e)) & 255u)) * ld + c] = static_cast<ST>(vq.v[e]);
+    }
+    fbase += cnt * QB + ((cnt * 4 + 15) & ~15);
+  }
+}
+
+// k_slice_gather_sub — the sub-matrix of M induced by a node list (the exact DSD rounding's input,
+// dsd.cpp:274-320) straight from the slices: pos[g] = position of node g in the list or -1; one wave per
+// slice of this shard's columns (c0 = its first column), a lane whose column is listed walks its quads
+// and writes out[pos[row] * k + pos[column]] for the listed rows. `out` is zeroed by the caller; every
+// stored entry is written by exactly one lane. No dense copy of M exists for this (m = 300 000: there
+// could not be one).
+template <typename VT, int H>
+__global__ __launch_bounds__(256) void k_slice_gather_sub(SliceView M, const int32_t* __restrict__ pos,
+                                                           int64_t c0, int64_t m, int k,
+                                                           double* __restrict__ out) {
+  constexpr int QB = 4 * static_cast<int>(sizeof(VT));
+  constexpr int R = SL_SUB * H;
+  const int lane = threadIdx.x & 63;
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (s >= static_cast<int64_t>(M.ncg) * M.nchunks) return;
+  const int cg = static_cast<int>(s / M.nchunks), kc = static_cast<int>(s - static_cast<int64_t>(cg) * M.nchunks);
+  const int64_t c = c0 + static_cast<int64_t>(cg) * SL_W + lane;
+  const int pc = c < m ? pos[c] : -1;
+  if (__ballot(pc >= 0) == 0) return;  // none of the 64 columns is listed
+  const int64_t r0 = static_cast<int64_t>(kc) * R;
+  SliceHead<H> hd;
+  hd.load(static_cast<gbytes_t>((gbytes_t)M.data + 16 * M.Pre[s]), lane);
+  const int maxq = __builtin_amdgcn_readfirstlane(hd.maxq);
+  int tot = 0;
+#pragma unroll
+  for (int h = 0; h < H; ++h) tot += hd.nq[h];
+  gbytes_t fbase = hd.sp + 16 + H * 64 + sl_so_bytes(maxq);
+  for (int q = 0; q < maxq; ++q) {
+    const bool active = q < tot;
+    const uint64_t mask = __ballot(active);
+    const int cnt = __popcll(mask);
+    if (active && pc >= 0) {
+      const uint32_t rank = sl_lane_rank(mask);
+      SliceQuad<VT> vq;
+      vq.load(fbase + rank * QB);
+      const uint32_t rq = *reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(fbase + cnt * QB + rank * 4);
+      int rowbase = 0, edge = hd.nq[0];
+#pragma unroll
+      for (int h = 1; h < H; ++h) {
+        rowbase = (q >= edge) ? h * SL_SUB : rowbase;
+        edge += hd.nq[h];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (vq.v[e] != VT(0)) {
+          const int64_t row = r0 + rowbase + ((rq >> (8 * e)) & 255u);
+          const int pr = pos[row];
+          if (pr >= 0) out[static_cast<int64_t>(pr) * k + pc] = static_cast<double>(vq.v[e]);
+        }
     }
     fbase += cnt * QB + ((cnt * 4 + 15) & ~15);
   }

@@ -149,6 +149,38 @@ def test_dsd_rounding_on_compressed_storage():
     assert sorted(out[abi.STORE_F32].nodes.tolist()) == sorted(out[abi.STORE_F32_CSC].nodes.tolist())
 
 
+@pytest.mark.parametrize("storage", [abi.STORE_F32_CSC, abi.STORE_F64_CSC])
+def test_dsd_gathers_its_sub_matrix_from_the_slices(storage):
+    """dsd::solve(M, S) (dsd.cpp:274-320) with M in slices: the induced sub-matrix is gathered by
+    k_slice_gather_sub from the slices themselves (no dense copy of M is made) — several chunks and
+    column groups, a node list in arbitrary order, column shards, and a list that names a node twice
+    (gathered by index from a dense copy, as before): all against the oracle's procedure on the matrix
+    the device holds."""
+    from oracle import dsd_ref
+    p = synth.make_euclidean_problem(700, 0.85, seed=33)
+    g = abi.HipClipper(storage=storage)
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+    M = g.get_affinity_matrix()
+    s = g.solve(p.u0)
+    S = np.flatnonzero(s.u > 0).astype(np.int32)
+    assert 20 <= S.size <= 400
+    want = dsd_ref.densest_subgraph(M, S.tolist())
+    assert g.densest_subgraph(S).tolist() == want
+    rng = np.random.default_rng(5)
+    assert sorted(g.densest_subgraph(rng.permutation(S).astype(np.int32)).tolist()) == want
+    # a list reaching over every chunk of rows and a sparse part of the graph
+    S2 = np.unique(np.concatenate([S[:40], rng.choice(700, 60, replace=False)])).astype(np.int32)
+    assert g.densest_subgraph(S2).tolist() == dsd_ref.densest_subgraph(M, S2.tolist())
+    twice = np.concatenate([S[:30], S[:1]]).astype(np.int32)
+    assert sorted(g.densest_subgraph(twice).tolist()) == dsd_ref.densest_subgraph(M, twice.tolist())
+    for nshards in (2, 3):
+        grp = abi.HipClipper(storage=storage, group=[0] * nshards)
+        grp.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **INV)
+        assert grp.densest_subgraph(S).tolist() == want
+        grp.close()
+    g.close()
+
+
 def test_column_shards_keep_a_compressed_copy_each(monkeypatch):
     """what bench.py --gpus N > 1 does with its default storage: every column shard (here a
     1-rank RCCL world, and in-process groups of 2, 3 and 5 shards on the one GPU) builds a
