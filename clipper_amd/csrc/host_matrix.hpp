@@ -647,6 +647,7 @@ int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32
     p = a;
   }
   const bool from_slices = h->csc_valid && listed_once;
+  const auto t0 = std::chrono::high_resolution_clock::now();
   if (!from_slices)
     if (int rc = ensure_dense(h, true)) return rc;
   for (auto& s : h->sh) {
@@ -686,7 +687,14 @@ int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32
     for (size_t e = 0; e < tmp.size(); ++e) Wsub[e] += tmp[e];  // disjoint column sets
   }
   if (h->csc_valid) drop_dense(h);  // a copy materialised for this gather only: M lives in the slices
-  for (int32_t a : dsd::densest_subgraph(Wsub, k, h->m)) nodes.push_back(S[static_cast<size_t>(a)]);
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  int flows = 0;
+  for (int32_t a : dsd::densest_subgraph(Wsub, k, h->m, &flows)) nodes.push_back(S[static_cast<size_t>(a)]);
+  if (std::getenv("CLIPPER_HIP_HOST_TIMING"))
+    std::fprintf(stderr, "[dsd] k = %d: gather (%s) %.2f ms, host %.2f ms, %d maximum flows%s, %zu nodes\n", k,
+                 from_slices ? "slices" : "dense store", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t1).count(),
+                 flows < 0 ? 0 : flows, flows < 0 ? " (plain bisection)" : "", nodes.size());
   return 0;
 }
 
