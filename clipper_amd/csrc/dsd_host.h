@@ -20,6 +20,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -271,14 +272,32 @@ struct Problem {
       degree[static_cast<size_t>(a)] = s;
     }
   }
-  // the source side of the minimum cut at density g (empty = only the source)
+  // The source side of the minimum cut at density g (returns false = only the source). The flow sees g
+  // only through the sink capacities, and in double precision these stop changing with g once the
+  // bisection's interval is below their resolution (half = k(k-1)/2 dominates the sum): a capacity vector
+  // seen before gives the result computed then — the same flow would compute the same bits.
   bool cut(double g, std::vector<char>& side) {
     for (int a = 0; a < k; ++a) ct[static_cast<size_t>(a)] = half + 2 * g - degree[static_cast<size_t>(a)];  // dsd.cpp:33
+    for (const Seen& m : seen)
+      if (m.ct == ct) {
+        side = m.side;
+        return m.any;
+      }
+    ++flows;
     net.solve(half, ct, side);
     bool any = false;
     for (char c : side) any = any || c;
+    if (seen.size() >= 8) seen.erase(seen.begin());
+    seen.push_back(Seen{ct, side, any});
     return any;
   }
+  struct Seen {
+    std::vector<double> ct;
+    std::vector<char> side;
+    bool any;
+  };
+  std::vector<Seen> seen;
+  int flows = 0;  // maximum flows computed
 };
 
 // The reference's procedure as it stands: one maximum flow per bisection step (about
@@ -354,50 +373,74 @@ inline std::vector<char> peel(const Problem& P) {
 //
 // The minimum cut at density g is more than the source alone exactly when g < d* = the maximum density
 // (Goldberg): every step of the reference's bisection only compares its midpoint with d*. Given a
-// candidate set of density d the whole bisection is replayed with "g < d" in place of a flow — it ends at
-// some (L, U) — and then CERTIFIED by the two flows the reference would have run there: the cut at U must
-// be the source alone (no set is denser than U: every step that lowered U was right, monotonicity), the
-// cut at L must not be (every step that raised L was right), and that cut is the answer, the same set
-// the reference remembers at its last successful step. If the cut at U finds a set, it is denser than
-// the candidate: it becomes the candidate (Dinkelbach's step) and the replay is repeated. Two flows
-// instead of ~45 when the peeling finds the optimum; anything unexpected falls back to the plain
-// procedure.
+// candidate set of density d the bisection is REPLAYED: a midpoint further than `zone` from d (a few
+// units in the last place of the capacities — beyond that the flow's own rounding cannot change its
+// answer) is decided by "g < d", a midpoint inside the zone by the flow itself, exactly as the reference
+// would. The replay ends at some (L, U) and is then CERTIFIED by the flows the reference ran there, where
+// they were not run already: the cut at U must be the source alone (no set is denser than U — every step
+// that lowered U was right, by monotonicity), the cut at L must not be (every step that raised L was
+// right), and that cut is the answer, the set the reference remembers from its last successful step.
+// Whenever a flow finds a set denser than the candidate, it becomes the candidate (Dinkelbach's step) and
+// the replay is repeated. Two flows instead of ~45 at m = 10k when the peeling finds the optimum, up to
+// ~8 where n_total^2 k^2 exhausts double precision and the last steps of the reference's bisection
+// are decided inside the zone; anything unexpected falls back to the plain procedure.
 inline std::vector<int32_t> densest_subgraph(std::vector<double>& W, int k, int64_t n_total,
                                              int* flows_out = nullptr) {
   std::vector<int32_t> out;
   if (k < 2) return out;
   Problem P(W, k, n_total);
-  std::vector<char> final_side, side, cand = peel(P);
-  int flows = 0;
+  const long double zone = 8.0L * (std::nextafter(P.half, std::numeric_limits<double>::infinity()) - P.half);
+  std::vector<char> final_side, side, last_side, cand = peel(P);
   bool done = false;
   for (int round = 0; round < 16 && !done; ++round) {
     long double e, n;
     weight_and_size(W, k, cand, e, n);
     if (n < 1.0L) break;
-    const Bisection b = bisect(P.half, n_total, [&](double g) { return static_cast<long double>(g) * n < e; });
-    if (b.moved_U) {
-      ++flows;
-      if (P.cut(b.U, side)) {  // a set denser than U exists: the candidate was not the optimum
-        long double e2, n2;
-        weight_and_size(W, k, side, e2, n2);
-        if (!(e2 * n > e * n2)) break;  // (not denser than the candidate: numerical noise — plain procedure)
-        cand = side;
-        continue;
+    bool improved = false, L_by_flow = false, U_by_flow = false;
+    auto denser_than_candidate = [&](const std::vector<char>& set) {
+      long double e2, n2;
+      weight_and_size(W, k, set, e2, n2);
+      return n2 >= 1.0L && e2 * n > e * n2;
+    };
+    const Bisection b = bisect(P.half, n_total, [&](double g) {
+      if (improved) return false;  // (this replay is abandoned)
+      const long double gap = static_cast<long double>(g) - e / n;
+      if (gap > zone || gap < -zone) {
+        const bool below = gap < 0.0L;
+        (below ? L_by_flow : U_by_flow) = false;
+        return below;
       }
+      const bool any = P.cut(g, side);
+      if (any && denser_than_candidate(side)) {
+        cand = side;
+        improved = true;
+        return false;
+      }
+      if (any) last_side = side;
+      (any ? L_by_flow : U_by_flow) = true;
+      return any;
+    });
+    if (improved) continue;
+    if (b.moved_U && !U_by_flow && P.cut(b.U, side)) {
+      if (!denser_than_candidate(side)) break;  // (a set no denser than the candidate beyond the zone: plain procedure)
+      cand = side;
+      continue;
     }
-    if (b.moved_L) {
-      ++flows;
-      if (!P.cut(b.L, final_side)) break;  // (the candidate's own density refuted: noise — plain procedure)
-    } else {
+    if (!b.moved_L) {
       final_side.assign(static_cast<size_t>(k), 0);  // no step ever succeeded: the reference returns nothing
+    } else if (L_by_flow) {
+      final_side = last_side;
+    } else if (!P.cut(b.L, final_side)) {
+      break;  // (the candidate's own density refuted beyond the zone: plain procedure)
     }
     done = true;
   }
+  int flows = P.flows;
   if (!done) {
     final_side = side_by_bisection(P);
-    flows = -1;
+    flows = -P.flows;
   }
-  if (flows_out) *flows_out = flows;
+  if (flows_out) *flows_out = flows;  // (negative: the plain procedure ran)
   for (int a = 0; a < static_cast<int>(final_side.size()); ++a)
     if (final_side[static_cast<size_t>(a)]) out.push_back(a);
   return out;

@@ -694,7 +694,7 @@ int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32
     std::fprintf(stderr, "[dsd] k = %d: gather (%s) %.2f ms, host %.2f ms, %d maximum flows%s, %zu nodes\n", k,
                  from_slices ? "slices" : "dense store", std::chrono::duration<double, std::milli>(t1 - t0).count(),
                  std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t1).count(),
-                 flows < 0 ? 0 : flows, flows < 0 ? " (plain bisection)" : "", nodes.size());
+                 flows < 0 ? -flows : flows, flows < 0 ? " (plain bisection)" : "", nodes.size());
   return 0;
 }
 

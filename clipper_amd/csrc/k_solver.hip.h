@@ -218,6 +218,9 @@ struct SolveArgs {
                            // it covers the live rows of every outcome, whatever the tail counted
   int rv_rows;             // rows of the view
   ViewPolicy rvp;
+  // arrival counters of the tail's fold groups ([nwg_in], zero between launches), or null: the fold is a
+  // launch of its own (k_scal_fold)
+  int* fold_cnt;
 };
 constexpr int KIND_CAP = 1 << 16;
 
@@ -1125,6 +1128,37 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   if (threadIdx.x < NR) out[v * NR + threadIdx.x] = tot;
   if (v == 0 && threadIdx.x >= NR && threadIdx.x < NRED)
     out[V * NR + (threadIdx.x - NR)] = tot;  // "all rejected" window sums, then the penalty sums
+  // The fold of the partial scalars (large m: what the next pass's workgroups sum at their heads) by the
+  // LAST workgroup of each group of SCAL_FOLD rows to get here, instead of a launch of its own (~10 us per
+  // iteration): rows are written, released at device scope and counted; whoever counts the last arrival
+  // acquires and sums the rows of the group in row order — the same sums whichever workgroup that is.
+  if (A.fold_cnt != nullptr) {
+    int* flag = reinterpret_cast<int*>(red);
+    __threadfence();
+    __syncthreads();
+    const int grp = blockIdx.x / SCAL_FOLD;
+    const int w0 = grp * SCAL_FOLD;
+    const int w1 = (w0 + SCAL_FOLD < A.nwg) ? w0 + SCAL_FOLD : A.nwg;
+    if (threadIdx.x == 0) {
+      const int expected = (w1 - w0) * (phase == PH_BUILD ? 1 : V);  // (PH_BUILD: the v = 0 workgroups only)
+      const int before = __hip_atomic_fetch_add(A.fold_cnt + grp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (before == expected - 1) ? 1 : 0;
+      if (last) __hip_atomic_store(A.fold_cnt + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[0] = last;
+    }
+    __syncthreads();
+    if (flag[0]) {
+      __threadfence();
+      double* fo = const_cast<double*>(A.scal_in) + static_cast<int64_t>(grp) * Q;
+      for (int q = threadIdx.x; q < Q; q += blockDim.x) {
+        const double* p = A.scal + static_cast<int64_t>(w0) * Q + q;
+        double acc = 0.0;
+        for (int w = 0; w < w1 - w0; ++w)
+          acc += __hip_atomic_load(p + static_cast<int64_t>(w) * Q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fo[q] = acc;
+      }
+    }
+  }
 }
 
 }  // namespace clipper_hip

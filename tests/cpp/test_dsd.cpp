@@ -21,7 +21,7 @@ static void check(std::vector<double> W, int k, int64_t n, const char* what, int
   const auto a = densest_subgraph(W, k, n, &flows);
   const auto b = densest_subgraph_by_bisection(W2, k, n);
   ++cases;
-  if (flows < 0) { ++fallbacks; if (fallbacks <= 5) std::printf("fallback: %s #%d k=%d n=%ld\n", what, id, k, static_cast<long>(n)); } else total_flows += flows;
+  if (flows <= 0) { ++fallbacks; if (fallbacks <= 5) std::printf("fallback: %s #%d k=%d n=%ld\n", what, id, k, static_cast<long>(n)); } else total_flows += flows;
   if (a != b) {
     ++failures;
     std::printf("MISMATCH %s #%d k=%d n=%ld: replay %zu nodes (flows %d), bisection %zu nodes\n", what, id, k,
@@ -38,10 +38,11 @@ int main(int argc, char** argv) {
   const int reps = argc > 1 ? std::atoi(argv[1]) : 60;
   std::mt19937_64 rng(12345);
   std::uniform_real_distribution<double> U(0.0, 1.0);
-  const int64_t totals[3] = {0, 10000, 300000};  // 0: n = k (dsd::solve on the whole graph)
+  const int64_t totals[4] = {0, 10000, 300000, 1000000};  // 0: n = k (dsd::solve on the whole graph); 10^6: the
+                                                            // last steps fall below the capacities' resolution
   for (int r = 0; r < reps; ++r) {
     const int k = 2 + static_cast<int>(rng() % 70);
-    const int64_t n = totals[r % 3] ? totals[r % 3] : k;
+    const int64_t n = totals[r % 4] ? totals[r % 4] : k;
     // 1. random weights, random sparsity
     {
       std::vector<double> W(static_cast<size_t>(k) * k, 0.0);
