@@ -18,7 +18,7 @@ SliceView slice_view(const Ctx* h, const Shard& s) {
   M.nwork = s.s_nwork;
   M.rowmap = nullptr;
   M.nrows = h->m;
-  M.pad = 0;
+  M.colmap = nullptr;
   return M;
 }
 
@@ -34,6 +34,7 @@ SliceView row_view(const Ctx* h, const Shard& s) {
   R.nwork = s.rv.st.s_nwork;
   R.rowmap = s.rv.rowmap[s.rv.cur];
   R.nrows = s.rv.nrows;
+  R.colmap = s.rv.sorted ? s.rv.colmap : nullptr;
   return R;
 }
 
@@ -455,7 +456,7 @@ int csc_rebuild(Ctx* h) {
 
 bool rect_fill_possible(const Ctx* h);
 int gather_slice_bytes(Ctx* h);
-int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O);
+int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O, const int32_t* colmap);
 
 // Every compressed build the symmetric kernel cannot serve (fp64 values, column shards): the
 // rectangular tile kernel writes each shard's slices straight from its LDS images — no dense store, no
@@ -484,7 +485,7 @@ int run_affinity_rect(Ctx* h, double& kernel_ms) {
       if (rc) return rc;
       // (emit_prepare stages the arenas' start values in pinned memory shared by all shards)
       if (h->sh.size() > 1) HIPCHK(hipStreamSynchronize(s.stream));
-      if ((rc = launch_rect(h, s, nullptr, h->m, outs[k]))) return rc;
+      if ((rc = launch_rect(h, s, nullptr, h->m, outs[k], nullptr))) return rc;
     }
     HIPCHK(hipSetDevice(s0.device));
     HIPCHK(hipEventRecord(h->ev_aff[1], s0.stream));

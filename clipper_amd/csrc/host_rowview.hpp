@@ -35,12 +35,15 @@ bool rect_fill_possible(const Ctx* h) {
 }
 
 // The slices of M[rows, this shard's columns] into the store O describes. rowmap == null: all rows.
-int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O) {
+int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O,
+                const int32_t* colmap) {
   if (!rect_fill_possible(h)) return fail(CLIPPER_HIP_E_STATE, "no built-in invariant is staged");
   RectGeom G;
   G.m = h->m;
   G.nrows = nrows;
   G.rowmap = rowmap;
+  G.colmap = colmap;
+  G.ncolmap = h->W;
   G.col0 = static_cast<int64_t>(s.slot) * h->W;
   G.ncols = std::max<int64_t>(0, std::min<int64_t>(h->W, h->m - G.col0));
   const int64_t nTr = ceil_div(nrows, AT);
@@ -93,8 +96,10 @@ void rowview_free(Shard& s) {
   fr(v.in_view[0]);
   fr(v.in_view[1]);
   fr(v.blk);
+  fr(v.colmap);
   fr(v.desc);
-  v.cap_rows = v.cap_flags = v.cap_blk = 0;
+  v.cap_rows = v.cap_flags = v.cap_blk = v.cap_cols = 0;
+  v.sorted = false;
   v.valid = false;
   v.nrows = 0;
 }
@@ -243,10 +248,19 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
     return 0;
   }
   v.valid = false;  // its store is about to be overwritten
+  // the view's column order (k_rv_colsort): by the b of the last evaluated point, which every shard holds
+  // for all columns; CLIPPER_HIP_RV_COLSORT=0 keeps the matrix's order (measurement)
+  static const bool colsort = !(std::getenv("CLIPPER_HIP_RV_COLSORT") && std::atoi(std::getenv("CLIPPER_HIP_RV_COLSORT")) == 0);
+  v.sorted = colsort;
+  if (colsort) {
+    if ((rc = rv_grow(v.colmap, v.cap_cols, static_cast<size_t>(h->W)))) return rc;
+    hipLaunchKernelGGL(k_rv_colsort, dim3(1), dim3(RV_CT), 0, s.stream, s.cab + mp,
+                       static_cast<int64_t>(s.slot) * h->W, m, static_cast<int>(h->W), v.colmap);
+  }
   for (int attempt = 0;; ++attempt) {
     SliceOut O{};
     if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
-    if ((rc = launch_rect(h, s, v.rowmap[next], nrows, O))) return rc;
+    if ((rc = launch_rect(h, s, v.rowmap[next], nrows, O, colsort ? v.colmap : nullptr))) return rc;
     if ((rc = emit_enqueue(h, s, v.st))) return rc;
     HIPCHK(hipStreamSynchronize(s.stream));
     HIPCHK(hipGetLastError());

@@ -78,7 +78,11 @@ struct SliceView {
   // staged. The matrix itself: rowmap == null, nrows == m.
   const int32_t* rowmap;
   int64_t nrows;
-  int64_t pad;  // (64 bytes: the row view's descriptor is copied to the device in 16-byte words)
+  // Column order of a row view: column position j of the view is column colmap[j] of this shard (null:
+  // j itself). A view sorts its columns by expected length (host_rowview.hpp): the lanes of a slice then
+  // run lists of similar length, and the lock-step chain of a slice is as long as its average list rather
+  // than as its longest. Only the address a lane's sums are written to depends on it.
+  const int32_t* colmap;  // (64 bytes: the row view's descriptor is copied to the device in 16-byte words)
 };
 static_assert(sizeof(SliceView) == 64, "SliceView is copied in 16-byte words");
 
@@ -96,6 +100,7 @@ struct SliceViewG {
   int nchunks, ncg, nwork;
   const CLIPPER_GLOBAL int32_t* rowmap;
   int64_t nrows;
+  const CLIPPER_GLOBAL int32_t* colmap;
 };
 __device__ __forceinline__ SliceViewG to_global(const SliceView& M) {
   SliceViewG G;
@@ -107,6 +112,7 @@ __device__ __forceinline__ SliceViewG to_global(const SliceView& M) {
   G.nwork = M.nwork;
   G.rowmap = (const CLIPPER_GLOBAL int32_t*)M.rowmap;
   G.nrows = M.nrows;
+  G.colmap = (const CLIPPER_GLOBAL int32_t*)M.colmap;
   return G;
 }
 
@@ -474,8 +480,9 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
     __syncthreads();
   }
 
-  const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
+  int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
   if (c < ld && static_cast<int>(blockIdx.x) < M.nwork) {
+    if (M.colmap != nullptr) c = M.colmap[c];  // (a row view's column order)
 #pragma unroll
     for (int v = 0; v < NS; ++v) {
       const int slot = (v == NS - 1) ? NSLOT - 1 : v;
