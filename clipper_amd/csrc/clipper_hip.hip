@@ -829,8 +829,6 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, 0);
-    if (a.fold_cnt)  // (a solve that was abandoned half-way may have left arrivals counted)
-      HIPCHK(hipMemsetAsync(a.fold_cnt, 0, static_cast<size_t>(a.nwg_in) * sizeof(int), s.stream));
     hipLaunchKernelGGL(k_init, dim3(static_cast<unsigned>(ceil_div(m, 256))), dim3(256), 0,
                        s.stream, a, init, s.st, s.X[0]);
   }

@@ -361,11 +361,14 @@ int slices_plan(Ctx* h, Shard& sh, SliceStore& s, bool whole) {
     if (h->sh.size() > 1) HIPCHK(hipStreamSynchronize(sh.stream));
   }
   const size_t NSLOT = static_cast<size_t>(nslot(h->V));
-  if (static_cast<size_t>(nslots) > sh.part_tiles) {
+  // (a view with its own column order writes part_ls doubles per column and slot, not NSLOT)
+  const size_t tiles_needed = whole ? static_cast<size_t>(nslots)
+                                    : (static_cast<size_t>(nslots) * part_ls(static_cast<int>(NSLOT)) + NSLOT - 1) / NSLOT;
+  if (tiles_needed > sh.part_tiles) {
     HIPCHK(hipStreamSynchronize(sh.stream));
     HIPCHK(hipFree(sh.part));
     sh.part = nullptr;
-    sh.part_tiles = static_cast<size_t>(nslots) + 8;
+    sh.part_tiles = tiles_needed + 8;
     HIPCHK(hipMalloc(&sh.part, sh.part_tiles * NSLOT * static_cast<size_t>(h->W) * sizeof(double)));
   }
   s.s_nwork = static_cast<int>(nw);

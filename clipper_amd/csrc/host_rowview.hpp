@@ -248,10 +248,13 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
     return 0;
   }
   v.valid = false;  // its store is about to be overwritten
-  // the view's column order (k_rv_colsort): by the b of the last evaluated point, which every shard holds
-  // for all columns; CLIPPER_HIP_RV_COLSORT=0 keeps the matrix's order (measurement)
-  static const bool colsort = !(std::getenv("CLIPPER_HIP_RV_COLSORT") && std::atoi(std::getenv("CLIPPER_HIP_RV_COLSORT")) == 0);
-  v.sorted = colsort;
+  // the view's column order (k_rv_colsort): by the b of the last evaluated point. CLIPPER_HIP_RV_COLSORT=1
+  // turns it on (measured: see DESIGN.md); = 2 is a measurement mode whose sums land in the WRONG columns
+  // (the view is filled in its column order, a pass writes as if there were none: what the order is worth
+  // without any scattered store)
+  static const int colsort_env = std::getenv("CLIPPER_HIP_RV_COLSORT") ? std::atoi(std::getenv("CLIPPER_HIP_RV_COLSORT")) : 0;
+  const bool colsort = colsort_env != 0 && csc_single(h);  // (column shards reduce their slots in k_reduce_pass: not taught the layout)
+  v.sorted = colsort && colsort_env != 2;
   if (colsort) {
     if ((rc = rv_grow(v.colmap, v.cap_cols, static_cast<size_t>(h->W)))) return rc;
     hipLaunchKernelGGL(k_rv_colsort, dim3(1), dim3(RV_CT), 0, s.stream, s.cab + mp,

@@ -24,7 +24,6 @@ int free_shard_buffers(Shard& s) {
   fr(s.X[1]);
   fr(s.ab);
   fr(s.scal);
-  fr(s.fold_cnt);
   fr(s.st);
   fr(s.shared);
   fr(s.marks);
@@ -146,8 +145,6 @@ int ensure_problem(Ctx* h, int64_t m) {
     const size_t Q = static_cast<size_t>(tail_q(h->V));
     const size_t nwg = static_cast<size_t>(ceil_div(m, TAIL_THREADS));
     HIPCHK(hipMalloc(&s.scal, (nwg + ceil_div(nwg, SCAL_FOLD) + 1) * Q * sizeof(double)));
-    HIPCHK(hipMalloc(&s.fold_cnt, (ceil_div(nwg, SCAL_FOLD) + 1) * sizeof(int)));
-    HIPCHK(hipMemsetAsync(s.fold_cnt, 0, (ceil_div(nwg, SCAL_FOLD) + 1) * sizeof(int), s.stream));
     HIPCHK(hipMalloc(&s.ab, NSLOT * nvec));
     HIPCHK(hipMemsetAsync(s.ab, 0, NSLOT * nvec, s.stream));
     s.part_tiles = static_cast<size_t>(max_tiles(h));
@@ -375,7 +372,7 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.rv_fresh = (view && h->rv_fresh) ? 1 : 0;
   a.rv_rows = view ? static_cast<int>(s.rv.nrows) : 0;
   a.rvp = h->rvp;
-  a.fold_cnt = (a.nwg_in != a.nwg && h->fold_in_tail) ? s.fold_cnt : nullptr;
+  a.rv_sorted = (view && s.rv.sorted) ? 1 : 0;
   return a;
 }
 
@@ -442,7 +439,7 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
       if (tables) hipLaunchKernelGGL((k_tail<V, true, true>), grid, dim3(TAIL_THREADS * TAIL_SPLIT), 0, s.stream, a);
       else hipLaunchKernelGGL((k_tail<V, true, false>), grid, dim3(TAIL_THREADS * TAIL_SPLIT), 0, s.stream, a);
     }
-    if (a.nwg_in != a.nwg && a.fold_cnt == nullptr)
+    if (a.nwg_in != a.nwg)
       hipLaunchKernelGGL(k_scal_fold, dim3(static_cast<unsigned>(a.nwg_in)), dim3(128), 0, s.stream,
                          a.scal, a.nwg, tail_q(V),
                          const_cast<double*>(a.scal_in), a.shared);

@@ -139,7 +139,6 @@ struct Shard : SliceStore {
   double* X[2] = {nullptr, nullptr};  // candidate tables [V+1][mp][VS], see SolveArgs
   double* ab = nullptr;    // [P][NSLOT][W]
   double* scal = nullptr;  // [nwg][Q] partial scalars of k_tail
-  int* fold_cnt = nullptr; // arrival counters of the tail's fold groups (SolveArgs::fold_cnt)
   SolverState* st = nullptr;      // ST[2], see SolverState
   uint8_t* marks = nullptr;       // [KIND_CAP] per-iteration pass marks (profiling), see SolveArgs
   SolveShared* shared = nullptr;
@@ -256,9 +255,6 @@ struct clipper_hip_ctx {
   double total_slice_bytes = 0.0;  // column shards: bytes of all shards' slices (gather_slice_bytes)
   ViewPolicy rvp{};           // the cost model the device-side policy works with (host_rowview.hpp)
   bool rv_fresh = false;      // the next iteration is the first after a view was built
-  // the fold of the tail's partial scalars (m > 16k): by the last workgroup of the tail itself, or
-  // (CLIPPER_HIP_FOLD=kernel, measurement) by a launch of its own
-  bool fold_in_tail = !(std::getenv("CLIPPER_HIP_FOLD") && std::string(std::getenv("CLIPPER_HIP_FOLD")) == "kernel");
   int rv_mode = 0;            // 0 = automatic, 1 = never (clipper_hip_set_row_view / CLIPPER_HIP_ROW_VIEW=0)
   SliceView* rv_desc_host = nullptr;     // pinned + mapped staging of a view's descriptor
   SliceView* rv_desc_host_dev = nullptr;

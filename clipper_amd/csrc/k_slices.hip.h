@@ -480,9 +480,14 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
     __syncthreads();
   }
 
-  int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
-  if (c < ld && static_cast<int>(blockIdx.x) < M.nwork) {
-    if (M.colmap != nullptr) c = M.colmap[c];  // (a row view's column order)
+  const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
+  if (c < ld && static_cast<int>(blockIdx.x) < M.nwork && M.colmap != nullptr) {
+    // a row view's column order: the sums of column colmap[c], side by side (part_ls) — one line per lane
+    // wherever the column lies; plain stores, so that the line is put together in L2
+    double* dst = part + (static_cast<int64_t>(J.slot) * ld + M.colmap[c]) * part_ls(NSLOT);
+#pragma unroll
+    for (int v = 0; v < NS; ++v) dst[(v == NS - 1) ? NSLOT - 1 : v] = acc[v];
+  } else if (c < ld && static_cast<int>(blockIdx.x) < M.nwork) {
 #pragma unroll
     for (int v = 0; v < NS; ++v) {
       const int slot = (v == NS - 1) ? NSLOT - 1 : v;

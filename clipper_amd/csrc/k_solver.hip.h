@@ -44,6 +44,11 @@ constexpr int VS = 8;       // doubles per table row; window sizes V <= VS
 // partial-sum slots per row tile: slot 0 = a = M_off x_0, slots 1..V-1 = g_v of the other
 // candidates, slot V = b = C_off x_0 (a pair-mode pass fills slots 0 and V only)
 constexpr int nslot(int V) { return V + 1; }
+// A pass on a row view with its own column order writes the NSLOT sums of a column side by side
+// (part[slot][column][part_ls]: one 64-byte line per lane, wherever the column lies) instead of
+// part[slot][NSLOT][W] (a lane's NSLOT sums in NSLOT different lines, coalesced only while adjacent lanes
+// own adjacent columns)
+constexpr int part_ls(int NSLOT) { return (NSLOT + 1) & ~1; }
 // what a tail workgroup sums per candidate: Fnew, ||x - u||^2, the V (z, sum) pairs of the next
 // window's norms, and the LIVE CODE of the point the candidate would become (below)
 constexpr int tail_nr(int V) { return 3 + 2 * V; }
@@ -218,9 +223,8 @@ struct SolveArgs {
                            // it covers the live rows of every outcome, whatever the tail counted
   int rv_rows;             // rows of the view
   ViewPolicy rvp;
-  // arrival counters of the tail's fold groups ([nwg_in], zero between launches), or null: the fold is a
-  // launch of its own (k_scal_fold)
-  int* fold_cnt;
+  int rv_sorted;           // the view has its own column order: a pass on it writes its sums in the
+                           // per-column layout (part_ls), see SliceView::colmap
 };
 constexpr int KIND_CAP = 1 << 16;
 
@@ -958,12 +962,13 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   // loads do not depend on the solver state
   double p0 = 0.0, p1 = 0.0;
   if (FUSED_REDUCE) {  // single shard: W >= m; this group's quarter of the slots, in slot order
-    const int64_t o1 = (v == 0) ? static_cast<int64_t>(V) * A.W : 0;  // slot V relative to slot 0
+    const bool percol = st->view && A.rv_sorted;  // (part_ls: the layout a view with a column order writes)
+    const int64_t o1 = (v == 0) ? (percol ? static_cast<int64_t>(V) : static_cast<int64_t>(V) * A.W) : 0;  // slot V relative to slot 0
     const int per = (nslots_pass + TAIL_SPLIT - 1) / TAIL_SPLIT;
     const int t0 = grp * per, t1 = (t0 + per < nslots_pass) ? t0 + per : nslots_pass;
     if (i < A.m) {
-      const double* p = A.part + static_cast<int64_t>(v) * A.W + i;
-      const int64_t ts = static_cast<int64_t>(NSLOT) * A.W;
+      const double* p = percol ? A.part + i * part_ls(NSLOT) + v : A.part + static_cast<int64_t>(v) * A.W + i;
+      const int64_t ts = static_cast<int64_t>(percol ? part_ls(NSLOT) : NSLOT) * A.W;
       // 16 slots per round trip, every load issued (a slot past the end re-reads the last one and
       // is not added): ~28 slots at m = 10k are two round trips (32 at once measured slower)
       for (int t = t0; t < t1; t += 16) {
@@ -1128,37 +1133,6 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   if (threadIdx.x < NR) out[v * NR + threadIdx.x] = tot;
   if (v == 0 && threadIdx.x >= NR && threadIdx.x < NRED)
     out[V * NR + (threadIdx.x - NR)] = tot;  // "all rejected" window sums, then the penalty sums
-  // The fold of the partial scalars (large m: what the next pass's workgroups sum at their heads) by the
-  // LAST workgroup of each group of SCAL_FOLD rows to get here, instead of a launch of its own (~10 us per
-  // iteration): rows are written, released at device scope and counted; whoever counts the last arrival
-  // acquires and sums the rows of the group in row order — the same sums whichever workgroup that is.
-  if (A.fold_cnt != nullptr) {
-    int* flag = reinterpret_cast<int*>(red);
-    __threadfence();
-    __syncthreads();
-    const int grp = blockIdx.x / SCAL_FOLD;
-    const int w0 = grp * SCAL_FOLD;
-    const int w1 = (w0 + SCAL_FOLD < A.nwg) ? w0 + SCAL_FOLD : A.nwg;
-    if (threadIdx.x == 0) {
-      const int expected = (w1 - w0) * (phase == PH_BUILD ? 1 : V);  // (PH_BUILD: the v = 0 workgroups only)
-      const int before = __hip_atomic_fetch_add(A.fold_cnt + grp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (before == expected - 1) ? 1 : 0;
-      if (last) __hip_atomic_store(A.fold_cnt + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      flag[0] = last;
-    }
-    __syncthreads();
-    if (flag[0]) {
-      __threadfence();
-      double* fo = const_cast<double*>(A.scal_in) + static_cast<int64_t>(grp) * Q;
-      for (int q = threadIdx.x; q < Q; q += blockDim.x) {
-        const double* p = A.scal + static_cast<int64_t>(w0) * Q + q;
-        double acc = 0.0;
-        for (int w = 0; w < w1 - w0; ++w)
-          acc += __hip_atomic_load(p + static_cast<int64_t>(w) * Q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fo[q] = acc;
-      }
-    }
-  }
 }
 
 }  // namespace clipper_hip
