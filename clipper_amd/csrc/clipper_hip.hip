@@ -1300,7 +1300,7 @@ int clipper_hip_view_matvec(clipper_hip_t* h, const int32_t* rows, int64_t nrows
   for (int attempt = 0;; ++attempt) {
     SliceOut O{};
     if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
-    if ((rc = launch_rect(h, s, v.rowmap[0], nrows, O, nullptr))) return rc;
+    if ((rc = launch_rect(h, s, v.rowmap[0], nrows, O))) return rc;
     if ((rc = emit_enqueue(h, s, v.st))) return rc;
     HIPCHK(hipStreamSynchronize(s.stream));
     HIPCHK(hipGetLastError());
@@ -1321,7 +1321,7 @@ int clipper_hip_view_matvec(clipper_hip_t* h, const int32_t* rows, int64_t nrows
   R.nwork = v.st.s_nwork;
   R.rowmap = v.rowmap[0];
   R.nrows = nrows;
-  R.colmap = nullptr;
+  R.pad = 0;
   dim3 grid(static_cast<unsigned>(R.nwork)), block(SL_NW * 64);
   if (h->storage == CLIPPER_HIP_STORE_F64)
     hipLaunchKernelGGL((k_gemv_slices_plain<double, 1>), grid, block, 0, s.stream, R, W, m, s.X[0], s.part);

@@ -18,7 +18,7 @@ SliceView slice_view(const Ctx* h, const Shard& s) {
   M.nwork = s.s_nwork;
   M.rowmap = nullptr;
   M.nrows = h->m;
-  M.colmap = nullptr;
+  M.pad = 0;
   return M;
 }
 
@@ -34,7 +34,6 @@ SliceView row_view(const Ctx* h, const Shard& s) {
   R.nwork = s.rv.st.s_nwork;
   R.rowmap = s.rv.rowmap[s.rv.cur];
   R.nrows = s.rv.nrows;
-  R.colmap = s.rv.sorted ? s.rv.colmap : nullptr;
   return R;
 }
 
@@ -361,14 +360,11 @@ int slices_plan(Ctx* h, Shard& sh, SliceStore& s, bool whole) {
     if (h->sh.size() > 1) HIPCHK(hipStreamSynchronize(sh.stream));
   }
   const size_t NSLOT = static_cast<size_t>(nslot(h->V));
-  // (a view with its own column order writes part_ls doubles per column and slot, not NSLOT)
-  const size_t tiles_needed = whole ? static_cast<size_t>(nslots)
-                                    : (static_cast<size_t>(nslots) * part_ls(static_cast<int>(NSLOT)) + NSLOT - 1) / NSLOT;
-  if (tiles_needed > sh.part_tiles) {
+  if (static_cast<size_t>(nslots) > sh.part_tiles) {
     HIPCHK(hipStreamSynchronize(sh.stream));
     HIPCHK(hipFree(sh.part));
     sh.part = nullptr;
-    sh.part_tiles = tiles_needed + 8;
+    sh.part_tiles = static_cast<size_t>(nslots) + 8;
     HIPCHK(hipMalloc(&sh.part, sh.part_tiles * NSLOT * static_cast<size_t>(h->W) * sizeof(double)));
   }
   s.s_nwork = static_cast<int>(nw);
@@ -459,7 +455,7 @@ int csc_rebuild(Ctx* h) {
 
 bool rect_fill_possible(const Ctx* h);
 int gather_slice_bytes(Ctx* h);
-int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O, const int32_t* colmap);
+int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O);
 
 // Every compressed build the symmetric kernel cannot serve (fp64 values, column shards): the
 // rectangular tile kernel writes each shard's slices straight from its LDS images — no dense store, no
@@ -488,7 +484,7 @@ int run_affinity_rect(Ctx* h, double& kernel_ms) {
       if (rc) return rc;
       // (emit_prepare stages the arenas' start values in pinned memory shared by all shards)
       if (h->sh.size() > 1) HIPCHK(hipStreamSynchronize(s.stream));
-      if ((rc = launch_rect(h, s, nullptr, h->m, outs[k], nullptr))) return rc;
+      if ((rc = launch_rect(h, s, nullptr, h->m, outs[k]))) return rc;
     }
     HIPCHK(hipSetDevice(s0.device));
     HIPCHK(hipEventRecord(h->ev_aff[1], s0.stream));

@@ -35,15 +35,12 @@ bool rect_fill_possible(const Ctx* h) {
 }
 
 // The slices of M[rows, this shard's columns] into the store O describes. rowmap == null: all rows.
-int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O,
-                const int32_t* colmap) {
+int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O) {
   if (!rect_fill_possible(h)) return fail(CLIPPER_HIP_E_STATE, "no built-in invariant is staged");
   RectGeom G;
   G.m = h->m;
   G.nrows = nrows;
   G.rowmap = rowmap;
-  G.colmap = colmap;
-  G.ncolmap = h->W;
   G.col0 = static_cast<int64_t>(s.slot) * h->W;
   G.ncols = std::max<int64_t>(0, std::min<int64_t>(h->W, h->m - G.col0));
   const int64_t nTr = ceil_div(nrows, AT);
@@ -96,10 +93,8 @@ void rowview_free(Shard& s) {
   fr(v.in_view[0]);
   fr(v.in_view[1]);
   fr(v.blk);
-  fr(v.colmap);
   fr(v.desc);
-  v.cap_rows = v.cap_flags = v.cap_blk = v.cap_cols = 0;
-  v.sorted = false;
+  v.cap_rows = v.cap_flags = v.cap_blk = 0;
   v.valid = false;
   v.nrows = 0;
 }
@@ -248,22 +243,10 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
     return 0;
   }
   v.valid = false;  // its store is about to be overwritten
-  // the view's column order (k_rv_colsort): by the b of the last evaluated point. CLIPPER_HIP_RV_COLSORT=1
-  // turns it on (measured: see DESIGN.md); = 2 is a measurement mode whose sums land in the WRONG columns
-  // (the view is filled in its column order, a pass writes as if there were none: what the order is worth
-  // without any scattered store)
-  static const int colsort_env = std::getenv("CLIPPER_HIP_RV_COLSORT") ? std::atoi(std::getenv("CLIPPER_HIP_RV_COLSORT")) : 0;
-  const bool colsort = colsort_env != 0 && csc_single(h);  // (column shards reduce their slots in k_reduce_pass: not taught the layout)
-  v.sorted = colsort && colsort_env != 2;
-  if (colsort) {
-    if ((rc = rv_grow(v.colmap, v.cap_cols, static_cast<size_t>(h->W)))) return rc;
-    hipLaunchKernelGGL(k_rv_colsort, dim3(1), dim3(RV_CT), 0, s.stream, s.cab + mp,
-                       static_cast<int64_t>(s.slot) * h->W, m, static_cast<int>(h->W), v.colmap);
-  }
   for (int attempt = 0;; ++attempt) {
     SliceOut O{};
     if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
-    if ((rc = launch_rect(h, s, v.rowmap[next], nrows, O, colsort ? v.colmap : nullptr))) return rc;
+    if ((rc = launch_rect(h, s, v.rowmap[next], nrows, O))) return rc;
     if ((rc = emit_enqueue(h, s, v.st))) return rc;
     HIPCHK(hipStreamSynchronize(s.stream));
     HIPCHK(hipGetLastError());

@@ -118,9 +118,7 @@ struct RowView {
   int cur = 0;                 // which of the two the view in use owns
   SliceView* desc = nullptr;   // device copy of the view's descriptor (what a pass on the view reads)
   uint32_t* blk = nullptr;     // [nblk + 2] per-block live counts, then their offsets
-  int32_t* colmap = nullptr;   // [W] column order of the view in use (SliceView::colmap)
-  bool sorted = false;         // ... the view in use has one
-  size_t cap_rows = 0, cap_flags = 0, cap_blk = 0, cap_cols = 0;
+  size_t cap_rows = 0, cap_flags = 0, cap_blk = 0;
   int64_t nrows = 0;
   bool valid = false;
 };

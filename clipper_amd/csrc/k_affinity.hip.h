@@ -748,8 +748,6 @@ struct RectGeom {
   int64_t nrows;         // rows of the view
   const int32_t* rowmap; // [nrows] association of view row r' (null: r' itself)
   int64_t col0, ncols;   // the view's columns are associations [col0, col0 + ncols)
-  const int32_t* colmap; // column position j of the view is association col0 + colmap[j] (null: col0 + j)
-  int64_t ncolmap;       // entries of colmap
   int nTc;               // column tiles (tile t = row tile t / nTc, column tile t % nTc)
   int64_t tile0;         // first tile of this launch (a dispatch holds at most 2^32 work-items: the 11 M
                          // tiles of m = 300 000 with fp64 values take three launches)
@@ -761,7 +759,7 @@ template <typename VT>
 constexpr int rect_img_bytes() { return (AT * (rect_tw<VT>() + 1) * static_cast<int>(sizeof(VT)) + 15) / 16 * 16; }
 template <typename VT>
 constexpr int rect_lds_bytes() {
-  return rect_img_bytes<VT>() + AT_WAVES * AT_QUEUE * 4 + rect_tw<VT>() * 16 + AT * 4 + rect_tw<VT>() * 4;
+  return rect_img_bytes<VT>() + AT_WAVES * AT_QUEUE * 4 + rect_tw<VT>() * 16 + AT * 4;
 }
 
 template <int D, bool POINTNORMAL, typename VT>
@@ -781,13 +779,11 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_rect(
   uint32_t* queue = reinterpret_cast<uint32_t*>(rect_smem + rect_img_bytes<VT>()) + wave * AT_QUEUE;
   uint32_t* colmask = reinterpret_cast<uint32_t*>(rect_smem + rect_img_bytes<VT>() + AT_WAVES * AT_QUEUE * 4);
   int32_t* rowidx = reinterpret_cast<int32_t*>(colmask + TW * 4);
-  int32_t* colidx = rowidx + AT;  // association of tile column cl (-1: none)
   // heaviest tiles first where that is known: the consistent associations sit at the end of the
   // list in the reference's benchmark layout (bm_utils.cpp:311-314), so the column tiles run backwards
   const int64_t tile = G.tile0 + blockIdx.x;
   const int I = static_cast<int>(tile / G.nTc);
-  // (a view with its own column order has the long columns first)
-  const int J = G.colmap ? static_cast<int>(tile % G.nTc) : G.nTc - 1 - static_cast<int>(tile % G.nTc);
+  const int J = G.nTc - 1 - static_cast<int>(tile % G.nTc);
   const int64_t r0 = static_cast<int64_t>(I) * AT;          // first view row of the tile
   const int64_t cl0 = static_cast<int64_t>(J) * TW;          // first view column of the tile
   const double affinityeps = POINTNORMAL ? nprm.affinityeps : eprm.affinityeps;
@@ -798,12 +794,10 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_rect(
   float p1c[CPL][D], p2c[CPL][D];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
-    const int64_t pc = cl0 + CPL * lane + q;  // column position in the view
-    const int64_t lc = (G.colmap != nullptr && pc < G.ncolmap) ? G.colmap[pc] : pc;
+    const int64_t lc = cl0 + CPL * lane + q;
     const int64_t g = G.col0 + lc;
     validc[q] = lc < G.ncols && g < G.m;
     const int64_t gi = validc[q] ? g : (G.m - 1);
-    colidx[CPL * lane + q] = validc[q] ? static_cast<int32_t>(g) : -1;
     a0c[q] = A0[gi];
     a1c[q] = A1[gi];
 #pragma unroll
@@ -825,7 +819,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_rect(
       const uint32_t code = queue[(head + lane) & (AT_QUEUE - 1)];
       const int rl = static_cast<int>(code >> 8);
       const int cl = static_cast<int>(code & 0xffu);
-      const int64_t ra = rowidx[rl], ca = colidx[cl];
+      const int64_t ra = rowidx[rl], ca = G.col0 + cl0 + cl;
       double scr;
       if (POINTNORMAL) scr = exact_pointnormal_score<VT>(P1, P2, pstride, ra, ca, nprm);
       else scr = exact_euclid_score<VT, D>(P1, P2, pstride, ra, ca, eprm);

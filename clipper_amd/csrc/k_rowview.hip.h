@@ -124,71 +124,4 @@ __global__ void k_rv_resume(SolverState* st, SolveShared* shared, int refused_ro
   }
 }
 
-// k_rv_colsort — the column order of a view: columns by descending b = C x of the last evaluated point
-// (`b`, the tail's cab array: the pattern's product with a vector that is positive on the rows the view
-// keeps, a measure of how many of a column's entries fall into the view — measured at m = 10k, 64
-// buckets: the slices' lock-step efficiency rises from 0.35 to 0.75, as with the exact lengths). A stable
-// counting sort into RV_CB buckets by one workgroup; thread t owns the columns [t per, t per + per). A
-// heuristic for speed only: any permutation of the columns gives the same sums.
-constexpr int RV_CB = 64;
-constexpr int RV_CT = 128;
-__global__ __launch_bounds__(RV_CT) void k_rv_colsort(const double* __restrict__ b, int64_t col0, int64_t m,
-                                                      int W, int32_t* __restrict__ colmap) {
-  __shared__ int cnt[RV_CB][RV_CT];
-  __shared__ int tot[RV_CB];
-  __shared__ double mx_s[RV_CT];
-  const int t = threadIdx.x;
-  const int per = (W + RV_CT - 1) / RV_CT;
-  const int j0 = t * per, j1 = (j0 + per < W) ? j0 + per : W;
-  auto weight = [&](int j) {
-    const int64_t g = col0 + j;
-    const double v = g < m ? b[g] : 0.0;
-    return v > 0.0 ? v : 0.0;  // (also a NaN)
-  };
-  double mx = 0.0;
-  for (int j = j0; j < j1; ++j) {
-    const double v = weight(j);
-    mx = v > mx ? v : mx;
-  }
-  mx_s[t] = mx;
-  for (int q = 0; q < RV_CB; ++q) cnt[q][t] = 0;
-  __syncthreads();
-  for (int o = RV_CT / 2; o > 0; o >>= 1) {
-    if (t < o) mx_s[t] = mx_s[t + o] > mx_s[t] ? mx_s[t + o] : mx_s[t];
-    __syncthreads();
-  }
-  const double bmax = mx_s[0];
-  const double scale = (bmax > 0.0 && bmax < 1e300) ? static_cast<double>(RV_CB) / bmax : 0.0;
-  auto bucket = [&](int j) {  // 0 = longest
-    const int q = static_cast<int>(weight(j) * scale);
-    return RV_CB - 1 - (q < RV_CB - 1 ? q : RV_CB - 1);
-  };
-  for (int j = j0; j < j1; ++j) cnt[bucket(j)][t] += 1;
-  __syncthreads();
-  if (t < RV_CB) {  // bucket t: counts -> exclusive prefix over the threads
-    int run = 0;
-    for (int u = 0; u < RV_CT; ++u) {
-      const int c = cnt[t][u];
-      cnt[t][u] = run;
-      run += c;
-    }
-    tot[t] = run;
-  }
-  __syncthreads();
-  if (t == 0) {
-    int run = 0;
-    for (int q = 0; q < RV_CB; ++q) {
-      const int c = tot[q];
-      tot[q] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-  for (int j = j0; j < j1; ++j) {
-    const int q = bucket(j);
-    colmap[tot[q] + cnt[q][t]] = j;
-    cnt[q][t] += 1;
-  }
-}
-
 }  // namespace clipper_hip

@@ -78,11 +78,7 @@ struct SliceView {
   // staged. The matrix itself: rowmap == null, nrows == m.
   const int32_t* rowmap;
   int64_t nrows;
-  // Column order of a row view: column position j of the view is column colmap[j] of this shard (null:
-  // j itself). A view sorts its columns by expected length (host_rowview.hpp): the lanes of a slice then
-  // run lists of similar length, and the lock-step chain of a slice is as long as its average list rather
-  // than as its longest. Only the address a lane's sums are written to depends on it.
-  const int32_t* colmap;  // (64 bytes: the row view's descriptor is copied to the device in 16-byte words)
+  int64_t pad;  // (64 bytes: the row view's descriptor is copied to the device in 16-byte words)
 };
 static_assert(sizeof(SliceView) == 64, "SliceView is copied in 16-byte words");
 
@@ -100,7 +96,6 @@ struct SliceViewG {
   int nchunks, ncg, nwork;
   const CLIPPER_GLOBAL int32_t* rowmap;
   int64_t nrows;
-  const CLIPPER_GLOBAL int32_t* colmap;
 };
 __device__ __forceinline__ SliceViewG to_global(const SliceView& M) {
   SliceViewG G;
@@ -112,7 +107,6 @@ __device__ __forceinline__ SliceViewG to_global(const SliceView& M) {
   G.nwork = M.nwork;
   G.rowmap = (const CLIPPER_GLOBAL int32_t*)M.rowmap;
   G.nrows = M.nrows;
-  G.colmap = (const CLIPPER_GLOBAL int32_t*)M.colmap;
   return G;
 }
 
@@ -481,13 +475,7 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
   }
 
   const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
-  if (c < ld && static_cast<int>(blockIdx.x) < M.nwork && M.colmap != nullptr) {
-    // a row view's column order: the sums of column colmap[c], side by side (part_ls) — one line per lane
-    // wherever the column lies; plain stores, so that the line is put together in L2
-    double* dst = part + (static_cast<int64_t>(J.slot) * ld + M.colmap[c]) * part_ls(NSLOT);
-#pragma unroll
-    for (int v = 0; v < NS; ++v) dst[(v == NS - 1) ? NSLOT - 1 : v] = acc[v];
-  } else if (c < ld && static_cast<int>(blockIdx.x) < M.nwork) {
+  if (c < ld && static_cast<int>(blockIdx.x) < M.nwork) {
 #pragma unroll
     for (int v = 0; v < NS; ++v) {
       const int slot = (v == NS - 1) ? NSLOT - 1 : v;

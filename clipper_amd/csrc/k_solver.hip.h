@@ -44,11 +44,6 @@ constexpr int VS = 8;       // doubles per table row; window sizes V <= VS
 // partial-sum slots per row tile: slot 0 = a = M_off x_0, slots 1..V-1 = g_v of the other
 // candidates, slot V = b = C_off x_0 (a pair-mode pass fills slots 0 and V only)
 constexpr int nslot(int V) { return V + 1; }
-// A pass on a row view with its own column order writes the NSLOT sums of a column side by side
-// (part[slot][column][part_ls]: one 64-byte line per lane, wherever the column lies) instead of
-// part[slot][NSLOT][W] (a lane's NSLOT sums in NSLOT different lines, coalesced only while adjacent lanes
-// own adjacent columns)
-constexpr int part_ls(int NSLOT) { return (NSLOT + 1) & ~1; }
 // what a tail workgroup sums per candidate: Fnew, ||x - u||^2, the V (z, sum) pairs of the next
 // window's norms, and the LIVE CODE of the point the candidate would become (below)
 constexpr int tail_nr(int V) { return 3 + 2 * V; }
@@ -223,8 +218,6 @@ struct SolveArgs {
                            // it covers the live rows of every outcome, whatever the tail counted
   int rv_rows;             // rows of the view
   ViewPolicy rvp;
-  int rv_sorted;           // the view has its own column order: a pass on it writes its sums in the
-                           // per-column layout (part_ls), see SliceView::colmap
 };
 constexpr int KIND_CAP = 1 << 16;
 
@@ -962,13 +955,12 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   // loads do not depend on the solver state
   double p0 = 0.0, p1 = 0.0;
   if (FUSED_REDUCE) {  // single shard: W >= m; this group's quarter of the slots, in slot order
-    const bool percol = st->view && A.rv_sorted;  // (part_ls: the layout a view with a column order writes)
-    const int64_t o1 = (v == 0) ? (percol ? static_cast<int64_t>(V) : static_cast<int64_t>(V) * A.W) : 0;  // slot V relative to slot 0
+    const int64_t o1 = (v == 0) ? static_cast<int64_t>(V) * A.W : 0;  // slot V relative to slot 0
     const int per = (nslots_pass + TAIL_SPLIT - 1) / TAIL_SPLIT;
     const int t0 = grp * per, t1 = (t0 + per < nslots_pass) ? t0 + per : nslots_pass;
     if (i < A.m) {
-      const double* p = percol ? A.part + i * part_ls(NSLOT) + v : A.part + static_cast<int64_t>(v) * A.W + i;
-      const int64_t ts = static_cast<int64_t>(percol ? part_ls(NSLOT) : NSLOT) * A.W;
+      const double* p = A.part + static_cast<int64_t>(v) * A.W + i;
+      const int64_t ts = static_cast<int64_t>(NSLOT) * A.W;
       // 16 slots per round trip, every load issued (a slot past the end re-reads the last one and
       // is not added): ~28 slots at m = 10k are two round trips (32 at once measured slower)
       for (int t = t0; t < t1; t += 16) {
