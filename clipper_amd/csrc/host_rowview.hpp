@@ -69,6 +69,57 @@ int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const Sl
   return 0;
 }
 
+// The slices of M[rows, this shard's columns] filtered out of the shard's own slices of M
+// (k_slice_filter_rows): for any matrix that lives in slices, whatever it was built from.
+int launch_filter(Ctx* h, Shard& s, const int32_t* rowmap, const int32_t* viewpos, int64_t nrows, const SliceOut& O) {
+  FilterGeom G;
+  G.nrows = nrows;
+  G.rowmap = rowmap;
+  G.viewpos = viewpos;
+  const int64_t nTr = ceil_div(nrows, AT);
+  const SliceView M = slice_view(h, s);
+  dispatch_vt(h, [&](auto t) {
+    using VT = decltype(t);
+    constexpr int TW = rect_tw<VT>();
+    G.nTc = static_cast<int>(ceil_div(h->W, TW));
+    const int64_t ntiles = nTr * G.nTc;
+    constexpr int64_t PER_LAUNCH = int64_t(1) << 22;  // x 512 threads < 2^32 work-items per dispatch
+    constexpr int L = rect_lds_bytes<VT>();
+    static bool raised = false;  // (per instantiation)
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_slice_filter_rows<VT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, L);
+      raised = true;
+    }
+    for (int64_t t0 = 0; t0 < ntiles; t0 += PER_LAUNCH) {
+      G.tile0 = t0;
+      const dim3 grid(static_cast<unsigned>(std::min<int64_t>(PER_LAUNCH, ntiles - t0)));
+      hipLaunchKernelGGL((k_slice_filter_rows<VT>), grid, dim3(AT_WAVES * 64), L, s.stream, M, G, O);
+    }
+  });
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// how a view is built: filtered out of M's slices (default), or scored again from the staged points
+// (CLIPPER_HIP_RV_BUILD=rect; measurement, and what round 3 started with)
+bool rowview_by_filter() {
+  static const bool rect = [] {
+    const char* e = std::getenv("CLIPPER_HIP_RV_BUILD");
+    return e && std::string(e) == "rect";
+  }();
+  return !rect;
+}
+// (CLIPPER_HIP_RV_BUILD=rectfill: the rectangular fill under the filter's cost model — the two builds must
+// then give the same solve bit for bit, tests/test_gpu_rowview.py)
+bool rowview_fill_by_filter() {
+  static const bool rectfill = [] {
+    const char* e = std::getenv("CLIPPER_HIP_RV_BUILD");
+    return e && std::string(e) == "rectfill";
+  }();
+  return rowview_by_filter() && !rectfill;
+}
+
 // ---- the row view -----------------------------------------------------------------------------------
 
 void rowview_drop(Ctx* h) {
@@ -93,21 +144,24 @@ void rowview_free(Shard& s) {
   fr(v.in_view[0]);
   fr(v.in_view[1]);
   fr(v.blk);
+  fr(v.viewpos);
   fr(v.desc);
-  v.cap_rows = v.cap_flags = v.cap_blk = 0;
+  v.cap_rows = v.cap_flags = v.cap_blk = v.cap_pos = 0;
   v.valid = false;
   v.nrows = 0;
 }
 
-// a view can exist at all: slices with C == pattern(M), scored from staged points; column shards: the
+// a view can exist at all: slices with C == pattern(M) (built by the rectangular fill: scored from staged
+// points); column shards: the
 // bytes of all shards are known (the policy's cost model must be the same on every rank)
 bool rowview_possible(const Ctx* h) {
   static const bool env_off = [] {
     const char* e = std::getenv("CLIPPER_HIP_ROW_VIEW");
     return e && std::atoi(e) == 0;
   }();
-  return !env_off && h->rv_mode == 0 && h->csc_valid && !h->explicitC && rect_fill_possible(h) &&
-         h->m >= RV_MIN_M && (csc_single(h) || h->total_slice_bytes > 0.0);
+  return !env_off && h->rv_mode == 0 && h->csc_valid && !h->explicitC &&
+         (rowview_fill_by_filter() || rect_fill_possible(h)) && h->m >= RV_MIN_M &&
+         (csc_single(h) || h->total_slice_bytes > 0.0);
 }
 
 // Column shards: the bytes all shards' slices hold, by one all-gather of a one-slot block at build time
@@ -151,8 +205,13 @@ ViewPolicy rowview_policy(const Ctx* h) {
   const double bytes = csc_single(h) ? static_cast<double>(h->sh[0].s_bytes)
                                      : h->total_slice_bytes / static_cast<double>(std::max(1, h->world));
   p.pass_per_row = bytes / static_cast<double>(h->m) / 3.3e12;
-  p.build_fixed = 60e-6 * scale_env;
-  p.build_per_row = static_cast<double>(h->W) * 4.5e-12 * scale_env;  // (a shard fills its own columns of the rows)
+  if (rowview_by_filter()) {  // one read of the shard's slices whatever the rows + what the rows' slices take to write
+    p.build_fixed = (60e-6 + bytes / 3.0e12) * scale_env;
+    p.build_per_row = static_cast<double>(h->W) * 1.0e-12 * scale_env;
+  } else {
+    p.build_fixed = 60e-6 * scale_env;
+    p.build_per_row = static_cast<double>(h->W) * 4.5e-12 * scale_env;  // (a shard fills its own columns of the rows)
+  }
   return p;
 }
 
@@ -213,6 +272,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
     if ((rc = rv_grow(v.rowmap[1], r1, static_cast<size_t>(mp)))) return rc;
     v.cap_rows = static_cast<size_t>(mp);
     if ((rc = rv_grow(v.blk, v.cap_blk, static_cast<size_t>(nblk) + 2))) return rc;
+    if ((rc = rv_grow(v.viewpos, v.cap_pos, static_cast<size_t>(mp)))) return rc;
   }
   if (!h->rv_count) {
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->rv_count), 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -225,7 +285,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
                      s.st + h->par, s.pt, mp, m, v.in_view[next], v.blk);
   hipLaunchKernelGGL(k_rv_scan, dim3(1), dim3(1024), 0, s.stream, v.blk, nblk, h->rv_count_dev);
   hipLaunchKernelGGL(k_rv_scatter, dim3(static_cast<unsigned>(nblk)), dim3(256), 0, s.stream,
-                     v.in_view[next], m, v.blk, v.rowmap[next], static_cast<int64_t>(v.cap_rows));
+                     v.in_view[next], m, v.blk, v.rowmap[next], static_cast<int64_t>(v.cap_rows), v.viewpos, mp);
   HIPCHK(hipStreamSynchronize(s.stream));
   const int64_t nrows = *h->rv_count;
   if (nrows < 0) return fail(CLIPPER_HIP_E_HIP, "row view: the row count did not arrive");
@@ -246,7 +306,9 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   for (int attempt = 0;; ++attempt) {
     SliceOut O{};
     if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
-    if ((rc = launch_rect(h, s, v.rowmap[next], nrows, O))) return rc;
+    if (rowview_fill_by_filter()) rc = launch_filter(h, s, v.rowmap[next], v.viewpos, nrows, O);
+    else rc = launch_rect(h, s, v.rowmap[next], nrows, O);
+    if (rc) return rc;
     if ((rc = emit_enqueue(h, s, v.st))) return rc;
     HIPCHK(hipStreamSynchronize(s.stream));
     HIPCHK(hipGetLastError());

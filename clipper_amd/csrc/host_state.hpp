@@ -118,7 +118,8 @@ struct RowView {
   int cur = 0;                 // which of the two the view in use owns
   SliceView* desc = nullptr;   // device copy of the view's descriptor (what a pass on the view reads)
   uint32_t* blk = nullptr;     // [nblk + 2] per-block live counts, then their offsets
-  size_t cap_rows = 0, cap_flags = 0, cap_blk = 0;
+  int32_t* viewpos = nullptr;  // [mp] position of a row of M in the view being built, or -1
+  size_t cap_rows = 0, cap_flags = 0, cap_blk = 0, cap_pos = 0;
   int64_t nrows = 0;
   bool valid = false;
 };

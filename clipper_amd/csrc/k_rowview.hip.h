@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "k_affinity.hip.h"
+#include "k_csc.hip.h"
 #include "k_solver.hip.h"
 
 namespace clipper_hip {
@@ -82,9 +84,11 @@ __global__ __launch_bounds__(1024) void k_rv_scan(uint32_t* __restrict__ blk, in
 
 // rowmap[rank of i among the live rows] = i (ascending: the order of the additions of a pass on
 // the view is a function of the row SET alone)
+// viewpos[i] = that rank, or -1 (what k_slice_filter_rows asks of every entry's row)
 __global__ __launch_bounds__(256) void k_rv_scatter(const uint8_t* __restrict__ flags, int64_t m,
                                                      const uint32_t* __restrict__ blk,
-                                                     int32_t* __restrict__ rowmap, int64_t cap) {
+                                                     int32_t* __restrict__ rowmap, int64_t cap,
+                                                     int32_t* __restrict__ viewpos, int64_t mp) {
   __shared__ uint32_t wsum[4];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * RV_BLK + threadIdx.x * 4;
   uint32_t f[4], n = 0;
@@ -105,11 +109,105 @@ __global__ __launch_bounds__(256) void k_rv_scatter(const uint8_t* __restrict__ 
   for (int w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
   uint32_t at = off + inc - n;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < mp) viewpos[base + k] = f[k] ? static_cast<int32_t>(at) : -1;
     if (f[k]) {
       if (static_cast<int64_t>(at) < cap) rowmap[at] = static_cast<int32_t>(base + k);
       ++at;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_slice_filter_rows — the slices of M[rows, :] from the slices of M itself. A view keeps the entries
+// of M whose row is in its list: they are already scored and stored, so a view is a FILTER of the
+// matrix's own column lists (one read of M at streaming rate) rather than a second evaluation of
+// nrows x m pairs from the points (k_affinity_rect: 2-5 x the time at m >= 100k, and only for matrices
+// that were scored from staged points). Geometry and emission as k_affinity_rect: a workgroup owns a
+// tile of 128 view rows x TW columns, fills an LDS image of it and writes the tile's slices from the
+// image (slice_emit_lds) — the same bytes the rectangular fill writes, values bit for bit (both are
+// the stored roundings of the same scores). The 128 rows of view chunk I are rows rowmap[128 I ..] of
+// M, ascending: they lie in M's chunks k0 .. k1 = those rows / 128, and wave w walks the slices
+// (column group of the tile, chunk k0 + w, k0 + w + 8, ...): an entry whose row has a position in this
+// view chunk (viewpos) goes into the image. Different chunks are different rows: no two waves write
+// the same element; a column's row mask is or-ed with LDS atomics.
+// ------------------------------------------------------------------------------------------
+struct FilterGeom {
+  int64_t nrows;           // rows of the view
+  const int32_t* rowmap;   // [nrows]
+  const int32_t* viewpos;  // [m padded] position of a row of M in the view, or -1
+  int nTc;                 // column tiles
+  int64_t tile0;           // first tile of this launch (as RectGeom::tile0)
+};
+
+template <typename VT>
+__global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_slice_filter_rows(SliceView M, FilterGeom G,
+                                                                                     SliceOut O) {
+  constexpr int TW = rect_tw<VT>();
+  constexpr int CPL = TW / 64;
+  constexpr int PITCH = TW + 1;
+  constexpr int QB = 4 * static_cast<int>(sizeof(VT));
+  static_assert(AT == SL_SUB, "a tile is as tall as a slice");
+  extern __shared__ __attribute__((aligned(16))) char filt_smem[];
+  VT* img = reinterpret_cast<VT*>(filt_smem);
+  uint32_t* colmask = reinterpret_cast<uint32_t*>(filt_smem + rect_img_bytes<VT>() + AT_WAVES * AT_QUEUE * 4);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = G.tile0 + blockIdx.x;
+  const int I = static_cast<int>(tile / G.nTc);
+  const int J = static_cast<int>(tile % G.nTc);
+  const int64_t v0 = static_cast<int64_t>(I) * AT;  // first view row of the tile
+  for (int t = threadIdx.x; t < TW * 4; t += AT_WAVES * 64) colmask[t] = 0;
+  const int64_t vlast = (v0 + AT - 1 < G.nrows) ? v0 + AT - 1 : G.nrows - 1;
+  const int k0 = G.rowmap[v0] / SL_SUB, k1 = G.rowmap[vlast] / SL_SUB;
+  __syncthreads();
+  for (int k = k0 + wave; k <= k1; k += AT_WAVES) {  // (wave-uniform)
+    const int64_t r0 = static_cast<int64_t>(k) * SL_SUB;
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+      const int cg = J * CPL + e;
+      if (cg >= M.ncg) continue;
+      SliceHead<1> hd;
+      hd.load(static_cast<gbytes_t>((gbytes_t)M.data + 16 * M.Pre[static_cast<int64_t>(cg) * M.nchunks + k]), lane);
+      const int maxq = __builtin_amdgcn_readfirstlane(hd.maxq);
+      const int tot = hd.nq[0];
+      gbytes_t fbase = hd.sp + 16 + 64 + sl_so_bytes(maxq);
+      for (int q = 0; q < maxq; ++q) {
+        const bool active = q < tot;
+        const uint64_t mask = __ballot(active);
+        const int cnt = __popcll(mask);
+        if (active) {
+          const uint32_t rank = sl_lane_rank(mask);
+          SliceQuad<VT> vq;
+          vq.load(fbase + rank * QB);
+          const uint32_t rq = *reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(fbase + cnt * QB + rank * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (vq.v[j] != VT(0)) {
+              const int64_t vr = static_cast<int64_t>(G.viewpos[r0 + ((rq >> (8 * j)) & 255u)]) - v0;
+              if (vr >= 0 && vr < AT) {  // (-1 - v0 < 0: a row outside the view)
+                const int cl = 64 * e + lane;
+                img[vr * PITCH + cl] = vq.v[j];
+                atomicOr(&colmask[cl * 4 + (static_cast<int>(vr) >> 5)], 1u << (static_cast<int>(vr) & 31));
+              }
+            }
+        }
+        fbase += cnt * QB + ((cnt * 4 + 15) & ~15);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the tile's CPL slices (column group J * CPL + e, chunk I), two waves per slice: as k_affinity_rect
+  unsigned long long* base_s = reinterpret_cast<unsigned long long*>(filt_smem + rect_img_bytes<VT>());
+  const int sl = wave & 3, half = wave >> 2;
+  const int e = sl < CPL ? sl : 0;
+  const VT* col = img + 64 * e + lane;
+  const uint4 mk = *reinterpret_cast<const uint4*>(colmask + (64 * e + lane) * 4);
+  const uint64_t mlo = static_cast<uint64_t>(mk.x) | (static_cast<uint64_t>(mk.y) << 32);
+  const uint64_t mhi = static_cast<uint64_t>(mk.z) | (static_cast<uint64_t>(mk.w) << 32);
+  const int cg = J * CPL + e;
+  const int64_t s = (sl < CPL && cg < O.ncg && I < O.nchunks) ? static_cast<int64_t>(cg) * O.nchunks + I : -1;
+  slice_emit_lds<VT>(col, PITCH, mlo, mhi, s, sl, half, O, base_s, nullptr);
 }
 
 // the host has built the view the state asked for (or refused: too many rows once the pending

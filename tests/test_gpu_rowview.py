@@ -184,3 +184,61 @@ def test_column_shards_build_their_own_views(storage, nshards):
     s0 = g.solve(p.u0)
     assert s0.nodes.tolist() == sr.nodes.tolist() and g.view_stats().builds == 0
     g.close()
+
+
+_BUILD_PROBE = r"""
+import hashlib, json, sys
+import numpy as np
+from clipper_amd import _abi as abi
+from clipper_amd import synth
+out = []
+for m, rho, storage in ((6000, 0.9, abi.STORE_F32_CSC), (10000, 0.95, abi.STORE_F32_CSC), (5000, 0.9, abi.STORE_F64_CSC)):
+    p = synth.make_euclidean_problem(m, rho, seed=4242 + m)
+    g = abi.HipClipper(storage=storage)
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    s = g.solve(p.u0)
+    st = g.view_stats()
+    out.append(dict(m=m, u=hashlib.sha256(np.ascontiguousarray(s.u).tobytes()).hexdigest(), nodes=s.nodes.tolist(),
+                    trials=int(s.n_trials), builds=int(st.builds), rows=int(st.rows), bytes=int(st.bytes),
+                    view_passes=int(st.view_passes)))
+    g.close()
+print(json.dumps(out))
+"""
+
+
+def test_a_view_filtered_from_the_slices_is_the_view_scored_from_the_points():
+    """The default build of a view filters the rows out of M's own slices (k_slice_filter_rows); round 3's
+    first build scored the rows' pairs again from the staged points (k_affinity_rect, CLIPPER_HIP_RV_BUILD=
+    rectfill keeps it under the same cost model). Both write the slices of the same sub-matrix: the same
+    bytes held, the same builds, and the solve bit for bit. (The switch is read once per process: two
+    child processes.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("filter", "rectfill"):
+        env = dict(os.environ, CLIPPER_HIP_RV_BUILD=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        o = subprocess.check_output([sys.executable, "-c", _BUILD_PROBE], env=env, cwd=root, timeout=300).decode()
+        res[mode] = json.loads(o.strip().splitlines()[-1])
+    for a, b in zip(res["filter"], res["rectfill"]):
+        assert a["builds"] >= 1 and a["view_passes"] > 0, a
+        assert a == b, (a, b)
+
+
+def test_views_for_a_matrix_that_was_handed_over():
+    """setSparseMatrixData / setMatrixData (clipper.cpp:149-166) have no points behind them: a view of such
+    a matrix can only come from its slices — it does now."""
+    p = synth.make_euclidean_problem(5000, 0.9, seed=99)
+    r, sr = _oracle(p, **synth.EUCLID_BENCH_PARAMS)
+    M = r.get_affinity_matrix()
+    Mu = np.triu(M, 1)
+    g = abi.HipClipper(storage=abi.STORE_F32_CSC)
+    g.set_matrix_data(Mu + Mu.T, (Mu + Mu.T != 0).astype(float))
+    s = g.solve(p.u0)
+    st = g.view_stats()
+    assert st.builds >= 1 and st.view_passes > 0, (st.builds, st.view_passes)
+    assert sorted(s.nodes.tolist()) == sorted(sr.nodes.tolist())
+    assert abs(s.score - sr.score) <= 1e-6 * abs(sr.score)
+    g.close()
