@@ -101,24 +101,23 @@ int launch_filter(Ctx* h, Shard& s, const int32_t* rowmap, const int32_t* viewpo
   return 0;
 }
 
-// how a view is built: filtered out of M's slices (default), or scored again from the staged points
-// (CLIPPER_HIP_RV_BUILD=rect; measurement, and what round 3 started with)
-bool rowview_by_filter() {
-  static const bool rect = [] {
+// How a view is built. Scored again from the staged points (k_affinity_rect) where the matrix was scored
+// from points: measured 1.8 x faster than the filter at every size (profiles/r03_view_by_filter.txt).
+// Filtered out of M's own slices (k_slice_filter_rows) where there are no points — matrices handed over
+// with setMatrixData / setSparseMatrixData, custom invariants — which had no views before.
+// CLIPPER_HIP_RV_BUILD = filter: always the filter; rectfill: the rectangular fill under the filter's cost
+// model (the two builds must then give the same solve bit for bit, tests/test_gpu_rowview.py).
+int rowview_build_env() {
+  static const int mode = [] {
     const char* e = std::getenv("CLIPPER_HIP_RV_BUILD");
-    return e && std::string(e) == "rect";
+    if (!e) return 0;
+    const std::string v(e);
+    return v == "filter" ? 1 : (v == "rectfill" ? 2 : 0);
   }();
-  return !rect;
+  return mode;
 }
-// (CLIPPER_HIP_RV_BUILD=rectfill: the rectangular fill under the filter's cost model — the two builds must
-// then give the same solve bit for bit, tests/test_gpu_rowview.py)
-bool rowview_fill_by_filter() {
-  static const bool rectfill = [] {
-    const char* e = std::getenv("CLIPPER_HIP_RV_BUILD");
-    return e && std::string(e) == "rectfill";
-  }();
-  return rowview_by_filter() && !rectfill;
-}
+bool rowview_fill_by_filter(const Ctx* h) { return rowview_build_env() == 1 || !rect_fill_possible(h); }
+bool rowview_cost_of_filter(const Ctx* h) { return rowview_build_env() != 0 || !rect_fill_possible(h); }
 
 // ---- the row view -----------------------------------------------------------------------------------
 
@@ -151,8 +150,7 @@ void rowview_free(Shard& s) {
   v.nrows = 0;
 }
 
-// a view can exist at all: slices with C == pattern(M) (built by the rectangular fill: scored from staged
-// points); column shards: the
+// a view can exist at all: slices with C == pattern(M); column shards: the
 // bytes of all shards are known (the policy's cost model must be the same on every rank)
 bool rowview_possible(const Ctx* h) {
   static const bool env_off = [] {
@@ -160,7 +158,7 @@ bool rowview_possible(const Ctx* h) {
     return e && std::atoi(e) == 0;
   }();
   return !env_off && h->rv_mode == 0 && h->csc_valid && !h->explicitC &&
-         (rowview_fill_by_filter() || rect_fill_possible(h)) && h->m >= RV_MIN_M &&
+         h->m >= RV_MIN_M &&
          (csc_single(h) || h->total_slice_bytes > 0.0);
 }
 
@@ -205,8 +203,9 @@ ViewPolicy rowview_policy(const Ctx* h) {
   const double bytes = csc_single(h) ? static_cast<double>(h->sh[0].s_bytes)
                                      : h->total_slice_bytes / static_cast<double>(std::max(1, h->world));
   p.pass_per_row = bytes / static_cast<double>(h->m) / 3.3e12;
-  if (rowview_by_filter()) {  // one read of the shard's slices whatever the rows + what the rows' slices take to write
-    p.build_fixed = (60e-6 + bytes / 3.0e12) * scale_env;
+  if (rowview_cost_of_filter(h)) {  // one read of the shard's slices whatever the rows (0.55 TB/s measured:
+                                    // the walk is latency-bound) + what the rows' slices take to write
+    p.build_fixed = (100e-6 + bytes / 0.55e12) * scale_env;
     p.build_per_row = static_cast<double>(h->W) * 1.0e-12 * scale_env;
   } else {
     p.build_fixed = 60e-6 * scale_env;
@@ -306,7 +305,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   for (int attempt = 0;; ++attempt) {
     SliceOut O{};
     if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
-    if (rowview_fill_by_filter()) rc = launch_filter(h, s, v.rowmap[next], v.viewpos, nrows, O);
+    if (rowview_fill_by_filter(h)) rc = launch_filter(h, s, v.rowmap[next], v.viewpos, nrows, O);
     else rc = launch_rect(h, s, v.rowmap[next], nrows, O);
     if (rc) return rc;
     if ((rc = emit_enqueue(h, s, v.st))) return rc;

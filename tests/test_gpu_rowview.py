@@ -206,39 +206,65 @@ print(json.dumps(out))
 """
 
 
-def test_a_view_filtered_from_the_slices_is_the_view_scored_from_the_points():
-    """The default build of a view filters the rows out of M's own slices (k_slice_filter_rows); round 3's
-    first build scored the rows' pairs again from the staged points (k_affinity_rect, CLIPPER_HIP_RV_BUILD=
-    rectfill keeps it under the same cost model). Both write the slices of the same sub-matrix: the same
-    bytes held, the same builds, and the solve bit for bit. (The switch is read once per process: two
-    child processes.)"""
+def _child(code, **env):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for mode in ("filter", "rectfill"):
-        env = dict(os.environ, CLIPPER_HIP_RV_BUILD=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        o = subprocess.check_output([sys.executable, "-c", _BUILD_PROBE], env=env, cwd=root, timeout=300).decode()
-        res[mode] = json.loads(o.strip().splitlines()[-1])
+    e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
+    o = subprocess.check_output([sys.executable, "-c", code], env=e, cwd=root, timeout=300).decode()
+    return json.loads(o.strip().splitlines()[-1])
+
+
+def test_a_view_filtered_from_the_slices_is_the_view_scored_from_the_points():
+    """A view is built by scoring the rows' pairs again from the staged points (k_affinity_rect) or — where
+    there are no points — by filtering the rows out of M's own slices (k_slice_filter_rows). Both write the
+    slices of the same sub-matrix: under the same cost model (CLIPPER_HIP_RV_BUILD=filter | rectfill) the
+    same bytes held, the same builds, and the solve bit for bit. (The switch is read once per process: two
+    child processes.)"""
+    res = {mode: _child(_BUILD_PROBE, CLIPPER_HIP_RV_BUILD=mode, CLIPPER_HIP_RV_BUILD_SCALE="0.2")
+           for mode in ("filter", "rectfill")}
     for a, b in zip(res["filter"], res["rectfill"]):
         assert a["builds"] >= 1 and a["view_passes"] > 0, a
         assert a == b, (a, b)
 
 
-def test_views_for_a_matrix_that_was_handed_over():
-    """setSparseMatrixData / setMatrixData (clipper.cpp:149-166) have no points behind them: a view of such
-    a matrix can only come from its slices — it does now."""
-    p = synth.make_euclidean_problem(5000, 0.9, seed=99)
-    r, sr = _oracle(p, **synth.EUCLID_BENCH_PARAMS)
-    M = r.get_affinity_matrix()
-    Mu = np.triu(M, 1)
+_HANDED_OVER = r"""
+import json
+import numpy as np
+from clipper_amd import _abi as abi
+from clipper_amd import synth
+from oracle import clipper_ref as ref
+p = synth.make_euclidean_problem(5000, 0.9, seed=99)
+r = ref.RefClipper()
+r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+sr = r.solve(p.u0)
+M = r.get_affinity_matrix()
+Mu = np.triu(M, 1)
+Ms = Mu + Mu.T
+out = {}
+for views in (1, 0):
     g = abi.HipClipper(storage=abi.STORE_F32_CSC)
-    g.set_matrix_data(Mu + Mu.T, (Mu + Mu.T != 0).astype(float))
+    g.set_row_view(0 if views else 1)
+    g.set_matrix_data(Ms, (Ms != 0).astype(float))
     s = g.solve(p.u0)
     st = g.view_stats()
-    assert st.builds >= 1 and st.view_passes > 0, (st.builds, st.view_passes)
-    assert sorted(s.nodes.tolist()) == sorted(sr.nodes.tolist())
-    assert abs(s.score - sr.score) <= 1e-6 * abs(sr.score)
+    out[views] = dict(nodes=sorted(s.nodes.tolist()), score=float(s.score), builds=int(st.builds), view_passes=int(st.view_passes))
     g.close()
+out["oracle"] = dict(nodes=sorted(sr.nodes.tolist()), score=float(sr.score))
+print(json.dumps(out))
+"""
+
+
+def test_views_for_a_matrix_that_was_handed_over():
+    """setMatrixData / setSparseMatrixData (clipper.cpp:149-166) have no points behind them: a view of such
+    a matrix can only come from its slices (k_slice_filter_rows). (CLIPPER_HIP_RV_BUILD_SCALE makes the
+    policy build one at this small size.)"""
+    out = _child(_HANDED_OVER, CLIPPER_HIP_RV_BUILD_SCALE="0.05")
+    on, off, orc = out["1"], out["0"], out["oracle"]
+    assert on["builds"] >= 1 and on["view_passes"] > 0, on
+    assert off["builds"] == 0
+    assert on["nodes"] == off["nodes"] == orc["nodes"]
+    assert abs(on["score"] - orc["score"]) <= 1e-6 * abs(orc["score"])
+    assert abs(on["score"] - off["score"]) <= 1e-10 * abs(off["score"])
