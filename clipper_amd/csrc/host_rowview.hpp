@@ -80,11 +80,10 @@ int launch_filter(Ctx* h, Shard& s, const int32_t* rowmap, const int32_t* viewpo
   const SliceView M = slice_view(h, s);
   dispatch_vt(h, [&](auto t) {
     using VT = decltype(t);
-    constexpr int TW = rect_tw<VT>();
-    G.nTc = static_cast<int>(ceil_div(h->W, TW));
+    G.nTc = static_cast<int>(ceil_div(h->W, FILT_TW));
     const int64_t ntiles = nTr * G.nTc;
     constexpr int64_t PER_LAUNCH = int64_t(1) << 22;  // x 512 threads < 2^32 work-items per dispatch
-    constexpr int L = rect_lds_bytes<VT>();
+    constexpr int L = filt_lds_bytes<VT>();
     static bool raised = false;  // (per instantiation)
     if (!raised) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_slice_filter_rows<VT>),

@@ -140,73 +140,88 @@ struct FilterGeom {
   int64_t tile0;           // first tile of this launch (as RectGeom::tile0)
 };
 
+// One slice per tile (64 columns: a 33 KB image of fp32 values, four workgroups per CU); the walk keeps
+// FILT_D steps of a slice and the header of the wave's next slice in flight (every lane issues every load,
+// as in the pass: k_slices.hip.h).
+constexpr int FILT_TW = 64;
+constexpr int FILT_D = 4;
+template <typename VT>
+constexpr int filt_img_bytes() { return (AT * (FILT_TW + 1) * static_cast<int>(sizeof(VT)) + 15) / 16 * 16; }
+template <typename VT>
+constexpr int filt_lds_bytes() { return filt_img_bytes<VT>() + 64 + FILT_TW * 16; }
+
 template <typename VT>
 __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_slice_filter_rows(SliceView M, FilterGeom G,
                                                                                      SliceOut O) {
-  constexpr int TW = rect_tw<VT>();
-  constexpr int CPL = TW / 64;
-  constexpr int PITCH = TW + 1;
+  constexpr int PITCH = FILT_TW + 1;
   constexpr int QB = 4 * static_cast<int>(sizeof(VT));
   static_assert(AT == SL_SUB, "a tile is as tall as a slice");
   extern __shared__ __attribute__((aligned(16))) char filt_smem[];
   VT* img = reinterpret_cast<VT*>(filt_smem);
-  uint32_t* colmask = reinterpret_cast<uint32_t*>(filt_smem + rect_img_bytes<VT>() + AT_WAVES * AT_QUEUE * 4);
+  unsigned long long* base_s = reinterpret_cast<unsigned long long*>(filt_smem + filt_img_bytes<VT>());
+  uint32_t* colmask = reinterpret_cast<uint32_t*>(filt_smem + filt_img_bytes<VT>() + 64);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t tile = G.tile0 + blockIdx.x;
   const int I = static_cast<int>(tile / G.nTc);
-  const int J = static_cast<int>(tile % G.nTc);
+  const int cg = static_cast<int>(tile % G.nTc);
   const int64_t v0 = static_cast<int64_t>(I) * AT;  // first view row of the tile
-  for (int t = threadIdx.x; t < TW * 4; t += AT_WAVES * 64) colmask[t] = 0;
+  for (int t = threadIdx.x; t < FILT_TW * 4; t += AT_WAVES * 64) colmask[t] = 0;
   const int64_t vlast = (v0 + AT - 1 < G.nrows) ? v0 + AT - 1 : G.nrows - 1;
   const int k0 = G.rowmap[v0] / SL_SUB, k1 = G.rowmap[vlast] / SL_SUB;
   __syncthreads();
-  for (int k = k0 + wave; k <= k1; k += AT_WAVES) {  // (wave-uniform)
-    const int64_t r0 = static_cast<int64_t>(k) * SL_SUB;
+  if (cg < M.ncg) {
+    const gbytes_t data = (gbytes_t)M.data;
+    const CLIPPER_GLOBAL uint64_t* pre = (const CLIPPER_GLOBAL uint64_t*)M.Pre + static_cast<int64_t>(cg) * M.nchunks;
+    SliceHead<1> cur;
+    int k = k0 + wave;
+    if (k <= k1) cur.load(data + 16 * pre[k], lane);
+    for (; k <= k1; k += AT_WAVES) {  // (wave-uniform)
+      SliceHead<1> nxt = cur;
+      if (k + AT_WAVES <= k1) nxt.load(data + 16 * pre[k + AT_WAVES], lane);
+      const int64_t r0 = static_cast<int64_t>(k) * SL_SUB;
+      const int maxq = __builtin_amdgcn_readfirstlane(cur.maxq);
+      const int tot = cur.nq[0];
+      gbytes_t fbase = cur.sp + 16 + 64 + sl_so_bytes(maxq);
+      for (int qb = 0; qb < maxq; qb += FILT_D) {
+        SliceQuad<VT> vq[FILT_D];
+        uint32_t rq[FILT_D];
 #pragma unroll
-    for (int e = 0; e < CPL; ++e) {
-      const int cg = J * CPL + e;
-      if (cg >= M.ncg) continue;
-      SliceHead<1> hd;
-      hd.load(static_cast<gbytes_t>((gbytes_t)M.data + 16 * M.Pre[static_cast<int64_t>(cg) * M.nchunks + k]), lane);
-      const int maxq = __builtin_amdgcn_readfirstlane(hd.maxq);
-      const int tot = hd.nq[0];
-      gbytes_t fbase = hd.sp + 16 + 64 + sl_so_bytes(maxq);
-      for (int q = 0; q < maxq; ++q) {
-        const bool active = q < tot;
-        const uint64_t mask = __ballot(active);
-        const int cnt = __popcll(mask);
-        if (active) {
-          const uint32_t rank = sl_lane_rank(mask);
-          SliceQuad<VT> vq;
-          vq.load(fbase + rank * QB);
-          const uint32_t rq = *reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(fbase + cnt * QB + rank * 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (vq.v[j] != VT(0)) {
-              const int64_t vr = static_cast<int64_t>(G.viewpos[r0 + ((rq >> (8 * j)) & 255u)]) - v0;
-              if (vr >= 0 && vr < AT) {  // (-1 - v0 < 0: a row outside the view)
-                const int cl = 64 * e + lane;
-                img[vr * PITCH + cl] = vq.v[j];
-                atomicOr(&colmask[cl * 4 + (static_cast<int>(vr) >> 5)], 1u << (static_cast<int>(vr) & 31));
-              }
-            }
+        for (int j = 0; j < FILT_D; ++j) {
+          const bool active = qb + j < tot;
+          const uint64_t mask = __ballot(active);
+          const int cnt = __builtin_amdgcn_readfirstlane(__popcll(mask));
+          const uint32_t rank = active ? sl_lane_rank(mask) : 0u;
+          vq[j].load(fbase + rank * QB);
+          rq[j] = *reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(fbase + cnt * QB + rank * 4);
+          fbase += cnt * QB + ((cnt * 4 + 15) & ~15);
         }
-        fbase += cnt * QB + ((cnt * 4 + 15) & ~15);
+#pragma unroll
+        for (int j = 0; j < FILT_D; ++j) {
+          if (qb + j < tot) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (vq[j].v[e] != VT(0)) {
+                const int64_t vr = static_cast<int64_t>(G.viewpos[r0 + ((rq[j] >> (8 * e)) & 255u)]) - v0;
+                if (vr >= 0 && vr < AT) {  // (-1 - v0 < 0: a row outside the view)
+                  img[vr * PITCH + lane] = vq[j].v[e];
+                  atomicOr(&colmask[lane * 4 + (static_cast<int>(vr) >> 5)], 1u << (static_cast<int>(vr) & 31));
+                }
+              }
+          }
+        }
       }
+      cur = nxt;
     }
   }
   __syncthreads();
-  // ---- the tile's CPL slices (column group J * CPL + e, chunk I), two waves per slice: as k_affinity_rect
-  unsigned long long* base_s = reinterpret_cast<unsigned long long*>(filt_smem + rect_img_bytes<VT>());
+  // ---- the tile's slice (column group cg, chunk I), written by waves 0 and 4 as the two halves --------
   const int sl = wave & 3, half = wave >> 2;
-  const int e = sl < CPL ? sl : 0;
-  const VT* col = img + 64 * e + lane;
-  const uint4 mk = *reinterpret_cast<const uint4*>(colmask + (64 * e + lane) * 4);
+  const VT* col = img + lane;
+  const uint4 mk = *reinterpret_cast<const uint4*>(colmask + lane * 4);
   const uint64_t mlo = static_cast<uint64_t>(mk.x) | (static_cast<uint64_t>(mk.y) << 32);
   const uint64_t mhi = static_cast<uint64_t>(mk.z) | (static_cast<uint64_t>(mk.w) << 32);
-  const int cg = J * CPL + e;
-  const int64_t s = (sl < CPL && cg < O.ncg && I < O.nchunks) ? static_cast<int64_t>(cg) * O.nchunks + I : -1;
+  const int64_t s = (sl == 0 && cg < O.ncg && I < O.nchunks) ? static_cast<int64_t>(cg) * O.nchunks + I : -1;
   slice_emit_lds<VT>(col, PITCH, mlo, mhi, s, sl, half, O, base_s, nullptr);
 }
 
