@@ -101,7 +101,8 @@ int launch_filter(Ctx* h, Shard& s, const int32_t* rowmap, const int32_t* viewpo
 }
 
 // How a view is built. Scored again from the staged points (k_affinity_rect) where the matrix was scored
-// from points: measured 1.8 x faster than the filter at every size (profiles/r03_view_by_filter.txt).
+// from points: its cost falls with the rows, the filter always reads all of M (profiles/r03_view_by_filter.txt:
+// the small views late in a solve are 2 x cheaper scored again, the large first one about the same).
 // Filtered out of M's own slices (k_slice_filter_rows) where there are no points — matrices handed over
 // with setMatrixData / setSparseMatrixData, custom invariants — which had no views before.
 // CLIPPER_HIP_RV_BUILD = filter: always the filter; rectfill: the rectangular fill under the filter's cost
@@ -202,10 +203,10 @@ ViewPolicy rowview_policy(const Ctx* h) {
   const double bytes = csc_single(h) ? static_cast<double>(h->sh[0].s_bytes)
                                      : h->total_slice_bytes / static_cast<double>(std::max(1, h->world));
   p.pass_per_row = bytes / static_cast<double>(h->m) / 3.3e12;
-  if (rowview_cost_of_filter(h)) {  // one read of the shard's slices whatever the rows (0.55 TB/s measured:
-                                    // the walk is latency-bound) + what the rows' slices take to write
-    p.build_fixed = (100e-6 + bytes / 0.55e12) * scale_env;
-    p.build_per_row = static_cast<double>(h->W) * 1.0e-12 * scale_env;
+  if (rowview_cost_of_filter(h)) {  // one read of the shard's slices whatever the rows + the rows' slices written:
+                                    // 1.1 TB/s over both, measured (profiles/r03_view_by_filter.txt)
+    p.build_fixed = (100e-6 + bytes / 1.1e12) * scale_env;
+    p.build_per_row = bytes / static_cast<double>(h->m) / 1.1e12 * scale_env;
   } else {
     p.build_fixed = 60e-6 * scale_env;
     p.build_per_row = static_cast<double>(h->W) * 4.5e-12 * scale_env;  // (a shard fills its own columns of the rows)
