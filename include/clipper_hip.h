@@ -266,10 +266,12 @@ int clipper_hip_last_solver(const clipper_hip_t* h);
 /* The row view. Row r of every line-search candidate max(u + alpha g, 0) (clipper.cpp:235-236) is
  * exactly zero unless u[r] > 0 or g[r] > 0, and such a row adds exact zeros to M x: once the
  * projected gradient ascent has driven most of u to zero (a few iterations on registration data)
- * a pass needs only the rows that are still live. On the scorePairwiseConsistency path (one
- * device, slices, built-in invariant) the solver then builds the slices of M[live rows, :] from the
- * staged points and streams THOSE while the device-side check "no live row outside the view" holds;
- * any pass for which it does not hold streams M itself. Same trial sequence, same sums up to the
+ * a pass needs only the rows that are still live. With M in slices (C == pattern(M)) the solver then
+ * builds the slices of M[live rows, :] — scored again from the staged points on the
+ * scorePairwiseConsistency path with a built-in invariant, filtered out of M's own slices for a
+ * matrix that was handed over (setMatrixData / setSparseMatrixData, custom invariants) — and
+ * streams THOSE while the device-side check "no live row outside the view" holds; any pass for
+ * which it does not hold streams M itself. Same trial sequence, same sums up to the
  * order of the partial sums. mode 0 = automatic, 1 = never (also: CLIPPER_HIP_ROW_VIEW=0). */
 int clipper_hip_set_row_view(clipper_hip_t* h, int mode);
 int clipper_hip_get_view_stats(const clipper_hip_t* h, clipper_hip_view_stats_t* out);
