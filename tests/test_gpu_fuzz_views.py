@@ -76,7 +76,7 @@ def test_fuzz_row_views_against_the_oracle():
     lines.append(f"{N_VIEWS} cases, seed {SEED}: {len(failures)} failures, {with_views} solves ran passes on a view")
     _log("fuzz_views.log", lines)
     assert not failures, "\n".join(failures)
-    assert with_views * 2 >= N_VIEWS, lines[-1]
+    assert with_views * 3 >= N_VIEWS, lines[-1]   # (coverage of the fuzz itself: a third of the solves at least used a view)
 
 
 def test_fuzz_exact_dsd_rounding_against_the_oracle():
