@@ -95,6 +95,16 @@ int main(int argc, char** argv) {
       check(W, k, n, "two clusters", r);
     }
   }
+  // 6. weights far above 1 (a caller's own matrix): sink capacities m/2 + 2g - degree go negative
+  for (int r = 0; r < reps; ++r) {
+    const int k = 2 + static_cast<int>(rng() % 24);
+    std::vector<double> W(static_cast<size_t>(k) * k, 0.0);
+    const double wmax = 1.0 + 40.0 * U(rng);
+    for (int a = 0; a < k; ++a)
+      for (int b = a + 1; b < k; ++b)
+        if (U(rng) < 0.6) sym(W, k, a, b, wmax * U(rng));
+    check(W, k, totals[r % 4] ? totals[r % 4] : k, "heavy weights", r);
+  }
   // degenerate inputs
   for (int k = 2; k <= 5; ++k) {
     std::vector<double> Z(static_cast<size_t>(k) * k, 0.0);
