@@ -637,9 +637,19 @@ int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32
   nodes.clear();
   const int k = static_cast<int>(S.size());
   if (k < 2) return 0;
-  std::vector<double> Wsub(static_cast<size_t>(k) * k, 0.0), tmp(static_cast<size_t>(k) * k);
-  // position of every node in the list; a list that names a node twice is gathered by index
-  std::vector<int32_t> pos(static_cast<size_t>(h->m), -1);
+  // k x k doubles on the host (twice while the shards' parts are added, once more inside the flow) and
+  // on the device: a list of 100 000 nodes would ask for 80 GB each — refused, not thrown
+  std::vector<double> Wsub, tmp;
+  std::vector<int32_t> pos;
+  try {
+    Wsub.assign(static_cast<size_t>(k) * k, 0.0);
+    tmp.resize(static_cast<size_t>(k) * k);
+    pos.assign(static_cast<size_t>(h->m), -1);  // position of every node in the list
+  } catch (const std::bad_alloc&) {
+    return fail(CLIPPER_HIP_E_NOMEM, "densest subgraph of %d nodes: %.1f GB of host memory per copy of the sub-matrix", k,
+                static_cast<double>(k) * k * 8e-9);
+  }
+  // a list that names a node twice is gathered by index
   bool listed_once = true;
   for (int a = 0; a < k; ++a) {
     int32_t& p = pos[static_cast<size_t>(S[static_cast<size_t>(a)])];
@@ -689,7 +699,12 @@ int densest_subgraph_of(Ctx* h, const std::vector<int32_t>& S, std::vector<int32
   if (h->csc_valid) drop_dense(h);  // a copy materialised for this gather only: M lives in the slices
   const auto t1 = std::chrono::high_resolution_clock::now();
   int flows = 0;
-  for (int32_t a : dsd::densest_subgraph(Wsub, k, h->m, &flows)) nodes.push_back(S[static_cast<size_t>(a)]);
+  tmp = std::vector<double>();  // (the flow's residual matrix takes its place)
+  try {
+    for (int32_t a : dsd::densest_subgraph(Wsub, k, h->m, &flows)) nodes.push_back(S[static_cast<size_t>(a)]);
+  } catch (const std::bad_alloc&) {
+    return fail(CLIPPER_HIP_E_NOMEM, "densest subgraph of %d nodes: the flow network does not fit the host's memory", k);
+  }
   if (std::getenv("CLIPPER_HIP_HOST_TIMING"))
     std::fprintf(stderr, "[dsd] k = %d: gather (%s) %.2f ms, host %.2f ms, %d maximum flows%s, %zu nodes\n", k,
                  from_slices ? "slices" : "dense store", std::chrono::duration<double, std::milli>(t1 - t0).count(),
