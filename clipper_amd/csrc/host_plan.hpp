@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace clipper_plan {
@@ -52,11 +53,21 @@ inline void plan_pass(const uint32_t* L, int ncg, int nchunks, const PassConsts&
   }
   // (this runs between the fill and the first pass of every build: buffers are kept, the order is a
   // counting sort)
+  // What a chunk of a strip costs: the longest of its waves' chains of lock-step steps (the latency
+  // view), blended with the entries its slices hold (the bytes view: entries / 256 = steps with every
+  // lane busy, x 2 for the usual lock-step efficiency) by CLIPPER_HIP_PLAN_ENTRY_WEIGHT in [0, 1]
+  // (0: steps only — the default; measurement knob, profiles/r03_plan_cost_model.txt)
+  static const double entry_weight = [] {
+    const char* e = std::getenv("CLIPPER_HIP_PLAN_ENTRY_WEIGHT");
+    return e ? std::min(1.0, std::max(0.0, std::atof(e))) : 0.0;
+  }();
   static thread_local std::vector<int> cost;
+  static thread_local std::vector<double> bcost;
   static thread_local std::vector<Work> items;
   static thread_local std::vector<double> key;
   static thread_local std::vector<int> nslot_of;
   cost.resize(static_cast<size_t>(nstrips) * nchunks);
+  bcost.assign(static_cast<size_t>(nstrips) * nchunks, 0.0);
   double total = 0.0;
   uint64_t entries = 0;
   for (int st = 0; st < nstrips; ++st) {
@@ -69,9 +80,14 @@ inline void plan_pass(const uint32_t* L, int ncg, int nchunks, const PassConsts&
         const uint32_t v = lrow[k];
         crow[k] = std::max(crow[k], static_cast<int>(v & 255u));
         entries += v >> 8;
+        bcost[static_cast<size_t>(st) * nchunks + k] += static_cast<double>(v >> 8);
       }
     }
-    for (int k = 0; k < nchunks; ++k) total += crow[k] + C0;
+    for (int k = 0; k < nchunks; ++k) {
+      double& b = bcost[static_cast<size_t>(st) * nchunks + k];
+      b = (1.0 - entry_weight) * crow[k] + entry_weight * (b / (256.0 * w1) * 2.0);  // the chunk's blended cost
+      total += b + C0;
+    }
   }
   out.entries = entries;
   const double T = std::max(8.0, total / target);
@@ -92,9 +108,10 @@ inline void plan_pass(const uint32_t* L, int ncg, int nchunks, const PassConsts&
       acc = 0.0;
     };
     const int* crow = cost.data() + static_cast<size_t>(st) * nchunks;
+    const double* brow = bcost.data() + static_cast<size_t>(st) * nchunks;
     for (int k = 0; k < nchunks; ++k) {
       const int mq = crow[k];
-      const double c = mq + C0;
+      const double c = brow[k] + C0;
       if (c > 1.5 * T && mq >= 2 * K.so) {
         // a dense block's chunk: a chain of steps several times the average — cut by step range
         flush(k);
