@@ -33,6 +33,9 @@
 #include <type_traits>
 #include <utility>
 #include <map>
+#include <mutex>
+#include <new>
+#include <exception>
 #include <vector>
 
 #include "../../include/clipper_hip.h"
@@ -68,30 +71,32 @@ int knn_run(const double* dP0, int64_t n0, const double* dP1, int64_t n1, int S,
 
 extern "C" {
 
-const char* clipper_hip_last_error(void) { return g_err.c_str(); }
+const char* clipper_hip_last_error(void) try {
+  return g_err.c_str();
+} CLIPPER_HIP_GUARD_STR
 
-int clipper_hip_device_count(void) {
+int clipper_hip_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
   return n;
-}
+} CLIPPER_HIP_GUARD_INT
 
-clipper_hip_t* clipper_hip_create(int device, int storage) {
+clipper_hip_t* clipper_hip_create(int device, int storage) try {
   return make_ctx(&device, 1, storage, 1, 0, false);
-}
+} CLIPPER_HIP_GUARD_PTR
 
-clipper_hip_t* clipper_hip_create_group(const int* devices, int nshards, int storage) {
+clipper_hip_t* clipper_hip_create_group(const int* devices, int nshards, int storage) try {
   if (!devices || nshards < 1) {
     fail(CLIPPER_HIP_E_INVALID, "invalid shard list");
     return nullptr;
   }
   return make_ctx(devices, nshards, storage, nshards, 0, false);
-}
+} CLIPPER_HIP_GUARD_PTR
 
-clipper_hip_t* clipper_hip_create_rank(int device, int storage, int rank, int world) {
+clipper_hip_t* clipper_hip_create_rank(int device, int storage, int rank, int world) try {
   if (world < 1 || rank < 0 || rank >= world) {
     fail(CLIPPER_HIP_E_INVALID, "rank %d / world %d invalid", rank, world);
     return nullptr;
@@ -101,9 +106,9 @@ clipper_hip_t* clipper_hip_create_rank(int device, int storage, int rank, int wo
   const char* force = std::getenv("CLIPPER_HIP_FORCE_RCCL");
   const bool multiproc = world > 1 || (force && force[0] == '1');
   return make_ctx(&device, 1, storage, world, rank, multiproc);
-}
+} CLIPPER_HIP_GUARD_PTR
 
-int clipper_hip_comm_unique_id(void* id128) {
+int clipper_hip_comm_unique_id(void* id128) try {
   if (!id128) return fail(CLIPPER_HIP_E_INVALID, "null id buffer");
   int rc = load_rccl();
   if (rc) return rc;
@@ -113,9 +118,9 @@ int clipper_hip_comm_unique_id(void* id128) {
   if (r != ncclSuccess) return fail(CLIPPER_HIP_E_COMM, "ncclGetUniqueId failed (%d)", (int)r);
   std::memcpy(id128, &id, sizeof(id));
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_comm_init(clipper_hip_t* h, const void* id128) {
+int clipper_hip_comm_init(clipper_hip_t* h, const void* id128) try {
   if (!h || !id128) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->multiproc) return 0;  // nothing to exchange
   int rc = load_rccl();
@@ -128,17 +133,17 @@ int clipper_hip_comm_init(clipper_hip_t* h, const void* id128) {
     return fail(CLIPPER_HIP_E_COMM, "ncclCommInitRank: %s",
                 g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_comm_init_callback(clipper_hip_t* h, clipper_hip_allgather_fn fn, void* user) {
+int clipper_hip_comm_init_callback(clipper_hip_t* h, clipper_hip_allgather_fn fn, void* user) try {
   if (!h || !fn) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->multiproc) return 0;  // nothing to exchange
   h->xchg_fn = fn;
   h->xchg_user = user;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-void clipper_hip_destroy(clipper_hip_t* h) {
+void clipper_hip_destroy(clipper_hip_t* h) try {
   if (!h) return;
   for (auto& s : h->sh) {
     hipSetDevice(s.device);
@@ -173,17 +178,17 @@ void clipper_hip_destroy(clipper_hip_t* h) {
   if (h->rv_count) hipHostFree(h->rv_count);
   if (h->rv_desc_host) hipHostFree(h->rv_desc_host);
   delete h;
-}
+} CLIPPER_HIP_GUARD_VOID
 
 // ---- affinity --------------------------------------------------------------------------
 
 int clipper_hip_stage_inputs(clipper_hip_t* h, const double* D1, int d, int64_t n1,
-                             const double* D2, int64_t n2, const int32_t* A, int64_t m) {
+                             const double* D2, int64_t n2, const int32_t* A, int64_t m) try {
   return stage_inputs(h, D1, d, n1, D2, n2, A, m);
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double epsilon,
-                                          double mindist, double affinityeps) {
+                                          double mindist, double affinityeps) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (h->staged_d < 1) return fail(CLIPPER_HIP_E_STATE, "clipper_hip_stage_inputs not called");
   const EuclidParams prm{sigma, epsilon, mindist, affinityeps};
@@ -240,10 +245,10 @@ int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double
 #undef LAUNCH_EUCLID_COMPACT
 #undef LAUNCH_EUCLID
   });
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, double epsp,
-                                            double sign, double epsn, double affinityeps) {
+                                            double sign, double epsn, double affinityeps) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (h->staged_d != 6)
     return fail(CLIPPER_HIP_E_STATE, "PointNormalDistance needs staged inputs with d == 6");
@@ -288,12 +293,12 @@ int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, doubl
                            s.P1f, s.P2f, pstride, s.Adev, s.Adev + mm, prm, thr);
     }
   });
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_affinity_euclidean(clipper_hip_t* h, const double* D1, int d, int64_t n1,
                                    const double* D2, int64_t n2, const int32_t* A, int64_t m,
                                    double sigma, double epsilon, double mindist,
-                                   double affinityeps) {
+                                   double affinityeps) try {
   const auto t0 = std::chrono::high_resolution_clock::now();
   int rc = stage_inputs(h, D1, d, n1, D2, n2, A, m);
   if (rc) return rc;
@@ -303,12 +308,12 @@ int clipper_hip_affinity_euclidean(clipper_hip_t* h, const double* D1, int d, in
       std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0)
           .count();
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_affinity_pointnormal(clipper_hip_t* h, const double* D1, int d, int64_t n1,
                                      const double* D2, int64_t n2, const int32_t* A, int64_t m,
                                      double sigp, double epsp, double sign, double epsn,
-                                     double affinityeps) {
+                                     double affinityeps) try {
   if (d != 6) return fail(CLIPPER_HIP_E_INVALID, "PointNormalDistance needs d == 6");
   const auto t0 = std::chrono::high_resolution_clock::now();
   int rc = stage_inputs(h, D1, d, n1, D2, n2, A, m);
@@ -319,21 +324,23 @@ int clipper_hip_affinity_pointnormal(clipper_hip_t* h, const double* D1, int d, 
       std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0)
           .count();
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int64_t clipper_hip_num_associations(const clipper_hip_t* h) { return h ? h->m : 0; }
+int64_t clipper_hip_num_associations(const clipper_hip_t* h) try {
+  return h ? h->m : 0;
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_get_associations(const clipper_hip_t* h, int32_t* A_out) {
+int clipper_hip_get_associations(const clipper_hip_t* h, int32_t* A_out) try {
   if (!h || !A_out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (h->A.size() != static_cast<size_t>(2 * h->m))
     return fail(CLIPPER_HIP_E_STATE, "no association list is held");
   std::memcpy(A_out, h->A.data(), h->A.size() * sizeof(int32_t));
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 // ---- matrix set / get ------------------------------------------------------------------
 
-int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, int64_t m) {
+int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, int64_t m) try {
   if (!h || !M || !C || m < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (h->A.size() != static_cast<size_t>(2 * m)) h->A.clear();
   h->nodes.clear();
@@ -433,15 +440,16 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
   if ((rc = csc_rebuild(h))) return rc;
   h->has_matrix = true;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-// setSparseMatrixData (clipper.cpp:162-166). Every stored (i, j), i != j, is an entry of the
-// symmetric matrix (either triangle; the reference reads the upper one); the diagonal is
-// implicit. With compressed storage and C == pattern(M) the slices are packed straight from the
-// lists (no dense intermediate: O(nnz) memory); otherwise through the dense store.
+// setSparseMatrixData (clipper.cpp:162-166). Every stored (i, j) with i < j stands for the symmetric
+// pair, as selfadjointView<Upper> reads it; entries below the diagonal are not read (the reference
+// never does); the diagonal is implicit. With compressed storage and C == pattern(M) the slices
+// are packed straight from the lists (no dense intermediate: O(nnz) memory); otherwise through the
+// dense store.
 int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
                            const int32_t* Mrow, const double* Mval, const int64_t* Ccolptr,
-                           const int32_t* Crow, const double* Cval) {
+                           const int32_t* Crow, const double* Cval) try {
   if (!h || !Mcolptr || !Ccolptr || m < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   // the caller's arrays are not trusted: structure first
   auto check_csc = [&](const char* what, const int64_t* cp, const int32_t* ri, const double* va) -> int {
@@ -458,36 +466,38 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
   int rc;
   if ((rc = check_csc("M", Mcolptr, Mrow, Mval))) return rc;
   if ((rc = check_csc("C", Ccolptr, Crow, Cval))) return rc;
-  // The reference reads M_.selfadjointView<Upper>() (clipper.cpp:194-271): of a matrix handed over with
-  // BOTH triangles stored (a full symmetric SpAffinity) only the upper entries count. Here every stored
-  // off-diagonal entry stands for the symmetric pair, so a pair stored in both triangles is taken once
-  // — the upper copy, as the reference would — for every storage mode alike; a pair stored only below
-  // the diagonal keeps counting (the reference would ignore it).
+  // The reference keeps what it is handed (clipper.cpp:162-166) and reads it through
+  // selfadjointView<Eigen::Upper> (clipper.cpp:194-271): an entry BELOW the diagonal is never read — a
+  // full symmetric SpAffinity counts through its upper half, a lower-triangular one is an empty matrix —
+  // and a stored diagonal would count once on top of the implicit identity. Same here for the lower
+  // triangle (dropped, whatever it holds); the diagonal is implicit in every storage of this library, so a
+  // stored non-zero diagonal — outside the reference's own contract, clipper.h:137-138 — is refused
+  // rather than silently dropped.
   struct Csc {
     std::vector<int64_t> cp;
     std::vector<int32_t> ri;
     std::vector<double> va;
   } Mn, Cn;
-  auto upper_wins = [&](const int64_t*& cp, const int32_t*& ri, const double*& va, Csc& out) {
-    bool lower = false;
-    for (int64_t j = 0; j < m && !lower; ++j)
+  auto upper_only = [&](const char* what, const int64_t*& cp, const int32_t*& ri, const double*& va, Csc& out) -> int {
+    bool strict = true;
+    for (int64_t j = 0; j < m && strict; ++j)
       for (int64_t p = cp[j]; p < cp[j + 1]; ++p)
-        if (ri[p] > j) {
-          lower = true;
+        if (ri[p] >= j) {
+          strict = false;
           break;
         }
-    if (!lower) return;
-    std::vector<uint64_t> up;  // (row << 32 | column) of the upper entries
-    for (int64_t j = 0; j < m; ++j)
-      for (int64_t p = cp[j]; p < cp[j + 1]; ++p)
-        if (ri[p] < j) up.push_back((static_cast<uint64_t>(ri[p]) << 32) | static_cast<uint64_t>(j));
-    std::sort(up.begin(), up.end());
+    if (strict) return 0;  // (what Eigen hands over from a strictly upper matrix: nothing to copy)
     out.cp.assign(static_cast<size_t>(m) + 1, 0);
     for (int64_t j = 0; j < m; ++j) {
       for (int64_t p = cp[j]; p < cp[j + 1]; ++p) {
         const int64_t i = ri[p];
-        if (i > j && std::binary_search(up.begin(), up.end(), (static_cast<uint64_t>(j) << 32) | static_cast<uint64_t>(i)))
-          continue;  // (i, j) below the diagonal, (j, i) stored above it: the upper copy stands for the pair
+        if (i > j) continue;
+        if (i == j) {
+          if (va[p] != 0.0)
+            return fail(CLIPPER_HIP_E_INVALID, "%s: a stored diagonal entry (%lld,%lld) — the matrices must not have diagonal values set",
+                        what, static_cast<long long>(i), static_cast<long long>(j));
+          continue;
+        }
         out.ri.push_back(static_cast<int32_t>(i));
         out.va.push_back(va[p]);
       }
@@ -496,15 +506,17 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
     cp = out.cp.data();
     ri = out.ri.data();
     va = out.va.data();
+    return 0;
   };
-  upper_wins(Mcolptr, Mrow, Mval, Mn);
-  upper_wins(Ccolptr, Crow, Cval, Cn);
+  if ((rc = upper_only("M", Mcolptr, Mrow, Mval, Mn))) return rc;
+  if ((rc = upper_only("C", Ccolptr, Crow, Cval, Cn))) return rc;
   const int64_t nnzM = Mcolptr[m], nnzC = Ccolptr[m];
   if (h->A.size() != static_cast<size_t>(2 * m)) h->A.clear();
   h->nodes.clear();
   h->has_matrix = false;
   h->csc_valid = false;
-  h->fill_kind = 0;  // no points behind this matrix: no row view
+  h->total_slice_bytes = 0.0;
+  h->fill_kind = 0;  // no points behind this matrix: its row views are filtered out of its own slices
   rowview_drop(h);
   if ((rc = ensure_problem(h, m))) return rc;
   h->has_matrix = false;
@@ -630,6 +642,7 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
     }
     if ((rc = sync_all(h))) return rc;
     h->csc_valid = true;
+    if ((rc = gather_slice_bytes(h))) return rc;  // column shards: the row-view policy's cost model
     h->has_matrix = true;
     return 0;
   }
@@ -680,9 +693,9 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
   if (rc) return rc;
   h->has_matrix = true;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_get_matrix(clipper_hip_t* h, double* M_out, double* C_out) {
+int clipper_hip_get_matrix(clipper_hip_t* h, double* M_out, double* C_out) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
   if (h->multiproc)
@@ -720,11 +733,11 @@ int clipper_hip_get_matrix(clipper_hip_t* h, double* M_out, double* C_out) {
   }
   if (h->csc_valid) drop_dense(h);  // the copy was materialised for this call only: M lives in the slices
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 // ---- solver ------------------------------------------------------------------------------
 
-int clipper_hip_stage_u0(clipper_hip_t* h, const double* u0) {
+int clipper_hip_stage_u0(clipper_hip_t* h, const double* u0) try {
   if (!h || !u0) return fail(CLIPPER_HIP_E_INVALID, "u0 is required");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
   const size_t vbytes = static_cast<size_t>(h->m) * sizeof(double);
@@ -736,10 +749,10 @@ int clipper_hip_stage_u0(clipper_hip_t* h, const double* u0) {
   if (rc) return rc;
   h->u0_staged = true;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_solve(clipper_hip_t* h, const double* u0, const clipper_params_t* P,
-                      double* u_out, clipper_solve_info_t* info) {
+                      double* u_out, clipper_solve_info_t* info) try {
   if (!h || !u0 || !P) return fail(CLIPPER_HIP_E_INVALID, "u0 and params are required");
   const auto t0 = std::chrono::high_resolution_clock::now();
   int rc = clipper_hip_stage_u0(h, u0);
@@ -751,10 +764,10 @@ int clipper_hip_solve(clipper_hip_t* h, const double* u0, const clipper_params_t
   h->tm.solve_total_ms = secs * 1e3;
   if (info) info->seconds = secs;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double* u_out,
-                             clipper_solve_info_t* info) {
+                             clipper_solve_info_t* info) try {
   if (!h || !P) return fail(CLIPPER_HIP_E_INVALID, "params are required");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
   if (!h->u0_staged) return fail(CLIPPER_HIP_E_STATE, "clipper_hip_stage_u0 not called");
@@ -1038,19 +1051,19 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     }
   }
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_get_nodes(const clipper_hip_t* h, int32_t* out, int32_t capacity) {
+int clipper_hip_get_nodes(const clipper_hip_t* h, int32_t* out, int32_t capacity) try {
   if (!h || !out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   const int32_t k = static_cast<int32_t>(h->nodes.size());
   if (capacity < k) return fail(CLIPPER_HIP_E_INVALID, "capacity %d < %d nodes", capacity, k);
   if (k) std::memcpy(out, h->nodes.data(), static_cast<size_t>(k) * sizeof(int32_t));
   return k;
-}
+} CLIPPER_HIP_GUARD_INT
 
 // utils::selectInlierAssociations — utils.cpp:101-108
 int clipper_hip_get_selected_associations(const clipper_hip_t* h, int32_t* A_out,
-                                          int32_t capacity) {
+                                          int32_t capacity) try {
   if (!h || !A_out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   const int32_t k = static_cast<int32_t>(h->nodes.size());
   if (capacity < k) return fail(CLIPPER_HIP_E_INVALID, "capacity %d < %d nodes", capacity, k);
@@ -1063,10 +1076,10 @@ int clipper_hip_get_selected_associations(const clipper_hip_t* h, int32_t* A_out
     A_out[k + r] = h->A[static_cast<size_t>(h->m) + n];
   }
   return k;
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_densest_subgraph(clipper_hip_t* h, const int32_t* S, int32_t k, int32_t* nodes_out,
-                                 int32_t capacity) {
+                                 int32_t capacity) try {
   if (!h || !nodes_out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
   if (h->multiproc)
@@ -1087,12 +1100,12 @@ int clipper_hip_densest_subgraph(clipper_hip_t* h, const int32_t* S, int32_t k, 
   if (capacity < n) return fail(CLIPPER_HIP_E_INVALID, "capacity %d < %d nodes", capacity, n);
   if (n) std::memcpy(nodes_out, nodes.data(), static_cast<size_t>(n) * sizeof(int32_t));
   return n;
-}
+} CLIPPER_HIP_GUARD_INT
 
 // ---- putative associations (before the path): brute-force nearest neighbours -------------------
 
 int clipper_hip_knn(int device, const double* P0, int64_t n0, const double* P1, int64_t n1, int d,
-                    int knn, int32_t* idx_out, double* sqd_out) {
+                    int knn, int32_t* idx_out, double* sqd_out) try {
   if (!P0 || !P1 || !idx_out || n0 < 1 || n1 < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (d != 2 && d != 3) return fail(CLIPPER_HIP_E_INVALID, "points must have 2 or 3 coordinates");
   if (knn < 1 || knn > 16) return fail(CLIPPER_HIP_E_INVALID, "knn must be in 1..16");
@@ -1156,12 +1169,12 @@ int clipper_hip_knn(int device, const double* P0, int64_t n0, const double* P1, 
   cleanup();
   if (!ok) return fail(CLIPPER_HIP_E_HIP, "nearest-neighbour search failed: %s", hipGetErrorString(hipGetLastError()));
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 int64_t clipper_hip_distance_based_correspondences(int device, const double* P0, int64_t n0,
                                                    const double* P1, int64_t n1, int d, int knn,
                                                    double radius, int enforce_1to1, int32_t* A_out,
-                                                   int64_t capacity) {
+                                                   int64_t capacity) try {
   if (!A_out && capacity > 0) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   std::vector<int32_t> idx(static_cast<size_t>(std::max<int64_t>(n0, 0)) * std::max(knn, 0));
   std::vector<double> sqd(idx.size());
@@ -1199,48 +1212,52 @@ int64_t clipper_hip_distance_based_correspondences(int device, const double* P0,
     A_out[n + r] = rows[static_cast<size_t>(r)].second;
   }
   return n;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_set_window(clipper_hip_t* h, int window) {
+int clipper_hip_set_window(clipper_hip_t* h, int window) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (window != 0 && window != 1 && window != 4 && window != 6 && window != 8)
     return fail(CLIPPER_HIP_E_INVALID, "window must be 0 (automatic), 1, 4, 6 or 8");
   h->V_forced = window;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_window(const clipper_hip_t* h) { return h ? h->V : 0; }
+int clipper_hip_window(const clipper_hip_t* h) try {
+  return h ? h->V : 0;
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_set_resident(clipper_hip_t* h, int mode) {
+int clipper_hip_set_resident(clipper_hip_t* h, int mode) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (mode != 0 && mode != 1) return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic) or 1 (never)");
   h->resident_mode = mode;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_last_solver(const clipper_hip_t* h) { return h ? h->last_solver : -1; }
+int clipper_hip_last_solver(const clipper_hip_t* h) try {
+  return h ? h->last_solver : -1;
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_set_row_view(clipper_hip_t* h, int mode) {
+int clipper_hip_set_row_view(clipper_hip_t* h, int mode) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (mode != 0 && mode != 1) return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic) or 1 (never)");
   h->rv_mode = mode;
   if (mode == 1) rowview_drop(h);
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_get_view_stats(const clipper_hip_t* h, clipper_hip_view_stats_t* out) {
+int clipper_hip_get_view_stats(const clipper_hip_t* h, clipper_hip_view_stats_t* out) try {
   if (!h || !out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   *out = h->rv_stats;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_storage_in_use(const clipper_hip_t* h) {
+int clipper_hip_storage_in_use(const clipper_hip_t* h) try {
   if (!h) return -1;
   if (!h->csc_valid) return h->storage;
   return h->storage == CLIPPER_HIP_STORE_F64 ? CLIPPER_HIP_STORE_F64_CSC : CLIPPER_HIP_STORE_F32_CSC;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC) {
+int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC) try {
   if (!h || !x) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
   const int64_t m = h->m, W = h->W;
@@ -1268,7 +1285,7 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
     if (yC) yC[i] = ab[static_cast<size_t>(p * 2 * W + W + off)];
   }
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 // The products of clipper_hip_matvec through a ROW VIEW of the given rows: yM = M_off[:, rows] x[rows],
 // yC likewise — what a pass of the solver computes when it streams the view instead of M. Builds the
@@ -1276,7 +1293,7 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
 // solve is built anew). For tests: equal to clipper_hip_matvec of x with every other entry zeroed, up
 // to the order of the partial sums.
 int clipper_hip_view_matvec(clipper_hip_t* h, const int32_t* rows, int64_t nrows, const double* x,
-                            double* yM, double* yC) {
+                            double* yM, double* yC) try {
   if (!h || !rows || !x || nrows < 1) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->has_matrix || !h->csc_valid || !csc_single(h) || !rect_fill_possible(h))
     return fail(CLIPPER_HIP_E_STATE, "a row view needs slices of a matrix scored from staged points on one device");
@@ -1338,11 +1355,11 @@ int clipper_hip_view_matvec(clipper_hip_t* h, const int32_t* rows, int64_t nrows
     if (yC) yC[i] = ab[static_cast<size_t>(W + i)];
   }
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 // ---- measurement ---------------------------------------------------------------------------
 
-int clipper_hip_set_profiling(clipper_hip_t* h, int on) {
+int clipper_hip_set_profiling(clipper_hip_t* h, int on) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   h->profiling = (on != 0);
   if (h->profiling && h->ev_pairs.empty()) {  // here, not inside the first profiled solve (~1 ms)
@@ -1355,15 +1372,15 @@ int clipper_hip_set_profiling(clipper_hip_t* h, int on) {
     for (auto& e : h->ev_xchg) HIPCHK(hipEventCreate(&e));
   }
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_get_timings(const clipper_hip_t* h, clipper_hip_timings_t* out) {
+int clipper_hip_get_timings(const clipper_hip_t* h, clipper_hip_timings_t* out) try {
   if (!h || !out) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   *out = h->tm;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
+int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) try {
   if (!h || reps < 1 || !avg_us) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->has_matrix) return fail(CLIPPER_HIP_E_STATE, "no matrix has been built or set");
   if (!h->csc_valid)
@@ -1385,9 +1402,9 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) {
   *avg_us = static_cast<double>(ms) * 1e3 / reps;
   h->tm.gemv_bytes = algorithmic_gemv_bytes(h, /*dense=*/!h->csc_valid);
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_debug_stamps(clipper_hip_t* h, int64_t* out, int capacity) {
+int clipper_hip_debug_stamps(clipper_hip_t* h, int64_t* out, int capacity) try {
   if (!h || !out || capacity < 0) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->stamps_dev) return fail(CLIPPER_HIP_E_STATE, "CLIPPER_HIP_STAMPS was not set when the context was created");
   const int n = std::min(capacity, 4096 * 4);
@@ -1395,9 +1412,9 @@ int clipper_hip_debug_stamps(clipper_hip_t* h, int64_t* out, int capacity) {
   HIPCHK(hipStreamSynchronize(h->sh[0].stream));
   HIPCHK(hipMemcpy(out, h->stamps_dev, static_cast<size_t>(n) * sizeof(long long), hipMemcpyDeviceToHost));
   return n;
-}
+} CLIPPER_HIP_GUARD_INT
 
-int clipper_hip_device_info(const clipper_hip_t* h, char* name64, int* cus, int64_t* hbm_bytes) {
+int clipper_hip_device_info(const clipper_hip_t* h, char* name64, int* cus, int64_t* hbm_bytes) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, h->sh[0].device));
@@ -1407,6 +1424,6 @@ int clipper_hip_device_info(const clipper_hip_t* h, char* name64, int* cus, int6
   if (cus) *cus = prop.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = static_cast<int64_t>(prop.totalGlobalMem);
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 }  // extern "C"

@@ -417,10 +417,13 @@ int slices_check(Ctx* h, Shard& s, bool with_groups, bool& again) {
   return slices_plan(h, s);  // the caller declares the slices valid once every shard has them
 }
 
+int gather_slice_bytes(Ctx* h);
+
 // groups from the dense store(s) + pack + wait + plan: the setMatrixData paths, and every fill
 // that went through a dense store. Shard by shard (the pinned staging is shared).
 int csc_rebuild(Ctx* h) {
   h->csc_valid = false;
+  h->total_slice_bytes = 0.0;
   if (!csc_applies(h)) return 0;
   int rc = 0;
   dispatch_vt(h, [&](auto t) {
@@ -450,7 +453,8 @@ int csc_rebuild(Ctx* h) {
   if (rc) return rc;
   h->csc_valid = true;
   drop_dense(h);  // M lives in the slices from here on (getters materialise a dense copy on demand)
-  return sync_all(h);
+  if ((rc = sync_all(h))) return rc;
+  return gather_slice_bytes(h);  // column shards: the row-view policy's cost model is about THIS matrix
 }
 
 bool rect_fill_possible(const Ctx* h);
@@ -516,6 +520,7 @@ template <typename Launch>
 int run_affinity(Ctx* h, bool emits, Launch launch) {
   h->has_matrix = false;  // until the build has succeeded (a failed rebuild leaves no matrix)
   h->csc_valid = false;
+  h->total_slice_bytes = 0.0;  // (column shards: gathered again once this build's slices exist)
   for (auto& s : h->sh) s.rv.valid = false;  // a row view of the previous matrix
   h->nodes.clear();
   // explicit constraint storage is not needed on this path: C == pattern(M)

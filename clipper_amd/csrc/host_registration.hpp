@@ -219,7 +219,7 @@ void rotation_from_cross_covariance(const double H[9], double R[9]) {
 
 extern "C" {
 
-int64_t clipper_hip_read_ply_xyz(const char* path, double* pts_out, int64_t capacity) {
+int64_t clipper_hip_read_ply_xyz(const char* path, double* pts_out, int64_t capacity) try {
   if (!path) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   std::vector<double> pts;
   int64_t n = 0;
@@ -233,12 +233,12 @@ int64_t clipper_hip_read_ply_xyz(const char* path, double* pts_out, int64_t capa
   // column-major 3 x n (clipper::invariants::Data): datum i = pts_out[3 i .. 3 i + 2]
   std::memcpy(pts_out, pts.data(), pts.size() * sizeof(double));
   return n;
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_generate_synthetic_correspondences(int64_t n0, int64_t n1, const int32_t* Agood,
                                                    int64_t p, int64_t m, double rho, uint64_t seed,
                                                    int32_t* A_out, int32_t* Agt_out,
-                                                   int64_t* ni_out) {
+                                                   int64_t* ni_out) try {
   if (n0 < 1 || n1 < 1 || m < 1 || p < 0 || (p > 0 && !Agood) || !A_out || !Agt_out)
     return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!(rho >= 0.0 && rho <= 1.0)) return fail(CLIPPER_HIP_E_INVALID, "outlier ratio must be in [0, 1]");
@@ -283,10 +283,10 @@ int clipper_hip_generate_synthetic_correspondences(int64_t n0, int64_t n1, const
   }
   if (ni_out) *ni_out = ni;
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_precision_recall(const int32_t* A, int64_t na, const int32_t* Agt, int64_t ngt,
-                                 double* precision, double* recall) {
+                                 double* precision, double* recall) try {
   if (!precision || !recall || na < 0 || ngt < 0 || (na > 0 && !A) || (ngt > 0 && !Agt))
     return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   *precision = *recall = 0.0;
@@ -298,10 +298,10 @@ int clipper_hip_precision_recall(const int32_t* A, int64_t na, const int32_t* Ag
   *precision = static_cast<double>(TP) / static_cast<double>(na);
   *recall = static_cast<double>(TP) / static_cast<double>(ngt);
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_estimate_rigid_transform(const double* D1, int64_t n1, const double* D2, int64_t n2,
-                                         const int32_t* A, int64_t k, double* T_out) {
+                                         const int32_t* A, int64_t k, double* T_out) try {
   if (!D1 || !D2 || !A || !T_out || k < 3)
     return fail(CLIPPER_HIP_E_INVALID, "at least 3 associations and non-null arguments are needed");
   double cp[3] = {0, 0, 0}, cq[3] = {0, 0, 0};
@@ -337,6 +337,6 @@ int clipper_hip_estimate_rigid_transform(const double* D1, int64_t n1, const dou
     T_out[3 * 4 + r] = t;
   }
   return 0;
-}
+} CLIPPER_HIP_GUARD_INT
 
 }  // extern "C"

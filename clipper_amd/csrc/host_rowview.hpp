@@ -19,12 +19,7 @@ template <typename K>
 void launch_rect_kernel(K kernel, int lds_bytes, dim3 grid, hipStream_t stream, const RectGeom& G,
                         const Shard& s, int64_t pstride, const int32_t* A0, const int32_t* A1,
                         const EuclidParams& e, const PointNormalParams& n, float E2, const SliceOut& O) {
-  static std::vector<const void*> raised;  // once per kernel instantiation
-  const void* fn = reinterpret_cast<const void*>(kernel);
-  if (std::find(raised.begin(), raised.end(), fn) == raised.end()) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    raised.push_back(fn);
-  }
+  raise_dynamic_lds(reinterpret_cast<const void*>(kernel), s.device, lds_bytes);
   hipLaunchKernelGGL(kernel, grid, dim3(AT_WAVES * 64), lds_bytes, stream, G, s.P1, s.P2, s.P1f, s.P2f,
                      pstride, A0, A1, e, n, E2, O);
 }
@@ -84,12 +79,7 @@ int launch_filter(Ctx* h, Shard& s, const int32_t* rowmap, const int32_t* viewpo
     const int64_t ntiles = nTr * G.nTc;
     constexpr int64_t PER_LAUNCH = int64_t(1) << 22;  // x 512 threads < 2^32 work-items per dispatch
     constexpr int L = filt_lds_bytes<VT>();
-    static bool raised = false;  // (per instantiation)
-    if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_slice_filter_rows<VT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, L);
-      raised = true;
-    }
+    raise_dynamic_lds(reinterpret_cast<const void*>(k_slice_filter_rows<VT>), s.device, L);
     for (int64_t t0 = 0; t0 < ntiles; t0 += PER_LAUNCH) {
       G.tile0 = t0;
       const dim3 grid(static_cast<unsigned>(std::min<int64_t>(PER_LAUNCH, ntiles - t0)));
@@ -291,11 +281,19 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   const double rows_now = v.valid ? static_cast<double>(v.nrows) : static_cast<double>(m);
   // the union over the pending outcomes may be larger than the live count the decision asked with:
   // the same cost model, now with the rows the view would really have (a function of the state alone)
-  const ViewPolicy pol = rowview_policy(h);
-  const double horizon = std::max<double>(12.0, static_cast<double>(h->mirror->iters));
-  if (nrows == 0 || static_cast<double>(nrows) > 0.85 * rows_now ||
-      pol.build_fixed + pol.build_per_row * static_cast<double>(nrows) >
-          horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row) {
+  // (the predicate of view_wanted, k_solver.hip.h — same threshold, same horizon: the deciding iteration
+  // counted itself, the progress record holds the one before it — so the two sides only disagree if the
+  // row count itself differs from the live count the decision asked with)
+  // The device asked (view_wanted, k_solver.hip.h) with the live count its tail summed; the list just
+  // built is the same set, so the count agrees and the request stands as it is. Only if it does not
+  // (it never has) is the same cost model evaluated again with the rows the view would really have.
+  const ViewPolicy pol = h->rvp;
+  const double horizon = std::max<double>(12.0, static_cast<double>(h->mirror->iters + 1));
+  const bool as_asked = nrows > 0 && nrows == static_cast<int64_t>(h->mirror->hold_nlive);
+  if (!as_asked &&
+      (nrows == 0 || static_cast<double>(nrows) > RV_ROWS_RATIO * rows_now ||
+       pol.build_fixed + pol.build_per_row * static_cast<double>(nrows) >=
+           horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row)) {
     hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows));
     h->rv_stats.build_ms +=
         std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -330,6 +328,9 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
     std::atomic_thread_fence(std::memory_order_seq_cst);
     hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(64), 0, s.stream, reinterpret_cast<const uint4*>(h->rv_desc_host_dev),
                        reinterpret_cast<uint4*>(v.desc), static_cast<int64_t>(sizeof(SliceView) / 16));
+    // the pinned staging slot is the context's: the copy has to be through before the next shard of an
+    // in-process group writes ITS descriptor there
+    if (h->sh.size() > 1) HIPCHK(hipStreamSynchronize(s.stream));
   }
   hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0);
   h->rv_stats.build_ms +=

@@ -7,6 +7,7 @@ namespace {
 using Ctx = clipper_hip_ctx;
 
 void rowview_free(Shard& s);
+void rowview_drop(Ctx* h);
 
 int free_shard_buffers(Shard& s) {
   hipSetDevice(s.device);
@@ -667,6 +668,12 @@ int stage_inputs(Ctx* h, const double* D1, int d, int64_t n1, const double* D2, 
                   static_cast<long long>(r), a0, a1);
   }
   h->nodes.clear();
+  // The point tables are about to be replaced. A matrix that is still held was scored from the OLD
+  // points: a row view of it must no longer be re-scored from what is staged (it would mix two point
+  // sets, and the device-side coverage check looks at rows, not at values) — from here on it is
+  // viewed through the filter of its own slices, until an affinity call scores the new points.
+  h->fill_kind = 0;
+  rowview_drop(h);
   int rc = ensure_problem(h, m);
   if (rc) return rc;
   const int64_t pstride = round_up(m, 64);
@@ -710,17 +717,30 @@ bool use_sym_fill(const Ctx* h) {
          h->storage == CLIPPER_HIP_STORE_F32;
 }
 
+// Kernels that need more dynamic LDS than the 64 KiB a kernel gets by default: the attribute is
+// per (function, device) — contexts on distinct devices each raise it, concurrent contexts do not
+// race on the record. Returns false if the device refuses (the launch that follows then fails and is
+// reported by the caller's launch check).
+bool raise_dynamic_lds(const void* fn, int device, int bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> raised;
+  std::lock_guard<std::mutex> lock(mu);
+  const std::pair<const void*, int> key{fn, device};
+  if (std::find(raised.begin(), raised.end(), key) != raised.end()) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  raised.push_back(key);
+  return true;
+}
+
 // k_affinity_sym needs more dynamic LDS than the 64 KiB a kernel gets by default
 template <typename K>
 void launch_sym(K kernel, dim3 grid, hipStream_t stream, float* S, int64_t W, int64_t mm, int nT,
                 const Shard& s, int64_t pstride, const int32_t* A0, const int32_t* A1,
                 const EuclidParams& e, const PointNormalParams& n, float E2, const CscOut& O) {
-  static std::vector<const void*> raised;  // once per kernel instantiation and device
-  const void* fn = reinterpret_cast<const void*>(kernel);
-  if (std::find(raised.begin(), raised.end(), fn) == raised.end()) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, AT_SYM_LDS_BYTES);
-    raised.push_back(fn);
-  }
+  raise_dynamic_lds(reinterpret_cast<const void*>(kernel), s.device, AT_SYM_LDS_BYTES);
   hipLaunchKernelGGL(kernel, grid, dim3(AT_WAVES * 64), AT_SYM_LDS_BYTES, stream, S, W, mm, nT, s.P1, s.P2,
                      s.P1f, s.P2f, pstride, A0, A1, e, n, E2, O);
 }

@@ -16,6 +16,31 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// ---- no exception crosses the C ABI (SURVEY 8b "Error conventions") -------------------------------
+// Every entry point is a function-try-block closed by one of these: std::bad_alloc (host vectors sized by
+// the caller's nnz / m / k) becomes CLIPPER_HIP_E_NOMEM, anything else CLIPPER_HIP_E_INTERNAL, with the
+// message in clipper_hip_last_error(). tests/test_abi_exports.py scans the sources for the pairing.
+int guard_fail(int code, const char* what) noexcept {
+  try {
+    g_err = what;
+  } catch (...) {  // (even the message may not allocate: the code alone goes back)
+  }
+  return code;
+}
+#define CLIPPER_HIP_GUARD_CATCH(on_nomem, on_other)                                                     \
+  catch (const std::bad_alloc&) { on_nomem; }                                                            \
+  catch (const std::exception& e) { (void)e; on_other; }                                                 \
+  catch (...) { on_other; }
+#define CLIPPER_HIP_GUARD_INT                                                                            \
+  CLIPPER_HIP_GUARD_CATCH(return guard_fail(CLIPPER_HIP_E_NOMEM, "out of host memory inside the library"), \
+                          return guard_fail(CLIPPER_HIP_E_INTERNAL, "unexpected exception inside the library"))
+#define CLIPPER_HIP_GUARD_PTR                                                                            \
+  CLIPPER_HIP_GUARD_CATCH({ guard_fail(CLIPPER_HIP_E_NOMEM, "out of host memory inside the library"); return nullptr; }, \
+                          { guard_fail(CLIPPER_HIP_E_INTERNAL, "unexpected exception inside the library"); return nullptr; })
+#define CLIPPER_HIP_GUARD_STR CLIPPER_HIP_GUARD_CATCH(return "", return "")
+#define CLIPPER_HIP_GUARD_VOID CLIPPER_HIP_GUARD_CATCH(return, return)
+
+
 #define HIPCHK(expr)                                                                  \
   do {                                                                                \
     hipError_t e_ = (expr);                                                           \

@@ -231,7 +231,7 @@ __global__ void k_rv_resume(SolverState* st, SolveShared* shared, int refused_ro
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     shared->hold = 0;
     st->hold = 0;
-    st->rv_builds += 1;
+    if (refused_rows == 0) st->rv_builds += 1;  // a refusal does not use up one of the solve's views
     st->rv_last = static_cast<int32_t>(st->n_iters);
     st->rv_backoff = refused_rows;
   }

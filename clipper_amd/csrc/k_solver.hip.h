@@ -78,6 +78,8 @@ constexpr int tail_q(int V) { return V * tail_nr(V) + 2 * V + 2; }
 //     bit-reproducible from run to run, views included.
 // ------------------------------------------------------------------------------------------
 constexpr double LIVE_OUT = 67108864.0;  // 2^26: the "outside the view" digit of a live code
+constexpr double RV_ROWS_RATIO = 0.8;    // a new view must drop at least a fifth of the rows a pass streams today
+                                         // (one constant for the device's request and the host's acceptance)
 
 // cost model of the view policy (seconds; set by the host from the matrix at hand, see host_rowview.hpp)
 struct ViewPolicy {
@@ -136,6 +138,12 @@ struct SolverState {
   int32_t rv_backoff;  // the host refused a view of this many rows (0: none): ask again only well below
   int32_t hold_slot;   // while on hold: the point slot p * V + v the decision ends on — the window it
                        // will leave pending is built from that point, the view must cover ITS live rows
+  int32_t hold_nlive;  // ... and the live rows of that point the request was made with
+  int32_t resume;      // stage == ST_PASS only: 0 = the pass a transition iteration prepared (pair mode on
+                       // table `sel`); 1 = a WINDOW pass prepared from point slot (ubp, ubv) with step
+                       // `alpha`, norms nrm / sx (phase PH_TRIAL); 2 = a pair-mode pass on the u array of
+                       // that slot (phase PH_PENALTY) — what a decide-only launch and the resident solver
+                       // on a row view (k_rv_resident.hip.h) leave behind
 };
 
 // What outlives the alternating state: the end of the solve. Kernels launched after
@@ -161,7 +169,7 @@ struct HostMirror {
   int32_t nlive, nout;    // live rows of the current point / of them outside the view (reporting)
   int64_t n_view_passes;
   int32_t hold;           // the solve waits for the host to build a row view (SolverState::hold)
-  int32_t pad;
+  int32_t hold_nlive;     // ... of this many rows (SolverState::hold_nlive)
 };
 
 struct SolverParams {
@@ -333,8 +341,8 @@ __device__ __forceinline__ bool view_wanted(const SolveArgs& A, int nlive, int n
   if (nlive <= 0 || nlive >= A.m) return false;
   const double rows_now = (A.in_view != nullptr && nout == 0) ? static_cast<double>(A.rv_rows) : static_cast<double>(A.m);
   const double r = static_cast<double>(nlive);
-  if (r > 0.8 * rows_now) return false;
-  if (backoff > 0 && r > 0.8 * static_cast<double>(backoff)) return false;  // nothing much changed since a refusal
+  if (r > RV_ROWS_RATIO * rows_now) return false;
+  if (backoff > 0 && r > RV_ROWS_RATIO * static_cast<double>(backoff)) return false;  // nothing much changed since a refusal
   const double horizon = n_iters > 12 ? static_cast<double>(n_iters) : 12.0;
   const double gain = horizon * ((rows_now - r) * A.rvp.pass_per_row);
   return gain > A.rvp.build_fixed + r * A.rvp.build_per_row;
@@ -720,9 +728,12 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       if (tid == 0) {
         A.st_next->hold = 1;
         A.st_next->hold_slot = ubp * V + ubv;  // (after the decision: the accepted candidate's slot, or the unchanged point's)
+        A.st_next->hold_nlive = nlive;
         A.shared->hold = 1;
-        if (A.host != nullptr)
+        if (A.host != nullptr) {
+          __hip_atomic_store(&A.host->hold_nlive, nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __hip_atomic_store(&A.host->hold, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
     return false;
@@ -770,6 +781,8 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       o->rv_last = L.rv_last;
       o->rv_backoff = L.rv_backoff;
       o->hold_slot = 0;
+      o->hold_nlive = 0;
+      o->resume = 0;
     };
     if (action == ACT_PASS) record(stash, true);
     else record(A.st_next, false);

@@ -64,7 +64,8 @@ enum {
   CLIPPER_HIP_E_NODEVICE = -4, /* no gfx950 device visible           */
   CLIPPER_HIP_E_STATE = -5,    /* call out of order (no matrix yet)  */
   CLIPPER_HIP_E_COMM = -6,     /* RCCL error / communicator missing  */
-  CLIPPER_HIP_E_SCOPE = -7     /* not available in this configuration */
+  CLIPPER_HIP_E_SCOPE = -7,    /* not available in this configuration */
+  CLIPPER_HIP_E_INTERNAL = -8  /* an unexpected C++ exception was caught at the boundary */
 };
 
 /* Timings of the most recent calls, from HIP events on the context's own stream. */
@@ -179,11 +180,13 @@ int clipper_hip_get_associations(const clipper_hip_t* h, int32_t* A_out /* col-m
 int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, int64_t m);
 
 /* CLIPPER::setSparseMatrixData (clipper.cpp:162-166): CSC, int64 column pointers, int32 row
- * indices. The reference reads the upper triangle of what it is given (selfadjointView<Upper>).
- * Here every stored off-diagonal entry stands for the symmetric pair; a pair stored in BOTH
- * triangles (a full symmetric matrix) counts once, with the upper copy's value — the same matrix
- * the reference would see, in every storage mode. The same (row, column) stored twice is an error
- * with the compressed storage. The diagonal is implicit: stored diagonal entries are ignored. */
+ * indices. The reference reads the upper triangle of what it is given (selfadjointView<Upper>,
+ * clipper.cpp:194-271) and so does this: an entry (i, j) with i < j stands for the symmetric pair,
+ * entries below the diagonal are NOT read (a full symmetric matrix counts through its upper half; a
+ * lower-triangular one is an empty matrix, as in the reference). The same (row, column) stored twice
+ * is an error with the compressed storage. The diagonal is implicit in this library: a stored
+ * non-zero diagonal entry (outside the reference's contract, clipper.h:137-138; it would count once
+ * on top of the identity there) is refused with CLIPPER_HIP_E_INVALID; explicit zeros are dropped. */
 int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
                            const int32_t* Mrow, const double* Mval, const int64_t* Ccolptr,
                            const int32_t* Crow, const double* Cval);

@@ -192,6 +192,15 @@ void symv_upper(const Csc& S, const double* x, double* y) {
          ++p) {
       const int32_t i = S.row[static_cast<size_t>(p)];
       const double v = S.val[static_cast<size_t>(p)];
+      /* selfadjointView<Eigen::Upper>: only entries on or above the diagonal are read. The
+       * members the reference builds itself hold nothing else (clipper.cpp:61-64, 151-157);
+       * a matrix handed to setSparseMatrixData (clipper.cpp:162-166) may: an entry below the
+       * diagonal is ignored, a stored diagonal counts ONCE. */
+      if (i > j) continue;
+      if (i == j) {
+        yj += v * xj;
+        continue;
+      }
       y[i] += v * xj;
       yj += v * x[i];
     }
@@ -403,6 +412,7 @@ int clipper_ref_get_matrix(const clipper_ref_t* h, double* M_out, double* C_out)
            ++p) {
         const int64_t i = S.row[static_cast<size_t>(p)];
         const double v = S.val[static_cast<size_t>(p)];
+        if (i > j) continue; /* selfadjointView<Upper> (clipper.cpp:133,142): the lower triangle is not read */
         if (i == j) {
           D[j * m + j] += v; /* a stored diagonal (sparse setter) appears once */
         } else {

@@ -234,6 +234,17 @@ class RefClipper:
         M, Cm = _f64_colmajor(M), _f64_colmajor(Cm)
         self._check(self.L.clipper_ref_set_matrix(self.h, _dp(M), _dp(Cm), M.shape[0]))
 
+    def set_sparse_matrix_data(self, m, Mcolptr, Mrow, Mval, Ccolptr, Crow, Cval):
+        """CLIPPER::setSparseMatrixData (clipper.cpp:162-166): the CSC arrays are kept as handed over;
+        every product reads them through selfadjointView<Upper>."""
+        i64p = C.POINTER(C.c_int64)
+        a = [np.ascontiguousarray(Mcolptr, np.int64), np.ascontiguousarray(Mrow, np.int32),
+             np.ascontiguousarray(Mval, np.float64), np.ascontiguousarray(Ccolptr, np.int64),
+             np.ascontiguousarray(Crow, np.int32), np.ascontiguousarray(Cval, np.float64)]
+        self._check(self.L.clipper_ref_set_sparse(
+            self.h, int(m), a[0].ctypes.data_as(i64p), _ip(a[1]), _dp(a[2]),
+            a[3].ctypes.data_as(i64p), _ip(a[4]), _dp(a[5])))
+
     def matvec(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         yM, yC = np.zeros_like(x), np.zeros_like(x)

@@ -69,3 +69,21 @@ def test_enumerators_match_header(tmp_path):
     assert got[7:] == [-2, -7]
     facade = open(os.path.join(ROOT, "include", "clipper", "clipper.h")).read()
     assert "enum class Storage { F32 = 0, F64 = 1, F32_CSC = 2, F64_CSC = 3 }" in facade
+
+
+def test_every_entry_point_is_guarded():
+    """the C ABI must not throw. Every function include/clipper_hip.h declares is defined as a
+    function-try-block closed by a CLIPPER_HIP_GUARD_* macro (csrc/host_state.hpp: std::bad_alloc ->
+    CLIPPER_HIP_E_NOMEM, anything else -> CLIPPER_HIP_E_INTERNAL). Source scan: pairing and return kind."""
+    csrc = os.path.join(ROOT, "clipper_amd", "csrc")
+    text = "\n".join(open(os.path.join(csrc, f)).read() for f in ("clipper_hip.hip", "host_registration.hpp"))
+    kinds = {"int": "INT", "int64_t": "INT", "clipper_hip_t*": "PTR", "const char*": "STR", "void": "VOID"}
+    for name in _declared_functions():
+        m = re.search(r"^(const char\*|clipper_hip_t\*|void|int64_t|int)\s+" + name + r"\([^;{]*\)\s*try\s*\{", text, flags=re.M)
+        assert m, f"{name}: no definition of the form `T {name}(...) try {{`"
+        end = re.search(r"^\}(.*)$", text[m.end():], flags=re.M)       # the function's closing brace (column 0)
+        assert end and end.group(1).strip() == "CLIPPER_HIP_GUARD_" + kinds[m.group(1)], \
+            f"{name}: closed by {end.group(1).strip() if end else None!r}"
+    guard = open(os.path.join(csrc, "host_state.hpp")).read()
+    assert "catch (const std::bad_alloc&)" in guard and "catch (...)" in guard
+    assert "CLIPPER_HIP_E_INTERNAL" in open(os.path.join(ROOT, "include", "clipper_hip.h")).read()

@@ -234,3 +234,36 @@ def test_dsd_restatement_is_pinned_to_the_reference_answers(golden):
     assert dsd_ref.densest_subgraph(A + A.T) == clique
     assert dsd_ref.densest_subgraph(A + A.T, [0, 2, 7, 11, 12]) == [2, 7, 11]
     assert dsd_ref.densest_subgraph(np.zeros((1, 1))) == []
+
+
+def test_sparse_setter_is_read_through_the_upper_triangle():
+    """setSparseMatrixData keeps what it is handed (clipper.cpp:162-166); every product reads it
+    through selfadjointView<Eigen::Upper> (clipper.cpp:194-271): entries below the diagonal are
+    never read, a stored diagonal counts once (the oracle restates Eigen, not the
+    product)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    m = 40
+    W = np.triu(rng.random((m, m)) * (rng.random((m, m)) < 0.3), 1)
+    x = rng.random(m)
+    S = W + W.T
+
+    def handed(Mat):
+        Mc = sp.csc_matrix(Mat)
+        Mc.sort_indices()
+        Pc = sp.csc_matrix((np.ones_like(Mc.data), Mc.indices, Mc.indptr), shape=Mc.shape)
+        r = ref.RefClipper()
+        r.set_sparse_matrix_data(m, Mc.indptr, Mc.indices, Mc.data, Pc.indptr, Pc.indices, Pc.data)
+        return r
+
+    yU, cU = handed(W).matvec(x)                     # strictly upper: the contract (clipper.h:137-138)
+    assert np.allclose(yU, S @ x, rtol=1e-14, atol=1e-14)
+    assert np.allclose(cU, (S != 0) @ x, rtol=1e-14, atol=1e-14)
+    yF, _ = handed(W + 0.5 * W.T).matvec(x)          # both triangles, the lower copies differ: upper counts
+    assert np.array_equal(yF, yU)
+    yL, cL = handed(W.T).matvec(x)                   # lower only: an empty matrix
+    assert not yL.any() and not cL.any()
+    assert np.array_equal(handed(W.T).get_affinity_matrix(), np.eye(m))
+    yD, _ = handed(W + np.diag(np.full(m, 0.25))).matvec(x)   # a stored diagonal: once
+    assert np.allclose(yD, S @ x + 0.25 * x, rtol=1e-14, atol=1e-14)
+    assert np.allclose(np.diag(handed(W + np.diag(np.full(m, 0.25))).get_affinity_matrix()), 1.25)
