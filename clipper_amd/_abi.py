@@ -99,6 +99,7 @@ class ViewStats(C.Structure):
         ("builds", C.c_int64), ("rows", C.c_int64), ("bytes", C.c_int64),
         ("view_passes", C.c_int64), ("passes", C.c_int64), ("build_ms", C.c_double),
         ("view_pass_avg_us", C.c_double), ("view_pass_samples", C.c_int64),
+        ("resident_launches", C.c_int64),
     ]
 
 

@@ -51,6 +51,7 @@ using namespace clipper_hip;
 #include "host_matrix.hpp"
 #include "host_rowview.hpp"
 #include "host_resident.hpp"
+#include "host_rv_resident.hpp"
 #include "host_registration.hpp"
 
 // ============================================================================================
@@ -174,6 +175,7 @@ void clipper_hip_destroy(clipper_hip_t* h) try {
   if (h->csc_hctl) hipHostFree(h->csc_hctl);
   if (h->csc_htotal) hipHostFree(h->csc_htotal);
   resident_free(h);
+  rvr_free(h);
   if (h->csc_hwork) hipHostFree(h->csc_hwork);
   if (h->rv_count) hipHostFree(h->rv_count);
   if (h->rv_desc_host) hipHostFree(h->rv_desc_host);
@@ -872,8 +874,21 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         bool built = false;
         if ((rc = rowview_build(h, built))) return rc;
         h->rv_fresh = built;
+        if (built && h->vres.ready) {
+          // The view fits the LDS of the chip: the iterations on it run as ONE launch (k_rv_resident.hip.h).
+          // A decide-only iteration turns the held decision into a prepared pass; the resident launch starts
+          // from it and leaves a prepared pass (or the end of the solve) for whatever is queued behind it.
+          h->decide_only = true;
+          rc = enqueue_iteration(h, prm);
+          h->decide_only = false;
+          if (rc) return rc;
+          ++queued;
+          bool launched = false;
+          if ((rc = rvr_enqueue(h, prm, launched))) return rc;
+        }
         continue;
       }
+      if (hm->iters > queued) queued = hm->iters;  // (a resident launch retired many iterations at once)
       if (queued - hm->iters < run_ahead) {
         if ((rc = enqueue_iteration(h, prm))) return rc;
         ++queued;
@@ -1239,9 +1254,11 @@ int clipper_hip_last_solver(const clipper_hip_t* h) try {
 
 int clipper_hip_set_row_view(clipper_hip_t* h, int mode) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
-  if (mode != 0 && mode != 1) return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic) or 1 (never)");
+  if (mode != 0 && mode != 1 && mode != 2)
+    return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic), 1 (never) or 2 (views, but streamed: never the resident solver on one)");
   h->rv_mode = mode;
   if (mode == 1) rowview_drop(h);
+  if (mode != 0) h->vres.ready = false;
   return 0;
 } CLIPPER_HIP_GUARD_INT
 

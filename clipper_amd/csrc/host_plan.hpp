@@ -322,4 +322,137 @@ inline void plan_resident(const uint32_t* L, int ncg, int nchunks, int64_t m, in
   out.ok = true;
 }
 
+// ---- the resident solver on a row view (k_rv_resident.hip.h) -------------------------------------------
+
+struct ViewUnit {  // layout of clipper_hip::RvrUnit
+  int cg0, ncgs;   // column groups [cg0, cg0 + ncgs) x every chunk of the view
+  int l0, l1;      // lanes [l0, l1) of each
+  int pad0, pad1, pad2, pad3;
+};
+
+struct ViewResidentPlan {
+  bool ok = false;
+  uint32_t lds_slices = 0;        // bytes of LDS the slices of a unit may take
+  uint64_t entries = 0;           // stored entries of the view
+  std::vector<ViewUnit> units;
+  std::vector<uint8_t> npieces;   // [unit * nwv + wave]
+  std::vector<uint8_t> wave_cg;   // [unit * nwv + wave] column group of the unit the wave works for (255: none)
+  std::vector<uint32_t> pieces;   // [(unit * nwv + wave) * pmax + j] = chunk | q0 << 8 | q1 << 16
+};
+
+// Units of COMPLETE columns: a unit holds every chunk of its column groups (so that a column's sums never
+// leave the workgroup), as many groups as balance the ENTRIES (the LDS gathers of a pass go with them) up
+// to `target_units` workgroups; a group whose slices exceed a unit's LDS or its share of the entries (the
+// dense inlier block) is split by LANES into equal parts. Then the pieces, as plan_resident deals them.
+// xt_fixed: bytes of LDS a unit needs besides its slices.
+inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esize, int target_units, int max_units,
+                               uint32_t fixed_bytes, const ResidentConsts& K, ViewResidentPlan& out) {
+  out = ViewResidentPlan{};
+  if (ncg < 1 || nchunks < 1 || nchunks > K.tmax || fixed_bytes + K.slice_pad + 8192 >= K.lds_max) return;
+  const uint32_t cap = K.lds_max - fixed_bytes - K.slice_pad;
+  out.lds_slices = K.lds_max - fixed_bytes;
+  const uint32_t QBY = 4u * static_cast<uint32_t>(esize);
+  std::vector<uint64_t> ent(static_cast<size_t>(ncg)), byt(static_cast<size_t>(ncg));
+  uint64_t total = 0;
+  for (int cg = 0; cg < ncg; ++cg) {
+    uint64_t e = 0, b = 0;
+    for (int k = 0; k < nchunks; ++k) {
+      const uint32_t lq = L[static_cast<size_t>(cg) * nchunks + k];
+      e += lq >> 8;
+      b += slice_bound(lq, QBY, K.so);
+    }
+    ent[static_cast<size_t>(cg)] = e;
+    byt[static_cast<size_t>(cg)] = b;
+    total += e;
+  }
+  out.entries = total;
+  target_units = std::max(1, std::min(target_units, max_units));
+  const double Te = std::max(256.0, static_cast<double>(total) / target_units);
+  const int max_cgs = std::min(K.nwv, K.tmax / nchunks);  // one wave per group in the tail; slices per unit
+  if (max_cgs < 1) return;
+  std::vector<ViewUnit>& units = out.units;
+  int cg = 0;
+  while (cg < ncg) {
+    const uint64_t e = ent[static_cast<size_t>(cg)], b = byt[static_cast<size_t>(cg)];
+    // (a lane subset keeps every step's padding and the header: its bytes fall a little slower than its lanes)
+    int nsplit = std::max(static_cast<int>((b + cap - 1) / cap), static_cast<int>(std::floor(static_cast<double>(e) / (1.5 * Te) + 0.5)));
+    nsplit = std::max(1, nsplit);
+    if (nsplit > 1) {
+      while (nsplit < 16 && (b / nsplit) + static_cast<uint64_t>(nchunks) * (16 + 64 + 64 * 16) > cap) ++nsplit;
+      if (nsplit > 16) return;
+      for (int p = 0; p < nsplit; ++p)
+        units.push_back(ViewUnit{cg, 1, 64 * p / nsplit, 64 * (p + 1) / nsplit, 0, 0, 0, 0});
+      ++cg;
+      continue;
+    }
+    int n = 0;
+    uint64_t eacc = 0, bacc = 0;
+    while (cg + n < ncg && n < max_cgs) {
+      const uint64_t e2 = ent[static_cast<size_t>(cg + n)], b2 = byt[static_cast<size_t>(cg + n)];
+      if (n > 0 && (bacc + b2 > cap || static_cast<double>(eacc + e2) > 1.15 * Te || static_cast<double>(e2) > 1.5 * Te)) break;
+      eacc += e2;
+      bacc += b2;
+      ++n;
+    }
+    units.push_back(ViewUnit{cg, n, 0, 64, 0, 0, 0, 0});
+    cg += n;
+  }
+  if (static_cast<int>(units.size()) > max_units) return;
+
+  const size_t NWV = static_cast<size_t>(K.nwv), PM = static_cast<size_t>(K.pmax);
+  out.pieces.assign(units.size() * NWV * PM, 0u);
+  out.npieces.assign(units.size() * NWV, 0);
+  out.wave_cg.assign(units.size() * NWV, 255);
+  std::vector<int> T(NWV), nw(NWV);
+  for (size_t ui = 0; ui < units.size(); ++ui) {
+    const ViewUnit& U = units[ui];
+    std::fill(T.begin(), T.end(), 0);
+    std::fill(nw.begin(), nw.end(), 0);
+    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
+      const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
+      for (int k = 0; k < nchunks; ++k) T[static_cast<size_t>(cgl)] += static_cast<int>(lrow[k] & 255u);
+      nw[static_cast<size_t>(cgl)] = 1;
+    }
+    for (int spare = K.nwv - U.ncgs; spare > 0; --spare) {  // waves to groups in proportion to their steps
+      int best = 0;
+      for (int cgl = 1; cgl < U.ncgs; ++cgl)
+        if (static_cast<int64_t>(T[static_cast<size_t>(cgl)]) * nw[static_cast<size_t>(best)] >
+            static_cast<int64_t>(T[static_cast<size_t>(best)]) * nw[static_cast<size_t>(cgl)])
+          best = cgl;
+      ++nw[static_cast<size_t>(best)];
+    }
+    int wave = 0;
+    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
+      const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
+      const int nwc = nw[static_cast<size_t>(cgl)];
+      const int target = std::max(1, (T[static_cast<size_t>(cgl)] + nwc - 1) / nwc);
+      int kcur = 0, qcur = 0;
+      for (int sub = 0; sub < nwc; ++sub, ++wave) {
+        const size_t wv = ui * NWV + static_cast<size_t>(wave);
+        out.wave_cg[wv] = static_cast<uint8_t>(cgl);
+        int rem = (sub == nwc - 1) ? (1 << 30) : target, n = 0;
+        while (rem > 0 && kcur < nchunks) {
+          const int mq = static_cast<int>(lrow[kcur] & 255u);
+          if (qcur >= mq) {
+            ++kcur;
+            qcur = 0;
+            continue;
+          }
+          if (n == K.pmax) {
+            if (sub == nwc - 1) return;  // does not fit the piece lists: the streaming launches keep the view
+            break;
+          }
+          const int take = std::min(rem, mq - qcur);
+          out.pieces[wv * PM + static_cast<size_t>(n++)] = static_cast<uint32_t>(kcur) | (static_cast<uint32_t>(qcur) << 8) |
+                                                           (static_cast<uint32_t>(qcur + take) << 16);
+          qcur += take;
+          rem -= take;
+        }
+        out.npieces[wv] = static_cast<uint8_t>(n);
+      }
+    }
+  }
+  out.ok = true;
+}
+
 }  // namespace clipper_plan

@@ -111,8 +111,11 @@ bool rowview_cost_of_filter(const Ctx* h) { return rowview_build_env() != 0 || !
 
 // ---- the row view -----------------------------------------------------------------------------------
 
+int rvr_plan(Ctx* h, Shard& s);  // host_rv_resident.hpp: does the view just built fit the resident solver?
+
 void rowview_drop(Ctx* h) {
   for (auto& s : h->sh) s.rv.valid = false;
+  h->vres.ready = false;
 }
 
 void rowview_free(Shard& s) {
@@ -147,7 +150,7 @@ bool rowview_possible(const Ctx* h) {
     const char* e = std::getenv("CLIPPER_HIP_ROW_VIEW");
     return e && std::atoi(e) == 0;
   }();
-  return !env_off && h->rv_mode == 0 && h->csc_valid && !h->explicitC &&
+  return !env_off && h->rv_mode != 1 && h->csc_valid && !h->explicitC &&
          h->m >= RV_MIN_M &&
          (csc_single(h) || h->total_slice_bytes > 0.0);
 }
@@ -318,6 +321,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   v.nrows = nrows;
   v.valid = true;
   built = true;
+  if ((rc = rvr_plan(h, s))) return rc;  // (the view's directory is still in the pinned staging)
   {  // the descriptor a pass on the view reads, to the device
     if (!v.desc) HIPCHK(hipMalloc(reinterpret_cast<void**>(&v.desc), sizeof(SliceView)));
     if (!h->rv_desc_host) {

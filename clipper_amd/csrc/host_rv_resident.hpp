@@ -1,0 +1,162 @@
+// host_rv_resident.hpp — planning and launch of the resident solver on a row view (k_rv_resident.hip.h)
+// Part of clipper_hip.hip (one translation unit; included there, in order).
+#pragma once
+
+namespace {
+
+void rvr_free(Ctx* h) {
+  ViewResident& r = h->vres;
+  if (r.host_plan) hipHostFree(r.host_plan);
+  if (r.xb) hipFree(r.xb);
+  if (r.ctl) hipFree(r.ctl);
+  const unsigned long long ep = r.epoch;
+  const int tu = r.target_units;
+  r = ViewResident{};
+  r.epoch = ep;
+  r.target_units = tu;
+}
+
+bool rvr_enabled(const Ctx* h) {
+  static const bool env_off = [] {
+    const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT");
+    return e && std::atoi(e) == 0;
+  }();
+  // one device, one shard, a window the kernel is instantiated for, an inner loop that runs at all
+  return !env_off && h->rv_mode == 0 && csc_single(h) && h->sh.size() == 1 && (h->V == 6 || h->V == 4);
+}
+
+// Called when a view has just been built and its directory (csc_hLq) is on the host: does it fit the
+// resident solver? Lays out the units (host_plan.hpp) into mapped pinned memory.
+int rvr_plan(Ctx* h, Shard& s) {
+  ViewResident& r = h->vres;
+  r.ready = false;
+  if (!rvr_enabled(h) || !s.rv.valid) return 0;
+  const RowView& v = s.rv;
+  if (v.nrows < 1 || v.nrows > RVR_MAXROWS) return 0;
+  static_assert(sizeof(clipper_plan::ViewUnit) == sizeof(RvrUnit), "the planner's unit is the kernel's");
+  const clipper_plan::ResidentConsts K{RVR_NT, RVR_NWV, RVR_TMAX, RVR_PMAX, 2, RS_LDS_MAX,
+                                       RVR_RED_BYTES, RVR_TAB_BYTES, RS_SLICE_PAD, SL_SO};
+  static thread_local clipper_plan::ViewResidentPlan plan;
+  if (r.target_units == 0) {
+    const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT_WGS");
+    r.target_units = e ? std::max(1, std::atoi(e)) : -1;
+  }
+  const int max_units = std::min(RVR_MAXUNITS, h->cus - 8);
+  // one workgroup per CU (its LDS is the unit's): about two thirds of the chip by default — more units
+  // shorten the pass (the LDS gathers spread over more CUs), every unit adds a granule to everybody's sweep
+  const int target = r.target_units > 0 ? r.target_units : std::max(8, (2 * h->cus) / 3);
+  const uint32_t fixed = rvr_xt_bytes(h->V, static_cast<int>(v.nrows)) + RVR_RED_BYTES + RVR_TAB_BYTES;
+  clipper_plan::plan_view_resident(h->csc_hLq, v.st.s_ncg, v.st.s_nchunks, static_cast<int>(h->esize()), target,
+                                   max_units, fixed, K, plan);
+  if (rs_debug())
+    std::fprintf(stderr, "[view-resident] plan rows=%lld ncg=%d nchunks=%d entries=%llu -> units=%zu ok=%d\n",
+                 static_cast<long long>(v.nrows), v.st.s_ncg, v.st.s_nchunks,
+                 static_cast<unsigned long long>(plan.entries), plan.units.size(), plan.ok ? 1 : 0);
+  if (!plan.ok) return 0;
+  HIPCHK(hipSetDevice(s.device));
+  const size_t off_np = plan.units.size() * sizeof(RvrUnit);
+  const size_t off_wc = off_np + static_cast<size_t>(round_up(static_cast<int64_t>(plan.npieces.size()), 16));
+  const size_t off_pc = off_wc + static_cast<size_t>(round_up(static_cast<int64_t>(plan.wave_cg.size()), 16));
+  const size_t bytes = off_pc + plan.pieces.size() * sizeof(uint32_t) + 64;
+  if (bytes > r.host_plan_cap) {
+    if (r.host_plan) hipHostFree(r.host_plan);
+    r.host_plan = nullptr;
+    r.host_plan_cap = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r.host_plan), bytes + 4096, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.host_plan_dev), r.host_plan, 0));
+    r.host_plan_cap = bytes + 4096;
+  }
+  std::memcpy(r.host_plan, plan.units.data(), plan.units.size() * sizeof(RvrUnit));
+  std::memcpy(r.host_plan + off_np, plan.npieces.data(), plan.npieces.size());
+  std::memcpy(r.host_plan + off_wc, plan.wave_cg.data(), plan.wave_cg.size());
+  std::memcpy(r.host_plan + off_pc, plan.pieces.data(), plan.pieces.size() * sizeof(uint32_t));
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  r.off_np = off_np;
+  r.off_wc = off_wc;
+  r.off_pc = off_pc;
+  const size_t xb_bytes = static_cast<size_t>(rvr_xb_granules(6)) * sizeof(unsigned long long);
+  if (!r.xb) {
+    HIPCHK(hipMalloc(&r.xb, xb_bytes));
+    HIPCHK(hipMemsetAsync(r.xb, 0, xb_bytes, s.stream));  // no granule may carry a future epoch
+    r.xb_bytes = xb_bytes;
+  }
+  if (!r.ctl) HIPCHK(hipMalloc(&r.ctl, 64));
+  r.nunits = static_cast<int>(plan.units.size());
+  r.lds_slices = plan.lds_slices;
+  r.ready = true;
+  return 0;
+}
+
+template <typename VT, int V>
+int rvr_launch_t(Ctx* h, Shard& s, const RvrArgs& a) {
+  auto kern = k_solve_view_resident<VT, V>;
+  if (!raise_dynamic_lds(reinterpret_cast<const void*>(kern), s.device, static_cast<int>(RS_LDS_MAX))) return 1;
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(a.nunits)), dim3(RVR_NT), RS_LDS_MAX, s.stream, a);
+  if (const hipError_t e = hipGetLastError(); e != hipSuccess) {
+    if (rs_debug()) std::fprintf(stderr, "[view-resident] launch failed: %s\n", hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}
+
+// Enqueues the launch behind the decide-only iteration that prepared the pass it starts from. The launch
+// continues the solve from state copy h->par on the view in use and leaves a prepared pass (or the end of
+// the solve) in the same copy; if it cannot run (no prepared pass, a time-out, a device that refuses the
+// LDS) it changes nothing and the streaming launches queued behind it carry on. launched = false: nothing
+// was enqueued.
+int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
+  launched = false;
+  ViewResident& r = h->vres;
+  if (!r.ready || !rvr_enabled(h) || prm.maxiniters < 1) return 0;
+  Shard& s = h->sh[0];
+  if (!s.rv.valid) return 0;
+  HIPCHK(hipSetDevice(s.device));
+  RvrArgs a{};
+  a.R = row_view(h, s);
+  a.units = reinterpret_cast<const RvrUnit*>(r.host_plan_dev);
+  a.nunits = r.nunits;
+  a.npieces = r.host_plan_dev + r.off_np;
+  a.wave_cg = r.host_plan_dev + r.off_wc;
+  a.pieces = reinterpret_cast<const uint32_t*>(r.host_plan_dev + r.off_pc);
+  a.viewpos = s.rv.viewpos;
+  a.st = s.st + h->par;
+  a.shared = s.shared;
+  a.host = h->mirror_dev;
+  a.host_u = h->u_pinned_dev;
+  a.prm = prm;
+  a.m = h->m;
+  a.mp = h->mp;
+  a.pt = s.pt;
+  a.xb = r.xb;
+  // the granules carry the low 32 bits of the epoch: long before they wrap, start over on a clean buffer
+  if ((r.epoch & 0xffffffffull) > 0xf0000000ull) {
+    HIPCHK(hipMemsetAsync(r.xb, 0, r.xb_bytes, s.stream));
+    r.epoch = (r.epoch & ~0xffffffffull) + (1ull << 32);
+  }
+  a.epoch0 = r.epoch;
+  r.epoch += 1ull << 20;  // whatever this launch publishes (even if it gives up half-way) lies below the next one's
+  a.ctl = r.ctl;
+  a.lds_slices = r.lds_slices;
+  a.timeout_ticks = 20000000ll;  // 0.2 s on the 100 MHz wall clock
+  if (const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT_TIMEOUT_TICKS")) a.timeout_ticks = std::atoll(e);  // (test knob)
+  a.max_exchanges = 1 << 18;
+  if (const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT_MAX_EXCHANGES")) a.max_exchanges = std::max(0, std::atoi(e));  // (test knob)
+  a.rvp = h->rvp;
+  a.rv_rows = static_cast<int>(s.rv.nrows);
+  a.stamps = h->stamps_dev;
+  HIPCHK(hipMemsetAsync(r.ctl, 0, 64, s.stream));
+  int lr = 1;
+  dispatch_vt(h, [&](auto tag) {
+    using VT = decltype(tag);
+    lr = (h->V == 6) ? rvr_launch_t<VT, 6>(h, s, a) : rvr_launch_t<VT, 4>(h, s, a);
+  });
+  if (lr != 0) {
+    r.ready = false;  // this device does not take the launch: the streaming launches keep the view
+    return 0;
+  }
+  launched = true;
+  h->rv_stats.resident_launches += 1;
+  return 0;
+}
+
+}  // namespace

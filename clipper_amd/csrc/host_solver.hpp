@@ -373,6 +373,7 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.rv_fresh = (view && h->rv_fresh) ? 1 : 0;
   a.rv_rows = view ? static_cast<int>(s.rv.nrows) : 0;
   a.rvp = h->rvp;
+  a.decide_only = h->decide_only ? 1 : 0;
   return a;
 }
 

@@ -208,6 +208,22 @@ struct Resident {
   int home = -1;                     // this context's home XCD in that mode
 };
 
+// the resident solver on a row view (k_rv_resident.hip.h): plan of the view in use and its buffers
+struct ViewResident {
+  bool ready = false;        // the view in use fits: `plan` is valid
+  int nunits = 0;
+  uint32_t lds_slices = 0;
+  uint8_t* host_plan = nullptr;      // pinned + mapped: units, piece counts, wave map, pieces
+  uint8_t* host_plan_dev = nullptr;
+  size_t host_plan_cap = 0;
+  size_t off_np = 0, off_wc = 0, off_pc = 0;
+  unsigned long long* xb = nullptr;  // exchange buffer (granules), zero at allocation
+  size_t xb_bytes = 0;
+  uint32_t* ctl = nullptr;           // [0] error word, [1] arrivals at the exit
+  unsigned long long epoch = 0;      // every launch takes 2^20 epochs
+  int target_units = 0;              // CLIPPER_HIP_VIEW_RESIDENT_WGS (0: automatic)
+};
+
 }  // namespace
 
 struct clipper_hip_ctx {
@@ -266,6 +282,8 @@ struct clipper_hip_ctx {
   int64_t mp = 0;          // rows of a candidate table
   int par = 0;             // which table set the next launch reads
   Resident res;
+  ViewResident vres;
+  bool decide_only = false;  // the next iteration's G launch only decides (hand-over to the resident solver on a view)
   int resident_mode = 0;   // 0 = use the resident solver where the slices fit, 1 = never
   int last_solver = 0;     // what the last solve ran on: 0 = streaming launches, 1 = resident
 
@@ -279,7 +297,8 @@ struct clipper_hip_ctx {
   double total_slice_bytes = 0.0;  // column shards: bytes of all shards' slices (gather_slice_bytes)
   ViewPolicy rvp{};           // the cost model the device-side policy works with (host_rowview.hpp)
   bool rv_fresh = false;      // the next iteration is the first after a view was built
-  int rv_mode = 0;            // 0 = automatic, 1 = never (clipper_hip_set_row_view / CLIPPER_HIP_ROW_VIEW=0)
+  int rv_mode = 0;            // 0 = automatic, 1 = never (clipper_hip_set_row_view / CLIPPER_HIP_ROW_VIEW=0),
+                              // 2 = views, but never the resident solver on one (CLIPPER_HIP_VIEW_RESIDENT=0)
   SliceView* rv_desc_host = nullptr;     // pinned + mapped staging of a view's descriptor
   SliceView* rv_desc_host_dev = nullptr;
   int32_t* rv_count = nullptr;      // pinned + mapped: rows of the view being built

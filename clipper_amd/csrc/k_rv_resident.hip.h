@@ -1,0 +1,793 @@
+// k_rv_resident.hip.h — the resident solver ON A ROW VIEW: the iterations of findDenseClique that stream
+// a row view of M (k_solver.hip.h, LIVE ROWS) as ONE launch, for views whose slices fit the LDS of the
+// workgroups that share them (the headline problem: 524 rows x 10 000 columns, 4.8 MB).
+// Part of kernels.hip.h (include that one): hand-written gfx950 device code of the CLIPPER hot path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "k_resident.hip.h"
+
+namespace clipper_hip {
+
+// ------------------------------------------------------------------------------------------
+// Once a view covers the live rows, an iteration of the streaming solver at m = 10k is 16 us of pass
+// (a chain of latencies over 4.8 MB), 5 us of tail and two kernel boundaries, 25 times over. Here
+// those iterations (clipper.cpp:226-280: line-search windows, the penalty update, the start of the next
+// outer iteration) run inside one launch of P workgroups that keep the view on chip:
+//
+//   * COLUMN OWNERS. A unit = column groups [cg0, cg0 + ncgs) of the view x ALL its chunks (every row
+//     of the view), copied into LDS once. The sums of a unit's columns are therefore COMPLETE inside the
+//     workgroup: no partial sums cross workgroups, and the elementwise tail of a column (k_tail's
+//     expressions, clipper.cpp:237-242) is computed by the one thread that owns it. The slices of the
+//     dense inlier block (524 rows x 64 columns, all stored: 168 KB) exceed one LDS: such a column group
+//     is split by LANES — a unit takes lanes [l0, l1) of every step (the copy re-packs each step for the
+//     lane subset; the pass code is the resident solver's, rs_wave_pass, unchanged).
+//   * What everybody needs of everybody is SMALL, because x is zero outside the view's rows R: the
+//     objective, the step norms, the penalty sums, the convergence tests (clipper.cpp:242-262, 268-276)
+//     are sums over R only. Every workgroup keeps (u, gradF, a, b) on R (two rows per thread) and
+//     computes all of these — and every decision of the line search — redundantly on the same bits,
+//     as in the resident solver. The owners of the columns in R publish the candidates' gradients on R
+//     (V + 2 numbers per row of the view); the columns outside R only ever answer one question — did a
+//     row outside the view become live (gradient > 0)? — as one packed count per unit. One exchange per
+//     iteration, and the data is the flag (self-describing granules {epoch, half a double}, write-
+//     through stores, relaxed polls: k_resident.hip.h).
+//   * It STARTS from a prepared pass (SolverState::resume, left by a decide-only launch after the view
+//     was built) and LEAVES one behind the moment it cannot go on: a row outside the view became live,
+//     the policy wants a smaller view, or its budget of exchanges is used up; or it finishes the solve.
+//     Whatever it leaves is committed by the LAST unit to arrive, into a point slot the entry state does
+//     not name: a launch that gives up (a time-out of the exchange) leaves the entry state untouched
+//     and the streaming launches queued behind it carry on from there.
+//
+// Arithmetic: the streaming solver's expressions (k_tail, decide) on the same operands; what differs is
+// the association of the sums over R (one fixed tree per workgroup here, 256-element blocks and chains
+// there), as between any two work splits.
+// ------------------------------------------------------------------------------------------
+constexpr int RVR_NT = RS_NT;        // 512 threads: 8 waves, two per SIMD
+constexpr int RVR_NWV = RS_NWV;
+constexpr int RVR_TMAX = RS_TMAX;    // slices a unit holds at most
+constexpr int RVR_PMAX = RS_PMAX;    // pieces a wave works on at most
+constexpr int RVR_MAXROWS = 2 * RVR_NT;  // rows of the view: two per thread
+constexpr int RVR_MAXUNITS = 256;
+constexpr int RVR_NRED = 32;         // doubles a block reduction sums at most
+
+struct RvrUnit {
+  int cg0, ncgs;  // column groups [cg0, cg0 + ncgs), ncgs <= 8 (one per wave in the tail)
+  int l0, l1;     // lanes [l0, l1) of each (a proper subset only for a unit of one group)
+  int pad0, pad1, pad2, pad3;
+};
+
+struct RvrArgs {
+  SliceView R;                  // the view: slices, directory, rowmap, nrows
+  const RvrUnit* units;
+  int nunits;
+  const uint32_t* pieces;       // as ResidentArgs (k0 = 0)
+  const uint8_t* npieces;
+  const uint8_t* wave_cg;
+  const int32_t* viewpos;       // [mp] position of association i among the view's rows, or -1
+  SolverState* st;              // the state to resume from; overwritten only by a committed exit
+  SolveShared* shared;
+  HostMirror* host;             // pinned (may be null)
+  double* host_u;               // pinned (may be null)
+  SolverParams prm;
+  int64_t m, mp;
+  double* pt;                   // point slots [2][V][2][mp]
+  unsigned long long* xb;       // [2][(V + 2) * RVR_MAXROWS + RVR_MAXUNITS][2] granules, zero at allocation
+  unsigned long long epoch0;
+  uint32_t* ctl;                // [0] error word, [1] arrivals at the exit (zero at launch)
+  uint32_t lds_slices;          // bytes of LDS the slices of a unit may take
+  long long timeout_ticks;      // longest wait for the other units' granules, 100 MHz wall clock
+  int max_exchanges;            // leave to the streaming launches after this many
+  ViewPolicy rvp;
+  int rv_rows;
+  long long* stamps;            // measurement only (may be null): unit 0, [iteration][8] wall-clock stamps
+};
+enum : uint32_t { RVR_ERR_LDS = 1, RVR_ERR_TIMEOUT = 2, RVR_ERR_STATE = 3 };
+
+__host__ __device__ constexpr uint32_t rvr_xt_bytes(int V, int nrows) {
+  const uint32_t xt = static_cast<uint32_t>((nrows + 127) / 128 * 128) * V * 8u;
+  const uint32_t sc = RVR_NWV * (V + 1) * 64u * 8u;
+  return xt > sc ? xt : sc;
+}
+constexpr uint32_t RVR_RED_BYTES = RVR_NWV * RVR_NRED * 8 + RVR_NWV * 16 * 8 + 64 * 8;  // wave sums, the window's norm sums, totals
+constexpr uint32_t RVR_TAB_BYTES = RVR_TMAX * 4 + 64 + RVR_TMAX * 4;  // slice offsets, a few words, slice sizes
+__host__ __device__ constexpr int64_t rvr_xb_granules(int V) {
+  return 2 * (static_cast<int64_t>(V + 2) * RVR_MAXROWS + RVR_MAXUNITS) * 2;
+}
+
+// Sums over the workgroup, LEFT IN LDS: tot[q] = the sum of v[q] over the 512 threads, in a fixed order (DPP
+// wave sums, then the waves in order, by thread q). The totals are uniform: the code that follows reads the
+// few it needs at a time (broadcast reads) instead of holding all of them in registers — the 26 sums of a
+// window iteration as a register array cost 200 LDS reads per thread and spilled (tools/spill_report.py).
+// Ends with a barrier: tot[] may be read at once.
+template <int N>
+__device__ __forceinline__ void rvr_reduce(double (&v)[N], double* part /* [RVR_NWV * N] */, double* tot /* [N] */) {
+  static_assert(N <= RVR_NRED, "scratch");
+#pragma unroll
+  for (int q = 0; q < N; ++q) v[q] = wave_sum_to_lane63(v[q]);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) part[wave * N + q] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    double acc = part[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < RVR_NWV; ++w) acc += part[w * N + threadIdx.x];
+    tot[threadIdx.x] = acc;
+  }
+  __syncthreads();
+}
+// a uniform double out of LDS, told to the compiler as such (scalar registers)
+__device__ __forceinline__ double rvr_uni(const double* p) {
+  const double x = *p;
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
+__device__ __forceinline__ void rvr_publish(unsigned long long* gq, unsigned long long tag, double x) {
+  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(x));
+  __hip_atomic_store(gq, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(gq + 1, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one value: true if both granules carry the tag
+__device__ __forceinline__ bool rvr_poll(const unsigned long long* gq, unsigned long long tag, double& x) {
+  const unsigned long long g0 = rs_ld_granule(gq), g1 = rs_ld_granule(gq + 1);
+  x = __longlong_as_double(static_cast<long long>((g0 << 32) | (g1 & 0xffffffffull)));
+  return ((g0 ^ tag) >> 32) == 0 && ((g1 ^ tag) >> 32) == 0;
+}
+
+template <typename VT, int V>
+__global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t rvr_lds[];
+  constexpr int NS = V + 1;
+  constexpr int QB = 4 * static_cast<int>(sizeof(VT));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  static_assert(V >= 2 && V <= 6 && (V % 2) == 0, "window of the streaming solver on slices");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t m = A.m, mp = A.mp;
+  const int nrows = static_cast<int>(A.R.nrows);
+  const SolverParams P = A.prm;
+  const int unit = blockIdx.x;
+
+  // ---- carve -------------------------------------------------------------------------------
+  uint32_t off = 0;
+  double* Xt = reinterpret_cast<double*>(rvr_lds + off);   // [rows][V]; reused as the waves' sums
+  double* scr = Xt;                                        // [8 waves][NS][64]
+  off += rvr_xt_bytes(V, nrows);
+  double* red = reinterpret_cast<double*>(rvr_lds + off);  // block_reduce scratch
+  double* red2 = red + RVR_NWV * RVR_NRED;                 // the pending window's norm sums (read after the pass)
+  double* tot = red2 + RVR_NWV * 16;                       // [0 .. 31] totals of a reduction, [32 .. 32 + V) nrm, [40 .. 40 + V) sx
+  double* nrmL = tot + 32;
+  double* sxL = tot + 40;
+  off += RVR_RED_BYTES;
+  uint32_t* tab = reinterpret_cast<uint32_t*>(rvr_lds + off);  // [RVR_TMAX] slice offsets, then a few words
+  uint32_t* words = tab + RVR_TMAX;                            // [16]
+  uint32_t* sizes = words + 16;                                // [RVR_TMAX] bytes of the slices as they lie in LDS
+  off += RVR_TAB_BYTES;
+  uint8_t* sl = rvr_lds + off;
+
+  // ---- the state this launch starts from: a prepared pass, or nothing to do here --------------------
+  const SolverState* st = A.st;
+  const int e_done = A.shared->done, e_hold = st->hold, e_stage = st->stage, e_resume = st->resume;
+  if (e_done || e_hold || e_stage != ST_PASS || (e_resume != 1 && e_resume != 2) || st->nout != 0 ||
+      nrows > RVR_MAXROWS || nrows < 1 || P.maxiniters < 1)
+    return;  // (uniform over the grid: every unit reads the same state; the streaming launches go on)
+
+  // ---- this unit; its slices -> LDS (lanes [l0, l1) of every step) -------------------------------
+  const RvrUnit U = A.units[unit];
+  const unsigned long long wcg = *reinterpret_cast<const unsigned long long*>(A.wave_cg + static_cast<int64_t>(unit) * RVR_NWV);
+  const int cgl = static_cast<int>((wcg >> (8 * wave)) & 255ull);
+  const bool has_cg = cgl < U.ncgs && U.cg0 + cgl < A.R.ncg;
+  const int S = A.R.nchunks;
+  const int nslices = U.ncgs * S;  // local slice t = cgl * S + chunk
+  const bool whole = U.l0 <= 0 && U.l1 >= 64;
+  const bool in_lanes = lane >= U.l0 && lane < U.l1;
+  const gbytes_t rdata = (gbytes_t)A.R.data;
+  const CLIPPER_GLOBAL uint64_t* rpre = (const CLIPPER_GLOBAL uint64_t*)A.R.Pre;
+  auto src_of = [&](int t) -> gbytes_t {
+    const int tc = t / S, tk = t - tc * S;
+    return rdata + 16 * rpre[static_cast<int64_t>(U.cg0 + tc) * A.R.nchunks + tk];
+  };
+  // sizes: wave w sizes the slices t = w, w + 8, ... as they will lie in LDS
+  if (nslices <= RVR_TMAX) {
+    for (int t = wave; t < nslices; t += RVR_NWV) {
+      const gbytes_t sp = src_of(t);
+      const uint32_t nb = reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(sp)[2];
+      uint32_t bytes = nb;
+      if (!whole) {
+        const int maxq = __builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(sp)[1]));
+        const int tq = in_lanes ? static_cast<int>(sp[16 + lane]) : 0;
+        bytes = 16 + 64 + sl_so_bytes(maxq) + sl_steps_bytes(tq, maxq, QB);
+      }
+      if (lane == 0) sizes[t] = bytes;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const uint32_t bytes_t = (lane < nslices && nslices <= RVR_TMAX) ? sizes[lane] : 0u;
+    uint32_t inc = bytes_t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t2 = __shfl_up(inc, o);
+      if (lane >= o) inc += t2;
+    }
+    tab[lane] = inc - bytes_t;
+    if (lane == 63) words[0] = inc;
+  }
+  __syncthreads();
+  const uint32_t total = words[0];
+  const bool bad_plan = total + RS_SLICE_PAD > A.lds_slices || nslices > RVR_TMAX || U.ncgs > RVR_NWV;
+  if (__syncthreads_or(bad_plan ? 1 : 0)) {
+    if (tid == 0) __hip_atomic_store(A.ctl, static_cast<uint32_t>(RVR_ERR_LDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;  // (the other units time out on this one's granules — or see the error word — and leave: nothing is committed)
+  }
+  for (int t = wave; t < nslices; t += RVR_NWV) {
+    const gbytes_t src = src_of(t);
+    const uint32_t o = tab[t];
+    if (whole) {
+      const uint32_t nb = reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(src)[2];
+      for (uint32_t b = lane * 16; b < nb; b += 64 * 16)
+        *reinterpret_cast<u32x4*>(sl + o + b) = *reinterpret_cast<const CLIPPER_GLOBAL u32x4*>(src + b);
+    } else {
+      // the slice re-packed for the lane subset: same header, the other lanes' lists empty, every step
+      // holds the quads of the subset's active lanes in lane order (the format's own rule)
+      const int maxq = __builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(src)[1]));
+      const int tot_src = static_cast<int>(src[16 + lane]);
+      const int tot_dst = in_lanes ? tot_src : 0;
+      uint8_t* dp = sl + o;
+      if (lane < 4) reinterpret_cast<uint32_t*>(dp)[lane] = (lane == 1) ? static_cast<uint32_t>(maxq) : 0u;
+      dp[16 + lane] = static_cast<uint8_t>(tot_dst);
+      for (int b = lane * 4; b < sl_so_bytes(maxq); b += 256) *reinterpret_cast<uint32_t*>(dp + 16 + 64 + b) = 0u;
+      gbytes_t sfb = src + 16 + 64 + sl_so_bytes(maxq);
+      uint8_t* dfb = dp + 16 + 64 + sl_so_bytes(maxq);
+      for (int q = 0; q < maxq; ++q) {
+        const bool as = q < tot_src, ad = q < tot_dst;
+        const uint64_t ms = __ballot(as), md = __ballot(ad);
+        const int cs = __builtin_amdgcn_readfirstlane(__popcll(ms)), cd = __builtin_amdgcn_readfirstlane(__popcll(md));
+        if (ad) {
+          const uint32_t rs_ = sl_lane_rank(ms), rd_ = sl_lane_rank(md);
+          SliceQuad<VT> vq;
+          vq.load(sfb + rs_ * QB);
+          const uint32_t rq = *reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(sfb + cs * QB + rs_ * 4);
+          vq.store(dfb + rd_ * QB);
+          *reinterpret_cast<uint32_t*>(dfb + cd * QB + rd_ * 4) = rq;
+        }
+        sfb += cs * QB + ((cs * 4 + 15) & ~15);
+        dfb += cd * QB + ((cd * 4 + 15) & ~15);
+      }
+    }
+  }
+  const uint32_t* toff = tab + (has_cg ? cgl * S : 0);
+  const int np = has_cg ? A.npieces[unit * RVR_NWV + wave] : 0;
+  const uint32_t pc = (lane < RVR_PMAX) ? A.pieces[(static_cast<int64_t>(unit) * RVR_NWV + wave) * RVR_PMAX + lane] : 0u;
+
+  // ---- the solver state (every thread, scalar loads) ---------------------------------------------
+  double d = st->d, F = st->F, alpha = st->alpha, s = st->s;
+  int i_ = st->i, j_ = st->j, k_ = st->k;
+  const int e_ubp = st->ubp, e_ubv = st->ubv;
+  int64_t n_passes = st->n_passes, n_trials = st->n_trials, n_iters = st->n_iters, n_view_passes = st->n_view_passes;
+  int nlive = st->nlive, nout = 0;
+  const int rv_builds = st->rv_builds, rv_last = st->rv_last, rv_backoff = st->rv_backoff;
+
+  // ---- row role: rows t and t + 512 of the view; column role: this thread's own column --------------
+  const double* Ue = A.pt + ((static_cast<int64_t>(e_ubp) * V + e_ubv) * 2 + 0) * mp;
+  const double* Ge = A.pt + ((static_cast<int64_t>(e_ubp) * V + e_ubv) * 2 + 1) * mp;
+  double UR[2], GR[2], aR[2] = {0.0, 0.0}, bR[2] = {0.0, 0.0};
+  bool rok[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int r = tid + e * RVR_NT;
+    rok[e] = r < nrows;
+    const int64_t i = rok[e] ? A.R.rowmap[r] : 0;
+    UR[e] = rok[e] ? Ue[i] : 0.0;
+    GR[e] = rok[e] ? Ge[i] : 0.0;
+  }
+  const int64_t col = static_cast<int64_t>(U.cg0 + wave) * 64 + lane;  // (wave w owns column group cg0 + w in the tail)
+  const bool cown = wave < U.ncgs && in_lanes && col < m;
+  const int rpos = cown ? A.viewpos[col] : -1;
+  double u_c = cown ? Ue[col] : 0.0, g_c = cown ? Ge[col] : 0.0, a_c = 0.0, b_c = 0.0;
+  __syncthreads();
+
+  unsigned long long epoch = A.epoch0;
+  int exchanges = 0;
+  int stamp_row = 0;
+  auto stamp = [&](int c) {
+    if (A.stamps && unit == 0 && tid == 0 && stamp_row < 500) A.stamps[stamp_row * 8 + c] = wall_clock64();
+  };
+  unsigned long long* const xb0 = A.xb;
+  const int64_t par_stride = rvr_xb_granules(V) / 2;
+  auto sec_g = [&](int par, int v, int r) { return xb0 + par * par_stride + ((static_cast<int64_t>(v) * RVR_MAXROWS + r) << 1); };
+  auto sec_c = [&](int par, int p) { return xb0 + par * par_stride + ((static_cast<int64_t>(V + 2) * RVR_MAXROWS + p) << 1); };
+
+  // What is left behind: the point (u, gradF) of every column into slot (e_ubp ^ 1, 0) — the entry state
+  // names (e_ubp, e_ubv), which stays as it is —, then the LAST unit to arrive commits the state.
+  auto arrive_last = [&]() __attribute__((always_inline)) -> bool {  // true in every thread of the last unit to arrive
+    __threadfence_system();  // (every thread: its stores of the point are out before the unit counts as arrived)
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t k = __hip_atomic_fetch_add(A.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      words[1] = (k == static_cast<uint32_t>(A.nunits)) ? 1u : 0u;
+    }
+    __syncthreads();
+    return words[1] != 0u;
+  };
+  auto write_point = [&](bool to_host) __attribute__((always_inline)) {
+    double* Ux = A.pt + ((static_cast<int64_t>(e_ubp ^ 1) * V + 0) * 2 + 0) * mp;
+    double* Gx = A.pt + ((static_cast<int64_t>(e_ubp ^ 1) * V + 0) * 2 + 1) * mp;
+    if (cown) {
+      Ux[col] = u_c;
+      Gx[col] = g_c;
+      if (to_host && A.host_u) __hip_atomic_store(A.host_u + col, u_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  };
+
+  // ---- the loop: one turn = one iteration of the streaming solver (G + T) -----------------------------
+  //   K_TRIAL  a window pass: V step sizes alpha, alpha beta, ... from the current (u, g)   (:234-262)
+  //   K_PAIR   a pair-mode pass on x = u: M_off u and C_off u apart for the penalty update   (:268-271)
+  //   K_BUILD  no pass: gradient and objective at u under the new penalty                   (:219-220)
+  enum { K_TRIAL = 0, K_PAIR = 1, K_BUILD = 2 };
+  int kind = (e_resume == 2) ? K_PAIR : K_TRIAL;
+  bool want_out = false;  // a prepared pass is the next thing: leave it to the streaming launches
+  for (;;) {
+    stamp(0);
+    // ---- leave? (only ever in front of a pass: what goes out is a PREPARED pass) ----------------------
+    const bool out_now = kind != K_BUILD && (exchanges >= A.max_exchanges || (kind == K_TRIAL ? want_out : nout != 0));
+    // the pending window's candidates of this thread's rows, their norm sums (:235-237)
+    double r2[2 * V];
+#pragma unroll
+    for (int q = 0; q < 2 * V; ++q) r2[q] = 0.0;
+    if (kind == K_TRIAL) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        double al = alpha;
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          double t = UR[e] + al * GR[e];
+          t = (t > 0.0) ? t : 0.0;
+          r2[2 * l] += t * t;
+          r2[2 * l + 1] += t;
+          al = al * P.beta;
+        }
+      }
+    }
+    if (out_now) {
+      const int resume = (kind == K_TRIAL) ? 1 : 2;
+      if (resume == 1) rvr_reduce<2 * V>(r2, red, tot);  // the norms go out with the state
+      write_point(false);
+      if (arrive_last() && tid == 0) {
+        SolverState* o = A.st;
+        o->d = d;
+        o->F = F;
+        o->alpha = alpha;
+        o->s = s;
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          const double nl = (resume == 1 && tot[2 * l] > 0.0) ? sqrt(tot[2 * l]) : 1.0;
+          o->nrm[l] = nl;
+          o->sx[l] = (resume == 1) ? tot[2 * l + 1] / nl : 0.0;
+        }
+        o->sel = 0;
+        o->ubp = e_ubp ^ 1;
+        o->ubv = 0;
+        o->phase = (resume == 1) ? static_cast<int>(PH_TRIAL) : static_cast<int>(PH_PENALTY);
+        o->stage = ST_PASS;
+        o->i = i_;
+        o->j = j_;
+        o->k = k_;
+        o->n_passes = n_passes;
+        o->n_trials = n_trials;
+        o->n_iters = n_iters;
+        o->nlive = nlive;
+        o->nout = nout;
+        o->view = 0;
+        o->hold = 0;
+        o->n_view_passes = n_view_passes;
+        o->rv_builds = rv_builds;
+        o->rv_last = rv_last;
+        o->rv_backoff = rv_backoff;
+        o->hold_slot = 0;
+        o->hold_nlive = 0;
+        o->resume = resume;
+        if (A.host) {
+          HostMirror* hm = A.host;
+          __hip_atomic_store(&hm->nlive, nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->nout, nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->n_view_passes, n_view_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      return;
+    }
+
+    // ---- the pass: X table (raw candidates of the view's rows) -> the COMPLETE sums y[0 .. V] of this
+    // thread's own column (acc[0] = a, acc[1 .. V-1] = g_v, acc[V] = b: rs_wave_pass) ---------------------
+    double y[NS];
+#pragma unroll
+    for (int v = 0; v < NS; ++v) y[v] = 0.0;
+    if (kind != K_BUILD) {
+      // the norms are needed only after the pass: their wave sums wait in LDS while it runs
+      if (kind == K_TRIAL) {
+#pragma unroll
+        for (int q = 0; q < 2 * V; ++q) r2[q] = wave_sum_to_lane63(r2[q]);
+        if (lane == 63) {
+#pragma unroll
+          for (int q = 0; q < 2 * V; ++q) red2[wave * 2 * V + q] = r2[q];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int r = tid + e * RVR_NT;
+        if (r < (nrows + 127) / 128 * 128) {
+          double al = alpha;
+#pragma unroll
+          for (int l = 0; l < V; ++l) {
+            double t = UR[e] + al * GR[e];
+            t = (t > 0.0) ? t : 0.0;
+            if (kind == K_PAIR) t = (l == 0) ? UR[e] : 0.0;
+            Xt[r * V + l] = t;
+            al = al * P.beta;
+          }
+        }
+      }
+      __syncthreads();
+      double acc[NS];
+      rs_wave_pass<VT, V>(sl, toff, pc, np, 0, Xt, (kind == K_TRIAL) ? d : 0.0, acc);
+      __syncthreads();  // the X table is dead: its memory becomes the waves' sums
+#pragma unroll
+      for (int v = 0; v < NS; ++v) scr[(wave * NS + v) * 64 + lane] = acc[v];
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < NS; ++v) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < RVR_NWV; ++w)  // the waves that worked for this thread's column group, in wave order
+          if (static_cast<int>((wcg >> (8 * w)) & 255ull) == wave) sum += scr[(w * NS + v) * 64 + lane];
+        y[v] = sum;
+      }
+      __syncthreads();  // (the next X table overwrites the sums)
+    }
+    stamp(1);
+    // the window's norms (:237), by V threads, for everybody: nrmL[l], sxL[l] (a pair-mode pass, the start of
+    // an outer iteration: 1, 0)
+    if (tid < V) {
+      double nl = 1.0, sl_ = 0.0;
+      if (kind == K_TRIAL) {
+        double z = red2[2 * tid], t1 = red2[2 * tid + 1];
+#pragma unroll
+        for (int w = 1; w < RVR_NWV; ++w) {
+          z += red2[w * 2 * V + 2 * tid];
+          t1 += red2[w * 2 * V + 2 * tid + 1];
+        }
+        nl = (z > 0.0) ? sqrt(z) : 1.0;  // :237 Eigen normalize()
+        sl_ = t1 / nl;
+      }
+      nrmL[tid] = nl;
+      sxL[tid] = sl_;
+    }
+    __syncthreads();
+
+    // ---- the tail of this thread's own column (k_tail's expressions, :237-242), what it publishes -----------
+    ++epoch;
+    ++exchanges;
+    const int par = static_cast<int>(epoch & 1ull);
+    const unsigned long long tag = (epoch & 0xffffffffull) << 32;
+    double gn_c[V], an_c = a_c, bn_c = b_c;
+    uint32_t cbits = 0;  // bit v: this thread's column lies outside R and candidate v makes it live
+    if (kind == K_TRIAL) {
+      double al = alpha;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        double t = u_c + al * g_c;
+        t = (t > 0.0) ? t : 0.0;
+        const double nv = rvr_uni(nrmL + v), sv = rvr_uni(sxL + v);
+        const double xi = t / nv;
+        double gn;
+        if (v == 0) {
+          an_c = y[0] / nv;
+          bn_c = y[V] / nv;
+          gn = (1 + d) * xi - d * sv + an_c + bn_c * d;
+        } else {
+          const double gs = y[v] / nv;
+          gn = (1 + d) * xi - d * sv + gs;
+        }
+        gn_c[v] = gn;
+        if (cown && rpos < 0 && (xi > 0.0 || gn > 0.0)) cbits |= 1u << v;
+        if (cown && rpos >= 0) rvr_publish(sec_g(par, v, rpos), tag, gn);
+        al = al * P.beta;
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) gn_c[v] = 0.0;
+      if (kind == K_PAIR) {
+        an_c = y[0];
+        bn_c = y[V];
+      } else if (cown) {  // K_BUILD (:219)
+        gn_c[0] = (1 + d) * u_c - d * s + a_c + b_c * d;
+        if (rpos < 0 && (u_c > 0.0 || gn_c[0] > 0.0)) cbits = 1u;
+      }
+    }
+    if (kind != K_BUILD && cown && rpos >= 0) {
+      rvr_publish(sec_g(par, V, rpos), tag, an_c);
+      rvr_publish(sec_g(par, V + 1, rpos), tag, bn_c);
+    }
+    // (a, b) of candidate 0 replace the current ones whatever is accepted — as cab does in k_tail; they are
+    // read only when they are the current point's (penalty update, start of an outer iteration)
+    a_c = an_c;
+    b_c = bn_c;
+    {  // the unit's counts, 10 bits per candidate, as one value
+      unsigned long long w = 0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) w |= static_cast<unsigned long long>(__popcll(__ballot((cbits >> v) & 1u))) << (7 * v);
+      if (lane == 0) reinterpret_cast<unsigned long long*>(red)[wave] = w;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long pk = 0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          unsigned long long tot = 0;
+          for (int w2 = 0; w2 < RVR_NWV; ++w2) tot += (reinterpret_cast<unsigned long long*>(red)[w2] >> (7 * v)) & 127ull;
+          pk |= tot << (10 * v);
+        }
+        rvr_publish(sec_c(par, unit), tag, __longlong_as_double(static_cast<long long>(pk)));
+      }
+      __syncthreads();
+    }
+    stamp(2);
+
+    // ---- the exchange: every granule of this thread's rows (and one unit's counts) until it carries the
+    // iteration's epoch — no drain, no flag, no barrier (k_resident.hip.h) -----------------------------------
+    double gR[2][V], anR[2], bnR[2], cpack = 0.0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      anR[e] = aR[e];
+      bnR[e] = bR[e];
+#pragma unroll
+      for (int v = 0; v < V; ++v) gR[e][v] = 0.0;
+    }
+    {
+      int fail = 0;
+      const long long t_poll = wall_clock64();
+      for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r = tid + e * RVR_NT;
+          if (rok[e] && kind != K_BUILD) {
+            if (kind == K_TRIAL) {
+#pragma unroll
+              for (int v = 0; v < V; ++v) ok = rvr_poll(sec_g(par, v, r), tag, gR[e][v]) && ok;
+            }
+            ok = rvr_poll(sec_g(par, V, r), tag, anR[e]) && ok;
+            ok = rvr_poll(sec_g(par, V + 1, r), tag, bnR[e]) && ok;
+          }
+        }
+        if (tid < A.nunits) ok = rvr_poll(sec_c(par, tid), tag, cpack) && ok;
+        if (__all(ok)) break;
+        if ((spins & 63u) == 63u || A.timeout_ticks < 0) {
+          const bool late = wall_clock64() - t_poll > A.timeout_ticks;
+          const uint32_t e2 = __hip_atomic_load(A.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (late || e2 != 0) {
+            fail = 1;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (__syncthreads_or(fail)) {  // nothing is committed: the streaming launches carry on from the entry state
+        if (tid == 0) {
+          uint32_t expect = 0;
+          __hip_atomic_compare_exchange_strong(A.ctl, &expect, static_cast<uint32_t>(RVR_ERR_TIMEOUT), __ATOMIC_RELAXED,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+      }
+    }
+    stamp(3);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      aR[e] = anR[e];
+      bR[e] = bnR[e];
+    }
+
+    // ---- every scalar of the iteration, from R (:242, :253, :268-274) and the counts ------------------------
+    //   q2[4 v + 0] F_v   [4 v + 1] ||x_v - u||^2   [4 v + 2] live rows of candidate v in R   [4 v + 3] outside R
+    //   q2[4 V], [4 V + 1] the penalty terms (count, sum of ratios)
+    double q2[4 * V + 2];
+#pragma unroll
+    for (int q = 0; q < 4 * V + 2; ++q) q2[q] = 0.0;
+    if (kind == K_TRIAL) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        double al = alpha;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          double t = UR[e] + al * GR[e];
+          t = (t > 0.0) ? t : 0.0;
+          const double xi = t / rvr_uni(nrmL + v);
+          if (rok[e]) {
+            const double gv = gR[e][v];
+            q2[4 * v + 0] += xi * gv;  // :242
+            const double du = xi - UR[e];
+            q2[4 * v + 1] += du * du;  // :253
+            q2[4 * v + 2] += (xi > 0.0 || gv > 0.0) ? 1.0 : 0.0;
+            if (v == 0) {
+              const double cbu = rvr_uni(sxL) - bnR[e] - xi;
+              if (cbu > P.eps && xi > P.eps) {
+                q2[4 * V] += 1.0;
+                q2[4 * V + 1] += fabs((anR[e] + xi) / cbu);
+              }
+            }
+          }
+          al = al * P.beta;
+        }
+      }
+    } else if (kind == K_PAIR) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const double cbu = s - bR[e] - UR[e];             // :268
+        if (rok[e] && cbu > P.eps && UR[e] > P.eps) {    // :269
+          q2[4 * V] += 1.0;
+          q2[4 * V + 1] += fabs((aR[e] + UR[e]) / cbu);   // :271-274
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (rok[e]) {
+          const double gi = (1 + d) * UR[e] - d * s + aR[e] + bR[e] * d;  // :219
+          GR[e] = gi;
+          q2[0] += UR[e] * gi;  // :220
+          q2[2] += (UR[e] > 0.0 || gi > 0.0) ? 1.0 : 0.0;
+        }
+      }
+    }
+    if (tid < A.nunits) {
+      const unsigned long long pk = static_cast<unsigned long long>(__double_as_longlong(cpack));
+#pragma unroll
+      for (int v = 0; v < V; ++v) q2[4 * v + 3] = static_cast<double>((pk >> (10 * v)) & 1023ull);
+    }
+    rvr_reduce<4 * V + 2>(q2, red, tot);
+    stamp(4);
+    ++n_iters;
+    if (kind != K_BUILD) {
+      ++n_passes;
+      ++n_view_passes;
+    }
+    ++stamp_row;
+
+    // ---- what the sums mean: decide()'s rules ---------------------------------------------------------------
+    bool penalty = false;
+    if (kind == K_TRIAL) {
+      // :244-251 — walk the window in the reference's order
+      int jstar = -1;
+      double Fnew = 0.0, deltaF = 0.0;
+      const double alpha_w = alpha;  // the step size of this window's candidate 0
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        if (jstar < 0) {
+          ++n_trials;
+          Fnew = rvr_uni(tot + 4 * v);
+          deltaF = Fnew - F;        // :244
+          bool accept = true;
+          if (deltaF < -P.eps) {    // :246-248
+            alpha = alpha * P.beta;
+            ++k_;
+            if (k_ < P.maxlsiters) accept = false;
+          }
+          if (accept) jstar = v;
+        }
+      }
+      if (jstar < 0) continue;  // all V rejected: V more factors of beta are in alpha, the point is unchanged
+      // :256-258 — the accepted candidate becomes the point (its raw value: the window's own chain of step
+      // sizes from alpha_w, exactly what was staged and what k_tail forms)
+      double du2 = 0.0, lr = 0.0, no = 0.0;
+      {
+        double al = alpha_w;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          if (v == jstar) {
+            du2 = rvr_uni(tot + 4 * v + 1);
+            lr = rvr_uni(tot + 4 * v + 2);
+            no = rvr_uni(tot + 4 * v + 3);
+            s = rvr_uni(sxL + v);
+            double t = u_c + al * g_c;
+            t = (t > 0.0) ? t : 0.0;
+            u_c = t / rvr_uni(nrmL + v);
+            g_c = gn_c[v];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              double t2 = UR[e] + al * GR[e];
+              t2 = (t2 > 0.0) ? t2 : 0.0;
+              UR[e] = rok[e] ? t2 / rvr_uni(nrmL + v) : 0.0;
+              GR[e] = rok[e] ? gR[e][v] : 0.0;
+            }
+          }
+          al = al * P.beta;
+        }
+      }
+      const double deltau = sqrt(du2);
+      F = Fnew;
+      ++j_;
+      nout = static_cast<int>(no);
+      nlive = static_cast<int>(lr) + nout;
+      if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
+        if (jstar == 0) {
+          penalty = true;  // candidate 0 carries (a, b) and its penalty terms are summed
+        } else {
+          kind = K_PAIR;
+          continue;
+        }
+      } else {
+        alpha = 1.0;  // :227
+        k_ = 0;
+        want_out = nout != 0 || view_wanted_v(A.rvp, m, true, A.rv_rows, nlive, nout, n_iters + 1, rv_builds, rv_last, rv_backoff);
+        continue;
+      }
+    } else if (kind == K_PAIR) {
+      penalty = true;
+    } else {  // K_BUILD: the first window of the outer iteration is pending
+      if (cown) g_c = gn_c[0];
+      F = rvr_uni(tot + 0);
+      nout = static_cast<int>(rvr_uni(tot + 3));
+      nlive = static_cast<int>(rvr_uni(tot + 2)) + nout;
+      j_ = 0;
+      alpha = 1.0;
+      k_ = 0;
+      kind = K_TRIAL;
+      want_out = nout != 0 || view_wanted_v(A.rvp, m, true, A.rv_rows, nlive, nout, n_iters + 1, rv_builds, rv_last, rv_backoff);
+      continue;
+    }
+    if (penalty) {  // :276-280
+      bool done = true;
+      const double pen_cnt = rvr_uni(tot + 4 * V), pen_rs = rvr_uni(tot + 4 * V + 1);
+      if (pen_cnt > 0.0) {
+        d += pen_rs / pen_cnt;
+        ++i_;
+        done = i_ >= P.maxoliters;
+      }
+      if (!done) {
+        kind = K_BUILD;
+        continue;
+      }
+      // ---- the end of the solve (decide(): ACT_DONE) ----------------------------------------------------------
+      write_point(true);
+      if (arrive_last() && tid == 0) {
+        SolverState* o = A.st;  // (the launches queued behind see `done`; the state only names the final point)
+        o->ubp = e_ubp ^ 1;
+        o->ubv = 0;
+        SolveShared* sh = A.shared;
+        sh->F = F;
+        sh->d = d;
+        sh->n_passes = n_passes;
+        sh->n_trials = n_trials;
+        sh->ifinal = i_;
+        sh->ubp = e_ubp ^ 1;
+        sh->ubv = 0;
+        sh->done = 1;
+        if (A.host) {
+          HostMirror* hm = A.host;
+          __hip_atomic_store(&hm->F, F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->d, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->n_passes, n_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->n_trials, n_trials, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->n_view_passes, n_view_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->nlive, nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->nout, nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->ifinal, i_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->ubp, e_ubp ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->ubv, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // (every unit's u went out before it arrived)
+        }
+      }
+      return;
+    }
+  }
+}
+
+}  // namespace clipper_hip

@@ -226,6 +226,10 @@ struct SolveArgs {
                            // it covers the live rows of every outcome, whatever the tail counted
   int rv_rows;             // rows of the view
   ViewPolicy rvp;
+  int decide_only;         // this G launch only DECIDES: a decision that ends in a pass records that pass as
+                           // prepared (SolverState::resume) instead of running it — the hand-over to the
+                           // resident solver on a row view (k_rv_resident.hip.h), which starts from a
+                           // prepared pass and leaves one behind
 };
 constexpr int KIND_CAP = 1 << 16;
 
@@ -335,17 +339,22 @@ __device__ __forceinline__ bool is_writer_block() {
 // The view policy: build a view of the `nlive` live rows now? Rows a pass streams today: the view's
 // while it covers the live rows, else all of M's; as many passes to come as there have been
 // iterations (at least 12: the penalty homotopy's later outer iterations are the long ones).
-__device__ __forceinline__ bool view_wanted(const SolveArgs& A, int nlive, int nout, int64_t n_iters,
-                                            int builds, int last, int backoff) {
-  if (builds >= A.rvp.max_builds || n_iters < 2 || n_iters - last < 3) return false;
-  if (nlive <= 0 || nlive >= A.m) return false;
-  const double rows_now = (A.in_view != nullptr && nout == 0) ? static_cast<double>(A.rv_rows) : static_cast<double>(A.m);
+__device__ __forceinline__ bool view_wanted_v(const ViewPolicy& rvp, int64_t m, bool have_view, int rv_rows,
+                                              int nlive, int nout, int64_t n_iters, int builds, int last,
+                                              int backoff) {
+  if (builds >= rvp.max_builds || n_iters < 2 || n_iters - last < 3) return false;
+  if (nlive <= 0 || nlive >= m) return false;
+  const double rows_now = (have_view && nout == 0) ? static_cast<double>(rv_rows) : static_cast<double>(m);
   const double r = static_cast<double>(nlive);
   if (r > RV_ROWS_RATIO * rows_now) return false;
   if (backoff > 0 && r > RV_ROWS_RATIO * static_cast<double>(backoff)) return false;  // nothing much changed since a refusal
   const double horizon = n_iters > 12 ? static_cast<double>(n_iters) : 12.0;
-  const double gain = horizon * ((rows_now - r) * A.rvp.pass_per_row);
-  return gain > A.rvp.build_fixed + r * A.rvp.build_per_row;
+  const double gain = horizon * ((rows_now - r) * rvp.pass_per_row);
+  return gain > rvp.build_fixed + r * rvp.build_per_row;
+}
+__device__ __forceinline__ bool view_wanted(const SolveArgs& A, int nlive, int nout, int64_t n_iters,
+                                            int builds, int last, int backoff) {
+  return view_wanted_v(A.rvp, A.m, A.in_view != nullptr, A.rv_rows, nlive, nout, n_iters, builds, last, backoff);
 }
 
 // dst = *src by the threads of a workgroup, 8 bytes each
@@ -786,6 +795,15 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
     };
     if (action == ACT_PASS) record(stash, true);
     else record(A.st_next, false);
+    if (A.decide_only != 0 && action == ACT_PASS) {
+      // the pass is left PREPARED: window from point slot (ubp, ubv) with step `alpha` and the norms just
+      // parked, or (penalty update) the pair-mode pass on that slot's u
+      stash->stage = ST_PASS;
+      stash->resume = need_pair ? 2 : 1;
+      stash->n_passes = n_passes;
+      stash->view = 0;
+      stash->n_view_passes = L.n_view_passes;
+    }
     if (action == ACT_DONE) {
       SolveShared* sh = A.shared;
       sh->F = F;
@@ -810,12 +828,19 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         // every store above (and the vectors this workgroup wrote) before the flag
         __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      if (action != ACT_PASS) {
+      if (action != ACT_PASS || A.decide_only != 0) {
         __hip_atomic_store(&hm->nlive, nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->nout, nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
+  }
+  if (A.decide_only != 0 && action == ACT_PASS) {  // (block-uniform) nothing streams: the prepared pass goes out as the state
+    if (writer) {
+      __syncthreads();
+      copy_state(A.st_next, stash, tid, NT);
+    }
+    return false;
   }
   // the decision came out of LDS reads: tell the compiler it is wave-uniform, so that the
   // multipliers of the streaming loop stay scalar loads
@@ -849,14 +874,23 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
     return false;
   }
   if (L.stage == ST_RESULTS) return decide<V, NT>(A, L, lds, stash, plan);
-  // the pass was prepared by a transition iteration (or by k_init): run it as it stands
-  plan.view = 0;  // (pair-mode passes on a whole vector: u0, the normalised u)
+  // the pass was prepared — by a transition iteration or k_init (pair mode on candidate 0 of table
+  // `sel`: u0, the normalised u), or by a decide-only launch / the resident solver on a row view
+  // (SolverState::resume: a window from the point slot, or the pair-mode pass on its u): run it as it stands
+  const int resume = st->resume;
+  const int slot = L.ubp * V + L.ubv;
+  const int on_view = (resume != 0 && A.in_view != nullptr && L.nout == 0) ? 1 : 0;
+  if (A.decide_only != 0) {  // nothing to decide: the state goes on as it is
+    if (is_writer_block()) copy_state(A.st_next, st, threadIdx.x, NT);
+    return false;
+  }
+  plan.view = __builtin_amdgcn_readfirstlane(on_view);
   plan.phase = st->phase;
   plan.sel = st->sel;
-  plan.from_u = -1;
+  plan.from_u = __builtin_amdgcn_readfirstlane(resume == 2 ? slot : -1);
   plan.d = st->d;
-  plan.src = 0;  // (pair-mode passes only: never read)
-  plan.alpha0 = 1.0;
+  plan.src = __builtin_amdgcn_readfirstlane(slot);  // (read by window passes only)
+  plan.alpha0 = L.alpha;
   if (is_writer_block()) {  // (word by word by the whole workgroup: one thread's struct copy is 70 registers)
     copy_state(stash, st, threadIdx.x, NT);
     __syncthreads();
@@ -864,7 +898,9 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
       stash->stage = ST_RESULTS;
       stash->n_passes = L.n_passes + 1;
       stash->n_iters = L.n_iters + 1;
-      stash->view = 0;
+      stash->view = on_view;
+      stash->n_view_passes = L.n_view_passes + on_view;
+      stash->resume = 0;
     }
   }
   return true;

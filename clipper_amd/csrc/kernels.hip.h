@@ -30,6 +30,7 @@
 //   k_slices.hip.h    the compressed storage: layout, the pass on it (k_gemv_slices), packers, k_slice_expand
 //   k_csc.hip.h       producers of the slices: emission from the fill kernel's LDS image, groups
 //   k_resident.hip.h  the resident solver: findDenseClique as one launch for problems that fit on chip
+//   k_rv_resident.hip.h  the resident solver on a row view: the iterations that stream a view, as one launch
 //   k_affinity.hip.h  k_gather_points, k_affinity_* (plain, compacting strips, symmetric tiles + emission)
 //   k_matrix.hip.h    k_from_dense_upper, k_from_csc, k_gather_sub
 //   k_rowview.hip.h   the row list of a row view of M (the live rows of the solver's current points)
@@ -40,6 +41,7 @@
 #include "k_gemv.hip.h"
 #include "k_csc.hip.h"
 #include "k_resident.hip.h"
+#include "k_rv_resident.hip.h"
 #include "k_affinity.hip.h"
 #include "k_matrix.hip.h"
 #include "k_rowview.hip.h"

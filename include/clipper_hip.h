@@ -102,6 +102,8 @@ typedef struct clipper_hip_view_stats_t {
   double view_pass_avg_us; /* mean duration of the sampled pass launches that streamed a view
                               (profiling on; 0 = none sampled)                               */
   int64_t view_pass_samples;
+  int64_t resident_launches; /* launches of the resident solver on a view (k_rv_resident.hip.h): the passes
+                                on a view that ran inside one are counted in view_passes, not sampled   */
 } clipper_hip_view_stats_t;
 
 /* ---- life cycle --------------------------------------------------------------------- */
@@ -275,7 +277,11 @@ int clipper_hip_last_solver(const clipper_hip_t* h);
  * matrix that was handed over (setMatrixData / setSparseMatrixData, custom invariants) — and
  * streams THOSE while the device-side check "no live row outside the view" holds; any pass for
  * which it does not hold streams M itself. Same trial sequence, same sums up to the
- * order of the partial sums. mode 0 = automatic, 1 = never (also: CLIPPER_HIP_ROW_VIEW=0). */
+ * order of the partial sums. mode 0 = automatic, 1 = never (also: CLIPPER_HIP_ROW_VIEW=0).
+ * A view small enough for the LDS of the chip (at most 1024 rows, a few MB: the headline problem's 524
+ * rows x 10 000 columns) is not streamed at all: the iterations on it run as ONE launch of workgroups that
+ * each keep complete columns of the view on chip, until the solve ends or a row outside the view becomes
+ * live (csrc/k_rv_resident.hip.h); mode 2 (also: CLIPPER_HIP_VIEW_RESIDENT=0) keeps the views but streams them. */
 int clipper_hip_set_row_view(clipper_hip_t* h, int mode);
 int clipper_hip_get_view_stats(const clipper_hip_t* h, clipper_hip_view_stats_t* out);
 

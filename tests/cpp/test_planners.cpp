@@ -158,6 +158,81 @@ static bool check_resident(const std::vector<uint32_t>& L, int ncg, int nchunks,
   return true;
 }
 
+// plan_view_resident: the units partition every (column group, lane) — a group whole in one unit, or split
+// into lane ranges that tile [0, 64) — and hold ALL chunks of their groups; a unit fits its LDS share by the
+// planner's own bound (lane subsets: their share of the quads + every step's padding); the pieces of a unit
+// partition the steps of each of its slices among waves mapped to that column group.
+static bool check_view_resident(const std::vector<uint32_t>& L, int ncg, int nchunks, int esize, int target, int max_units,
+                                uint32_t fixed) {
+  const ResidentConsts K{512, 8, 64, 12, 2, 159u * 1024u, 2 * 8 * 16 * 8 + 64 * 8, 64 * 8 + 64, 2048, 16};
+  ViewResidentPlan P;
+  plan_view_resident(L.data(), ncg, nchunks, esize, target, max_units, fixed, K, P);
+  if (!P.ok) return false;
+  REQUIRE(static_cast<int>(P.units.size()) <= max_units && !P.units.empty());
+  std::vector<std::vector<int>> lanes(ncg, std::vector<int>(64, 0));
+  uint64_t entries = 0;
+  for (uint32_t v : L) entries += v >> 8;
+  REQUIRE(P.entries == entries);
+  for (size_t ui = 0; ui < P.units.size(); ++ui) {
+    const ViewUnit& U = P.units[ui];
+    REQUIRE(U.ncgs >= 1 && U.ncgs <= K.nwv && U.cg0 >= 0 && U.cg0 + U.ncgs <= ncg);
+    REQUIRE(U.l0 >= 0 && U.l0 < U.l1 && U.l1 <= 64);
+    REQUIRE(U.ncgs == 1 || (U.l0 == 0 && U.l1 == 64));
+    REQUIRE(U.ncgs * nchunks <= K.tmax);
+    uint64_t bytes = 0;
+    for (int c = 0; c < U.ncgs; ++c) {
+      for (int l = U.l0; l < U.l1; ++l) ++lanes[U.cg0 + c][l];
+      for (int k = 0; k < nchunks; ++k) {
+        const uint32_t lq = L[static_cast<size_t>(U.cg0 + c) * nchunks + k];
+        const uint64_t full = slice_bound(lq, 4u * esize, K.so);
+        bytes += (U.l0 == 0 && U.l1 == 64) ? full : full * (U.l1 - U.l0) / 64 + 16 + 64 + 64 * 16;
+      }
+    }
+    REQUIRE(bytes + K.slice_pad <= P.lds_slices + 8192);  // (the kernel checks the real sizes; the plan must be close)
+    std::map<std::pair<int, int>, std::vector<std::pair<int, int>>> steps;
+    std::vector<int> waves_of(U.ncgs, 0);
+    for (int w = 0; w < K.nwv; ++w) {
+      const size_t wv = ui * K.nwv + w;
+      const int cgl = P.wave_cg[wv];
+      if (cgl == 255) {
+        REQUIRE(P.npieces[wv] == 0);
+        continue;
+      }
+      REQUIRE(cgl < U.ncgs);
+      ++waves_of[cgl];
+      REQUIRE(P.npieces[wv] <= K.pmax);
+      for (int j = 0; j < P.npieces[wv]; ++j) {
+        const uint32_t pc = P.pieces[wv * K.pmax + j];
+        const int kl = pc & 255, q0 = (pc >> 8) & 255, q1 = (pc >> 16) & 255;
+        REQUIRE(kl < nchunks && q0 < q1);
+        steps[std::make_pair(cgl, kl)].push_back(std::make_pair(q0, q1));
+      }
+    }
+    for (int c = 0; c < U.ncgs; ++c) {
+      REQUIRE(waves_of[c] >= 1);
+      for (int k = 0; k < nchunks; ++k) {
+        const int mq = static_cast<int>(L[static_cast<size_t>(U.cg0 + c) * nchunks + k] & 255u);
+        auto it = steps.find(std::make_pair(c, k));
+        if (mq == 0) {
+          REQUIRE(it == steps.end());
+          continue;
+        }
+        REQUIRE(it != steps.end());
+        std::sort(it->second.begin(), it->second.end());
+        int at = 0;
+        for (auto& pr : it->second) {
+          REQUIRE(pr.first == at);
+          at = pr.second;
+        }
+        REQUIRE(at == mq);
+      }
+    }
+  }
+  for (int cg = 0; cg < ncg; ++cg)
+    for (int l = 0; l < 64; ++l) REQUIRE(lanes[cg][l] == 1);
+  return true;
+}
+
 int main() {
   std::mt19937 rng(20260926);
   int npass = 0, nres = 0, nres_ok = 0;
@@ -189,7 +264,25 @@ int main() {
       REQUIRE(nw >= 1536 && nw <= 8 * 1536 + 391 * 40);  // (+ the fillers of strips with fewer items than the fullest)
     }
   }
+  // row views of a few hundred rows over thousands of columns (the headline: 524 rows x 10 000 columns, a dense
+  // inlier block in the last column groups): complete columns per unit, dense groups split by lanes
+  int nview = 0, nview_ok = 0;
+  for (int ncg : {47, 79, 157, 235})
+    for (int nchunks : {1, 3, 5, 8})
+      for (double density : {0.02, 0.16, 0.5})
+        for (int esize : {4, 8})
+          for (int target : {40, 96, 170, 248}) {
+            std::snprintf(g_case, sizeof(g_case), "view ncg=%d nchunks=%d density=%.2f esize=%d target=%d", ncg, nchunks, density, esize, target);
+            auto L = directory(rng, ncg, nchunks, density, 0.0);
+            for (int cg = ncg - std::max(1, ncg / 18); cg < ncg; ++cg)  // the inlier block: every row of the view is stored
+              for (int k = 0; k < nchunks; ++k) L[static_cast<size_t>(cg) * nchunks + k] = 32u | (uint32_t(128 * 64) << 8);
+            const uint32_t fixed = std::max<uint32_t>(nchunks * 128 * 6 * 8, 8 * 7 * 64 * 8) + (2 * 8 * 16 * 8 + 64 * 8) + (64 * 8 + 64);
+            ++nview;
+            nview_ok += check_view_resident(L, ncg, nchunks, esize, target, 248, fixed) ? 1 : 0;
+          }
+  REQUIRE(nview_ok > nview / 2);
   REQUIRE(nres_ok > nres / 4);  // (the small and the sparse ones fit)
+  std::printf("view-resident plans: %d (%d fit the chip)\n", nview, nview_ok);
   std::printf("planners ok: %d pass plans, %d resident plans (%d fit the chip)\n", npass, nres, nres_ok);
   return 0;
 }

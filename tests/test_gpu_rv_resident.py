@@ -1,0 +1,134 @@
+"""The resident solver on a row view (csrc/k_rv_resident.hip.h; include/clipper_hip.h: clipper_hip_set_row_view
+mode 2 switches it off): once a view fits the LDS of the chip, the iterations on it (clipper.cpp:226-280) run as
+ONE launch of workgroups that keep complete columns of the view on chip. It starts from a prepared pass and
+leaves one behind; whatever it does must be the streaming launches' result — the oracle's — up to the order of
+the sums over the view's rows."""
+import os
+
+import numpy as np
+import pytest
+
+from clipper_amd import _abi as abi
+from clipper_amd import synth
+from oracle import clipper_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(p):
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    return r.solve(p.u0)
+
+
+def _ctx(p, storage, mode):
+    g = abi.HipClipper(storage=storage)
+    g.set_row_view(mode)
+    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    return g
+
+
+@pytest.mark.parametrize("storage", [abi.STORE_F32_CSC, abi.STORE_F64_CSC])
+@pytest.mark.parametrize("m,rho,seed", [(10000, 0.95, 12345), (10000, 0.95, 4), (6000, 0.9, 6777), (12000, 0.97, 5)])
+def test_resident_on_a_view_equals_the_streamed_view_and_the_oracle(storage, m, rho, seed):
+    p = synth.make_euclidean_problem(m, rho, seed=seed)
+    sr = _oracle(p)
+    g1, g2 = _ctx(p, storage, 0), _ctx(p, storage, 2)
+    s1, s2 = g1.solve(p.u0), g2.solve(p.u0)
+    st1, st2 = g1.view_stats(), g2.view_stats()
+    assert st2.resident_launches == 0 and st2.builds >= 1
+    assert st1.builds >= 1 and st1.rows <= 1024 and st1.resident_launches >= 1, (st1.builds, st1.rows, st1.resident_launches)
+    for s in (s1, s2):
+        assert s.nodes.tolist() == sr.nodes.tolist()
+        assert s.ifinal == sr.ifinal
+        assert abs(s.score - sr.score) <= 1e-6 * abs(sr.score)
+    assert abs(s1.score - s2.score) <= 1e-10 * abs(s2.score)
+    assert np.allclose(s1.u, s2.u, rtol=0, atol=1e-8)
+    assert abs(s1.n_trials - s2.n_trials) <= max(2, s2.n_trials // 20)
+    assert abs(s1.n_trials - sr.n_trials) <= max(2, sr.n_trials // 20)
+    assert st1.view_passes >= 1
+    # bit-reproducible from solve to solve (the exchange has a fixed order of additions)
+    s1b = g1.solve(p.u0)
+    assert np.array_equal(s1b.u, s1.u) and s1b.n_trials == s1.n_trials and s1b.n_passes == s1.n_passes
+    print(f"m={m} rho={rho} storage={storage}: rows {st1.rows}, passes {s1.n_passes} ({st1.view_passes} on the view, "
+          f"{st1.resident_launches} resident launch), trials {s1.n_trials} / streamed {s2.n_trials} / oracle {sr.n_trials}")
+    g1.close()
+    g2.close()
+
+
+def test_headline_trials_and_ordered_list():
+    """BASELINE's headline problem: 66 trials, the oracle's ordered node list."""
+    p = synth.make_euclidean_problem(10000, 0.95, seed=12345)
+    sr = _oracle(p)
+    g = _ctx(p, abi.STORE_F32_CSC, 0)
+    s = g.solve(p.u0)
+    st = g.view_stats()
+    assert st.resident_launches == 1
+    assert s.nodes.tolist() == sr.nodes.tolist()
+    assert s.n_trials == sr.n_trials == 66
+    assert s.ifinal == sr.ifinal and abs(s.score - sr.score) <= 1e-9 * abs(sr.score)
+    g.close()
+
+
+@pytest.mark.parametrize("budget", [0, 1, 2, 3, 5, 9])
+def test_leaving_after_a_few_exchanges_hands_a_prepared_pass_back(budget, monkeypatch):
+    """CLIPPER_HIP_VIEW_RESIDENT_MAX_EXCHANGES (test knob): the launch leaves after that many iterations — in
+    front of a window pass or of a penalty update's pair-mode pass, wherever the budget ends — and the
+    streaming launches queued behind it carry on from the prepared pass it committed."""
+    p = synth.make_euclidean_problem(10000, 0.95, seed=12345)
+    sr = _oracle(p)
+    monkeypatch.setenv("CLIPPER_HIP_VIEW_RESIDENT_MAX_EXCHANGES", str(budget))
+    g = _ctx(p, abi.STORE_F32_CSC, 0)
+    s = g.solve(p.u0)
+    st = g.view_stats()
+    assert st.resident_launches >= 1
+    assert s.nodes.tolist() == sr.nodes.tolist() and s.ifinal == sr.ifinal
+    assert abs(s.score - sr.score) <= 1e-9 * abs(sr.score)
+    assert abs(s.n_trials - sr.n_trials) <= 2
+    monkeypatch.delenv("CLIPPER_HIP_VIEW_RESIDENT_MAX_EXCHANGES")
+    g.close()
+
+
+def test_a_launch_that_gives_up_changes_nothing(monkeypatch):
+    """A time-out of the exchange (forced: CLIPPER_HIP_VIEW_RESIDENT_TIMEOUT_TICKS=-1) commits nothing: the
+    entry state is intact and the streaming launches run every iteration — bit for bit the solve of mode 2."""
+    p = synth.make_euclidean_problem(10000, 0.95, seed=12345)
+    g2 = _ctx(p, abi.STORE_F32_CSC, 2)
+    s2 = g2.solve(p.u0)
+    monkeypatch.setenv("CLIPPER_HIP_VIEW_RESIDENT_TIMEOUT_TICKS", "-1")
+    g = _ctx(p, abi.STORE_F32_CSC, 0)
+    s = g.solve(p.u0)
+    assert g.view_stats().resident_launches >= 1
+    assert np.array_equal(s.u, s2.u) and s.n_trials == s2.n_trials and s.nodes.tolist() == s2.nodes.tolist()
+    monkeypatch.delenv("CLIPPER_HIP_VIEW_RESIDENT_TIMEOUT_TICKS")
+    s3 = g.solve(p.u0)      # and the context is fine afterwards
+    assert s3.nodes.tolist() == s2.nodes.tolist()
+    g.close()
+    g2.close()
+
+
+def test_matrix_without_points_and_parameter_variants():
+    """A matrix that was handed over (its views are filtered out of its own slices) and solver parameters that
+    move the exits around (few inner iterations: many penalty updates; a loose line search)."""
+    p = synth.make_euclidean_problem(9000, 0.95, seed=99)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    M, Cm = r.get_affinity_matrix(), r.get_constraint_matrix()
+    for kw in ({}, {"maxiniters": 3}, {"beta": 0.5, "maxlsiters": 4}, {"tol_u": 1e-5, "tol_F": 1e-6}, {"rescale_u0": 0}):
+        prm = ref.Params()
+        for k, v in kw.items():
+            setattr(prm, k, v)
+        rr = ref.RefClipper(prm)
+        rr.set_matrix_data(M, Cm)
+        so = rr.solve(p.u0)
+        g = abi.HipClipper(storage=abi.STORE_F64_CSC)
+        g.set_matrix_data(M, Cm)
+        for k, v in kw.items():
+            setattr(g.params, k, v)
+        s = g.solve(p.u0)
+        st = g.view_stats()
+        assert s.nodes.tolist() == so.nodes.tolist(), kw
+        assert s.ifinal == so.ifinal and abs(s.score - so.score) <= 1e-9 * abs(so.score), kw
+        assert abs(s.n_trials - so.n_trials) <= max(2, so.n_trials // 20), (kw, s.n_trials, so.n_trials)
+        print(f"{kw}: views {st.builds}, rows {st.rows}, resident launches {st.resident_launches}, trials {s.n_trials} (oracle {so.n_trials})")
+        g.close()
