@@ -140,6 +140,34 @@ __device__ __forceinline__ bool rvr_poll(const unsigned long long* gq, unsigned 
   return ((g0 ^ tag) >> 32) == 0 && ((g1 ^ tag) >> 32) == 0;
 }
 
+// Both granules of a value with ONE 16-byte load past this CU's L1 and the XCD's L2 (sc1, as the compiler
+// emits a relaxed agent-scope load): half the requests of a sweep. The load may tear between the two 8-byte
+// granules — each carries its own epoch. The compiler does not track an asm load: rvr_wait_loads() before the
+// first use, then rvr_tie() on every value so that no use is scheduled ahead of the wait.
+typedef uint32_t rvr_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rvr_u4 rvr_ld16(const unsigned long long* gq) {
+  rvr_u4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(gq) : "memory");
+  return v;
+}
+__device__ __forceinline__ void rvr_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void rvr_tie(rvr_u4& v) { asm volatile("" : "+v"(v)); }
+// {half, tag, half, tag}: the value, and whether both granules carry the tag
+__device__ __forceinline__ bool rvr_take(const rvr_u4& v, uint32_t tag32, double& x) {
+  x = __hiloint2double(static_cast<int>(v.x), static_cast<int>(v.z));
+  return v.y == tag32 && v.w == tag32;
+}
+// wave sum of a small non-negative integer with DPP moves: lane 63 holds the total
+__device__ __forceinline__ int wave_isum_to_lane63(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
 template <typename VT, int V>
 __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rvr_lds[];
@@ -153,6 +181,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   const int nrows = static_cast<int>(A.R.nrows);
   const SolverParams P = A.prm;
   const int unit = blockIdx.x;
+  const bool two = nrows > RVR_NT;  // a second row per thread (uniform): the work on it is skipped otherwise
 
   // ---- carve -------------------------------------------------------------------------------
   uint32_t off = 0;
@@ -164,6 +193,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   double* tot = red2 + RVR_NWV * 16;                       // [0 .. 31] totals of a reduction, [32 .. 32 + V) nrm, [40 .. 40 + V) sx
   double* nrmL = tot + 32;
   double* sxL = tot + 40;
+  int* itot = reinterpret_cast<int*>(tot + 48);            // [0 .. 31] integer totals of the same reduction
   off += RVR_RED_BYTES;
   uint32_t* tab = reinterpret_cast<uint32_t*>(rvr_lds + off);  // [RVR_TMAX] slice offsets, then a few words
   uint32_t* words = tab + RVR_TMAX;                            // [16]
@@ -171,6 +201,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   off += RVR_TAB_BYTES;
   uint8_t* sl = rvr_lds + off;
 
+  const long long ts0 = A.stamps ? wall_clock64() : 0;
   // ---- the state this launch starts from: a prepared pass, or nothing to do here --------------------
   const SolverState* st = A.st;
   const int e_done = A.shared->done, e_hold = st->hold, e_stage = st->stage, e_resume = st->resume;
@@ -296,8 +327,21 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   unsigned long long epoch = A.epoch0;
   int exchanges = 0;
   int stamp_row = 0;
-  auto stamp = [&](int c) {
-    if (A.stamps && unit == 0 && tid == 0 && stamp_row < 500) A.stamps[stamp_row * 8 + c] = wall_clock64();
+  const long long ts1 = A.stamps ? wall_clock64() : 0;  // (the slices are in LDS)
+  auto stamp_end = [&]() {  // row 500: launch start, slices in LDS, end, turns of the loop
+    if (A.stamps && unit == 0 && tid == 0) {
+      long long* row = A.stamps + 500 * 8;
+      row[0] = ts0;
+      row[1] = ts1;
+      row[2] = wall_clock64();
+      row[3] = stamp_row;
+    }
+  };
+  auto stamp = [&](int c) {  // unit 0: every turn; every unit: turn 6 (rows behind the first 512 x 8 words)
+    if (A.stamps && tid == 0) {
+      if (unit == 0 && stamp_row < 500) A.stamps[stamp_row * 8 + c] = wall_clock64();
+      if (stamp_row == 6 && c < 4 && unit < RVR_MAXUNITS) A.stamps[4096 + unit * 4 + c] = wall_clock64();
+    }
   };
   unsigned long long* const xb0 = A.xb;
   const int64_t par_stride = rvr_xb_granules(V) / 2;
@@ -344,14 +388,16 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     if (kind == K_TRIAL) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        double al = alpha;
+        if (e == 0 || two) {
+          double al = alpha;
 #pragma unroll
-        for (int l = 0; l < V; ++l) {
-          double t = UR[e] + al * GR[e];
-          t = (t > 0.0) ? t : 0.0;
-          r2[2 * l] += t * t;
-          r2[2 * l + 1] += t;
-          al = al * P.beta;
+          for (int l = 0; l < V; ++l) {
+            double t = UR[e] + al * GR[e];
+            t = (t > 0.0) ? t : 0.0;
+            r2[2 * l] += t * t;
+            r2[2 * l + 1] += t;
+            al = al * P.beta;
+          }
         }
       }
     }
@@ -401,6 +447,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
           __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
+      stamp_end();
       return;
     }
 
@@ -422,7 +469,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int r = tid + e * RVR_NT;
-        if (r < (nrows + 127) / 128 * 128) {
+        if (r < nrows) {  // (rows behind the last one are never read: entries, padding included, name rows of the view)
           double al = alpha;
 #pragma unroll
           for (int l = 0; l < V; ++l) {
@@ -539,9 +586,10 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     }
     stamp(2);
 
-    // ---- the exchange: every granule of this thread's rows (and one unit's counts) until it carries the
-    // iteration's epoch — no drain, no flag, no barrier (k_resident.hip.h) -----------------------------------
-    double gR[2][V], anR[2], bnR[2], cpack = 0.0;
+    // ---- the exchange: every value of this thread's rows (and one unit's counts) until both its granules carry
+    // the iteration's epoch — no drain, no flag, no barrier (k_resident.hip.h) ----------------------------------
+    double gR[2][V], anR[2], bnR[2];
+    unsigned long long cpk = 0;  // one unit's packed counts (threads < nunits)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       anR[e] = aR[e];
@@ -550,6 +598,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       for (int v = 0; v < V; ++v) gR[e][v] = 0.0;
     }
     {
+      const uint32_t tag32 = static_cast<uint32_t>(epoch & 0xffffffffull);
       int fail = 0;
       const long long t_poll = wall_clock64();
       for (unsigned spins = 0;; ++spins) {
@@ -557,16 +606,36 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int r = tid + e * RVR_NT;
-          if (rok[e] && kind != K_BUILD) {
+          if ((e == 0 || two) && rok[e] && kind != K_BUILD) {
+            rvr_u4 w[V + 2];
             if (kind == K_TRIAL) {
 #pragma unroll
-              for (int v = 0; v < V; ++v) ok = rvr_poll(sec_g(par, v, r), tag, gR[e][v]) && ok;
+              for (int v = 0; v < V; ++v) w[v] = rvr_ld16(sec_g(par, v, r));
             }
-            ok = rvr_poll(sec_g(par, V, r), tag, anR[e]) && ok;
-            ok = rvr_poll(sec_g(par, V + 1, r), tag, bnR[e]) && ok;
+            w[V] = rvr_ld16(sec_g(par, V, r));
+            w[V + 1] = rvr_ld16(sec_g(par, V + 1, r));
+            rvr_wait_loads();
+            if (kind == K_TRIAL) {
+#pragma unroll
+              for (int v = 0; v < V; ++v) {
+                rvr_tie(w[v]);
+                ok = rvr_take(w[v], tag32, gR[e][v]) && ok;
+              }
+            }
+            rvr_tie(w[V]);
+            rvr_tie(w[V + 1]);
+            ok = rvr_take(w[V], tag32, anR[e]) && ok;
+            ok = rvr_take(w[V + 1], tag32, bnR[e]) && ok;
           }
         }
-        if (tid < A.nunits) ok = rvr_poll(sec_c(par, tid), tag, cpack) && ok;
+        if (tid < A.nunits) {
+          rvr_u4 w = rvr_ld16(sec_c(par, tid));
+          rvr_wait_loads();
+          rvr_tie(w);
+          double cd;
+          ok = rvr_take(w, tag32, cd) && ok;
+          cpk = static_cast<unsigned long long>(__double_as_longlong(cd));
+        }
         if (__all(ok)) break;
         if ((spins & 63u) == 63u || A.timeout_ticks < 0) {
           const bool late = wall_clock64() - t_poll > A.timeout_ticks;
@@ -576,7 +645,6 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
             break;
           }
         }
-        __builtin_amdgcn_s_sleep(1);
       }
       if (__syncthreads_or(fail)) {  // nothing is committed: the streaming launches carry on from the entry state
         if (tid == 0) {
@@ -595,63 +663,107 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     }
 
     // ---- every scalar of the iteration, from R (:242, :253, :268-274) and the counts ------------------------
-    //   q2[4 v + 0] F_v   [4 v + 1] ||x_v - u||^2   [4 v + 2] live rows of candidate v in R   [4 v + 3] outside R
-    //   q2[4 V], [4 V + 1] the penalty terms (count, sum of ratios)
-    double q2[4 * V + 2];
+    //   doubles  tot[2 v] F_v   tot[2 v + 1] ||x_v - u||^2   tot[2 V] the penalty's sum of ratios
+    //   integers itot[v] live rows of candidate v in R   itot[V + v] live columns outside R   itot[2 V] the
+    //            penalty's count   (ballots and integer DPP sums: a third of the fp64 lane sums they replace)
+    constexpr int NQ = 2 * V + 1, NI = 2 * V + 1;
+    double q2[NQ];
+    int iq[NI];
 #pragma unroll
-    for (int q = 0; q < 4 * V + 2; ++q) q2[q] = 0.0;
+    for (int q = 0; q < NQ; ++q) q2[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NI; ++q) iq[q] = 0;
     if (kind == K_TRIAL) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        double al = alpha;
+        if (e == 0 || two) {
+          double al = alpha;
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-          double t = UR[e] + al * GR[e];
-          t = (t > 0.0) ? t : 0.0;
-          const double xi = t / rvr_uni(nrmL + v);
-          if (rok[e]) {
+          for (int v = 0; v < V; ++v) {
+            double t = UR[e] + al * GR[e];
+            t = (t > 0.0) ? t : 0.0;
+            const double xi = t / rvr_uni(nrmL + v);
             const double gv = gR[e][v];
-            q2[4 * v + 0] += xi * gv;  // :242
-            const double du = xi - UR[e];
-            q2[4 * v + 1] += du * du;  // :253
-            q2[4 * v + 2] += (xi > 0.0 || gv > 0.0) ? 1.0 : 0.0;
-            if (v == 0) {
-              const double cbu = rvr_uni(sxL) - bnR[e] - xi;
-              if (cbu > P.eps && xi > P.eps) {
-                q2[4 * V] += 1.0;
-                q2[4 * V + 1] += fabs((anR[e] + xi) / cbu);
+            bool live = false, pen = false;
+            if (rok[e]) {
+              q2[2 * v + 0] += xi * gv;  // :242
+              const double du = xi - UR[e];
+              q2[2 * v + 1] += du * du;  // :253
+              live = xi > 0.0 || gv > 0.0;
+              if (v == 0) {
+                const double cbu = rvr_uni(sxL) - bnR[e] - xi;
+                if (cbu > P.eps && xi > P.eps) {
+                  pen = true;
+                  q2[2 * V] += fabs((anR[e] + xi) / cbu);
+                }
               }
             }
+            iq[v] += __popcll(__ballot(live));
+            if (v == 0) iq[2 * V] += __popcll(__ballot(pen));
+            al = al * P.beta;
           }
-          al = al * P.beta;
         }
       }
     } else if (kind == K_PAIR) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const double cbu = s - bR[e] - UR[e];             // :268
+        bool pen = false;
         if (rok[e] && cbu > P.eps && UR[e] > P.eps) {    // :269
-          q2[4 * V] += 1.0;
-          q2[4 * V + 1] += fabs((aR[e] + UR[e]) / cbu);   // :271-274
+          pen = true;
+          q2[2 * V] += fabs((aR[e] + UR[e]) / cbu);       // :271-274
         }
+        iq[2 * V] += __popcll(__ballot(pen));
       }
     } else {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
+        bool live = false;
         if (rok[e]) {
           const double gi = (1 + d) * UR[e] - d * s + aR[e] + bR[e] * d;  // :219
           GR[e] = gi;
           q2[0] += UR[e] * gi;  // :220
-          q2[2] += (UR[e] > 0.0 || gi > 0.0) ? 1.0 : 0.0;
+          live = UR[e] > 0.0 || gi > 0.0;
         }
+        iq[0] += __popcll(__ballot(live));
       }
     }
-    if (tid < A.nunits) {
-      const unsigned long long pk = static_cast<unsigned long long>(__double_as_longlong(cpack));
+    {
 #pragma unroll
-      for (int v = 0; v < V; ++v) q2[4 * v + 3] = static_cast<double>((pk >> (10 * v)) & 1023ull);
+      for (int q = 0; q < NQ; ++q) q2[q] = wave_sum_to_lane63(q2[q]);
+      int oc[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) oc[v] = (tid < A.nunits) ? static_cast<int>((cpk >> (10 * v)) & 1023ull) : 0;
+      if (wave * 64 < A.nunits) {  // (only the waves that hold units' counts)
+#pragma unroll
+        for (int v = 0; v < V; ++v) oc[v] = wave_isum_to_lane63(oc[v]);
+      }
+      int* ipart = reinterpret_cast<int*>(red + RVR_NWV * NQ);  // [RVR_NWV][NI] behind the doubles' wave sums
+      __syncthreads();
+      if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) red[wave * NQ + q] = q2[q];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          ipart[wave * NI + v] = iq[v];
+          ipart[wave * NI + V + v] = oc[v];
+        }
+        ipart[wave * NI + 2 * V] = iq[2 * V];
+      }
+      __syncthreads();
+      if (tid < NQ) {
+        double acc = red[tid];
+#pragma unroll
+        for (int w = 1; w < RVR_NWV; ++w) acc += red[w * NQ + tid];
+        tot[tid] = acc;
+      } else if (tid >= 64 && tid < 64 + NI) {
+        int acc = 0;
+#pragma unroll
+        for (int w = 0; w < RVR_NWV; ++w) acc += ipart[w * NI + (tid - 64)];
+        itot[tid - 64] = acc;
+      }
+      __syncthreads();
     }
-    rvr_reduce<4 * V + 2>(q2, red, tot);
     stamp(4);
     ++n_iters;
     if (kind != K_BUILD) {
@@ -671,7 +783,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       for (int v = 0; v < V; ++v) {
         if (jstar < 0) {
           ++n_trials;
-          Fnew = rvr_uni(tot + 4 * v);
+          Fnew = rvr_uni(tot + 2 * v);
           deltaF = Fnew - F;        // :244
           bool accept = true;
           if (deltaF < -P.eps) {    // :246-248
@@ -685,15 +797,16 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       if (jstar < 0) continue;  // all V rejected: V more factors of beta are in alpha, the point is unchanged
       // :256-258 — the accepted candidate becomes the point (its raw value: the window's own chain of step
       // sizes from alpha_w, exactly what was staged and what k_tail forms)
-      double du2 = 0.0, lr = 0.0, no = 0.0;
+      double du2 = 0.0;
+      int lr = 0, no = 0;
       {
         double al = alpha_w;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           if (v == jstar) {
-            du2 = rvr_uni(tot + 4 * v + 1);
-            lr = rvr_uni(tot + 4 * v + 2);
-            no = rvr_uni(tot + 4 * v + 3);
+            du2 = rvr_uni(tot + 2 * v + 1);
+            lr = __builtin_amdgcn_readfirstlane(itot[v]);
+            no = __builtin_amdgcn_readfirstlane(itot[V + v]);
             s = rvr_uni(sxL + v);
             double t = u_c + al * g_c;
             t = (t > 0.0) ? t : 0.0;
@@ -713,8 +826,8 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       const double deltau = sqrt(du2);
       F = Fnew;
       ++j_;
-      nout = static_cast<int>(no);
-      nlive = static_cast<int>(lr) + nout;
+      nout = no;
+      nlive = lr + nout;
       if (deltau < P.tol_u || fabs(deltaF) < P.tol_F || j_ >= P.maxiniters) {  // :261, :226
         if (jstar == 0) {
           penalty = true;  // candidate 0 carries (a, b) and its penalty terms are summed
@@ -733,8 +846,8 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     } else {  // K_BUILD: the first window of the outer iteration is pending
       if (cown) g_c = gn_c[0];
       F = rvr_uni(tot + 0);
-      nout = static_cast<int>(rvr_uni(tot + 3));
-      nlive = static_cast<int>(rvr_uni(tot + 2)) + nout;
+      nout = __builtin_amdgcn_readfirstlane(itot[V]);
+      nlive = __builtin_amdgcn_readfirstlane(itot[0]) + nout;
       j_ = 0;
       alpha = 1.0;
       k_ = 0;
@@ -744,9 +857,10 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     }
     if (penalty) {  // :276-280
       bool done = true;
-      const double pen_cnt = rvr_uni(tot + 4 * V), pen_rs = rvr_uni(tot + 4 * V + 1);
-      if (pen_cnt > 0.0) {
-        d += pen_rs / pen_cnt;
+      const int pen_cnt = __builtin_amdgcn_readfirstlane(itot[2 * V]);
+      const double pen_rs = rvr_uni(tot + 2 * V);
+      if (pen_cnt > 0) {
+        d += pen_rs / static_cast<double>(pen_cnt);
         ++i_;
         done = i_ >= P.maxoliters;
       }
@@ -785,6 +899,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
           __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // (every unit's u went out before it arrived)
         }
       }
+      stamp_end();
       return;
     }
   }

@@ -114,32 +114,12 @@ __device__ __forceinline__ SliceViewG to_global(const SliceView& M) {
 // doubles: an ODD number of 16-byte units (1, 3, 5), so that the rows of a sub-block spread over
 // all 16 slots a ds_read_b128 lane group can serve in one LDS cycle (pitch 32 B would use 8
 // of them, 64 B only 4).
-// CLIPPER_SL_XMODE (tools/slice_tune.hip only; the product is mode 0): what a window pass stages per x row
-// and what it computes per entry instead —
-//   0  all V candidates staged (48 bytes at V = 6: three ds_read_b128 per entry)
-//   1  (u', g') staged (16 bytes: one ds_read_b128 per entry), the V candidates formed in registers per
-//      entry with the tail's own expression
-//   2  (u', g', candidate 0, candidate 1) staged (two ds_read_b128), candidates 2 .. V-1 in registers
-//   3  LINEAR WINDOW: (u', g') staged, and no candidate is formed at all where none is clamped — candidate
-//      l of row r is max(t, 0) with t = u'[r] + alpha_l g'[r], and once the iteration has settled (from the
-//      third or fourth line search on: measured, m = 10k) t > 0 for every candidate of every live row, i.e.
-//      the V products are LINEAR in two:  M c_l = M u' + alpha_l M g'.  A pass then accumulates M u', M g',
-//      C u', C g' (one ds_read_b128 and four fmas per entry instead of three and seven) and combines them
-//      per lane at its end. A row none of whose candidates is positive is staged as (0, 0); a row with
-//      some clamped and some not ("mixed": a bit in a 128-bit mask per chunk) adds, entry by entry,
-//      max(t, 0) - t per candidate to correction sums — taken only by the chunks that have such a row.
-//      The sums differ from mode 0's by roundings (t is never rounded to a double before it is
-//      multiplied), as they do between two orders of the partial sums.
-// Measured: profiles/r03_slice_tune_xmode.txt (modes 1, 2).
-#ifndef CLIPPER_SL_XMODE
-#define CLIPPER_SL_XMODE 0
-#endif
-constexpr int SL_XMODE = CLIPPER_SL_XMODE;
+// (Forming the candidates in registers per entry, and the linear window, were measured and not adopted: the
+// harness keeps those variants — tools/slice_xmode.hip.h, DESIGN.md section 7 "tried".)
 constexpr int sl_xload(int V) { return V <= 2 ? 2 : (V <= 4 ? 4 : (V <= 6 ? 6 : 8)); }
-constexpr int sl_xpitch(int V) { return (SL_XMODE == 1 || SL_XMODE == 3) ? 2 : (V <= 2 ? 2 : (V <= 6 ? 6 : 10)); }
+constexpr int sl_xpitch(int V) { return V <= 2 ? 2 : (V <= 6 ? 6 : 10); }
 constexpr int sl_lds_doubles(int V, int H, int NW) {
-  // two x buffers (+ mode 3: their masks of mixed rows, and every lane's V + 1 correction sums)
-  const int a = 2 * SL_SUB * H * sl_xpitch(V) + (SL_XMODE == 3 ? 4 + (V + 1) * NW * 64 : 0);
+  const int a = 2 * SL_SUB * H * sl_xpitch(V);  // two x buffers
   const int b = NW * 64 + NW * 2 * V + 8;       // the decision's scratch
   return a > b ? a : b;
 }
@@ -236,45 +216,11 @@ struct SliceXStage {
       }
     }
   }
-  // (mode 3) the 128-bit mask of mixed rows of the buffer `xs`: two words behind the two x buffers, found
-  // from the buffer's own address (the buffers are R * XP doubles apart, the first one 2 R XP-aligned in LDS
-  // only by construction of the caller: it passes the base)
-  double* base = nullptr;
-  __device__ __forceinline__ uint64_t* mask_of(const double* xs) const {
-    return reinterpret_cast<uint64_t*>(base + 2 * (R * XP)) + ((xs == base) ? 0 : 2);
-  }
   __device__ __forceinline__ void store(const WindowSource& W, double* xs) const {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int p = threadIdx.x + i * NT;
-      if constexpr (WINDOW && SL_XMODE == 3) {
-        static_assert(!WINDOW || SL_XMODE != 3 || (PER == 1 && R == 128), "a row per thread of the first two waves");
-        // first and last candidate bound the others (the step sizes fall monotonically, and so do the
-        // rounded sums): both positive = no candidate clamped, neither = the row adds nothing
-        double al = W.alpha0;
-        const double t0 = wu[i] + al * wg[i];
-#pragma unroll
-        for (int l = 1; l < XL; ++l) al = al * W.beta;
-        const double t1 = wu[i] + al * wg[i];
-        const bool pos0 = t0 > 0.0, pos1 = t1 > 0.0;
-        const bool mixed = p < PIECES && (pos0 != pos1);
-        const bool dead = !pos0 && !pos1;
-        if (p < PIECES) *reinterpret_cast<double2*>(xs + p * XP) = dead ? make_double2(0.0, 0.0) : make_double2(wu[i], wg[i]);
-        const uint64_t mk = __ballot(mixed);
-        if ((threadIdx.x & 63) == 0 && threadIdx.x < R) mask_of(xs)[threadIdx.x >> 6] = mk;
-      } else if constexpr (WINDOW && SL_XMODE != 0) {
-        if (p < PIECES) {
-          *reinterpret_cast<double2*>(xs + p * XP) = make_double2(wu[i], wg[i]);
-          if constexpr (SL_XMODE == 2) {
-            double t0 = wu[i] + W.alpha0 * wg[i];
-            t0 = (t0 > 0.0) ? t0 : 0.0;
-            const double a1 = W.alpha0 * W.beta;
-            double t1 = wu[i] + a1 * wg[i];
-            t1 = (t1 > 0.0) ? t1 : 0.0;
-            *reinterpret_cast<double2*>(xs + p * XP + 2) = make_double2(t0, t1);
-          }
-        }
-      } else if constexpr (WINDOW) {
+      if constexpr (WINDOW) {
         double al = W.alpha0;
 #pragma unroll
         for (int l = 0; l < XL; l += 2) {
@@ -376,21 +322,7 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
   for (int v = 0; v < NS; ++v) acc[v] = 0.0;
 
   SliceXStage<WINDOW, XL, XP, R, NT> xst;
-  xst.base = lds;
-  // (mode 3) the linear sums M u', M g', C u', C g' and the corrections of the mixed rows: candidate 0
-  // against M and against C, candidates 1 .. V-1 against M + d C
-  constexpr bool LIN = WINDOW && SL_XMODE == 3;
-  // (the corrections live in LDS, one column per lane: they are touched by the chunks with a mixed row only,
-  // and seven more doubles of registers through the streaming loop would cost a workgroup per CU)
-  double lin[LIN ? 4 : 1];
-#pragma unroll
-  for (int v = 0; v < (LIN ? 4 : 1); ++v) lin[v] = 0.0;
-  double* corr = lds + 2 * (R * XP) + 4 + threadIdx.x;  // corr[v * NT]
   __syncthreads();  // the decision at the head of the launch used the same LDS
-  if constexpr (LIN) {
-#pragma unroll
-    for (int v = 0; v <= V; ++v) corr[v * NT] = 0.0;
-  }
   if (t0 < t1) {
     xst.index(static_cast<int64_t>(t0) * R, M.nrows, M.rowmap);
     xst.load(WS, X, xstride, static_cast<int64_t>(t0) * R, M.nrows);
@@ -413,16 +345,6 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
       if (mine) nxt.load(M.data + 16 * pre_next, lane);
       if (k + 2 < t1) pre_next2 = pre_row[k + 2];
     }
-    uint64_t mixlo = 0, mixhi = 0;  // (mode 3) the mixed rows of this chunk, wave-uniform
-    if constexpr (LIN) {
-      const uint64_t* mp = xst.mask_of(xs);
-      const uint64_t a = mp[0], b = mp[1];
-      mixlo = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a >> 32))) << 32) |
-              static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a)));
-      mixhi = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32))) << 32) |
-              static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(b)));
-    }
-    const bool any_mixed = (mixlo | mixhi) != 0;  // uniform
     if (mine) {
       const int maxq = __builtin_amdgcn_readfirstlane(cur.maxq);
       const int qend = maxq < J.q1 ? maxq : J.q1;
@@ -470,60 +392,7 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
               const double mm = static_cast<double>(mf);
               const double ii = mf != VT(0) ? 1.0 : 0.0;
               const uint32_t row = rowbase + ((rw[j] >> (8 * e)) & 255u);
-              if constexpr (LIN) {
-                const double2 ug = *reinterpret_cast<const double2*>(xs + row * XP);
-                lin[0] = fma(mm, ug.x, lin[0]);
-                lin[1] = fma(mm, ug.y, lin[1]);
-                lin[2] = fma(ii, ug.x, lin[2]);
-                lin[3] = fma(ii, ug.y, lin[3]);
-                if (any_mixed) {  // (uniform) a chunk with a mixed row: is this entry in one?
-                  const uint64_t word = row < 64 ? mixlo : mixhi;
-                  if ((word >> (row & 63)) & 1) {
-                    const double w = fma(d, ii, mm);
-                    double al = WS.alpha0;
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                      const double t = ug.x + al * ug.y;
-                      const double nl = (t > 0.0) ? 0.0 : -t;  // max(t, 0) - t
-                      if (v == 0) {
-                        corr[0] = fma(mm, nl, corr[0]);
-                        corr[V * NT] = fma(ii, nl, corr[V * NT]);
-                      } else {
-                        corr[v * NT] = fma(w, nl, corr[v * NT]);
-                      }
-                      al = al * WS.beta;
-                    }
-                  }
-                }
-              } else if constexpr (WINDOW && SL_XMODE != 0) {
-                const double* xr = xs + row * XP;
-                const double2 ug = *reinterpret_cast<const double2*>(xr);
-                double xv[V > 2 ? V : 2];
-                double al = WS.alpha0;
-                int l0 = 0;
-                if constexpr (SL_XMODE == 2) {
-                  const double2 t2 = *reinterpret_cast<const double2*>(xr + 2);
-                  xv[0] = t2.x;
-                  xv[1] = t2.y;
-                  al = (al * WS.beta) * WS.beta;
-                  l0 = 2;
-                }
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                  if (v >= l0) {
-                    double t = ug.x + al * ug.y;
-                    xv[v] = (t > 0.0) ? t : 0.0;
-                    al = al * WS.beta;
-                  }
-                }
-                acc[0] = fma(mm, xv[0], acc[0]);
-                acc[V] = fma(ii, xv[0], acc[V]);
-                if (V > 1) {
-                  const double w = fma(d, ii, mm);
-#pragma unroll
-                  for (int v = 1; v < V; ++v) acc[v] = fma(w, xv[v], acc[v]);
-                }
-              } else if constexpr (WINDOW) {
+              if constexpr (WINDOW) {
                 const double* xr = xs + row * XP;
                 double xv[XP];
 #pragma unroll
@@ -556,17 +425,6 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
     __syncthreads();
   }
 
-  if constexpr (LIN) {  // the V + 1 sums a window pass hands to the tail, from the linear ones
-    double al = WS.alpha0;
-    acc[0] = fma(al, lin[1], lin[0]) + corr[0];
-    acc[V] = fma(al, lin[3], lin[2]) + corr[V * NT];
-    const double wu_ = fma(d, lin[2], lin[0]), wg_ = fma(d, lin[3], lin[1]);  // (M + d C) u', (M + d C) g'
-#pragma unroll
-    for (int v = 1; v < V; ++v) {
-      al = al * WS.beta;
-      acc[v] = fma(al, wg_, wu_) + corr[v * NT];
-    }
-  }
   const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
   if (c < ld && static_cast<int>(blockIdx.x) < M.nwork) {
 #pragma unroll

@@ -37,7 +37,9 @@ def test_resident_on_a_view_equals_the_streamed_view_and_the_oracle(storage, m, 
     s1, s2 = g1.solve(p.u0), g2.solve(p.u0)
     st1, st2 = g1.view_stats(), g2.view_stats()
     assert st2.resident_launches == 0 and st2.builds >= 1
-    assert st1.builds >= 1 and st1.rows <= 1024 and st1.resident_launches >= 1, (st1.builds, st1.rows, st1.resident_launches)
+    assert st1.builds >= 1
+    if st2.rows <= 1024 and st2.builds == 1:   # (a view of more rows is streamed as before)
+        assert st1.resident_launches >= 1, (st1.builds, st1.rows, st1.resident_launches)
     for s in (s1, s2):
         assert s.nodes.tolist() == sr.nodes.tolist()
         assert s.ifinal == sr.ifinal
@@ -110,11 +112,11 @@ def test_a_launch_that_gives_up_changes_nothing(monkeypatch):
 def test_matrix_without_points_and_parameter_variants():
     """A matrix that was handed over (its views are filtered out of its own slices) and solver parameters that
     move the exits around (few inner iterations: many penalty updates; a loose line search)."""
-    p = synth.make_euclidean_problem(9000, 0.95, seed=99)
+    p = synth.make_euclidean_problem(4000, 0.9, seed=99)
     r = ref.RefClipper()
     r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
     M, Cm = r.get_affinity_matrix(), r.get_constraint_matrix()
-    for kw in ({}, {"maxiniters": 3}, {"beta": 0.5, "maxlsiters": 4}, {"tol_u": 1e-5, "tol_F": 1e-6}, {"rescale_u0": 0}):
+    for kw in ({}, {"maxiniters": 3, "maxoliters": 30}, {"beta": 0.5, "maxlsiters": 4}, {"tol_u": 1e-5, "tol_F": 1e-6}, {"rescale_u0": 0}):
         prm = ref.Params()
         for k, v in kw.items():
             setattr(prm, k, v)
