@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../clipper_amd/csrc/k_slices.hip.h"
+#include "slice_xmode.hip.h"  // CLIPPER_SL_XMODE = 1 | 2 | 3: the staging variants that were measured and not adopted
 
 using namespace clipper_hip;
 
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_pass(SliceView M, int64_t ld, 
   // window mode: candidate l = max(U + 0.5^l G, 0); U, G lie behind the table (main())
   const int64_t mp = (m + 63) / 64 * 64;
   const WindowSource WS{X + mp * VS, X + mp * VS + mp, 1.0, 0.5};
-  slice_core<VT, H, WINDOW, V, nslot(V), NW, D>(G, J, ld, m, d, WS, X, VS, part, lds);
+  if constexpr (xmode::SL_XMODE != 0) xmode::slice_core<VT, H, WINDOW, V, nslot(V), NW, D>(G, J, ld, m, d, WS, X, VS, part, lds);
+  else slice_core<VT, H, WINDOW, V, nslot(V), NW, D>(G, J, ld, m, d, WS, X, VS, part, lds);
   if (stamps && (threadIdx.x & 63) == 0) {
     stamps[(blockIdx.x * NW + (threadIdx.x >> 6)) * 2] = c0;
     stamps[(blockIdx.x * NW + (threadIdx.x >> 6)) * 2 + 1] = wall_clock64();
@@ -353,7 +355,8 @@ void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const 
   CK(hipMemcpy(dPre, P.Pre.data(), P.Pre.size() * 8, hipMemcpyHostToDevice));
   SliceView M{ddata, dPre, dwork, P.nchunks, P.ncg, static_cast<int>(work.size()), nullptr, c.m, 0};
   auto kern = k_pass<VT, H, (V > 0), VV, NW, D, OCC>;
-  const size_t lds_bytes = static_cast<size_t>(2) * SL_SUB * H * ((V > 0) ? sl_xpitch(VV) : 1) * 8;
+  const size_t lds_bytes = xmode::SL_XMODE != 0 ? static_cast<size_t>(xmode::sl_lds_doubles(VV, H, NW)) * 8
+                                                : static_cast<size_t>(2) * SL_SUB * H * ((V > 0) ? sl_xpitch(VV) : 1) * 8;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                          static_cast<int>(lds_bytes)));
   dim3 grid(static_cast<unsigned>(work.size())), block(NW * 64);
@@ -429,7 +432,7 @@ int main(int argc, char** argv) {
   CK(hipGetDeviceProperties(&prop, 0));
   c.cus = prop.multiProcessorCount;
   printf("device %s, %d CUs; m=%lld density=%.3f inliers=%.3f; CLIPPER_SL_XMODE=%d (x row pitch %d bytes)\n", prop.gcnArchName, c.cus,
-         (long long)m, density, inl, SL_XMODE, sl_xpitch(6) * 8);
+         (long long)m, density, inl, xmode::SL_XMODE, xmode::sl_xpitch(6) * 8);
   // matrix
   c.cols.assign(static_cast<size_t>(m), {});
   const int64_t i0 = m - static_cast<int64_t>(inl * m);
