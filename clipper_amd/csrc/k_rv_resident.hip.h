@@ -50,7 +50,7 @@ constexpr int RVR_TMAX = RS_TMAX;    // slices a unit holds at most
 constexpr int RVR_PMAX = RS_PMAX;    // pieces a wave works on at most
 constexpr int RVR_MAXROWS = 2 * RVR_NT;  // rows of the view: two per thread
 constexpr int RVR_MAXUNITS = 256;
-constexpr int RVR_NRED = 32;         // doubles a block reduction sums at most
+constexpr int RVR_NRED = 40;         // doubles per wave of the reductions' scratch
 
 struct RvrUnit {
   int cg0, ncgs;  // column groups [cg0, cg0 + ncgs), ncgs <= 8 (one per wave in the tail)
@@ -90,7 +90,7 @@ __host__ __device__ constexpr uint32_t rvr_xt_bytes(int V, int nrows) {
   const uint32_t sc = RVR_NWV * (V + 1) * 64u * 8u;
   return xt > sc ? xt : sc;
 }
-constexpr uint32_t RVR_RED_BYTES = RVR_NWV * RVR_NRED * 8 + RVR_NWV * 16 * 8 + 64 * 8;  // wave sums, the window's norm sums, totals
+constexpr uint32_t RVR_RED_BYTES = RVR_NWV * RVR_NRED * 8 + 64 * 8;  // the rounds' wave sums; totals, counts' scratch, norms
 constexpr uint32_t RVR_TAB_BYTES = RVR_TMAX * 4 + 64 + RVR_TMAX * 4;  // slice offsets, a few words, slice sizes
 __host__ __device__ constexpr int64_t rvr_xb_granules(int V) {
   return 2 * (static_cast<int64_t>(V + 2) * RVR_MAXROWS + RVR_MAXUNITS) * 2;
@@ -189,11 +189,9 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   double* scr = Xt;                                        // [8 waves][NS][64]
   off += rvr_xt_bytes(V, nrows);
   double* red = reinterpret_cast<double*>(rvr_lds + off);  // block_reduce scratch
-  double* red2 = red + RVR_NWV * RVR_NRED;                 // the pending window's norm sums (read after the pass)
-  double* tot = red2 + RVR_NWV * 16;                       // [0 .. 31] totals of a reduction, [32 .. 32 + V) nrm, [40 .. 40 + V) sx
+  double* tot = red + RVR_NWV * RVR_NRED;                  // [0 .. 31] totals of rvr_reduce / the counts' scratch, [32 .. 32 + V) nrm, [40 .. 40 + V) sx
   double* nrmL = tot + 32;
   double* sxL = tot + 40;
-  int* itot = reinterpret_cast<int*>(tot + 48);            // [0 .. 31] integer totals of the same reduction
   off += RVR_RED_BYTES;
   uint32_t* tab = reinterpret_cast<uint32_t*>(rvr_lds + off);  // [RVR_TMAX] slice offsets, then a few words
   uint32_t* words = tab + RVR_TMAX;                            // [16]
@@ -381,14 +379,14 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     stamp(0);
     // ---- leave? (only ever in front of a pass: what goes out is a PREPARED pass) ----------------------
     const bool out_now = kind != K_BUILD && (exchanges >= A.max_exchanges || (kind == K_TRIAL ? want_out : nout != 0));
-    // the pending window's candidates of this thread's rows, their norm sums (:235-237)
-    double r2[2 * V];
+    if (out_now) {
+      const int resume = (kind == K_TRIAL) ? 1 : 2;
+      if (resume == 1) {  // the pending window's norms (:235-237) go out with the state
+        double r2[2 * V];
 #pragma unroll
-    for (int q = 0; q < 2 * V; ++q) r2[q] = 0.0;
-    if (kind == K_TRIAL) {
+        for (int q = 0; q < 2 * V; ++q) r2[q] = 0.0;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (e == 0 || two) {
+        for (int e = 0; e < 2; ++e) {
           double al = alpha;
 #pragma unroll
           for (int l = 0; l < V; ++l) {
@@ -399,11 +397,8 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
             al = al * P.beta;
           }
         }
+        rvr_reduce<2 * V>(r2, red, tot);
       }
-    }
-    if (out_now) {
-      const int resume = (kind == K_TRIAL) ? 1 : 2;
-      if (resume == 1) rvr_reduce<2 * V>(r2, red, tot);  // the norms go out with the state
       write_point(false);
       if (arrive_last() && tid == 0) {
         SolverState* o = A.st;
@@ -457,15 +452,6 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
 #pragma unroll
     for (int v = 0; v < NS; ++v) y[v] = 0.0;
     if (kind != K_BUILD) {
-      // the norms are needed only after the pass: their wave sums wait in LDS while it runs
-      if (kind == K_TRIAL) {
-#pragma unroll
-        for (int q = 0; q < 2 * V; ++q) r2[q] = wave_sum_to_lane63(r2[q]);
-        if (lane == 63) {
-#pragma unroll
-          for (int q = 0; q < 2 * V; ++q) red2[wave * 2 * V + q] = r2[q];
-        }
-      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int r = tid + e * RVR_NT;
@@ -484,6 +470,25 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       __syncthreads();
       double acc[NS];
       rs_wave_pass<VT, V>(sl, toff, pc, np, 0, Xt, (kind == K_TRIAL) ? d : 0.0, acc);
+      // the window's norms (:237): wave l sums candidate l over the rows of the X table (64 rows per step, one
+      // DPP sum of two numbers: the thread-per-row sums of all 2 V numbers cost six times that in every wave)
+      if (wave < V) {
+        double z = 0.0, t1 = 0.0;
+        if (kind == K_TRIAL) {
+          for (int r = lane; r < nrows; r += 64) {
+            const double c = Xt[r * V + wave];
+            z += c * c;
+            t1 += c;
+          }
+          z = wave_sum_to_lane63(z);
+          t1 = wave_sum_to_lane63(t1);
+        }
+        if (lane == 63) {
+          const double nl = (kind == K_TRIAL && z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0
+          nrmL[wave] = nl;
+          sxL[wave] = (kind == K_TRIAL) ? t1 / nl : 0.0;
+        }
+      }
       __syncthreads();  // the X table is dead: its memory becomes the waves' sums
 #pragma unroll
       for (int v = 0; v < NS; ++v) scr[(wave * NS + v) * 64 + lane] = acc[v];
@@ -499,25 +504,6 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       __syncthreads();  // (the next X table overwrites the sums)
     }
     stamp(1);
-    // the window's norms (:237), by V threads, for everybody: nrmL[l], sxL[l] (a pair-mode pass, the start of
-    // an outer iteration: 1, 0)
-    if (tid < V) {
-      double nl = 1.0, sl_ = 0.0;
-      if (kind == K_TRIAL) {
-        double z = red2[2 * tid], t1 = red2[2 * tid + 1];
-#pragma unroll
-        for (int w = 1; w < RVR_NWV; ++w) {
-          z += red2[w * 2 * V + 2 * tid];
-          t1 += red2[w * 2 * V + 2 * tid + 1];
-        }
-        nl = (z > 0.0) ? sqrt(z) : 1.0;  // :237 Eigen normalize()
-        sl_ = t1 / nl;
-      }
-      nrmL[tid] = nl;
-      sxL[tid] = sl_;
-    }
-    __syncthreads();
-
     // ---- the tail of this thread's own column (k_tail's expressions, :237-242), what it publishes -----------
     ++epoch;
     ++exchanges;
@@ -570,15 +556,15 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       unsigned long long w = 0;
 #pragma unroll
       for (int v = 0; v < V; ++v) w |= static_cast<unsigned long long>(__popcll(__ballot((cbits >> v) & 1u))) << (7 * v);
-      if (lane == 0) reinterpret_cast<unsigned long long*>(red)[wave] = w;
+      if (lane == 0) reinterpret_cast<unsigned long long*>(tot)[wave] = w;
       __syncthreads();
       if (tid == 0) {
         unsigned long long pk = 0;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          unsigned long long tot = 0;
-          for (int w2 = 0; w2 < RVR_NWV; ++w2) tot += (reinterpret_cast<unsigned long long*>(red)[w2] >> (7 * v)) & 127ull;
-          pk |= tot << (10 * v);
+          unsigned long long tsum = 0;
+          for (int w2 = 0; w2 < RVR_NWV; ++w2) tsum += (reinterpret_cast<unsigned long long*>(tot)[w2] >> (7 * v)) & 127ull;
+          pk |= tsum << (10 * v);
         }
         rvr_publish(sec_c(par, unit), tag, __longlong_as_double(static_cast<long long>(pk)));
       }
@@ -662,128 +648,95 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       bR[e] = bnR[e];
     }
 
-    // ---- every scalar of the iteration, from R (:242, :253, :268-274) and the counts ------------------------
-    //   doubles  tot[2 v] F_v   tot[2 v + 1] ||x_v - u||^2   tot[2 V] the penalty's sum of ratios
-    //   integers itot[v] live rows of candidate v in R   itot[V + v] live columns outside R   itot[2 V] the
-    //            penalty's count   (ballots and integer DPP sums: a third of the fp64 lane sums they replace)
-    constexpr int NQ = 2 * V + 1, NI = 2 * V + 1;
-    double q2[NQ];
-    int iq[NI];
+    // ---- the sums of the iteration, from R (:242, :253, :268-274) and the units' counts, and what they mean
+    // (decide()'s rules). One ROUND per quantity set: wave sums (DPP) -> LDS -> one barrier -> every thread adds
+    // the eight wave sums in wave order. A window is walked LAZILY, candidate by candidate in the reference's order
+    // (:244-251): the sums of candidate v + 1 are formed only if candidate v was rejected — 1.8 rounds per window
+    // on the headline problem instead of the sums of all V.
+    //   round buffers: rbuf[round][wave][4] doubles, ibuf[round][wave][4] ints (a round never reuses one within a turn)
+    double* rbuf = red;
+    int* ibuf = reinterpret_cast<int*>(red + V * RVR_NWV * 4);
+    auto round_sums = [&](int rd, double (&dv)[3], int (&iv)[3]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) q2[q] = 0.0;
-#pragma unroll
-    for (int q = 0; q < NI; ++q) iq[q] = 0;
-    if (kind == K_TRIAL) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (e == 0 || two) {
-          double al = alpha;
-#pragma unroll
-          for (int v = 0; v < V; ++v) {
-            double t = UR[e] + al * GR[e];
-            t = (t > 0.0) ? t : 0.0;
-            const double xi = t / rvr_uni(nrmL + v);
-            const double gv = gR[e][v];
-            bool live = false, pen = false;
-            if (rok[e]) {
-              q2[2 * v + 0] += xi * gv;  // :242
-              const double du = xi - UR[e];
-              q2[2 * v + 1] += du * du;  // :253
-              live = xi > 0.0 || gv > 0.0;
-              if (v == 0) {
-                const double cbu = rvr_uni(sxL) - bnR[e] - xi;
-                if (cbu > P.eps && xi > P.eps) {
-                  pen = true;
-                  q2[2 * V] += fabs((anR[e] + xi) / cbu);
-                }
-              }
-            }
-            iq[v] += __popcll(__ballot(live));
-            if (v == 0) iq[2 * V] += __popcll(__ballot(pen));
-            al = al * P.beta;
-          }
-        }
-      }
-    } else if (kind == K_PAIR) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const double cbu = s - bR[e] - UR[e];             // :268
-        bool pen = false;
-        if (rok[e] && cbu > P.eps && UR[e] > P.eps) {    // :269
-          pen = true;
-          q2[2 * V] += fabs((aR[e] + UR[e]) / cbu);       // :271-274
-        }
-        iq[2 * V] += __popcll(__ballot(pen));
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        bool live = false;
-        if (rok[e]) {
-          const double gi = (1 + d) * UR[e] - d * s + aR[e] + bR[e] * d;  // :219
-          GR[e] = gi;
-          q2[0] += UR[e] * gi;  // :220
-          live = UR[e] > 0.0 || gi > 0.0;
-        }
-        iq[0] += __popcll(__ballot(live));
-      }
-    }
-    {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) q2[q] = wave_sum_to_lane63(q2[q]);
-      int oc[V];
-#pragma unroll
-      for (int v = 0; v < V; ++v) oc[v] = (tid < A.nunits) ? static_cast<int>((cpk >> (10 * v)) & 1023ull) : 0;
-      if (wave * 64 < A.nunits) {  // (only the waves that hold units' counts)
-#pragma unroll
-        for (int v = 0; v < V; ++v) oc[v] = wave_isum_to_lane63(oc[v]);
-      }
-      int* ipart = reinterpret_cast<int*>(red + RVR_NWV * NQ);  // [RVR_NWV][NI] behind the doubles' wave sums
-      __syncthreads();
+      for (int q = 0; q < 3; ++q) dv[q] = wave_sum_to_lane63(dv[q]);
+      if (wave * 64 < A.nunits) iv[2] = wave_isum_to_lane63(iv[2]);  // (the units' counts sit in the first threads)
       if (lane == 63) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) red[wave * NQ + q] = q2[q];
+        for (int q = 0; q < 3; ++q) rbuf[(rd * RVR_NWV + wave) * 4 + q] = dv[q];
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-          ipart[wave * NI + v] = iq[v];
-          ipart[wave * NI + V + v] = oc[v];
+        for (int q = 0; q < 3; ++q) ibuf[(rd * RVR_NWV + wave) * 4 + q] = iv[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        double acc = rbuf[(rd * RVR_NWV) * 4 + q];
+        int iacc = ibuf[(rd * RVR_NWV) * 4 + q];
+#pragma unroll
+        for (int w = 1; w < RVR_NWV; ++w) {
+          acc += rbuf[(rd * RVR_NWV + w) * 4 + q];
+          iacc += ibuf[(rd * RVR_NWV + w) * 4 + q];
         }
-        ipart[wave * NI + 2 * V] = iq[2 * V];
+        dv[q] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(acc)),
+                                 __builtin_amdgcn_readfirstlane(__double2loint(acc)));
+        iv[q] = __builtin_amdgcn_readfirstlane(iacc);
       }
-      __syncthreads();
-      if (tid < NQ) {
-        double acc = red[tid];
-#pragma unroll
-        for (int w = 1; w < RVR_NWV; ++w) acc += red[w * NQ + tid];
-        tot[tid] = acc;
-      } else if (tid >= 64 && tid < 64 + NI) {
-        int acc = 0;
-#pragma unroll
-        for (int w = 0; w < RVR_NWV; ++w) acc += ipart[w * NI + (tid - 64)];
-        itot[tid - 64] = acc;
-      }
-      __syncthreads();
-    }
-    stamp(4);
+    };
     ++n_iters;
     if (kind != K_BUILD) {
       ++n_passes;
       ++n_view_passes;
     }
     ++stamp_row;
-
-    // ---- what the sums mean: decide()'s rules ---------------------------------------------------------------
     bool penalty = false;
+    int pen_cnt = 0;
+    double pen_rs = 0.0;
     if (kind == K_TRIAL) {
-      // :244-251 — walk the window in the reference's order
       int jstar = -1;
-      double Fnew = 0.0, deltaF = 0.0;
+      double Fnew = 0.0, deltaF = 0.0, du2 = 0.0;
+      int lr = 0, no = 0;
       const double alpha_w = alpha;  // the step size of this window's candidate 0
+      double al = alpha_w;
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        if (jstar < 0) {
+        if (jstar < 0) {  // (uniform) candidate v is evaluated only if every one before it was rejected
+          // dv: F_v (:242), ||x_v - u||^2 (:253), [v = 0] the penalty's sum of ratios (:271-274)
+          // iv: live rows of candidate v in R, [v = 0] the penalty's count, live columns outside R
+          double dv[3] = {0.0, 0.0, 0.0};
+          int iv[3] = {0, 0, 0};
+          const double nv = rvr_uni(nrmL + v);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if (e == 0 || two) {
+              double t = UR[e] + al * GR[e];
+              t = (t > 0.0) ? t : 0.0;
+              const double xi = t / nv;
+              const double gv = gR[e][v];
+              bool live = false, pen = false;
+              if (rok[e]) {
+                dv[0] += xi * gv;
+                const double du = xi - UR[e];
+                dv[1] += du * du;
+                live = xi > 0.0 || gv > 0.0;
+                if (v == 0) {
+                  const double cbu = rvr_uni(sxL) - bnR[e] - xi;
+                  if (cbu > P.eps && xi > P.eps) {
+                    pen = true;
+                    dv[2] += fabs((anR[e] + xi) / cbu);
+                  }
+                }
+              }
+              iv[0] += __popcll(__ballot(live));
+              if (v == 0) iv[1] += __popcll(__ballot(pen));
+            }
+          }
+          iv[2] = (tid < A.nunits) ? static_cast<int>((cpk >> (10 * v)) & 1023ull) : 0;
+          round_sums(v, dv, iv);
+          if (v == 0) {
+            pen_rs = dv[2];
+            pen_cnt = iv[1];
+          }
           ++n_trials;
-          Fnew = rvr_uni(tot + 2 * v);
+          Fnew = dv[0];
           deltaF = Fnew - F;        // :244
           bool accept = true;
           if (deltaF < -P.eps) {    // :246-248
@@ -791,38 +744,31 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
             ++k_;
             if (k_ < P.maxlsiters) accept = false;
           }
-          if (accept) jstar = v;
-        }
-      }
-      if (jstar < 0) continue;  // all V rejected: V more factors of beta are in alpha, the point is unchanged
-      // :256-258 — the accepted candidate becomes the point (its raw value: the window's own chain of step
-      // sizes from alpha_w, exactly what was staged and what k_tail forms)
-      double du2 = 0.0;
-      int lr = 0, no = 0;
-      {
-        double al = alpha_w;
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          if (v == jstar) {
-            du2 = rvr_uni(tot + 2 * v + 1);
-            lr = __builtin_amdgcn_readfirstlane(itot[v]);
-            no = __builtin_amdgcn_readfirstlane(itot[V + v]);
+          if (accept) {
+            // :256-258 — the accepted candidate becomes the point (its raw value: the window's own chain of
+            // step sizes from alpha_w, exactly what was staged and what k_tail forms)
+            jstar = v;
+            du2 = dv[1];
+            lr = iv[0];
+            no = iv[2];
             s = rvr_uni(sxL + v);
             double t = u_c + al * g_c;
             t = (t > 0.0) ? t : 0.0;
-            u_c = t / rvr_uni(nrmL + v);
+            u_c = t / nv;
             g_c = gn_c[v];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               double t2 = UR[e] + al * GR[e];
               t2 = (t2 > 0.0) ? t2 : 0.0;
-              UR[e] = rok[e] ? t2 / rvr_uni(nrmL + v) : 0.0;
+              UR[e] = rok[e] ? t2 / nv : 0.0;
               GR[e] = rok[e] ? gR[e][v] : 0.0;
             }
           }
-          al = al * P.beta;
         }
+        al = al * P.beta;
       }
+      stamp(4);
+      if (jstar < 0) continue;  // all V rejected: V more factors of beta are in alpha, the point is unchanged
       const double deltau = sqrt(du2);
       F = Fnew;
       ++j_;
@@ -842,12 +788,44 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
         continue;
       }
     } else if (kind == K_PAIR) {
+      double dv[3] = {0.0, 0.0, 0.0};
+      int iv[3] = {0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const double cbu = s - bR[e] - UR[e];             // :268
+        bool pen = false;
+        if (rok[e] && cbu > P.eps && UR[e] > P.eps) {    // :269
+          pen = true;
+          dv[2] += fabs((aR[e] + UR[e]) / cbu);           // :271-274
+        }
+        iv[1] += __popcll(__ballot(pen));
+      }
+      round_sums(0, dv, iv);
+      pen_rs = dv[2];
+      pen_cnt = iv[1];
       penalty = true;
-    } else {  // K_BUILD: the first window of the outer iteration is pending
+      stamp(4);
+    } else {  // K_BUILD (:219-220): the first window of the outer iteration is pending
+      double dv[3] = {0.0, 0.0, 0.0};
+      int iv[3] = {0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        bool live = false;
+        if (rok[e]) {
+          const double gi = (1 + d) * UR[e] - d * s + aR[e] + bR[e] * d;  // :219
+          GR[e] = gi;
+          dv[0] += UR[e] * gi;  // :220
+          live = UR[e] > 0.0 || gi > 0.0;
+        }
+        iv[0] += __popcll(__ballot(live));
+      }
+      iv[2] = (tid < A.nunits) ? static_cast<int>(cpk & 1023ull) : 0;
+      round_sums(0, dv, iv);
+      stamp(4);
       if (cown) g_c = gn_c[0];
-      F = rvr_uni(tot + 0);
-      nout = __builtin_amdgcn_readfirstlane(itot[V]);
-      nlive = __builtin_amdgcn_readfirstlane(itot[0]) + nout;
+      F = dv[0];
+      nout = iv[2];
+      nlive = iv[0] + nout;
       j_ = 0;
       alpha = 1.0;
       k_ = 0;
@@ -857,8 +835,6 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     }
     if (penalty) {  // :276-280
       bool done = true;
-      const int pen_cnt = __builtin_amdgcn_readfirstlane(itot[2 * V]);
-      const double pen_rs = rvr_uni(tot + 2 * V);
       if (pen_cnt > 0) {
         d += pen_rs / static_cast<double>(pen_cnt);
         ++i_;
