@@ -785,6 +785,13 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   const auto t0 = std::chrono::high_resolution_clock::now();
   const int64_t m = h->m;
   const size_t vbytes = static_cast<size_t>(m) * sizeof(double);
+  // CLIPPER_HIP_HOST_TIMING: where the host side of a solve goes (us since entry, to stderr)
+  static const bool host_timing = std::getenv("CLIPPER_HIP_HOST_TIMING") != nullptr;
+  std::vector<std::pair<const char*, double>> marks_t;
+  auto mark_t = [&](const char* what) {
+    if (host_timing)
+      marks_t.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count());
+  };
 
   h->rv_stats = clipper_hip_view_stats_t{};
   h->ev_used = 0;
@@ -847,6 +854,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     hipLaunchKernelGGL(k_init, dim3(static_cast<unsigned>(ceil_div(m, 256))), dim3(256), 0,
                        s.stream, a, init, s.st, s.X[0]);
   }
+  mark_t("init queued");
   if (!h->multiproc) {
     // One process: the deciding workgroup reports progress into pinned host memory; the host
     // keeps RUN_AHEAD iterations queued ahead of what the device has retired and stops
@@ -864,7 +872,12 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         // The decision asked for a row view (k_solver.hip.h, LIVE ROWS) and put the solve on hold:
         // whatever was queued behind it does nothing. Drain, build the view from exactly the state
         // that asked, lift the hold, go on.
-        if ((rc = sync_all(h))) return rc;  // (every local shard: an in-process group holds on all of them)
+        mark_t("hold seen");
+        // (No drain: the iterations queued behind the hold do nothing but move the state between its two
+        // copies, in stream order — the build's launches queue behind them and read copy h->par, where the last
+        // of them leaves it; the build itself waits for the stream once. An in-process GROUP holds on every
+        // shard: its streams are drained, the shards' builds are not ordered with each other otherwise.)
+        if (h->sh.size() > 1 && (rc = sync_all(h))) return rc;
         std::atomic_thread_fence(std::memory_order_acquire);
         hm->hold = 0;
         queued = hm->iters;              // the iterations that did nothing never counted
@@ -873,6 +886,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
           --h->ev_used;                  // event pairs around launches that did nothing
         bool built = false;
         if ((rc = rowview_build(h, built))) return rc;
+        mark_t("view built");
         h->rv_fresh = built;
         if (built && h->vres.ready) {
           // The view fits the LDS of the chip: the iterations on it run as ONE launch (k_rv_resident.hip.h).
@@ -885,6 +899,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
           ++queued;
           bool launched = false;
           if ((rc = rvr_enqueue(h, prm, launched))) return rc;
+          mark_t("resident queued");
         }
         continue;
       }
@@ -903,6 +918,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
                       static_cast<long long>(hm->iters), static_cast<long long>(queued));
       }
     }
+    mark_t("done seen");
     std::atomic_thread_fence(std::memory_order_acquire);
     fin.F = hm->F;
     fin.d = hm->d;
@@ -993,6 +1009,12 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   }
   h->nodes = nodes;
   if (u_out) std::memcpy(u_out, u.data(), vbytes);
+  mark_t("rounded");
+  if (host_timing) {
+    std::fprintf(stderr, "[solve]");
+    for (const auto& mk : marks_t) std::fprintf(stderr, " %s %.1f |", mk.first, mk.second);
+    std::fprintf(stderr, "\n");
+  }
 
   const double secs =
       std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();

@@ -327,7 +327,10 @@ inline void plan_resident(const uint32_t* L, int ncg, int nchunks, int64_t m, in
 struct ViewUnit {  // layout of clipper_hip::RvrUnit
   int cg0, ncgs;   // column groups [cg0, cg0 + ncgs) x every chunk of the view
   int l0, l1;      // lanes [l0, l1) of each
-  int pad0, pad1, pad2, pad3;
+  int pack;        // 0, or G = 64 / (l1 - l0) >= 2: a unit of ONE group whose slices are packed G chunks side by
+                   // side — lane group g of packed slice s holds the unit's columns of chunk s * G + g — so that a
+                   // step keeps all 64 lanes busy and the chains of steps are G times shorter
+  int pad1, pad2, pad3;
 };
 
 struct ViewResidentPlan {
@@ -370,18 +373,44 @@ inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esiz
   const double Te = std::max(256.0, static_cast<double>(total) / target_units);
   const int max_cgs = std::min(K.nwv, K.tmax / nchunks);  // one wave per group in the tail; slices per unit
   if (max_cgs < 1) return;
+  // A pass's time in a unit goes with its lock-step STEPS (the CU's LDS pipe issues per wave-step, however few
+  // lanes are busy: measured 0.45 us per step and wave on top of 4 us), and the steps of a sparse group are those
+  // of its longest column: 30 .. 125 per group at the headline view for 3 400 .. 4 600 entries. A group far above
+  // the median is cut into two packed halves (its long column weighs on one of them only, and each half walks
+  // two chunks per step) — while the units still fit the chip.
+  std::vector<int> stp(static_cast<size_t>(ncg));
+  for (int c = 0; c < ncg; ++c) {
+    int t = 0;
+    for (int k = 0; k < nchunks; ++k) t += static_cast<int>(L[static_cast<size_t>(c) * nchunks + k] & 255u);
+    stp[static_cast<size_t>(c)] = t;
+  }
+  std::vector<int> sorted_stp(stp);
+  std::nth_element(sorted_stp.begin(), sorted_stp.begin() + ncg / 2, sorted_stp.end());
+  const double Tmed = std::max(1, sorted_stp[static_cast<size_t>(ncg / 2)]);
   std::vector<ViewUnit>& units = out.units;
+  for (int heavy_split = (nchunks >= 2 ? 1 : 0); heavy_split >= 0; --heavy_split) {
+  units.clear();
   int cg = 0;
   while (cg < ncg) {
     const uint64_t e = ent[static_cast<size_t>(cg)], b = byt[static_cast<size_t>(cg)];
     // (a lane subset keeps every step's padding and the header: its bytes fall a little slower than its lanes)
     int nsplit = std::max(static_cast<int>((b + cap - 1) / cap), static_cast<int>(std::floor(static_cast<double>(e) / (1.5 * Te) + 0.5)));
     nsplit = std::max(1, nsplit);
+    if (nsplit == 1 && heavy_split && static_cast<double>(stp[static_cast<size_t>(cg)]) > 1.35 * Tmed) {
+      units.push_back(ViewUnit{cg, 1, 0, 32, 2, 0, 0, 0});
+      units.push_back(ViewUnit{cg, 1, 32, 64, 2, 0, 0, 0});
+      ++cg;
+      continue;
+    }
     if (nsplit > 1) {
-      while (nsplit < 16 && (b / nsplit) + static_cast<uint64_t>(nchunks) * (16 + 64 + 64 * 16) > cap) ++nsplit;
-      if (nsplit > 16) return;
-      for (int p = 0; p < nsplit; ++p)
-        units.push_back(ViewUnit{cg, 1, 64 * p / nsplit, 64 * (p + 1) / nsplit, 0, 0, 0, 0});
+      // (lane parts of 32, 16 or 8 lanes: as many chunks side by side in a packed slice)
+      int parts = 2;
+      while (parts < nsplit) parts *= 2;
+      while (parts < 8 && parts < nchunks) parts *= 2;  // (as few packed slices as the lanes allow: the chains of steps end sooner)
+      while (parts < 8 && (b / parts) + static_cast<uint64_t>(nchunks) * (16 + 64 + 64 * 16) > cap) parts *= 2;
+      if (parts > 8 || (b / parts) + static_cast<uint64_t>(nchunks) * (16 + 64 + 64 * 16) > cap) return;
+      for (int p = 0; p < parts; ++p)
+        units.push_back(ViewUnit{cg, 1, 64 * p / parts, 64 * (p + 1) / parts, parts, 0, 0, 0});
       ++cg;
       continue;
     }
@@ -389,13 +418,17 @@ inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esiz
     uint64_t eacc = 0, bacc = 0;
     while (cg + n < ncg && n < max_cgs) {
       const uint64_t e2 = ent[static_cast<size_t>(cg + n)], b2 = byt[static_cast<size_t>(cg + n)];
-      if (n > 0 && (bacc + b2 > cap || static_cast<double>(eacc + e2) > 1.15 * Te || static_cast<double>(e2) > 1.5 * Te)) break;
+      if (n > 0 && (bacc + b2 > cap || static_cast<double>(eacc + e2) > 1.15 * Te || static_cast<double>(e2) > 1.5 * Te ||
+                    (heavy_split && static_cast<double>(stp[static_cast<size_t>(cg + n)]) > 1.35 * Tmed)))
+        break;
       eacc += e2;
       bacc += b2;
       ++n;
     }
     units.push_back(ViewUnit{cg, n, 0, 64, 0, 0, 0, 0});
     cg += n;
+  }
+  if (static_cast<int>(units.size()) <= max_units) break;
   }
   if (static_cast<int>(units.size()) > max_units) return;
 
@@ -408,9 +441,17 @@ inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esiz
     const ViewUnit& U = units[ui];
     std::fill(T.begin(), T.end(), 0);
     std::fill(nw.begin(), nw.end(), 0);
-    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
+    // (a packed unit: its slices are the packed ones, as long as the longest of the chunks in each)
+    const int G = U.pack > 1 ? U.pack : 1;
+    const int nsl = (nchunks + G - 1) / G;
+    auto steps_of = [&](int cgl, int sidx) {
       const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
-      for (int k = 0; k < nchunks; ++k) T[static_cast<size_t>(cgl)] += static_cast<int>(lrow[k] & 255u);
+      int mq = 0;
+      for (int g = 0; g < G && sidx * G + g < nchunks; ++g) mq = std::max(mq, static_cast<int>(lrow[sidx * G + g] & 255u));
+      return mq;
+    };
+    for (int cgl = 0; cgl < U.ncgs; ++cgl) {
+      for (int k = 0; k < nsl; ++k) T[static_cast<size_t>(cgl)] += steps_of(cgl, k);
       nw[static_cast<size_t>(cgl)] = 1;
     }
     for (int spare = K.nwv - U.ncgs; spare > 0; --spare) {  // waves to groups in proportion to their steps
@@ -423,7 +464,6 @@ inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esiz
     }
     int wave = 0;
     for (int cgl = 0; cgl < U.ncgs; ++cgl) {
-      const uint32_t* lrow = L + static_cast<size_t>(U.cg0 + cgl) * nchunks;
       const int nwc = nw[static_cast<size_t>(cgl)];
       const int target = std::max(1, (T[static_cast<size_t>(cgl)] + nwc - 1) / nwc);
       int kcur = 0, qcur = 0;
@@ -431,8 +471,8 @@ inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esiz
         const size_t wv = ui * NWV + static_cast<size_t>(wave);
         out.wave_cg[wv] = static_cast<uint8_t>(cgl);
         int rem = (sub == nwc - 1) ? (1 << 30) : target, n = 0;
-        while (rem > 0 && kcur < nchunks) {
-          const int mq = static_cast<int>(lrow[kcur] & 255u);
+        while (rem > 0 && kcur < nsl) {
+          const int mq = steps_of(cgl, kcur);
           if (qcur >= mq) {
             ++kcur;
             qcur = 0;

@@ -42,22 +42,32 @@ int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const Sl
   const int32_t* A0 = s.Adev;
   const int32_t* A1 = s.Adev + h->m;
   const int64_t ps = h->staged_pstride;
+  // a thin view (fewer 128-wide tiles than two per CU): 64-wide tiles — see k_affinity_rect
+  const bool thin = nTr * ceil_div(h->W, 128) <= 2 * static_cast<int64_t>(h->cus);
   dispatch_vt(h, [&](auto t) {
     using VT = decltype(t);
-    constexpr int TW = rect_tw<VT>();
-    G.nTc = static_cast<int>(ceil_div(h->W, TW));
-    const int64_t ntiles = nTr * G.nTc;
-    constexpr int64_t PER_LAUNCH = int64_t(1) << 22;  // x 512 threads < 2^32 work-items per dispatch
-    constexpr int L = rect_lds_bytes<VT>();
-    for (int64_t t0 = 0; t0 < ntiles; t0 += PER_LAUNCH) {
-      G.tile0 = t0;
-      const dim3 grid(static_cast<unsigned>(std::min<int64_t>(PER_LAUNCH, ntiles - t0)));
-      if (h->fill_kind == 2)
-        launch_rect_kernel(k_affinity_rect<3, true, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
-      else if (h->staged_d == 3)
-        launch_rect_kernel(k_affinity_rect<3, false, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
-      else
-        launch_rect_kernel(k_affinity_rect<2, false, VT>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+    auto run = [&](auto twc) {
+      constexpr int TW = decltype(twc)::value;
+      G.nTc = static_cast<int>(ceil_div(h->W, TW));
+      const int64_t ntiles = nTr * G.nTc;
+      constexpr int64_t PER_LAUNCH = int64_t(1) << 22;  // x 512 threads < 2^32 work-items per dispatch
+      constexpr int L = rect_lds_bytes<VT, TW>();
+      for (int64_t t0 = 0; t0 < ntiles; t0 += PER_LAUNCH) {
+        G.tile0 = t0;
+        const dim3 grid(static_cast<unsigned>(std::min<int64_t>(PER_LAUNCH, ntiles - t0)));
+        if (h->fill_kind == 2)
+          launch_rect_kernel(k_affinity_rect<3, true, VT, TW>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+        else if (h->staged_d == 3)
+          launch_rect_kernel(k_affinity_rect<3, false, VT, TW>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+        else
+          launch_rect_kernel(k_affinity_rect<2, false, VT, TW>, L, grid, s.stream, G, s, ps, A0, A1, h->fill_e, h->fill_n, h->fill_E2, O);
+      }
+    };
+    if constexpr (rect_tw<VT>() == 64) {
+      run(std::integral_constant<int, 64>{});
+    } else {
+      if (thin) run(std::integral_constant<int, 64>{});
+      else run(std::integral_constant<int, 128>{});
     }
   });
   HIPCHK(hipGetLastError());
@@ -278,32 +288,45 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   hipLaunchKernelGGL(k_rv_scan, dim3(1), dim3(1024), 0, s.stream, v.blk, nblk, h->rv_count_dev);
   hipLaunchKernelGGL(k_rv_scatter, dim3(static_cast<unsigned>(nblk)), dim3(256), 0, s.stream,
                      v.in_view[next], m, v.blk, v.rowmap[next], static_cast<int64_t>(v.cap_rows), v.viewpos, mp);
-  HIPCHK(hipStreamSynchronize(s.stream));
-  const int64_t nrows = *h->rv_count;
-  if (nrows < 0) return fail(CLIPPER_HIP_E_HIP, "row view: the row count did not arrive");
+  static const bool host_timing = std::getenv("CLIPPER_HIP_HOST_TIMING") != nullptr;
+  auto lap = [&](const char* what) {
+    if (host_timing)
+      std::fprintf(stderr, "[view] %s %.1f us\n", what,
+                   std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count());
+  };
+  // The device asked (view_wanted, k_solver.hip.h) with the live count its tail summed, and the list being
+  // built is that very set: its length is known before the three launches above have run. The fill is
+  // therefore sized and queued right behind them — ONE wait for the whole build instead of one for the
+  // count and one for the fill — and the count is only checked afterwards. Should it ever differ (it never
+  // has: then the same cost model is evaluated again with the rows the view would really have), the build
+  // is repeated with the real length.
+  const int64_t asked = h->mirror->hold_nlive;
+  int64_t nrows = asked;
+  bool counted = false;
+  if (asked <= 0 || asked > m) {
+    HIPCHK(hipStreamSynchronize(s.stream));
+    nrows = *h->rv_count;
+    counted = true;
+    lap("row list");
+  }
   const double rows_now = v.valid ? static_cast<double>(v.nrows) : static_cast<double>(m);
-  // the union over the pending outcomes may be larger than the live count the decision asked with:
-  // the same cost model, now with the rows the view would really have (a function of the state alone)
-  // (the predicate of view_wanted, k_solver.hip.h — same threshold, same horizon: the deciding iteration
-  // counted itself, the progress record holds the one before it — so the two sides only disagree if the
-  // row count itself differs from the live count the decision asked with)
-  // The device asked (view_wanted, k_solver.hip.h) with the live count its tail summed; the list just
-  // built is the same set, so the count agrees and the request stands as it is. Only if it does not
-  // (it never has) is the same cost model evaluated again with the rows the view would really have.
   const ViewPolicy pol = h->rvp;
   const double horizon = std::max<double>(12.0, static_cast<double>(h->mirror->iters + 1));
-  const bool as_asked = nrows > 0 && nrows == static_cast<int64_t>(h->mirror->hold_nlive);
-  if (!as_asked &&
-      (nrows == 0 || static_cast<double>(nrows) > RV_ROWS_RATIO * rows_now ||
-       pol.build_fixed + pol.build_per_row * static_cast<double>(nrows) >=
-           horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row)) {
-    hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows));
-    h->rv_stats.build_ms +=
-        std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
-    return 0;
-  }
-  v.valid = false;  // its store is about to be overwritten
   for (int attempt = 0;; ++attempt) {
+    if (counted) {
+      if (nrows < 0) return fail(CLIPPER_HIP_E_HIP, "row view: the row count did not arrive");
+      const bool as_asked = nrows > 0 && nrows == asked;
+      if (!as_asked &&
+          (nrows == 0 || static_cast<double>(nrows) > RV_ROWS_RATIO * rows_now ||
+           pol.build_fixed + pol.build_per_row * static_cast<double>(nrows) >=
+               horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row)) {
+        hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows));
+        h->rv_stats.build_ms +=
+            std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+        return 0;
+      }
+    }
+    v.valid = false;  // its store is about to be overwritten
     SliceOut O{};
     if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
     if (rowview_fill_by_filter(h)) rc = launch_filter(h, s, v.rowmap[next], v.viewpos, nrows, O);
@@ -312,16 +335,26 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
     if ((rc = emit_enqueue(h, s, v.st))) return rc;
     HIPCHK(hipStreamSynchronize(s.stream));
     HIPCHK(hipGetLastError());
+    lap("filled");
+    if (!counted) {
+      counted = true;
+      if (*h->rv_count != nrows) {  // (never seen) the list is not what the device counted: again, with its real length
+        nrows = *h->rv_count;
+        continue;
+      }
+    }
     bool again = false;
     if ((rc = emit_check(h, s, v.st, false, again))) return rc;
+    lap("planned");
     if (!again) break;
-    if (attempt >= 2) return fail(CLIPPER_HIP_E_HIP, "row view: the build keeps overflowing");
+    if (attempt >= 3) return fail(CLIPPER_HIP_E_HIP, "row view: the build keeps overflowing");
   }
   v.cur = next;
   v.nrows = nrows;
   v.valid = true;
   built = true;
   if ((rc = rvr_plan(h, s))) return rc;  // (the view's directory is still in the pinned staging)
+  lap("resident plan");
   {  // the descriptor a pass on the view reads, to the device
     if (!v.desc) HIPCHK(hipMalloc(reinterpret_cast<void**>(&v.desc), sizeof(SliceView)));
     if (!h->rv_desc_host) {

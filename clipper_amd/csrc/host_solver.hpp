@@ -488,8 +488,21 @@ std::vector<int32_t> indices_of_k_largest(const std::vector<double>& x, int k) {
   using T = std::pair<double, int>;
   if (k < 1) return {};
   if (static_cast<size_t>(k) > x.size()) k = static_cast<int>(x.size());
-  std::priority_queue<T, std::vector<T>, std::greater<T>> q;
+  // u >= 0 and mostly 0 after the solve. With at least k positive entries the zeros can be left out of the
+  // walk without changing what it keeps: a zero only ever sits in the queue until a positive entry replaces
+  // it (strict '<'), and the queue holds positives only from the k-th positive entry on — in the walk over
+  // the positives alone it is full at that same moment with the same content, and identical from there.
+  std::vector<int> pos;
+  bool nonneg = true;
   for (size_t i = 0; i < x.size(); ++i) {
+    if (x[i] > 0.0) pos.push_back(static_cast<int>(i));
+    else if (!(x[i] == 0.0)) nonneg = false;  // (negative or NaN: the plain walk)
+  }
+  const bool sparse_walk = nonneg && pos.size() >= static_cast<size_t>(k);
+  const size_t n = sparse_walk ? pos.size() : x.size();
+  std::priority_queue<T, std::vector<T>, std::greater<T>> q;
+  for (size_t t = 0; t < n; ++t) {
+    const size_t i = sparse_walk ? static_cast<size_t>(pos[t]) : t;
     if (q.size() < static_cast<size_t>(k)) {
       q.push({x[i], static_cast<int>(i)});
     } else if (q.top().first < x[i]) {

@@ -755,29 +755,30 @@ struct RectGeom {
 
 template <typename VT>
 constexpr int rect_tw() { return sizeof(VT) == 4 ? 128 : 64; }
-template <typename VT>
-constexpr int rect_img_bytes() { return (AT * (rect_tw<VT>() + 1) * static_cast<int>(sizeof(VT)) + 15) / 16 * 16; }
-template <typename VT>
+// (TW = 64 for fp32 values too: a THIN view — a few row tiles — is a launch of fewer workgroups than the chip
+// holds, whose duration is that of its heaviest tile, the inlier block's; half as wide, that tile takes half as long)
+template <typename VT, int TW = rect_tw<VT>()>
+constexpr int rect_img_bytes() { return (AT * (TW + 1) * static_cast<int>(sizeof(VT)) + 15) / 16 * 16; }
+template <typename VT, int TW = rect_tw<VT>()>
 constexpr int rect_lds_bytes() {
-  return rect_img_bytes<VT>() + AT_WAVES * AT_QUEUE * 4 + rect_tw<VT>() * 16 + AT * 4;
+  return rect_img_bytes<VT, TW>() + AT_WAVES * AT_QUEUE * 4 + TW * 16 + AT * 4;
 }
 
-template <int D, bool POINTNORMAL, typename VT>
+template <int D, bool POINTNORMAL, typename VT, int TW = rect_tw<VT>()>
 __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_rect(
     RectGeom G, const double* __restrict__ P1, const double* __restrict__ P2,
     const float* __restrict__ P1f, const float* __restrict__ P2f, int64_t pstride,
     const int32_t* __restrict__ A0, const int32_t* __restrict__ A1, EuclidParams eprm,
     PointNormalParams nprm, float E2, SliceOut O) {
-  constexpr int TW = rect_tw<VT>();
   constexpr int CPL = TW / 64;
   constexpr int PITCH = TW + 1;
-  static_assert(AT_WAVES == 8 && AT == SL_SUB, "a tile is as tall as a slice");
+  static_assert(AT_WAVES == 8 && AT == SL_SUB && (TW == 64 || TW == 128), "a tile is as tall as a slice");
   extern __shared__ __attribute__((aligned(16))) char rect_smem[];
   VT* img = reinterpret_cast<VT*>(rect_smem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint32_t* queue = reinterpret_cast<uint32_t*>(rect_smem + rect_img_bytes<VT>()) + wave * AT_QUEUE;
-  uint32_t* colmask = reinterpret_cast<uint32_t*>(rect_smem + rect_img_bytes<VT>() + AT_WAVES * AT_QUEUE * 4);
+  uint32_t* queue = reinterpret_cast<uint32_t*>(rect_smem + rect_img_bytes<VT, TW>()) + wave * AT_QUEUE;
+  uint32_t* colmask = reinterpret_cast<uint32_t*>(rect_smem + rect_img_bytes<VT, TW>() + AT_WAVES * AT_QUEUE * 4);
   int32_t* rowidx = reinterpret_cast<int32_t*>(colmask + TW * 4);
   // heaviest tiles first where that is known: the consistent associations sit at the end of the
   // list in the reference's benchmark layout (bm_utils.cpp:311-314), so the column tiles run backwards
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_rect(
   __syncthreads();
 
   // ---- the tile's CPL slices (column group cl0 / 64 + e, chunk I), two waves per slice ------------
-  unsigned long long* base_s = reinterpret_cast<unsigned long long*>(rect_smem + rect_img_bytes<VT>());  // the queues are drained
+  unsigned long long* base_s = reinterpret_cast<unsigned long long*>(rect_smem + rect_img_bytes<VT, TW>());  // the queues are drained
   const int sl = wave & 3, half = wave >> 2;
   const int e = sl < CPL ? sl : 0;
   const VT* col = img + 64 * e + lane;

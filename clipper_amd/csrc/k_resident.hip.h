@@ -108,9 +108,12 @@ __device__ __forceinline__ unsigned long long rs_ld_granule(const unsigned long 
 // The pieces of this wave against the X table: acc[0] = a, acc[1..V-1] = g_v, acc[V] = b
 // (clipper.cpp:238-241 with w = M + d C folded per entry, see k_gemv.hip.h). `toff` = LDS offsets of
 // the slices of the wave's column group (by chunk - k0), `pc` = this lane's copy of piece `lane`.
+// (kscale, lrow: a PACKED slice of the resident solver on a view, k_rv_resident.hip.h — slice kl stands for the
+// chunks kscale * kl ..., one per lane group, and this lane's rows start lrow rows into them; 1 and 0 otherwise)
 template <typename VT, int V>
 __device__ __forceinline__ void rs_wave_pass(const uint8_t* sl, const uint32_t* toff, uint32_t pc, int np,
-                                             int k0, const double* Xt, double d, double (&acc)[V + 1]) {
+                                             int k0, const double* Xt, double d, double (&acc)[V + 1],
+                                             int kscale = 1, int lrow = 0) {
   constexpr int QB = 4 * static_cast<int>(sizeof(VT));
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -128,7 +131,7 @@ __device__ __forceinline__ void rs_wave_pass(const uint8_t* sl, const uint32_t* 
       const int cnt = __builtin_amdgcn_readfirstlane(__popcll(__ballot(q < tot)));
       fb += cnt * QB + ((cnt * 4 + 15) & ~15);
     }
-    const double* xs = Xt + static_cast<int64_t>(k0 + kl) * SL_SUB * V;
+    const double* xs = Xt + (static_cast<int64_t>(k0 + kl * kscale) * SL_SUB + lrow) * V;
     // one step ahead: every lane loads (an idle lane the step's first quad, a step past the end the
     // bytes behind the slice), so that the loads of step q + 1 fly while step q is multiplied
     SliceQuad<VT> cur, nxt;

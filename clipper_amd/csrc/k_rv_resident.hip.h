@@ -55,7 +55,11 @@ constexpr int RVR_NRED = 40;         // doubles per wave of the reductions' scra
 struct RvrUnit {
   int cg0, ncgs;  // column groups [cg0, cg0 + ncgs), ncgs <= 8 (one per wave in the tail)
   int l0, l1;     // lanes [l0, l1) of each (a proper subset only for a unit of one group)
-  int pad0, pad1, pad2, pad3;
+  int pack;       // 0, or G = 64 / (l1 - l0): the unit's slices are PACKED — lane group g (lanes [g W, g W + W),
+                  // W = l1 - l0) of packed slice s holds the columns [l0, l1) of chunk s G + g: every step keeps
+                  // all 64 lanes busy, and the dense inlier block's chains of 32 steps per chunk are walked G
+                  // chunks at a time. The unit's column c sits in lane c - l0 of EVERY lane group.
+  int pad1, pad2, pad3;
 };
 
 struct RvrArgs {
@@ -212,22 +216,42 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   const unsigned long long wcg = *reinterpret_cast<const unsigned long long*>(A.wave_cg + static_cast<int64_t>(unit) * RVR_NWV);
   const int cgl = static_cast<int>((wcg >> (8 * wave)) & 255ull);
   const bool has_cg = cgl < U.ncgs && U.cg0 + cgl < A.R.ncg;
-  const int S = A.R.nchunks;
-  const int nslices = U.ncgs * S;  // local slice t = cgl * S + chunk
+  const int G = U.pack > 1 ? U.pack : 1;          // chunks side by side in a slice as it lies in LDS
+  const int Wd = U.l1 - U.l0;                     // lanes (= columns of a group) the unit owns
+  const int S = (A.R.nchunks + G - 1) / G;        // slices per column group as they lie in LDS
+  const int nslices = U.ncgs * S;                 // local slice t = cgl * S + (packed) chunk
   const bool whole = U.l0 <= 0 && U.l1 >= 64;
-  const bool in_lanes = lane >= U.l0 && lane < U.l1;
+  const bool packed = G > 1;
+  const int lgrp = packed ? lane / Wd : 0;        // this lane's group in a packed slice, its column's lane in M's slices
+  const int lsrc = packed ? U.l0 + (lane - lgrp * Wd) : lane;
+  const bool in_lanes = packed ? true : (lane >= U.l0 && lane < U.l1);
   const gbytes_t rdata = (gbytes_t)A.R.data;
   const CLIPPER_GLOBAL uint64_t* rpre = (const CLIPPER_GLOBAL uint64_t*)A.R.Pre;
-  auto src_of = [&](int t) -> gbytes_t {
+  auto src_of = [&](int t) -> gbytes_t {  // (not packed) the view's slice behind local slice t
     const int tc = t / S, tk = t - tc * S;
     return rdata + 16 * rpre[static_cast<int64_t>(U.cg0 + tc) * A.R.nchunks + tk];
+  };
+  auto src_chunk = [&](int k) -> gbytes_t {  // (packed: one column group) the view's slice of chunk k
+    return rdata + 16 * rpre[static_cast<int64_t>(U.cg0) * A.R.nchunks + k];
   };
   // sizes: wave w sizes the slices t = w, w + 8, ... as they will lie in LDS
   if (nslices <= RVR_TMAX) {
     for (int t = wave; t < nslices; t += RVR_NWV) {
+      uint32_t bytes = 0;
+      if (packed) {  // the lanes' lists: lane group g = the unit's columns in chunk t G + g
+        const int k = t * G + lgrp;
+        const bool have = k < A.R.nchunks;
+        const gbytes_t sp = src_chunk(have ? k : 0);
+        int mq = have ? static_cast<int>(reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(sp)[1]) : 0;
+        const int tq = have ? static_cast<int>(sp[16 + lsrc]) : 0;
+        mq = sl_wave_max(mq);
+        bytes = 16 + 64 + sl_so_bytes(mq) + sl_steps_bytes(tq, mq, QB);
+        if (lane == 0) sizes[t] = bytes;
+        continue;
+      }
       const gbytes_t sp = src_of(t);
       const uint32_t nb = reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(sp)[2];
-      uint32_t bytes = nb;
+      bytes = nb;
       if (!whole) {
         const int maxq = __builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(sp)[1]));
         const int tq = in_lanes ? static_cast<int>(sp[16 + lane]) : 0;
@@ -256,8 +280,57 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     return;  // (the other units time out on this one's granules — or see the error word — and leave: nothing is committed)
   }
   for (int t = wave; t < nslices; t += RVR_NWV) {
-    const gbytes_t src = src_of(t);
     const uint32_t o = tab[t];
+    if (packed) {
+      // Packed slice t: lane L = g Wd + c holds column l0 + c of chunk t G + g. Every step of it is the quads
+      // of its active lanes in lane order (the format's own rule); a lane finds its quad of step q in ITS
+      // chunk's slice at the rank of its column among that slice's active lanes.
+      const int k = t * G + lgrp;
+      const bool have = k < A.R.nchunks;
+      const gbytes_t src = src_chunk(have ? k : 0);
+      const int mq_own = have ? static_cast<int>(reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(src)[1]) : 0;
+      const int tot_dst = have ? static_cast<int>(src[16 + lsrc]) : 0;
+      const int maxq = __builtin_amdgcn_readfirstlane(sl_wave_max(mq_own));
+      uint8_t* dp = sl + o;
+      if (lane < 4) reinterpret_cast<uint32_t*>(dp)[lane] = (lane == 1) ? static_cast<uint32_t>(maxq) : 0u;
+      dp[16 + lane] = static_cast<uint8_t>(tot_dst);
+      for (int b = lane * 4; b < sl_so_bytes(maxq); b += 256) *reinterpret_cast<uint32_t*>(dp + 16 + 64 + b) = 0u;
+      uint8_t* dfb = dp + 16 + 64 + sl_so_bytes(maxq);
+      // this lane's walk through its own chunk's slice: the lists of all 64 columns of that slice are needed
+      // for the step sizes and the ranks — group by group (G <= 8), each group's wave-wide ballot
+      gbytes_t sfb = src + 16 + 64 + sl_so_bytes(mq_own);  // (per lane)
+      int tgs[8];  // lane l: the quads of column l of the slice of chunk t G + g
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int kg = t * G + g;
+        tgs[g] = (g < G && kg < A.R.nchunks) ? static_cast<int>(src_chunk(kg)[16 + lane]) : 0;
+      }
+      for (int q = 0; q < maxq; ++q) {
+        uint64_t ms_own = 0;  // the active columns of this lane's chunk at step q
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const uint64_t mg = __ballot(q < tgs[g]);
+          if (g == lgrp) ms_own = mg;
+        }
+        const bool ad = q < tot_dst;
+        const uint64_t md = __ballot(ad);
+        const int cd = __builtin_amdgcn_readfirstlane(__popcll(md));
+        const int cs = __popcll(ms_own);  // (per lane)
+        if (ad) {
+          const uint32_t rs_ = static_cast<uint32_t>(__popcll(ms_own & ((1ull << lsrc) - 1ull)));
+          const uint32_t rd_ = sl_lane_rank(md);
+          SliceQuad<VT> vq;
+          vq.load(sfb + rs_ * QB);
+          const uint32_t rq = *reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(sfb + cs * QB + rs_ * 4);
+          vq.store(dfb + rd_ * QB);
+          *reinterpret_cast<uint32_t*>(dfb + cd * QB + rd_ * 4) = rq;
+        }
+        sfb += cs * QB + ((cs * 4 + 15) & ~15);
+        dfb += cd * QB + ((cd * 4 + 15) & ~15);
+      }
+      continue;
+    }
+    const gbytes_t src = src_of(t);
     if (whole) {
       const uint32_t nb = reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(src)[2];
       for (uint32_t b = lane * 16; b < nb; b += 64 * 16)
@@ -316,8 +389,9 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     UR[e] = rok[e] ? Ue[i] : 0.0;
     GR[e] = rok[e] ? Ge[i] : 0.0;
   }
-  const int64_t col = static_cast<int64_t>(U.cg0 + wave) * 64 + lane;  // (wave w owns column group cg0 + w in the tail)
-  const bool cown = wave < U.ncgs && in_lanes && col < m;
+  // (wave w owns column group cg0 + w in the tail; a packed unit: wave 0, lane c = column l0 + c)
+  const int64_t col = static_cast<int64_t>(U.cg0 + wave) * 64 + (packed ? U.l0 + lane : lane);
+  const bool cown = wave < U.ncgs && (packed ? lane < Wd : in_lanes) && col < m;
   const int rpos = cown ? A.viewpos[col] : -1;
   double u_c = cown ? Ue[col] : 0.0, g_c = cown ? Ge[col] : 0.0, a_c = 0.0, b_c = 0.0;
   __syncthreads();
@@ -469,7 +543,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       }
       __syncthreads();
       double acc[NS];
-      rs_wave_pass<VT, V>(sl, toff, pc, np, 0, Xt, (kind == K_TRIAL) ? d : 0.0, acc);
+      rs_wave_pass<VT, V>(sl, toff, pc, np, 0, Xt, (kind == K_TRIAL) ? d : 0.0, acc, G, lgrp * SL_SUB);
       // the window's norms (:237): wave l sums candidate l over the rows of the X table (64 rows per step, one
       // DPP sum of two numbers: the thread-per-row sums of all 2 V numbers cost six times that in every wave)
       if (wave < V) {
@@ -490,6 +564,12 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
         }
       }
       __syncthreads();  // the X table is dead: its memory becomes the waves' sums
+      if (packed) {  // a column sits in one lane of every lane group: their sums meet in a butterfly (fixed order)
+        for (int o = Wd; o < 64; o <<= 1) {
+#pragma unroll
+          for (int v = 0; v < NS; ++v) acc[v] += __shfl_xor(acc[v], o);
+        }
+      }
 #pragma unroll
       for (int v = 0; v < NS; ++v) scr[(wave * NS + v) * 64 + lane] = acc[v];
       __syncthreads();

@@ -179,6 +179,16 @@ static bool check_view_resident(const std::vector<uint32_t>& L, int ncg, int nch
     REQUIRE(U.l0 >= 0 && U.l0 < U.l1 && U.l1 <= 64);
     REQUIRE(U.ncgs == 1 || (U.l0 == 0 && U.l1 == 64));
     REQUIRE(U.ncgs * nchunks <= K.tmax);
+    // a lane part is a PACKED unit: G = 64 / width chunks side by side per slice
+    const int G = U.pack > 1 ? U.pack : 1;
+    REQUIRE((U.l0 == 0 && U.l1 == 64) ? U.pack == 0 : (U.pack >= 2 && U.pack <= 8 && (U.l1 - U.l0) * U.pack == 64 && U.l0 % (U.l1 - U.l0) == 0));
+    const int nsl = (nchunks + G - 1) / G;
+    auto steps_of = [&](int c, int sidx) {
+      int mq = 0;
+      for (int g = 0; g < G && sidx * G + g < nchunks; ++g)
+        mq = std::max(mq, static_cast<int>(L[static_cast<size_t>(U.cg0 + c) * nchunks + sidx * G + g] & 255u));
+      return mq;
+    };
     uint64_t bytes = 0;
     for (int c = 0; c < U.ncgs; ++c) {
       for (int l = U.l0; l < U.l1; ++l) ++lanes[U.cg0 + c][l];
@@ -204,14 +214,14 @@ static bool check_view_resident(const std::vector<uint32_t>& L, int ncg, int nch
       for (int j = 0; j < P.npieces[wv]; ++j) {
         const uint32_t pc = P.pieces[wv * K.pmax + j];
         const int kl = pc & 255, q0 = (pc >> 8) & 255, q1 = (pc >> 16) & 255;
-        REQUIRE(kl < nchunks && q0 < q1);
+        REQUIRE(kl < nsl && q0 < q1);
         steps[std::make_pair(cgl, kl)].push_back(std::make_pair(q0, q1));
       }
     }
     for (int c = 0; c < U.ncgs; ++c) {
       REQUIRE(waves_of[c] >= 1);
-      for (int k = 0; k < nchunks; ++k) {
-        const int mq = static_cast<int>(L[static_cast<size_t>(U.cg0 + c) * nchunks + k] & 255u);
+      for (int k = 0; k < nsl; ++k) {
+        const int mq = steps_of(c, k);
         auto it = steps.find(std::make_pair(c, k));
         if (mq == 0) {
           REQUIRE(it == steps.end());

@@ -267,3 +267,34 @@ def test_sparse_setter_is_read_through_the_upper_triangle():
     yD, _ = handed(W + np.diag(np.full(m, 0.25))).matvec(x)   # a stored diagonal: once
     assert np.allclose(yD, S @ x + 0.25 * x, rtol=1e-14, atol=1e-14)
     assert np.allclose(np.diag(handed(W + np.diag(np.full(m, 0.25))).get_affinity_matrix()), 1.25)
+
+
+def test_k_largest_walk_over_the_positive_entries_alone():
+    """csrc/host_solver.hpp:indices_of_k_largest walks only the positive entries of u when there are at least k
+    of them (u >= 0 is mostly zeros after a solve): the same list as the reference's walk over all entries
+    (utils.cpp:33-55: strict '<' replacement, ties keep the earlier index), here against the oracle's."""
+    import heapq
+    rng = np.random.default_rng(5)
+
+    def sparse_walk(x, k):
+        pos = [i for i in range(len(x)) if x[i] > 0.0]
+        if k < 1:
+            return []
+        k = min(k, len(x))
+        idx = pos if len(pos) >= k else list(range(len(x)))
+        q = []
+        for i in idx:
+            if len(q) < k:
+                heapq.heappush(q, (float(x[i]), i))
+            elif q[0][0] < x[i]:
+                heapq.heapreplace(q, (float(x[i]), i))
+        out = [0] * k
+        for j in range(k):
+            out[k - j - 1] = heapq.heappop(q)[1]
+        return out
+
+    for trial in range(300):
+        n = int(rng.integers(1, 60))
+        x = np.round(rng.random(n), 1) * (rng.random(n) < rng.random())   # zeros and many exact ties
+        for k in (1, 2, int(np.count_nonzero(x)), int(np.count_nonzero(x)) + 1, n):
+            assert sparse_walk(x, k) == ref.k_largest(x, k).tolist(), (x.tolist(), k)
