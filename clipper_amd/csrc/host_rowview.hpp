@@ -318,7 +318,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
       const bool as_asked = nrows > 0 && nrows == asked;
       if (!as_asked &&
           (nrows == 0 || static_cast<double>(nrows) > RV_ROWS_RATIO * rows_now ||
-           pol.build_fixed + pol.build_per_row * static_cast<double>(nrows) >=
+           RV_GAIN_MARGIN * (pol.build_fixed + pol.build_per_row * static_cast<double>(nrows)) >=
                horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row)) {
         hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows));
         h->rv_stats.build_ms +=

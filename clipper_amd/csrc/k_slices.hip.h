@@ -258,16 +258,16 @@ struct SliceHead {
 template <int H, int NW>
 struct SliceJob {
   int strip, slot, cg, t0, t1, q0, q1;
+  int live;  // the workgroup has an item of this list (its partial sums are written)
   SliceHead<H> first;
   uint64_t pre1;  // Pre of the slice after the first one (its header is requested one chunk ahead)
 };
 
 template <int H, int NW>
-__device__ __forceinline__ void slice_begin(const SliceViewG& M, SliceJob<H, NW>& J) {
+__device__ __forceinline__ void slice_begin(const SliceViewG& M, SliceJob<H, NW>& J, int item) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // (a struct cannot be copied out of an address space: the work item as its six ints)
-  const CLIPPER_GLOBAL int* w = reinterpret_cast<const CLIPPER_GLOBAL int*>(
-      M.work + (static_cast<int>(blockIdx.x) < M.nwork ? blockIdx.x : 0));
+  const CLIPPER_GLOBAL int* w = reinterpret_cast<const CLIPPER_GLOBAL int*>(M.work + (item < M.nwork ? item : 0));
   J.strip = w[0];
   J.slot = w[1];
   J.cg = J.strip * NW + wave;
@@ -275,12 +275,13 @@ __device__ __forceinline__ void slice_begin(const SliceViewG& M, SliceJob<H, NW>
   J.t1 = w[3];
   J.q0 = w[4];
   J.q1 = w[5];
+  J.live = item < M.nwork ? 1 : 0;
   J.first.maxq = 0;
   J.first.sp = M.data;
   J.pre1 = 0;
 #pragma unroll
   for (int h = 0; h < H; ++h) J.first.nq[h] = 0;
-  if (static_cast<int>(blockIdx.x) >= M.nwork) {  // no item of this view for this workgroup
+  if (item >= M.nwork) {  // no item of this list for this workgroup
     J.strip = J.slot = J.t0 = J.t1 = J.q0 = J.q1 = 0;
     J.cg = M.ncg;
     J.first.maxq = 0;
@@ -426,7 +427,7 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
   }
 
   const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
-  if (c < ld && static_cast<int>(blockIdx.x) < M.nwork) {
+  if (c < ld && J.live != 0) {
 #pragma unroll
     for (int v = 0; v < NS; ++v) {
       const int slot = (v == NS - 1) ? NSLOT - 1 : v;
@@ -472,7 +473,11 @@ constexpr int SL_OCC = CLIPPER_SL_OCC;  // waves per SIMD the pass kernel is com
 // G of a solver iteration on the slices (one shard): decision, then the pass
 // `RV`: the descriptor of the row view of M, in device memory (read only by a launch whose decision
 // chose the view: PassPlan::view — as a second by-value argument it cost 130 registers spilled to
-// scratch, some of them inside the streaming loop). The grid covers the larger of the two work lists.
+// scratch, some of them inside the streaming loop). The grid covers the larger of the two work lists: one
+// workgroup per item, also where the list is 3 - 8 times the workgroups the chip holds (m >= 30k). A PERSISTENT
+// grid for those lists — each workgroup decides once and claims further items with an atomic — was measured in
+// round 4 and is 4 - 9 % slower: with six workgroups per CU a new workgroup's decision runs while the others
+// stream, and the dispatcher hands out the items in the same greedy order (profiles/r04_persistent_grid.txt).
 template <typename VT, int H, int V>
 __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M, const SliceView* __restrict__ RV, SolveArgs A) {
   __shared__ __attribute__((aligned(16))) double lds[sl_lds_doubles(V, H, SL_NW)];
@@ -480,14 +485,14 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   const long long c0 = A.stamps ? wall_clock64() : 0;
   SliceViewG G = to_global(M);
   SliceJob<H, SL_NW> J, JV;
-  slice_begin<H, SL_NW>(G, J);
+  slice_begin<H, SL_NW>(G, J, blockIdx.x);
   // Both jobs are requested ahead of the decision, which hides them: a pass on a small view is a chain
   // of latencies (work item -> directory -> header), not a stream. (Also requesting this thread's
   // row-list entry for the first chunk here tips the register allocation into scratch: not done.)
   SliceViewG GV = G;
   if (A.in_view != nullptr) {
     GV = to_global(*RV);
-    slice_begin<H, SL_NW>(GV, JV);
+    slice_begin<H, SL_NW>(GV, JV, blockIdx.x);
   }
   PassPlan plan;
   if (!iteration_head<V, SL_NW * 64>(A, lds, &stash, plan)) return;
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(SL_NW * 64, 2) void k_gemv_slices_plain(SliceView M
   __shared__ __attribute__((aligned(16))) double lds[2 * SL_SUB * H];
   const SliceViewG G = to_global(M);
   SliceJob<H, SL_NW> J;
-  slice_begin<H, SL_NW>(G, J);
+  slice_begin<H, SL_NW>(G, J, blockIdx.x);
   slice_core<VT, H, false, 1, 2, SL_NW, SL_D>(G, J, ld, m, 0.0, WindowSource{}, X, VS, part, lds);
 }
 

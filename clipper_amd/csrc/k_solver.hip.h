@@ -78,6 +78,7 @@ constexpr int tail_q(int V) { return V * tail_nr(V) + 2 * V + 2; }
 //     bit-reproducible from run to run, views included.
 // ------------------------------------------------------------------------------------------
 constexpr double LIVE_OUT = 67108864.0;  // 2^26: the "outside the view" digit of a live code
+constexpr double RV_GAIN_MARGIN = 1.3;   // the modelled gain of a view over its modelled cost, at least
 constexpr double RV_ROWS_RATIO = 0.8;    // a new view must drop at least a fifth of the rows a pass streams today
                                          // (one constant for the device's request and the host's acceptance)
 
@@ -350,7 +351,10 @@ __device__ __forceinline__ bool view_wanted_v(const ViewPolicy& rvp, int64_t m, 
   if (backoff > 0 && r > RV_ROWS_RATIO * static_cast<double>(backoff)) return false;  // nothing much changed since a refusal
   const double horizon = n_iters > 12 ? static_cast<double>(n_iters) : 12.0;
   const double gain = horizon * ((rows_now - r) * rvp.pass_per_row);
-  return gain > rvp.build_fixed + r * rvp.build_per_row;
+  // (a margin: a view that only just pays by this model does not — at m = 100k / 300k a marginal middle view between
+  // the first, large one and the last, small one cost 10 / 89 ms of fill for passes that the next view took over a
+  // few iterations later: profiles/r04_view_policy_margin.txt)
+  return gain > RV_GAIN_MARGIN * (rvp.build_fixed + r * rvp.build_per_row);
 }
 __device__ __forceinline__ bool view_wanted(const SolveArgs& A, int nlive, int nout, int64_t n_iters,
                                             int builds, int last, int backoff) {
