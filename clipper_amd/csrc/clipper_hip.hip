@@ -901,6 +901,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
           if ((rc = rvr_enqueue(h, prm, launched))) return rc;
           mark_t("resident queued");
         }
+        if ((rc = rowview_finish_plan(h))) return rc;  // (a work list put off while the resident launch was prepared)
         continue;
       }
       if (hm->iters > queued) queued = hm->iters;  // (a resident launch retired many iterations at once)

@@ -191,7 +191,7 @@ int slices_plan(Ctx* h, Shard& sh, SliceStore& s, bool whole);
 int slices_plan(Ctx* h, Shard& s) { return slices_plan(h, s, s, true); }
 int resident_plan(Ctx* h, Shard& s);
 
-int emit_check(Ctx* h, Shard& sh, SliceStore& s, bool whole, bool& again) {
+int emit_check(Ctx* h, Shard& sh, SliceStore& s, bool whole, bool& again, bool plan = true) {
   again = false;
   HIPCHK(hipSetDevice(sh.device));
   bool over = false;
@@ -218,6 +218,10 @@ int emit_check(Ctx* h, Shard& sh, SliceStore& s, bool whole, bool& again) {
     return 0;
   }
   s.s_bytes = sum * 16;
+  if (!plan) {  // (a row view the resident solver takes: its work list is planned behind that launch, host_rowview.hpp)
+    s.s_nwork = 0;
+    return 0;
+  }
   return slices_plan(h, sh, s, whole);
 }
 int emit_check(Ctx* h, Shard& s, bool& again) { return emit_check(h, s, s, true, again); }

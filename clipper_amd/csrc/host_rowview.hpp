@@ -122,6 +122,8 @@ bool rowview_cost_of_filter(const Ctx* h) { return rowview_build_env() != 0 || !
 // ---- the row view -----------------------------------------------------------------------------------
 
 int rvr_plan(Ctx* h, Shard& s);  // host_rv_resident.hpp: does the view just built fit the resident solver?
+bool rvr_candidate(const Ctx* h, int64_t nrows);
+int rowview_put_descriptor(Ctx* h, Shard& s);
 
 void rowview_drop(Ctx* h) {
   for (auto& s : h->sh) s.rv.valid = false;
@@ -344,9 +346,15 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
       }
     }
     bool again = false;
-    if ((rc = emit_check(h, s, v.st, false, again))) return rc;
+    // (one shard, a view small enough for the resident solver: the work list of the STREAMED pass on it — what the
+    // launches behind the resident one fall back to — is planned while that launch runs: rowview_finish_plan)
+    const bool defer = rvr_candidate(h, nrows);
+    if ((rc = emit_check(h, s, v.st, false, again, !defer))) return rc;
     lap("planned");
-    if (!again) break;
+    if (!again) {
+      v.plan_pending = defer;
+      break;
+    }
     if (attempt >= 3) return fail(CLIPPER_HIP_E_HIP, "row view: the build keeps overflowing");
   }
   v.cur = next;
@@ -355,23 +363,49 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   built = true;
   if ((rc = rvr_plan(h, s))) return rc;  // (the view's directory is still in the pinned staging)
   lap("resident plan");
-  {  // the descriptor a pass on the view reads, to the device
-    if (!v.desc) HIPCHK(hipMalloc(reinterpret_cast<void**>(&v.desc), sizeof(SliceView)));
-    if (!h->rv_desc_host) {
-      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->rv_desc_host), sizeof(SliceView), hipHostMallocMapped | hipHostMallocCoherent));
-      HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->rv_desc_host_dev), h->rv_desc_host, 0));
-    }
-    *h->rv_desc_host = row_view(h, s);
-    std::atomic_thread_fence(std::memory_order_seq_cst);
-    hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(64), 0, s.stream, reinterpret_cast<const uint4*>(h->rv_desc_host_dev),
-                       reinterpret_cast<uint4*>(v.desc), static_cast<int64_t>(sizeof(SliceView) / 16));
-    // the pinned staging slot is the context's: the copy has to be through before the next shard of an
-    // in-process group writes ITS descriptor there
-    if (h->sh.size() > 1) HIPCHK(hipStreamSynchronize(s.stream));
+  if (v.plan_pending && !h->vres.ready) {  // the resident solver does not take it after all
+    if ((rc = slices_plan(h, s, v.st, false))) return rc;
+    v.plan_pending = false;
   }
+  if ((rc = rowview_put_descriptor(h, s))) return rc;  // (no work list yet while its plan is pending: no item for anybody)
   hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0);
   h->rv_stats.build_ms +=
       std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+  return 0;
+}
+
+// the descriptor a pass on the view reads, to the device
+int rowview_put_descriptor(Ctx* h, Shard& s) {
+  RowView& v = s.rv;
+  if (!v.desc) HIPCHK(hipMalloc(reinterpret_cast<void**>(&v.desc), sizeof(SliceView)));
+  if (!h->rv_desc_host) {  // two staging slots, used in turn: a view whose work list is planned behind the resident
+                           // launch sends a second descriptor while the copy of the first may still be queued
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->rv_desc_host), 2 * sizeof(SliceView), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->rv_desc_host_dev), h->rv_desc_host, 0));
+  }
+  const int slot = (h->rv_desc_slot ^= 1);
+  h->rv_desc_host[slot] = row_view(h, s);
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(64), 0, s.stream, reinterpret_cast<const uint4*>(h->rv_desc_host_dev + slot),
+                     reinterpret_cast<uint4*>(v.desc), static_cast<int64_t>(sizeof(SliceView) / 16));
+  // the pinned staging slot is the context's: the copy has to be through before the next shard of an
+  // in-process group writes ITS descriptor there
+  if (h->sh.size() > 1) HIPCHK(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+// The work list of the streamed pass on a view whose plan was put off (see rowview_build_shard): queued behind
+// the resident launch, in front of the streaming launches that may need it.
+int rowview_finish_plan(Ctx* h) {
+  for (auto& s : h->sh) {
+    RowView& v = s.rv;
+    if (!v.valid || !v.plan_pending) continue;
+    HIPCHK(hipSetDevice(s.device));
+    // (the view's directory words are still in the pinned staging: nothing was built since)
+    if (int rc = slices_plan(h, s, v.st, false)) return rc;
+    v.plan_pending = false;
+    if (int rc = rowview_put_descriptor(h, s)) return rc;
+  }
   return 0;
 }
 

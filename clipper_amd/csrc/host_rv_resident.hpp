@@ -25,6 +25,9 @@ bool rvr_enabled(const Ctx* h) {
   return !env_off && h->rv_mode == 0 && csc_single(h) && h->sh.size() == 1 && (h->V == 6 || h->V == 4);
 }
 
+// could a view of this many rows go to the resident solver? (what rvr_plan checks before it looks at the directory)
+bool rvr_candidate(const Ctx* h, int64_t nrows) { return rvr_enabled(h) && nrows >= 1 && nrows <= RVR_MAXROWS; }
+
 // Called when a view has just been built and its directory (csc_hLq) is on the host: does it fit the
 // resident solver? Lays out the units (host_plan.hpp) into mapped pinned memory.
 int rvr_plan(Ctx* h, Shard& s) {

@@ -147,6 +147,7 @@ struct RowView {
   size_t cap_rows = 0, cap_flags = 0, cap_blk = 0, cap_pos = 0;
   int64_t nrows = 0;
   bool valid = false;
+  bool plan_pending = false;    // the work list of the streamed pass is not planned yet (the resident solver took the view)
 };
 
 // ---- one column slice of M on one device ------------------------------------------------
@@ -299,7 +300,8 @@ struct clipper_hip_ctx {
   bool rv_fresh = false;      // the next iteration is the first after a view was built
   int rv_mode = 0;            // 0 = automatic, 1 = never (clipper_hip_set_row_view / CLIPPER_HIP_ROW_VIEW=0),
                               // 2 = views, but never the resident solver on one (CLIPPER_HIP_VIEW_RESIDENT=0)
-  SliceView* rv_desc_host = nullptr;     // pinned + mapped staging of a view's descriptor
+  SliceView* rv_desc_host = nullptr;     // pinned + mapped staging of a view's descriptor (two slots, used in turn)
+  int rv_desc_slot = 0;
   SliceView* rv_desc_host_dev = nullptr;
   int32_t* rv_count = nullptr;      // pinned + mapped: rows of the view being built
   int32_t* rv_count_dev = nullptr;
