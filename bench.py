@@ -30,7 +30,7 @@ Prints ONE JSON line on rank 0 (see the contract in the task statement), extende
                  roofline figure. `regime` says whether those bytes fit the 256 MiB Infinity
                  Cache (then every pass after the first is served on-die and "hbm" names the
                  peak it is normalised by, not the wire it crossed). `traffic` = HBM-side bytes
-                 per launch from the PMC run recorded in profiles/gemv_traffic.json
+                 per launch from the PMC run recorded in profiles/pmc_r04.json
                  (`traffic_source` names the entry and the commit it was measured at).
                  --storage f32: k_gemv on the dense store, bytes per launch = 4*m*W
   "roofline_affinity"  the fill kernel: bytes of M written per build / its duration.
@@ -50,6 +50,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PMC_RECORD = "profiles/pmc_r04.json"
+# the sources of the kernels the PMC record is about (the pass, its decision, the planner that cuts its work, the
+# fill): a record is quoted only if it was measured on exactly these bytes
+PMC_SOURCES = ("clipper_amd/csrc/k_slices.hip.h", "clipper_amd/csrc/k_solver.hip.h", "clipper_amd/csrc/host_plan.hpp",
+               "clipper_amd/csrc/k_affinity.hip.h", "clipper_amd/csrc/k_csc.hip.h")
+
+
+def kernel_sources_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in PMC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def parse():
@@ -71,6 +85,7 @@ def parse():
                     help="size of the `scaling_probe` object: the same step at the size whose pass is "
                          "HBM-bound and whose shards scale (0 = no probe)")
     ap.add_argument("--probe-steps", type=int, default=3)
+    ap.add_argument("--sources-sha", action="store_true", help="print the sha256 of the kernel sources a PMC record is tied to, and exit")
     return ap.parse_args()
 
 
@@ -107,6 +122,9 @@ def cpu_baseline(problem, args):
 
 def main():
     args = parse()
+    if args.sources_sha:
+        print(kernel_sources_sha256())
+        return
     N = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -243,11 +261,11 @@ def main():
                   abi.STORE_F64_CSC: "csc64"}[g.storage_in_use]
         compressed = in_use in ("csc", "csc64")
         # PMC figures cannot be collected inside this process (rocprofv3 wraps a command): they come
-        # from profiles/pmc_r03.json, written by tools/pmc_summary.py from a rocprofv3 --pmc run of this
-        # same command, with the commit and the kernel's byte count at that time. A record taken on
-        # other bytes than today's is NOT quoted.
+        # from profiles/pmc_r04.json, written by tools/pmc_summary.py from a rocprofv3 --pmc run of this
+        # same command, with the commit, the kernel's byte count and the sha256 of the kernel sources at that
+        # time. A record taken on other sources or other bytes than today's is NOT quoted.
         traffic, traffic_source, issue = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_r03.json")
+        pmc = os.path.join(ROOT, PMC_RECORD)
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(f"m{args.m}_{in_use}")
@@ -255,15 +273,19 @@ def main():
                 rec = None
             if rec:
                 then = rec.get("pass_bytes_per_launch")
-                if then is not None and abs(then - tm.gemv_bytes) > 1e-6 * max(1.0, tm.gemv_bytes):
-                    print(f"bench.py: profiles/pmc_r03.json was measured on {then} bytes per pass, the kernel "
-                          f"reads {tm.gemv_bytes} today: STALE, not quoted — re-run tools/gpu_pmc_r03.sh",
-                          file=sys.stderr, flush=True)
-                    traffic_source = {"file": "profiles/pmc_r03.json", "stale": True, "kernel_bytes_then": then}
+                sha_then, sha_now = rec.get("kernel_sources_sha256"), kernel_sources_sha256()
+                stale_bytes = then is not None and abs(then - tm.gemv_bytes) > 1e-6 * max(1.0, tm.gemv_bytes)
+                if stale_bytes or sha_then != sha_now:
+                    print(f"bench.py: {PMC_RECORD} was measured on other kernel sources or bytes ({then} bytes per pass then, "
+                          f"{tm.gemv_bytes} today; sources {str(sha_then)[:12]} then, {sha_now[:12]} today): STALE, not quoted — "
+                          f"re-run tools/gpu_prof_r04.sh", file=sys.stderr, flush=True)
+                    traffic_source = {"file": PMC_RECORD, "stale": True, "kernel_bytes_then": then,
+                                      "kernel_sources_sha256_then": sha_then, "kernel_sources_sha256_now": sha_now}
                 else:
                     traffic = rec.get("pass_hbm_bytes_per_launch")
-                    traffic_source = {"file": "profiles/pmc_r03.json", "key": f"m{args.m}_{in_use}",
+                    traffic_source = {"file": PMC_RECORD, "key": f"m{args.m}_{in_use}",
                                       "measured_at_commit": rec.get("commit"), "kernel_bytes_then": then,
+                                      "kernel_sources_sha256": sha_then,
                                       "read_bytes": rec.get("pass_read_bytes"), "written_bytes": rec.get("pass_written_bytes"),
                                       "how": rec.get("how")}
                     issue = rec.get("affinity_issue")

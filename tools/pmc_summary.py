@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """PMC counters of a rocprofv3 --pmc run of bench.py, per kernel, and the record bench.py quotes
-(profiles/pmc_r03.json). The pass kernel is launched for passes on M, for passes on a row view
+(profiles/pmc_r04.json). The pass kernel is launched for passes on M, for passes on a row view
 (far fewer bytes) and for iterations that do nothing: a launch counts as a PASS ON M when it runs at
 least 0.6 x the longest launch of that kernel in the run.
-  tools/pmc_summary.py --key m10000_csc --bytes <bytes per pass> --commit <sha> --json profiles/pmc_r03.json <db> [...]"""
+  tools/pmc_summary.py --key m10000_csc --bytes <bytes per pass> --commit <sha> --json profiles/pmc_r04.json <db> [...]"""
 import argparse
 import json
 import os
@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--bytes", type=float, default=None)
     ap.add_argument("--commit", default="")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--sources-sha", default="", help="sha256 over the kernel sources the counters were measured on "
+                    "(bench.py:kernel_sources_sha256): bench.py refuses a record taken on other sources")
     a = ap.parse_args()
     per = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [(value, duration)]
     for db in a.dbs:
@@ -46,6 +48,8 @@ def main():
         rec = json.load(open(a.json))
     e = rec.setdefault(a.key, {})
     e["commit"] = a.commit
+    if a.sources_sha:
+        e["kernel_sources_sha256"] = a.sources_sha
     if a.bytes is not None:
         e["pass_bytes_per_launch"] = a.bytes
     pk = next((k for k in summary if k.startswith("k_gemv_slices")), None) or next((k for k in summary if k.startswith("k_gemv")), None)
