@@ -232,14 +232,13 @@ def main():
 
     # The same step at the size whose pass is HBM-bound and whose column shards scale:
     # recorded beside the headline for every N, so that a scaling run shows a curve that CAN scale
-    probe = None
-    if args.probe_m and args.probe_m != args.m:
-        pp = synth.make_euclidean_problem(args.probe_m, 0.95, seed=args.seed)
-        P = timed_steps(pp, args.probe_steps, 1, not args.no_profile)
+    def scaling_probe(pm, psteps):
+        pp = synth.make_euclidean_problem(pm, 0.95, seed=args.seed)
+        P = timed_steps(pp, psteps, 1, not args.no_profile)
         ptm, pvs = P["tm"], P["vs"]
         pass_us = P["gemv_us"] / max(1, P["gemv_n"])
-        probe = {
-            "m": args.probe_m, "rho": 0.95, "steps": args.probe_steps, "n_gpus": N,
+        return {
+            "m": pm, "rho": 0.95, "steps": psteps, "n_gpus": N,
             "ms_per_step": round(P["ms_per_step"], 3),
             "affinity_ms": round(sum(P["aff_ms"]) / len(P["aff_ms"]), 3),
             "solve_ms": round(sum(P["solve_ms"]) / len(P["solve_ms"]), 3),
@@ -253,6 +252,15 @@ def main():
             "exchange_bytes_per_rank": ptm.exchange_bytes if N > 1 else None,
             "nodes": int(len(P["sol"].nodes)), "score": P["sol"].score,
         }
+
+    probe = None
+    if args.probe_m and args.probe_m != args.m:
+        probe = scaling_probe(args.probe_m, args.probe_steps)
+    # BASELINE.json's configuration for the 8-GPU node (m = 300 000 row-sharded): recorded whenever there is more
+    # than one rank (one GPU holds it too — 57 GB — but the default run must finish within minutes)
+    probe_cfg5 = None
+    if N >= 2 and args.probe_m and args.m != 300000:
+        probe_cfg5 = scaling_probe(300000, 1)
 
     out = None
     if rank == 0:
@@ -359,6 +367,7 @@ def main():
                 "pass_on_view_us": round(R["view_us"] / max(1, R["view_n"]), 2),
             },
             "scaling_probe": probe,
+            "scaling_probe_cfg5": probe_cfg5,
         }
         if N == 1 and not args.no_cpu_baseline:
             cb, sref = cpu_baseline(problem, args)

@@ -15,6 +15,8 @@ first FAIL names the layer that is broken:
                      identical gathered products on every rank, equal to a single-GPU product on rank 0
   5 solve            per-rank fill + the whole solver (one [V+1][W] all-gather per pass): identical u
                      hashes on every rank, the single-GPU node list on every rank; pass / exchange times
+  6 row views        the same solve built a row view on EVERY rank (each its own columns of the same rows) and
+                     ran passes on it: the same build and view-pass counts everywhere (m >= 3000)
 """
 import argparse
 import hashlib
@@ -123,6 +125,14 @@ def main():
            f"u {'identical' if same else 'DIFFERS'} across ranks; {s.n_passes} passes in {dt * 1e3:.1f} ms, pass on this rank's "
            f"shard {tm.gemv_avg_us:.1f} us ({tm.gemv_bytes / 1e6:.1f} MB), exchange {tm.exchange_avg_us:.1f} us "
            f"({tm.exchange_bytes / 1e3:.1f} KB per rank, {tm.exchange_samples} sampled){ref_msg}")
+    # 6 row views: every rank built its columns of the same views and ran the same passes on them
+    st = g.view_stats()
+    vs = [None] * world
+    tdist.all_gather_object(vs, (int(st.builds), int(st.rows), int(st.view_passes)))
+    want_views = a.m >= 3000 and a.storage != "f32"
+    report(6, (len(set(vs)) == 1) and (not want_views or (st.builds >= 1 and st.view_passes >= 1)),
+           f"views built {st.builds} (last: {st.rows} rows, {st.bytes / 1e6:.1f} MB on this rank), passes on a view {st.view_passes} of "
+           f"{st.passes}, view pass on this rank's shard {st.view_pass_avg_us:.1f} us; per rank (builds, rows, view passes): {vs}")
     g.close()
     tdist.barrier()
     tdist.destroy_process_group()
