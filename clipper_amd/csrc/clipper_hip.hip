@@ -863,10 +863,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     int64_t queued = 0;
     uint64_t spins = 0;
     h->rv_fresh = false;
-    static const int run_ahead = [] {  // (measurement knob)
-      const char* e = std::getenv("CLIPPER_HIP_RUN_AHEAD");
-      return e ? std::max(1, std::atoi(e)) : RUN_AHEAD;
-    }();
+    constexpr int run_ahead = RUN_AHEAD;
     while (!hm->done) {
       if (hm->hold) {
         // The decision asked for a row view (k_solver.hip.h, LIVE ROWS) and put the solve on hold:

@@ -328,11 +328,10 @@ GroupSource<VT> group_source(const Ctx* h, const Shard& s) {
 // chunk that alone exceeds the target is split by step range. Most expensive first.
 int slices_plan(Ctx* h, Shard& sh, SliceStore& s, bool whole) {
   static const double target_env = std::getenv("CLIPPER_HIP_CSC_WGS") ? std::max(1.0, std::atof(std::getenv("CLIPPER_HIP_CSC_WGS"))) : 0.0;
-  static const double c0_env = std::getenv("CLIPPER_HIP_CSC_C0") ? std::max(0.0, std::atof(std::getenv("CLIPPER_HIP_CSC_C0"))) : -1.0;
   static_assert(sizeof(clipper_plan::Work) == sizeof(SliceWork), "the planner's work item is the kernel's");
   static thread_local clipper_plan::PassPlan plan;  // (buffers kept from build to build)
   clipper_plan::plan_pass(h->csc_hLq, s.s_ncg, s.s_nchunks, clipper_plan::PassConsts{SL_NW, SL_SO, SL_OCC, whole ? 12 : 8},
-                          h->cus, target_env, c0_env >= 0.0 ? c0_env : 2.0, plan);
+                          h->cus, target_env, 2.0, plan);
   s.s_entries = plan.entries;
   const int nslots = plan.nslots;
   const size_t nw = plan.work.size();
@@ -539,8 +538,7 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
   plan_tiles(h);
   int rc = 0;
   const bool emit = csc_applies(h) && csc_single(h) && emits && h->storage == CLIPPER_HIP_STORE_F32;
-  static const bool rect_off = std::getenv("CLIPPER_HIP_RECT_FILL") && std::atoi(std::getenv("CLIPPER_HIP_RECT_FILL")) == 0;
-  if (!emit && csc_applies(h) && rect_fill_possible(h) && !h->plain_affinity && !h->strip_affinity && !rect_off) {
+  if (!emit && csc_applies(h) && rect_fill_possible(h) && !h->plain_affinity && !h->strip_affinity) {
     double kms = 0.0;
     if ((rc = run_affinity_rect(h, kms))) return rc;
     h->csc_valid = true;

@@ -53,14 +53,9 @@ inline void plan_pass(const uint32_t* L, int ncg, int nchunks, const PassConsts&
   }
   // (this runs between the fill and the first pass of every build: buffers are kept, the order is a
   // counting sort)
-  // What a chunk of a strip costs: the longest of its waves' chains of lock-step steps (the latency
-  // view), blended with the entries its slices hold (the bytes view: entries / 256 = steps with every
-  // lane busy, x 2 for the usual lock-step efficiency) by CLIPPER_HIP_PLAN_ENTRY_WEIGHT in [0, 1]
-  // (0: steps only — the default; measurement knob, profiles/r03_plan_cost_model.txt)
-  static const double entry_weight = [] {
-    const char* e = std::getenv("CLIPPER_HIP_PLAN_ENTRY_WEIGHT");
-    return e ? std::min(1.0, std::max(0.0, std::atof(e))) : 0.0;
-  }();
+  // What a chunk of a strip costs: the longest of its waves' chains of lock-step steps. (Blending in the entries
+  // the slices hold — the bytes view — was measured worse at every weight: profiles/r03_plan_cost_model.txt.)
+  constexpr double entry_weight = 0.0;
   static thread_local std::vector<int> cost;
   static thread_local std::vector<double> bcost;
   static thread_local std::vector<Work> items;

@@ -71,7 +71,6 @@ int plan_unr(const Ctx* h) {
 int64_t max_tiles(const Ctx* h) {
   const int64_t slots = static_cast<int64_t>(h->cus) * GEMV_WG_PER_CU;
   int64_t nt = std::max<int64_t>(16, ceil_div(slots, std::max(1, h->nstrips)) + 1);
-  if (const char* e = std::getenv("CLIPPER_HIP_TILES")) nt = std::max<int64_t>(nt, std::atoll(e));
   return nt;
 }
 
@@ -101,10 +100,6 @@ void plan_tiles(Ctx* h) {
       best_cost = cost;
       best = nt;
     }
-  }
-  if (const char* e = std::getenv("CLIPPER_HIP_TILES")) {  // tuning knob (measurements only)
-    const int64_t v = std::atoll(e);
-    if (v > 0) best = std::min<int64_t>(v, std::max<int64_t>(1, ceil_div(h->m, chunk)));
   }
   int64_t rpt = round_up(ceil_div(h->m, best), chunk);
   h->rows_per_tile = static_cast<int>(rpt);
@@ -384,13 +379,10 @@ template <int V>
 int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   const int par = h->par;
   h->par ^= 1;
-  // CLIPPER_HIP_FORCE_SHARDED: test / measurement knob — the column-shard protocol (reduce launch,
-  // exchange, k_tail<V, false>) on a single unsharded device
-  static const bool force_sharded = std::getenv("CLIPPER_HIP_FORCE_SHARDED") != nullptr;
-  const bool sharded = !(h->world == 1 && !h->multiproc) || force_sharded;
+  const bool sharded = !(h->world == 1 && !h->multiproc);
   // timing events cost ~5-10 us of stream time each: sample every 8th launch only
   Shard& s0 = h->sh[0];
-  static const int every = std::getenv("CLIPPER_HIP_PROFILE_EVERY") ? std::max(4, std::atoi(std::getenv("CLIPPER_HIP_PROFILE_EVERY"))) : PROFILE_EVERY;
+  constexpr int every = PROFILE_EVERY;
   // iterations 4, 11, then every `every`-th: short solves (20 iterations) still get samples, and
   // one of them is a pass (3 and 9 both hit transitions at cfg4)
   const bool prof = h->profiling && (h->launch_counter % every == 4 || h->launch_counter == 11) &&
@@ -608,13 +600,9 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     const int v = std::atoi(w);
     if (v == 1 || v == 4 || v == 6 || v == 8) h->V_forced = v;
   }
-  // CLIPPER_HIP_RESIDENT = 0: never the resident solver; CLIPPER_HIP_RESIDENT_V = 1 | 2: its window
+  // CLIPPER_HIP_RESIDENT = 0: never the resident solver
   if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT"))
     if (std::atoi(e) == 0) h->resident_mode = 1;
-  if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT_V")) {
-    const int v = std::atoi(e);
-    if (v == 1 || v == 2) h->res.V_forced = v;
-  }
   return h;
 }
 

