@@ -221,12 +221,19 @@ int clipper_hip_affinity_euclidean_staged(clipper_hip_t* h, double sigma, double
       dim3 g(static_cast<unsigned>(static_cast<int64_t>(nT) * (nT + 1) / 2));
       const PointNormalParams none{};
       const float E2 = guarded_threshold_sq(thr);
-      if (d == 3)
-        launch_sym(k_affinity_sym<3, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
-                   pstride, A0, A1, prm, none, E2, h->csc_out);
+      if (h->storage == CLIPPER_HIP_STORE_F64) {  // (slices with fp64 values: no dense store on this route)
+        if (d == 3)
+          launch_sym<double>(k_affinity_sym<3, false, double>, g, s.stream, static_cast<double*>(nullptr), W, mm, nT, s,
+                             pstride, A0, A1, prm, none, E2, h->csc_out);
+        else
+          launch_sym<double>(k_affinity_sym<2, false, double>, g, s.stream, static_cast<double*>(nullptr), W, mm, nT, s,
+                             pstride, A0, A1, prm, none, E2, h->csc_out);
+      } else if (d == 3)
+        launch_sym<float>(k_affinity_sym<3, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
+                          pstride, A0, A1, prm, none, E2, h->csc_out);
       else
-        launch_sym(k_affinity_sym<2, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
-                   pstride, A0, A1, prm, none, E2, h->csc_out);
+        launch_sym<float>(k_affinity_sym<2, false>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
+                          pstride, A0, A1, prm, none, E2, h->csc_out);
       h->csc_emitted = (h->csc_out.Pre != nullptr);
       return;
     }
@@ -270,8 +277,12 @@ int clipper_hip_affinity_pointnormal_staged(clipper_hip_t* h, double sigp, doubl
       const int nT = static_cast<int>(ceil_div(mm, AT));
       dim3 g(static_cast<unsigned>(static_cast<int64_t>(nT) * (nT + 1) / 2));
       const EuclidParams none{};
-      launch_sym(k_affinity_sym<3, true>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
-                 pstride, s.Adev, s.Adev + mm, none, prm, guarded_threshold_sq(thr), h->csc_out);
+      if (h->storage == CLIPPER_HIP_STORE_F64)
+        launch_sym<double>(k_affinity_sym<3, true, double>, g, s.stream, static_cast<double*>(nullptr), W, mm, nT, s,
+                           pstride, s.Adev, s.Adev + mm, none, prm, guarded_threshold_sq(thr), h->csc_out);
+      else
+        launch_sym<float>(k_affinity_sym<3, true>, g, s.stream, static_cast<float*>(s.S), W, mm, nT, s,
+                          pstride, s.Adev, s.Adev + mm, none, prm, guarded_threshold_sq(thr), h->csc_out);
       h->csc_emitted = (h->csc_out.Pre != nullptr);
       return;
     }

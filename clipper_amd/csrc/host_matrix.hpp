@@ -537,7 +537,7 @@ int run_affinity(Ctx* h, bool emits, Launch launch) {
   h->explicitC = false;
   plan_tiles(h);
   int rc = 0;
-  const bool emit = csc_applies(h) && csc_single(h) && emits && h->storage == CLIPPER_HIP_STORE_F32;
+  const bool emit = csc_applies(h) && csc_single(h) && emits;  // (fp32 values, or fp64 values: k_affinity_sym<.., VT>)
   if (!emit && csc_applies(h) && rect_fill_possible(h) && !h->plain_affinity && !h->strip_affinity) {
     double kms = 0.0;
     if ((rc = run_affinity_rect(h, kms))) return rc;

@@ -714,9 +714,11 @@ float guarded_threshold_sq(float E) {
   return std::nextafter(static_cast<float>(e2), std::numeric_limits<float>::infinity());
 }
 
+// the symmetric tile kernel: one shard; fp32 values (dense store or slices), or fp64 values in SLICES (its fp64
+// image leaves no room for a second workgroup per CU, but the rectangular kernel scores every pair twice)
 bool use_sym_fill(const Ctx* h) {
   return !h->plain_affinity && !h->strip_affinity && h->world == 1 && !h->multiproc &&
-         h->storage == CLIPPER_HIP_STORE_F32;
+         (h->storage == CLIPPER_HIP_STORE_F32 || (h->storage == CLIPPER_HIP_STORE_F64 && h->compressed));
 }
 
 // Kernels that need more dynamic LDS than the 64 KiB a kernel gets by default: the attribute is
@@ -738,12 +740,13 @@ bool raise_dynamic_lds(const void* fn, int device, int bytes) {
 }
 
 // k_affinity_sym needs more dynamic LDS than the 64 KiB a kernel gets by default
-template <typename K>
-void launch_sym(K kernel, dim3 grid, hipStream_t stream, float* S, int64_t W, int64_t mm, int nT,
+template <typename VT, typename K>
+void launch_sym(K kernel, dim3 grid, hipStream_t stream, VT* S, int64_t W, int64_t mm, int nT,
                 const Shard& s, int64_t pstride, const int32_t* A0, const int32_t* A1,
                 const EuclidParams& e, const PointNormalParams& n, float E2, const CscOut& O) {
-  raise_dynamic_lds(reinterpret_cast<const void*>(kernel), s.device, AT_SYM_LDS_BYTES);
-  hipLaunchKernelGGL(kernel, grid, dim3(AT_WAVES * 64), AT_SYM_LDS_BYTES, stream, S, W, mm, nT, s.P1, s.P2,
+  constexpr int L = at_sym_lds_bytes<VT>();
+  raise_dynamic_lds(reinterpret_cast<const void*>(kernel), s.device, L);
+  hipLaunchKernelGGL(kernel, grid, dim3(AT_WAVES * 64), L, stream, S, W, mm, nT, s.P1, s.P2,
                      s.P1f, s.P2f, pstride, A0, A1, e, n, E2, O);
 }
 

@@ -514,9 +514,16 @@ constexpr int AT_PITCH = AT + 1;  // LDS image row pitch in floats
 constexpr int AT_WAVES = CLIPPER_AT_WAVES;       // waves per workgroup
 constexpr int AT_ROWS_PER_WAVE = AT / AT_WAVES;  // tile rows a wave owns
 constexpr int AT_QUEUE = 256;     // ring entries per wave: < 64 waiting + one row's 128 candidates
-constexpr int AT_SYM_IMG_BYTES = (AT * AT_PITCH * 4 + 15) / 16 * 16;
+// (VT = float: 76.5 KiB, two workgroups per CU; VT = double — the slices with fp64 values, round 4 —: 141 KiB, one
+// workgroup per CU, but every pair of the matrix is scored ONCE: the rectangular kernel, which has no mirror image,
+// scores it twice)
+template <typename VT = float>
+constexpr int at_sym_img_bytes() { return (AT * AT_PITCH * static_cast<int>(sizeof(VT)) + 15) / 16 * 16; }
 constexpr int AT_SYM_MASK_BYTES = 2 * AT * 16;  // nonzero masks of the tile's columns and of its rows
-constexpr int AT_SYM_LDS_BYTES = AT_SYM_IMG_BYTES + AT_WAVES * AT_QUEUE * 4 + AT_SYM_MASK_BYTES;
+template <typename VT = float>
+constexpr int at_sym_lds_bytes() { return at_sym_img_bytes<VT>() + AT_WAVES * AT_QUEUE * 4 + AT_SYM_MASK_BYTES; }
+constexpr int AT_SYM_IMG_BYTES = at_sym_img_bytes<float>();
+constexpr int AT_SYM_LDS_BYTES = at_sym_lds_bytes<float>();
 
 // linear index t of the upper block triangle (row-major: (0,0) (0,1) ... (1,1) ...) -> (I, J)
 __device__ __forceinline__ void tile_of(int t, int nT, int& I, int& J) {
@@ -531,9 +538,9 @@ __device__ __forceinline__ void tile_of(int t, int nT, int& I, int& J) {
   J = i + (t - (i * nT - i * (i - 1) / 2));
 }
 
-template <int D, bool POINTNORMAL>
+template <int D, bool POINTNORMAL, typename VT = float>
 __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
-    float* __restrict__ S, int64_t ld, int64_t m, int nT, const double* __restrict__ P1,
+    VT* __restrict__ S, int64_t ld, int64_t m, int nT, const double* __restrict__ P1,
     const double* __restrict__ P2, const float* __restrict__ P1f, const float* __restrict__ P2f,
     int64_t pstride, const int32_t* __restrict__ A0, const int32_t* __restrict__ A1,
     EuclidParams eprm, PointNormalParams nprm, float E2 /* guarded threshold squared, rounded up */,
@@ -543,10 +550,11 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
   const bool stamp = O.stamps != nullptr && blockIdx.x < 800 && threadIdx.x == 0;
   long long ts[5] = {0, 0, 0, 0, 0};
   if (stamp) ts[0] = wall_clock64();
-  float* img = reinterpret_cast<float*>(sym_smem);
+  VT* img = reinterpret_cast<VT*>(sym_smem);
+  constexpr int IMG_BYTES = at_sym_img_bytes<VT>();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint32_t* queue = reinterpret_cast<uint32_t*>(sym_smem + AT_SYM_IMG_BYTES) + wave * AT_QUEUE;
+  uint32_t* queue = reinterpret_cast<uint32_t*>(sym_smem + IMG_BYTES) + wave * AT_QUEUE;
   int I, J;
   // Tiles from both ends of the row-major order towards the middle: the tiles of a dense block —
   // twice the work of the others — sit where the consistent associations sit in the list, at its
@@ -577,16 +585,16 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
   }
   // colmask[cl][4] / rowmask[rl][4]: which rows of tile column cl / columns of tile row rl hold a
   // nonzero — set by the scatter below, read by the emission of the slices
-  uint32_t* colmask = reinterpret_cast<uint32_t*>(sym_smem + AT_SYM_IMG_BYTES + AT_WAVES * AT_QUEUE * 4);
+  uint32_t* colmask = reinterpret_cast<uint32_t*>(sym_smem + IMG_BYTES + AT_WAVES * AT_QUEUE * 4);
   uint32_t* rowmask = colmask + AT * 4;
   colmask[threadIdx.x] = 0;
   rowmask[threadIdx.x] = 0;
   if (S != nullptr) {  // the dense store gets the whole image: zero this wave's rows of it
 #pragma unroll 4
     for (int rr = 0; rr < AT_ROWS_PER_WAVE; ++rr) {
-      float* row = img + (wave * AT_ROWS_PER_WAVE + rr) * AT_PITCH;
-      row[2 * lane] = 0.f;
-      row[2 * lane + 1] = 0.f;
+      VT* row = img + (wave * AT_ROWS_PER_WAVE + rr) * AT_PITCH;
+      row[2 * lane] = VT(0);
+      row[2 * lane + 1] = VT(0);
     }
   }
   __syncthreads();  // the column masks are shared by all waves
@@ -598,11 +606,11 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
       const int rl = static_cast<int>(code >> 8);
       const int cl = static_cast<int>(code & 0xffu);
       double scr;
-      if (POINTNORMAL) scr = exact_pointnormal_score<float>(P1, P2, pstride, r0 + rl, c0 + cl, nprm);
-      else scr = exact_euclid_score<float, D>(P1, P2, pstride, r0 + rl, c0 + cl, eprm);
-      const float v = store_score<float>(scr, affinityeps);
+      if (POINTNORMAL) scr = exact_pointnormal_score<VT>(P1, P2, pstride, r0 + rl, c0 + cl, nprm);
+      else scr = exact_euclid_score<VT, D>(P1, P2, pstride, r0 + rl, c0 + cl, eprm);
+      const VT v = store_score<VT>(scr, affinityeps);
       img[rl * AT_PITCH + cl] = v;
-      if (v != 0.f) {
+      if (v != VT(0)) {
         atomicOr(&colmask[cl * 4 + (rl >> 5)], 1u << (rl & 31));
         atomicOr(&rowmask[rl * 4 + (cl >> 5)], 1u << (cl & 31));
       }
@@ -684,12 +692,12 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
   // (column group 2J + e, chunk I) and (column group 2I + e, chunk J), two waves per slice ----------
   if (O.Pre != nullptr) {
     static_assert(AT_WAVES == 8 && AT == SL_SUB && AT == 2 * SL_W, "four slices per tile");
-    unsigned long long* base_s = reinterpret_cast<unsigned long long*>(sym_smem + AT_SYM_IMG_BYTES);  // the queues are drained
+    unsigned long long* base_s = reinterpret_cast<unsigned long long*>(sym_smem + IMG_BYTES);  // the queues are drained
     const int sl = wave & 3, half = wave >> 2;
     const int e = sl & 1;
     const bool mirror = sl >= 2;
     // element q of the lane's column: tile (q, 64 e + lane), or (64 e + lane, q) of the mirror
-    const float* col = mirror ? img + (64 * e + lane) * AT_PITCH : img + 64 * e + lane;
+    const VT* col = mirror ? img + (64 * e + lane) * AT_PITCH : img + 64 * e + lane;
     const uint4 mk = *reinterpret_cast<const uint4*>((mirror ? rowmask : colmask) + (64 * e + lane) * 4);
     const uint64_t mlo = static_cast<uint64_t>(mk.x) | (static_cast<uint64_t>(mk.y) << 32);
     const uint64_t mhi = static_cast<uint64_t>(mk.z) | (static_cast<uint64_t>(mk.w) << 32);
@@ -710,8 +718,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
       const int rl = wave * AT_ROWS_PER_WAVE + rr;
       const int64_t r = r0 + rl;
       if (r < m) {
-        const float* row = img + rl * AT_PITCH + 2 * lane;
-        *reinterpret_cast<float2*>(S + r * ld + c0 + 2 * lane) = make_float2(row[0], row[1]);
+        const VT* row = img + rl * AT_PITCH + 2 * lane;
+        if constexpr (sizeof(VT) == 4) *reinterpret_cast<float2*>(S + r * ld + c0 + 2 * lane) = make_float2(row[0], row[1]);
+        else *reinterpret_cast<double2*>(S + r * ld + c0 + 2 * lane) = make_double2(row[0], row[1]);
       }
     }
   }
@@ -721,9 +730,10 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_affinity_sym(
       const int cl = wave * AT_ROWS_PER_WAVE + cc;
       const int64_t c = c0 + cl;
       if (c < m) {
-        const float v0 = img[(2 * lane) * AT_PITCH + cl];
-        const float v1 = img[(2 * lane + 1) * AT_PITCH + cl];
-        *reinterpret_cast<float2*>(S + c * ld + r0 + 2 * lane) = make_float2(v0, v1);
+        const VT v0 = img[(2 * lane) * AT_PITCH + cl];
+        const VT v1 = img[(2 * lane + 1) * AT_PITCH + cl];
+        if constexpr (sizeof(VT) == 4) *reinterpret_cast<float2*>(S + c * ld + r0 + 2 * lane) = make_float2(v0, v1);
+        else *reinterpret_cast<double2*>(S + c * ld + r0 + 2 * lane) = make_double2(v0, v1);
       }
     }
   }
