@@ -999,7 +999,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     // every later call behind them)
     HIPCHK(hipGetLastError());
   }
-  std::vector<double> u(h->u_pinned, h->u_pinned + m);
+  std::vector<double>& u = h->u_host;  // (kept from solve to solve: no allocation on the way out)
+  u.assign(h->u_pinned, h->u_pinned + m);
 
   // rounding — clipper.cpp:287-310 with utils.cpp:33-68, on the host
   std::vector<int32_t> nodes;

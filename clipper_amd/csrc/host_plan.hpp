@@ -336,6 +336,9 @@ struct ViewResidentPlan {
   std::vector<uint8_t> npieces;   // [unit * nwv + wave]
   std::vector<uint8_t> wave_cg;   // [unit * nwv + wave] column group of the unit the wave works for (255: none)
   std::vector<uint32_t> pieces;   // [(unit * nwv + wave) * pmax + j] = chunk | q0 << 8 | q1 << 16
+  // scratch of the planner, kept from call to call (a view is planned between two iterations of a solve)
+  std::vector<uint64_t> ent, byt;
+  std::vector<int> stp, sorted_stp, T, nw;
 };
 
 // Units of COMPLETE columns: a unit holds every chunk of its column groups (so that a column's sums never
@@ -345,12 +348,16 @@ struct ViewResidentPlan {
 // xt_fixed: bytes of LDS a unit needs besides its slices.
 inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esize, int target_units, int max_units,
                                uint32_t fixed_bytes, const ResidentConsts& K, ViewResidentPlan& out) {
-  out = ViewResidentPlan{};
+  out.ok = false;
+  out.units.clear();
+  out.entries = 0;
   if (ncg < 1 || nchunks < 1 || nchunks > K.tmax || fixed_bytes + K.slice_pad + 8192 >= K.lds_max) return;
   const uint32_t cap = K.lds_max - fixed_bytes - K.slice_pad;
   out.lds_slices = K.lds_max - fixed_bytes;
   const uint32_t QBY = 4u * static_cast<uint32_t>(esize);
-  std::vector<uint64_t> ent(static_cast<size_t>(ncg)), byt(static_cast<size_t>(ncg));
+  std::vector<uint64_t>&ent = out.ent, &byt = out.byt;
+  ent.assign(static_cast<size_t>(ncg), 0);
+  byt.assign(static_cast<size_t>(ncg), 0);
   uint64_t total = 0;
   for (int cg = 0; cg < ncg; ++cg) {
     uint64_t e = 0, b = 0;
@@ -373,13 +380,14 @@ inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esiz
   // of its longest column: 30 .. 125 per group at the headline view for 3 400 .. 4 600 entries. A group far above
   // the median is cut into two packed halves (its long column weighs on one of them only, and each half walks
   // two chunks per step) — while the units still fit the chip.
-  std::vector<int> stp(static_cast<size_t>(ncg));
+  std::vector<int>&stp = out.stp, &sorted_stp = out.sorted_stp;
+  stp.assign(static_cast<size_t>(ncg), 0);
   for (int c = 0; c < ncg; ++c) {
     int t = 0;
     for (int k = 0; k < nchunks; ++k) t += static_cast<int>(L[static_cast<size_t>(c) * nchunks + k] & 255u);
     stp[static_cast<size_t>(c)] = t;
   }
-  std::vector<int> sorted_stp(stp);
+  sorted_stp = stp;
   std::nth_element(sorted_stp.begin(), sorted_stp.begin() + ncg / 2, sorted_stp.end());
   const double Tmed = std::max(1, sorted_stp[static_cast<size_t>(ncg / 2)]);
   std::vector<ViewUnit>& units = out.units;
@@ -431,7 +439,9 @@ inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esiz
   out.pieces.assign(units.size() * NWV * PM, 0u);
   out.npieces.assign(units.size() * NWV, 0);
   out.wave_cg.assign(units.size() * NWV, 255);
-  std::vector<int> T(NWV), nw(NWV);
+  std::vector<int>&T = out.T, &nw = out.nw;
+  T.assign(NWV, 0);
+  nw.assign(NWV, 0);
   for (size_t ui = 0; ui < units.size(); ++ui) {
     const ViewUnit& U = units[ui];
     std::fill(T.begin(), T.end(), 0);

@@ -72,7 +72,12 @@ int rvr_plan(Ctx* h, Shard& s) {
   std::memcpy(r.host_plan, plan.units.data(), plan.units.size() * sizeof(RvrUnit));
   std::memcpy(r.host_plan + off_np, plan.npieces.data(), plan.npieces.size());
   std::memcpy(r.host_plan + off_wc, plan.wave_cg.data(), plan.wave_cg.size());
-  std::memcpy(r.host_plan + off_pc, plan.pieces.data(), plan.pieces.size() * sizeof(uint32_t));
+  {  // the pieces: only the ones in use (a few per wave of the pmax slots: a tenth of the table, into pinned memory)
+    uint32_t* dst = reinterpret_cast<uint32_t*>(r.host_plan + off_pc);
+    const uint32_t* src = plan.pieces.data();
+    for (size_t wv = 0; wv < plan.npieces.size(); ++wv)
+      for (int j = 0; j < plan.npieces[wv]; ++j) dst[wv * RVR_PMAX + j] = src[wv * RVR_PMAX + j];
+  }
   std::atomic_thread_fence(std::memory_order_seq_cst);
   r.off_np = off_np;
   r.off_wc = off_wc;

@@ -267,6 +267,7 @@ struct clipper_hip_ctx {
 
   std::vector<int32_t> A;  // column-major m x 2 (host copy)
   std::vector<int32_t> nodes;
+  std::vector<double> u_host;  // the last solve's u on the host (rounding works on it)
 
   SolveShared* host_state = nullptr;  // pinned, 2 slots (multi-process snapshots)
   hipEvent_t ev_poll[2] = {nullptr, nullptr};
