@@ -360,11 +360,14 @@ def main():
                                          "(prefilter + exact fp64 scores of the survivors), see `issue`"},
             },
             "row_view": {
-                "what": "passes that streamed the slices of M[live rows, :] instead of M (rows with u = 0 and "
-                        "g <= 0 are exact zeros in every line-search candidate; DESIGN.md 3c)",
+                "what": "passes on the slices of M[live rows, :] instead of M (rows with u = 0 and g <= 0 are exact "
+                        "zeros in every line-search candidate; DESIGN.md 3c) - streamed by the pass kernel, or, for a "
+                        "view of <= 1024 rows that fits the chip's LDS, run inside ONE resident launch (DESIGN.md 3d)",
                 "passes_on_view": int(vstats.view_passes), "passes": int(sol.n_passes), "views_built": int(vstats.builds),
                 "rows": int(vstats.rows), "bytes": int(vstats.bytes), "build_ms": round(vstats.build_ms, 4),
-                "pass_on_view_us": round(R["view_us"] / max(1, R["view_n"]), 2),
+                "resident_launches": int(vstats.resident_launches),
+                # HIP events around streamed view passes; none when the view's iterations ran inside the resident launch
+                "pass_on_view_us": round(R["view_us"] / R["view_n"], 2) if R["view_n"] > 0 else None,
             },
             "scaling_probe": probe,
             "scaling_probe_cfg5": probe_cfg5,

@@ -131,6 +131,9 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   a.shared = s.shared;
   a.host = h->mirror_dev;
   a.host_u = h->u_pinned_dev;
+  a.marks = h->profiling ? s.marks : nullptr;
+  a.kind = a.marks ? h->kind_dev : nullptr;
+  a.marks_n = h->launch_counter;  // (profiling: launch index = the device's iteration count)
   a.prm = prm;
   a.m = h->m;
   a.mp = h->mp;

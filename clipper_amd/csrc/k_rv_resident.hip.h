@@ -86,6 +86,9 @@ struct RvrArgs {
   ViewPolicy rvp;
   int rv_rows;
   long long* stamps;            // measurement only (may be null): unit 0, [iteration][8] wall-clock stamps
+  const uint8_t* marks;         // profiling only (may be null): the streaming iterations' marks (SolveArgs::marks) and
+  uint8_t* kind;                // their pinned copy — a launch that ENDS the solve hands them over, as decide() does
+  int64_t marks_n;              // the iterations queued before this launch
 };
 enum : uint32_t { RVR_ERR_LDS = 1, RVR_ERR_TIMEOUT = 2, RVR_ERR_STATE = 3 };
 
@@ -926,6 +929,11 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       }
       // ---- the end of the solve (decide(): ACT_DONE) ----------------------------------------------------------
       write_point(true);
+      if (blockIdx.x == 0 && A.kind != nullptr && A.marks != nullptr) {
+        const int64_t n = (A.marks_n < KIND_CAP) ? A.marks_n : KIND_CAP;
+        for (int64_t i = tid; i < n; i += RVR_NT)
+          __hip_atomic_store(A.kind + i, A.marks[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       if (arrive_last() && tid == 0) {
         SolverState* o = A.st;  // (the launches queued behind see `done`; the state only names the final point)
         o->ubp = e_ubp ^ 1;

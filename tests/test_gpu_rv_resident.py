@@ -91,6 +91,22 @@ def test_leaving_after_a_few_exchanges_hands_a_prepared_pass_back(budget, monkey
     g.close()
 
 
+@pytest.mark.parametrize("wgs", [96, 200])
+def test_other_numbers_of_units(wgs, monkeypatch):
+    """CLIPPER_HIP_VIEW_RESIDENT_WGS: another split of the view's columns over the workgroups (other lane groups,
+    other pieces) — the same decisions, the sums associated differently."""
+    p = synth.make_euclidean_problem(10000, 0.95, seed=12345)
+    sr = _oracle(p)
+    monkeypatch.setenv("CLIPPER_HIP_VIEW_RESIDENT_WGS", str(wgs))
+    g = _ctx(p, abi.STORE_F32_CSC, 0)
+    s = g.solve(p.u0)
+    assert g.view_stats().resident_launches == 1
+    assert s.nodes.tolist() == sr.nodes.tolist() and s.ifinal == sr.ifinal and s.n_trials == sr.n_trials
+    assert abs(s.score - sr.score) <= 1e-9 * abs(sr.score)
+    monkeypatch.delenv("CLIPPER_HIP_VIEW_RESIDENT_WGS")
+    g.close()
+
+
 def test_a_launch_that_gives_up_changes_nothing(monkeypatch):
     """A time-out of the exchange (forced: CLIPPER_HIP_VIEW_RESIDENT_TIMEOUT_TICKS=-1) commits nothing: the
     entry state is intact and the streaming launches run every iteration — bit for bit the solve of mode 2."""
