@@ -483,9 +483,10 @@ class HipClipper:
     def debug_stamps(self):
         """per workgroup of the last pass launch: (start, decision done, end, info); needs
         CLIPPER_HIP_STAMPS=1 in the environment when the context is created"""
-        out = np.zeros(4096 * 4, dtype=np.int64)
+        rows = 16384 if os.environ.get("CLIPPER_HIP_STAMPS") == "2" else 4096
+        out = np.zeros(rows * 4, dtype=np.int64)
         self._check(self.L.clipper_hip_debug_stamps(self.h, out.ctypes.data_as(C.POINTER(C.c_int64)), out.size))
-        return out.reshape(4096, 4)
+        return out.reshape(rows, 4)
 
     def device_info(self):
         name = C.create_string_buffer(64)

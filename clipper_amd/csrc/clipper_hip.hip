@@ -1456,7 +1456,7 @@ int clipper_hip_bench_matvec(clipper_hip_t* h, int reps, double* avg_us) try {
 int clipper_hip_debug_stamps(clipper_hip_t* h, int64_t* out, int capacity) try {
   if (!h || !out || capacity < 0) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   if (!h->stamps_dev) return fail(CLIPPER_HIP_E_STATE, "CLIPPER_HIP_STAMPS was not set when the context was created");
-  const int n = std::min(capacity, 4096 * 4);
+  const int n = std::min(capacity, h->stamps_rows * 4);
   HIPCHK(hipSetDevice(h->sh[0].device));
   HIPCHK(hipStreamSynchronize(h->sh[0].stream));
   HIPCHK(hipMemcpy(out, h->stamps_dev, static_cast<size_t>(n) * sizeof(long long), hipMemcpyDeviceToHost));

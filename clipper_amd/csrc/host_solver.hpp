@@ -360,6 +360,7 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.kind = (a.marks && !h->multiproc) ? h->kind_dev : nullptr;
   a.host_u = (!h->multiproc && &s == &h->sh[0]) ? h->u_pinned_dev : nullptr;
   a.stamps = (&s == &h->sh[0]) ? h->stamps_dev : nullptr;
+  a.stamps_wide = h->stamps_rows > 4096 ? 1 : 0;
   // the row view, while one is in use (one shard)
   const bool view = h->csc_valid && s.rv.valid;
   a.in_view = view ? s.rv.in_view[s.rv.cur] : nullptr;
@@ -590,9 +591,10 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     return nullptr;
   }
   std::memset(h->kind, 0, KIND_CAP);
-  if (std::getenv("CLIPPER_HIP_STAMPS")) {  // measurement only
-    if (hipMalloc(&h->stamps_dev, 4096 * 4 * sizeof(long long)) == hipSuccess)
-      (void)hipMemset(h->stamps_dev, 0, 4096 * 4 * sizeof(long long));
+  if (const char* e = std::getenv("CLIPPER_HIP_STAMPS")) {  // measurement only; 2 = every workgroup of a pass
+    h->stamps_rows = std::atoi(e) == 2 ? 16384 : 4096;
+    const size_t bytes = static_cast<size_t>(h->stamps_rows) * 4 * sizeof(long long);
+    if (hipMalloc(&h->stamps_dev, bytes) == hipSuccess) (void)hipMemset(h->stamps_dev, 0, bytes);
     else h->stamps_dev = nullptr;
   }
   // CLIPPER_HIP_WINDOW = 1 | 4 | 6 | 8: line-search candidates multiplied per pass over M

@@ -308,7 +308,8 @@ struct clipper_hip_ctx {
   int32_t* rv_count_dev = nullptr;
   clipper_hip_view_stats_t rv_stats{};
 
-  long long* stamps_dev = nullptr;  // CLIPPER_HIP_STAMPS=1: [4096][4], see SolveArgs::stamps
+  long long* stamps_dev = nullptr;  // CLIPPER_HIP_STAMPS=1: [4096][4], see SolveArgs::stamps; =2: [16384][4]
+  int stamps_rows = 4096;
   bool profiling = false;
   std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created by clipper_hip_set_profiling
   std::vector<int64_t> ev_launch_index;  // which mat-vec launch of the solve each pair timed

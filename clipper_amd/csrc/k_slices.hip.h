@@ -503,11 +503,15 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   }
   slices_by_plan<VT, H, V, SL_NW, SL_D>(G, J, A, plan, lds);
   flush_state(A, &stash);
-  if (A.stamps && threadIdx.x == 0 && blockIdx.x < 1536) {
+  if (A.stamps && threadIdx.x == 0 && blockIdx.x < (A.stamps_wide ? 16384u : 1536u)) {
     A.stamps[blockIdx.x * 4 + 0] = c0;
     A.stamps[blockIdx.x * 4 + 1] = c1;
     A.stamps[blockIdx.x * 4 + 2] = wall_clock64();
-    A.stamps[blockIdx.x * 4 + 3] = (static_cast<long long>(J.t1 - J.t0) << 32) | static_cast<unsigned>(plan.phase);
+    // chunks of the item | (wide) HW_ID[15:0] and the XCD the workgroup ran on | phase
+    const unsigned where = A.stamps_wide ? ((__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu) << 12) |
+                                               ((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) << 8)
+                                         : 0u;
+    A.stamps[blockIdx.x * 4 + 3] = (static_cast<long long>(J.t1 - J.t0) << 32) | where | static_cast<unsigned>(plan.phase);
   }
 }
 

@@ -219,6 +219,8 @@ struct SolveArgs {
   double* host_u; // pinned host memory [m] (may be null): the final u, written before `done`
   long long* stamps;  // measurement only (may be null): per workgroup {start, head done, end} of the
                       // last pass launch, 100 MHz wall clock (clipper_hip_debug_stamps)
+  int stamps_wide;    // CLIPPER_HIP_STAMPS=2: every workgroup of the pass is stamped (16384 rows, and where it
+                      // ran: XCD and HW_ID), the tail is not
   // the row view (null / 0: none), see LIVE ROWS
   const uint8_t* in_view;  // [m] 1 = the row is in the view
   int rv_nslots;           // partial-sum slots of a pass on the view (ntiles: of a pass on M)
@@ -1166,7 +1168,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   }
   const double tot = block_reduce_pick<NRED, NTW>(r, red);
   double* out = A.scal + static_cast<int64_t>(blockIdx.x) * Q;
-  if (A.stamps && threadIdx.x == 0) {
+  if (A.stamps && !A.stamps_wide && threadIdx.x == 0) {
     const int w = 1536 + static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x);
     if (w < 2048) {
       A.stamps[w * 4 + 0] = c0;

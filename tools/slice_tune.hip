@@ -229,13 +229,20 @@ Packed<VT> pack(const std::vector<std::vector<Entry>>& cols, int64_t m, int H, i
 }
 
 // the work list of a pass: mirror of slices_plan (clipper_amd/csrc/host_matrix.hpp)
-std::vector<SliceWork> plan(const std::vector<uint32_t>& Lq, int ncg, int nchunks, int NW, double target,
-                            int& nslots, bool split, bool heavy_first) {
+std::vector<SliceWork> plan(const std::vector<uint32_t>& Lq, int ncg, int nchunks_all, int NW, double target,
+                            int& nslots, bool split, bool heavy_first, bool upper = false) {
+  // (upper: a strip of column groups stores nothing below its last column's row)
+  auto chunks_of = [&](int st) {
+    if (!upper) return nchunks_all;
+    const int64_t last_col = static_cast<int64_t>(st * NW + NW) * SL_W;
+    return static_cast<int>(std::min<int64_t>(nchunks_all, (last_col + SL_SUB - 1) / SL_SUB));
+  };
+  const int nchunks = nchunks_all;
   const int nstrips = (ncg + NW - 1) / NW;
   std::vector<int> cost(static_cast<size_t>(nstrips) * nchunks);
   double total = 0.0;
   for (int st = 0; st < nstrips; ++st)
-    for (int k = 0; k < nchunks; ++k) {
+    for (int k = 0; k < chunks_of(st); ++k) {
       int c = 0;
       for (int w = 0; w < NW; ++w) {
         const int cg = st * NW + w;
@@ -257,7 +264,7 @@ std::vector<SliceWork> plan(const std::vector<uint32_t>& Lq, int ncg, int nchunk
       start = end;
       acc = 0.0;
     };
-    for (int k = 0; k < nchunks; ++k) {
+    for (int k = 0; k < chunks_of(st); ++k) {
       const int mq = cost[static_cast<size_t>(st) * nchunks + k];
       const double c = mq + 2.0;
       if (split && c > 1.5 * T && mq >= 2 * SL_SO) {
@@ -272,7 +279,7 @@ std::vector<SliceWork> plan(const std::vector<uint32_t>& Lq, int ncg, int nchunk
         if (acc >= T) flush(k + 1);
       }
     }
-    flush(nchunks);
+    flush(chunks_of(st));
     nslot_of[static_cast<size_t>(st)] = slot;
     nslots = std::max(nslots, slot);
   }
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_pass(SliceView M, int64_t ld, 
   const long long c0 = stamps ? wall_clock64() : 0;
   const SliceViewG G = to_global(M);
   SliceJob<H, NW> J;
-  slice_begin<H, NW>(G, J);
+  slice_begin<H, NW>(G, J, static_cast<int>(blockIdx.x));
   // window mode: candidate l = max(U + 0.5^l G, 0); U, G lie behind the table (main())
   const int64_t mp = (m + 63) / 64 * 64;
   const WindowSource WS{X + mp * VS, X + mp * VS + mp, 1.0, 0.5};
@@ -337,7 +344,8 @@ template <typename VT, int H, int V, int NW, int D, int OCC>
 void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const std::vector<double>& ref,
                  bool split = true, const char* tag = "") {
   int nslots;
-  std::vector<SliceWork> work = plan(P.Lq, P.ncg, P.nchunks, NW, wg_target, nslots, split, true);
+  constexpr bool SYM = xmode::SL_XMODE == 4;
+  std::vector<SliceWork> work = plan(P.Lq, P.ncg, P.nchunks, NW, wg_target, nslots, split, true, SYM);
   SliceWork* dwork;
   CK(hipMalloc(&dwork, work.size() * sizeof(SliceWork)));
   CK(hipMemcpy(dwork, work.data(), work.size() * sizeof(SliceWork), hipMemcpyHostToDevice));
@@ -349,8 +357,13 @@ void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const 
   CK(hipMalloc(&dPre, P.Pre.size() * 8));
   constexpr int VV = V > 0 ? V : 1;
   const size_t npart = static_cast<size_t>(nslots) * (VV + 1) * ld;
-  CK(hipMalloc(&dpart, npart * 8));
-  CK(hipMemset(dpart, 0, npart * 8));
+  const size_t ny = SYM ? static_cast<size_t>(VV + 1) * ld : 0;  // (mode 4) the mirrored contributions
+  CK(hipMalloc(&dpart, (npart + ny + 8) * 8));
+  CK(hipMemset(dpart, 0, (npart + ny + 8) * 8));
+  if (SYM) {
+    double* yp = dpart + npart;
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(xmode::g_ypart), &yp, sizeof(yp)));
+  }
   CK(hipMemcpy(ddata, P.data.data(), P.data.size(), hipMemcpyHostToDevice));
   CK(hipMemcpy(dPre, P.Pre.data(), P.Pre.size() * 8, hipMemcpyHostToDevice));
   SliceView M{ddata, dPre, dwork, P.nchunks, P.ncg, static_cast<int>(work.size()), nullptr, c.m, 0};
@@ -372,8 +385,13 @@ void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const 
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / reps;
-  std::vector<double> hp(npart);
-  CK(hipMemcpy(hp.data(), dpart, npart * 8, hipMemcpyDeviceToHost));
+  if (SYM) {  // the timed launches kept adding: one clean launch for the check
+    CK(hipMemset(dpart, 0, (npart + ny) * 8));
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, 0, M, ld, c.m, c.d, c.dX, dpart, (long long*)nullptr);
+    CK(hipDeviceSynchronize());
+  }
+  std::vector<double> hp(npart + ny);
+  CK(hipMemcpy(hp.data(), dpart, (npart + ny) * 8, hipMemcpyDeviceToHost));
   double maxerr = 0.0, maxref = 0.0;
   const int NSL = VV + 1;
   const int nout = (V > 0) ? V + 1 : 2;
@@ -382,6 +400,7 @@ void run_variant(Ctx& c, const Packed<VT>& P, double wg_target, int reps, const 
     for (int64_t col = 0; col < c.m; ++col) {
       double sum = 0.0;
       for (int t = 0; t < nslots; ++t) sum += hp[(static_cast<size_t>(t) * NSL + slot) * ld + col];
+      if (SYM) sum += hp[npart + static_cast<size_t>(slot) * ld + col];
       const double r = ref[static_cast<size_t>((V > 0) ? v : (v == 0 ? 0 : VV)) * c.m + col];
       maxerr = std::max(maxerr, std::fabs(sum - r));
       maxref = std::max(maxref, std::fabs(r));
@@ -426,6 +445,7 @@ int main(int argc, char** argv) {
   const double inl = argc > 3 ? atof(argv[3]) : 0.05;
   const int reps = argc > 4 ? atoi(argv[4]) : 200;
   c.timeline = argc > 5 && atoi(argv[5]) != 0;
+  const int norders = argc > 6 ? atoi(argv[6]) : 3;  // how many of the entry orders to run (1 = rows ascending only)
   const int64_t m = c.m;
   c.mp = (m + 63) / 64 * 64;
   hipDeviceProp_t prop;
@@ -474,18 +494,34 @@ int main(int argc, char** argv) {
   host_ref(c, 1, ref1);
   host_ref(c, 8, ref8);
   const double cu = c.cus;
-  Packed<float> P = pack<float>(c.cols, m, 1, 0);
+  std::vector<std::vector<Entry>> upper;
+  if (xmode::SL_XMODE == 4) {  // what is stored: row < column
+    upper.assign(static_cast<size_t>(m), {});
+    for (int64_t col = 0; col < m; ++col)
+      for (const Entry& e : c.cols[static_cast<size_t>(col)])
+        if (e.row < col) upper[static_cast<size_t>(col)].push_back(e);
+  }
+  const std::vector<std::vector<Entry>>& stored = xmode::SL_XMODE == 4 ? upper : c.cols;
+  Packed<float> P = pack<float>(stored, m, 1, 0);
   printf("SL_SUB=%d H=1: %zu quads (%.3f padded entries per entry), %zu lock-step steps, lane efficiency %.3f, %.2f MB (%.2f B/entry)\n",
          SL_SUB, P.quads, P.quads * 4.0 / P.entries, P.steps, P.quads / (64.0 * P.steps), P.data.size() * 1e-6,
          double(P.data.size()) / P.entries);
   const char* names[3] = {"rows-ascending", "greedy-per-group", "rotated-classes"};
-  for (int order = 0; order < 3; ++order) {
+  for (int order = 0; order < norders; ++order) {
     g_sim_cycles = g_sim_instr = 0;
-    Packed<float> Q = pack<float>(c.cols, m, 1, order);
+    if (xmode::SL_XMODE == 4 && order > 0) break;
+    Packed<float> Q = pack<float>(stored, m, 1, order);
     printf("%s: model %.2f LDS cycles per lane group and gather (1.0 = conflict-free)\n", names[order],
            g_sim_cycles / g_sim_instr);
     // the product's geometry: 4 waves, 3 steps in flight, compiled for 6 workgroups per CU
     for (int rep = 0; rep < 3; ++rep) run_variant<float, 1, 6, 4, 3, 6>(c, Q, 4.0 * cu, reps, ref6, true, names[order]);
+    if (xmode::SL_XMODE == 4 || norders == 1) {
+      // other work-list sizes and (mode 4: 12 more registers for the lane's own column) fewer workgroups per CU
+      for (double f : {6.0, 12.0, 24.0}) run_variant<float, 1, 6, 4, 3, 6>(c, Q, f * cu, reps, ref6, true, names[order]);
+      for (double f : {4.0, 5.0, 10.0, 20.0}) run_variant<float, 1, 6, 4, 3, 5>(c, Q, f * cu, reps, ref6, true, names[order]);
+      for (double f : {4.0, 8.0, 16.0}) run_variant<float, 1, 6, 4, 3, 4>(c, Q, f * cu, reps, ref6, true, names[order]);
+      run_variant<float, 1, 6, 4, 2, 5>(c, Q, 10.0 * cu, reps, ref6, true, names[order]);
+    }
   }
   return 0;
 }

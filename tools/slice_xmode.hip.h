@@ -30,7 +30,14 @@ namespace xmode {
 //      max(t, 0) - t per candidate to correction sums — taken only by the chunks that have such a row.
 //      The sums differ from mode 0's by roundings (t is never rounded to a double before it is
 //      multiplied), as they do between two orders of the partial sums.
-// Measured: profiles/r03_slice_tune_xmode.txt (modes 1, 2).
+//   4  SYMMETRIC HALF (round 4; VERDICT r01-r03 "upper-triangle pass"): only the entries ABOVE the diagonal are
+//      stored (row < column: what selfadjointView<Upper> reads, clipper.cpp:195). A stored entry (r, c) then owes
+//      two contributions: the column sum acc_c += w x[r] (the lane's own registers, as in mode 0) and the
+//      MIRRORED one y[r] += w x[c] — c is the lane's column, r is anybody's row: V + 1 ds_add_f64 per entry
+//      into a [128][V + 1] accumulator of the chunk in LDS (double buffered), flushed with global fp64 atomics
+//      when the workgroup leaves the chunk (128 x (V + 1) per chunk and workgroup; their order is not fixed:
+//      bit-reproducibility is gone). Half the bytes, 3 gathers + 7 atomic adds per entry through the LDS pipe.
+// Measured: profiles/r03_slice_tune_xmode.txt (modes 1, 2), profiles/r04_symmetric_half.txt (mode 4).
 #ifndef CLIPPER_SL_XMODE
 #define CLIPPER_SL_XMODE 0
 #endif
@@ -39,10 +46,12 @@ constexpr int sl_xload(int V) { return V <= 2 ? 2 : (V <= 4 ? 4 : (V <= 6 ? 6 : 
 constexpr int sl_xpitch(int V) { return (SL_XMODE == 1 || SL_XMODE == 3) ? 2 : (V <= 2 ? 2 : (V <= 6 ? 6 : 10)); }
 constexpr int sl_lds_doubles(int V, int H, int NW) {
   // two x buffers (+ mode 3: their masks of mixed rows, and every lane's V + 1 correction sums)
-  const int a = 2 * SL_SUB * H * sl_xpitch(V) + (SL_XMODE == 3 ? 4 + (V + 1) * NW * 64 : 0);
+  const int a = 2 * SL_SUB * H * sl_xpitch(V) + (SL_XMODE == 3 ? 4 + (V + 1) * NW * 64 : 0) +
+                (SL_XMODE == 4 ? 2 * SL_SUB * H * (V + 1) : 0);
   const int b = NW * 64 + NW * 2 * V + 8;       // the decision's scratch
   return a > b ? a : b;
 }
+__device__ double* g_ypart = nullptr;  // (mode 4) [V + 1][ld]: where the mirrored contributions are added
 __host__ __device__ constexpr int sl_so_bytes(int maxq) {
   return ((maxq + SL_SO - 1) / SL_SO * 4 + 15) & ~15;
 }
@@ -114,7 +123,7 @@ struct SliceXStage {
         if (p < PIECES) *reinterpret_cast<double2*>(xs + p * XP) = dead ? make_double2(0.0, 0.0) : make_double2(wu[i], wg[i]);
         const uint64_t mk = __ballot(mixed);
         if ((threadIdx.x & 63) == 0 && threadIdx.x < R) mask_of(xs)[threadIdx.x >> 6] = mk;
-      } else if constexpr (WINDOW && SL_XMODE != 0) {
+      } else if constexpr (WINDOW && (SL_XMODE == 1 || SL_XMODE == 2)) {
         if (p < PIECES) {
           *reinterpret_cast<double2*>(xs + p * XP) = make_double2(wu[i], wg[i]);
           if constexpr (SL_XMODE == 2) {
@@ -180,7 +189,35 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
 #pragma unroll
   for (int v = 0; v < (LIN ? 4 : 1); ++v) lin[v] = 0.0;
   double* corr = lds + 2 * (R * XP) + 4 + threadIdx.x;  // corr[v * NT]
+  // (mode 4) the mirrored contributions of a chunk: Y[2][R][NS] behind the x buffers; the lane's own column as a
+  // multiplier: its V candidates, formed like a staged row's
+  constexpr bool SYM = WINDOW && SL_XMODE == 4;
+  double* const Ybase = lds + 2 * (R * XP);
+  double xc[SYM ? V : 1];
+  double* const ypart = g_ypart;
   __syncthreads();  // the decision at the head of the launch used the same LDS
+  if constexpr (SYM) {
+    for (int i = threadIdx.x; i < 2 * R * NS; i += NT) Ybase[i] = 0.0;
+    const int64_t cc = static_cast<int64_t>(cg) * SL_W + lane;
+    const bool has = mine && cc < m;
+    const double uc = has ? WS.U[cc] : 0.0, gc = has ? WS.G[cc] : 0.0;
+    double al = WS.alpha0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const double t = uc + al * gc;
+      xc[v] = (t > 0.0) ? t : 0.0;
+      al = al * WS.beta;
+    }
+  }
+  auto flush_y = [&](int k) {  // chunk k's accumulator -> global, and zero again
+    double* Yb = Ybase + ((k - t0) & 1) * (R * NS);
+    for (int i = threadIdx.x; i < R * NS; i += NT) {
+      const double val = Yb[i];
+      Yb[i] = 0.0;
+      const int64_t r = static_cast<int64_t>(k) * R + i / NS;
+      if (val != 0.0 && r < m) atomicAdd(&ypart[static_cast<int64_t>(i % NS) * ld + r], val);
+    }
+  };
   if constexpr (LIN) {
 #pragma unroll
     for (int v = 0; v <= V; ++v) corr[v * NT] = 0.0;
@@ -198,6 +235,8 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
   for (int k = t0; k < t1; ++k) {
     const double* xs = lds + ((k - t0) & 1) * (R * XP);
     double* xnext = lds + (((k - t0) & 1) ^ 1) * (R * XP);
+    double* const Ycur = Ybase + ((k - t0) & 1) * (R * NS);
+    (void)Ycur;
     const bool more = k + 1 < t1;
     SliceHead<H> nxt = cur;
     uint64_t pre_next2 = 0;
@@ -289,7 +328,7 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
                     }
                   }
                 }
-              } else if constexpr (WINDOW && SL_XMODE != 0) {
+              } else if constexpr (WINDOW && (SL_XMODE == 1 || SL_XMODE == 2)) {
                 const double* xr = xs + row * XP;
                 const double2 ug = *reinterpret_cast<const double2*>(xr);
                 double xv[V > 2 ? V : 2];
@@ -328,10 +367,23 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
                 }
                 acc[0] = fma(mm, xv[0], acc[0]);
                 acc[V] = fma(ii, xv[0], acc[V]);
+                const double w = fma(d, ii, mm);
                 if (V > 1) {
-                  const double w = fma(d, ii, mm);
 #pragma unroll
                   for (int v = 1; v < V; ++v) acc[v] = fma(w, xv[v], acc[v]);
+                }
+                if constexpr (SYM) {
+                  {  // (a padded entry adds zeros to row 0: a branch around the adds costs registers — the compiler
+                     // then forms the products of all four entries ahead of the branches — and so occupancy)
+                    double* yr = Ycur + row * NS;
+                    atomicAdd(yr, mm * xc[0]);
+                    atomicAdd(yr + V, ii * xc[0]);
+#pragma unroll
+                    for (int v = 1; v < V; ++v) atomicAdd(yr + v, w * xc[v]);
+                  }
+                  // (entry by entry: with the four entries' gathers and products in flight at once the kernel
+                  // spills at every occupancy the LDS allows)
+                  __builtin_amdgcn_sched_barrier(0);
                 }
               } else {
                 const double xv = xs[row];
@@ -348,6 +400,7 @@ __device__ __forceinline__ void slice_core(const SliceViewG& M, const SliceJob<H
     cur = nxt;
     pre_next = pre_next2;
     __syncthreads();
+    if constexpr (SYM) flush_y(k);  // (beside the other waves' next chunk: that one adds into the other buffer)
   }
 
   if constexpr (LIN) {  // the V + 1 sums a window pass hands to the tail, from the linear ones
