@@ -503,7 +503,8 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   }
   slices_by_plan<VT, H, V, SL_NW, SL_D>(G, J, A, plan, lds);
   flush_state(A, &stash);
-  if (A.stamps && threadIdx.x == 0 && blockIdx.x < (A.stamps_wide ? 16384u : 1536u)) {
+  // (wide: window passes only, so that what is left behind is the last WINDOW pass of the solve)
+  if (A.stamps && threadIdx.x == 0 && blockIdx.x < (A.stamps_wide ? 16384u : 1536u) && (!A.stamps_wide || plan.phase == PH_TRIAL)) {
     A.stamps[blockIdx.x * 4 + 0] = c0;
     A.stamps[blockIdx.x * 4 + 1] = c1;
     A.stamps[blockIdx.x * 4 + 2] = wall_clock64();

@@ -35,6 +35,8 @@ xcd = ((st[:, 3] >> 8) & 0xF).astype(np.int64)
 hwid = ((st[:, 3] >> 12) & 0xFFFF).astype(np.int64)
 cu = xcd * 64 + ((hwid >> 13) & 7) * 16 + ((hwid >> 8) & 0xF)   # XCD, SE_ID, CU_ID (SH_ID folded into the CU bits' top)
 pc = lambda v, f: float(np.sort(v)[int(f * (len(v) - 1))])
+phase = (st[:, 3] & 0xFF).astype(np.int64)
+print('phases of the stamped workgroups (3 = window pass):', dict(zip(*np.unique(phase, return_counts=True))))
 print(f"m={m} views={'on' if views else 'off'}: {len(st)} workgroups stamped, {int((chunks > 0).sum())} with chunks; passes {s.n_passes} "
       f"({vs.view_passes} on a view of {vs.rows} rows, {vs.bytes} bytes); span of the launch {end.max():.1f} us")
 w = chunks > 0
