@@ -23,7 +23,7 @@ for m in $SIZES; do
   [ $m -le 20000 ] && prof m${m}_dense_f32 -- --m $m --steps $steps --warmup 1 --no-cpu-baseline --probe-m 0 --storage f32
   bytes=$(grep '^{"metric"' $OUT/trace_m$m.log | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.readline())['roofline']['bytes_per_launch'])")
   B2="python $ROOT/bench.py --m $m --steps 2 --warmup 1 --no-cpu-baseline --probe-m 0 --no-profile"
-  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT" "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32"; do
     name=$(echo $set | tr ' ' '_')
     ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --pmc $set -d $ROOT/$OUT/pmc_m${m}_$name -o pmc -- $B2 > $ROOT/$OUT/pmc_m${m}_$name.log 2>&1 )
   done

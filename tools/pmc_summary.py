@@ -67,6 +67,9 @@ def main():
                   "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"):
             if c in s:
                 e.setdefault("pass_counters", {})[c] = s[c]["median"]
+        mixc = [c for c in s if c.startswith("SQ_INSTS_VALU_")]
+        if mixc:   # the pass's VALU instruction mix (wave-instructions per launch, by type)
+            e["pass_instruction_mix"] = {c: s[c]["median"] for c in sorted(mixc)}
         if "SQ_LDS_BANK_CONFLICT" in s and "SQ_LDS_IDX_ACTIVE" in s and s["SQ_LDS_IDX_ACTIVE"]["median"] > 0:
             e["pass_lds_conflict_share"] = s["SQ_LDS_BANK_CONFLICT"]["median"] / s["SQ_LDS_IDX_ACTIVE"]["median"]
     ak = next((k for k in summary if k.startswith("k_affinity_sym")), None) or next((k for k in summary if k.startswith("k_affinity")), None)
@@ -83,6 +86,22 @@ def main():
             "note": "SQ_INSTS_VALU x cycles a wave64 VALU instruction holds its SIMD (2: fp32, 4: fp64) / (kernel time x "
                     "1024 SIMDs x 2.4 GHz); the fill mixes an fp32 prefilter with exact fp64 scores, the truth lies between",
         }
+        # the instruction mix (separate PMC passes): what pins the fraction between the two bounds above.
+        # Cycles a wave64 instruction holds its SIMD-32: 2 for fp32 / int32, 4 for fp64 / int64 / conversions that touch
+        # an fp64 operand (counted as CVT: all of them priced at 4), 8 for transcendentals (quarter rate); whatever the
+        # typed counters do not cover (moves, compares, permutes, bit ops) at 2.
+        types = {"SQ_INSTS_VALU_ADD_F64": 4, "SQ_INSTS_VALU_MUL_F64": 4, "SQ_INSTS_VALU_FMA_F64": 4, "SQ_INSTS_VALU_INT64": 4,
+                 "SQ_INSTS_VALU_CVT": 4, "SQ_INSTS_VALU_TRANS_F64": 8, "SQ_INSTS_VALU_TRANS_F32": 8,
+                 "SQ_INSTS_VALU_ADD_F32": 2, "SQ_INSTS_VALU_MUL_F32": 2, "SQ_INSTS_VALU_FMA_F32": 2, "SQ_INSTS_VALU_INT32": 2}
+        if all(c in s for c in types):
+            mix = {c: s[c]["median"] for c in types}
+            typed = sum(mix.values())
+            cycles = sum(mix[c] * types[c] for c in types) + max(0.0, insts - typed) * 2.0
+            e["affinity_issue"]["instruction_mix"] = mix
+            e["affinity_issue"]["untyped_instructions"] = insts - typed
+            e["affinity_issue"]["frac_by_instruction_mix"] = cycles / simd_cycles
+            e["affinity_issue"]["mix_note"] = ("cycles = 4 x (fp64 add/mul/fma, int64, cvt) + 8 x transcendentals + 2 x (fp32 add/mul/fma, "
+                                               "int32, and the instructions no typed counter covers), over the SIMD cycles of the launch")
         for c in ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
             if c in s:
                 e["affinity_issue"][c] = s[c]["median"]
