@@ -287,11 +287,16 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   const int next = v.cur ^ 1;
   *h->rv_count = -1;
   std::atomic_thread_fence(std::memory_order_seq_cst);
-  hipLaunchKernelGGL((k_rv_flags<V>), dim3(static_cast<unsigned>(nblk)), dim3(256), 0, s.stream,
-                     s.st + h->par, s.pt, mp, m, v.in_view[next], v.blk);
-  hipLaunchKernelGGL(k_rv_scan, dim3(1), dim3(1024), 0, s.stream, v.blk, nblk, h->rv_count_dev);
-  hipLaunchKernelGGL(k_rv_scatter, dim3(static_cast<unsigned>(nblk)), dim3(256), 0, s.stream,
-                     v.in_view[next], m, v.blk, v.rowmap[next], static_cast<int64_t>(v.cap_rows), v.viewpos, mp);
+  if (mp <= RV_ONE_MAX) {  // flags, scan and scatter by one workgroup: one launch instead of three
+    hipLaunchKernelGGL((k_rv_list_one<V>), dim3(1), dim3(1024), 0, s.stream, s.st + h->par, s.pt, mp, m, v.in_view[next],
+                       v.rowmap[next], static_cast<int64_t>(v.cap_rows), v.viewpos, h->rv_count_dev);
+  } else {
+    hipLaunchKernelGGL((k_rv_flags<V>), dim3(static_cast<unsigned>(nblk)), dim3(256), 0, s.stream,
+                       s.st + h->par, s.pt, mp, m, v.in_view[next], v.blk);
+    hipLaunchKernelGGL(k_rv_scan, dim3(1), dim3(1024), 0, s.stream, v.blk, nblk, h->rv_count_dev);
+    hipLaunchKernelGGL(k_rv_scatter, dim3(static_cast<unsigned>(nblk)), dim3(256), 0, s.stream,
+                       v.in_view[next], m, v.blk, v.rowmap[next], static_cast<int64_t>(v.cap_rows), v.viewpos, mp);
+  }
   static const bool host_timing = std::getenv("CLIPPER_HIP_HOST_TIMING") != nullptr;
   auto lap = [&](const char* what) {
     if (host_timing)

@@ -85,6 +85,87 @@ __global__ __launch_bounds__(1024) void k_rv_scan(uint32_t* __restrict__ blk, in
 // rowmap[rank of i among the live rows] = i (ascending: the order of the additions of a pass on
 // the view is a function of the row SET alone)
 // viewpos[i] = that rank, or -1 (what k_slice_filter_rows asks of every entry's row)
+// The three launches above as ONE workgroup, for mp <= RV_ONE_MAX (round 4: each of them runs at the floor of a
+// launch, ~4.7 us for a microsecond of work; the headline's view is listed in one launch instead of three). The same
+// flags, the same ascending list: coalesced loads of (u', g') -> a bit per row in LDS -> one count per 64-row word,
+// scanned -> every thread writes 16 rows of its word.
+constexpr int RV_ONE_E = 16;
+constexpr int64_t RV_ONE_MAX = 1024 * RV_ONE_E;
+template <int V>
+__global__ __launch_bounds__(1024) void k_rv_list_one(const SolverState* __restrict__ st, const double* __restrict__ pt,
+                                                       int64_t mp, int64_t m, uint8_t* __restrict__ flags,
+                                                       int32_t* __restrict__ rowmap, int64_t cap,
+                                                       int32_t* __restrict__ viewpos, int32_t* __restrict__ count_out) {
+  __shared__ unsigned long long word[RV_ONE_E * 16];  // bit r of word w: row 64 w + r is live
+  __shared__ uint32_t pre[RV_ONE_E * 16];             // live rows in front of word w
+  __shared__ uint32_t wsum[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int E = static_cast<int>((mp + 1023) / 1024);
+  const int64_t slot = st->hold_slot;
+  const double* u = pt + (slot * 2 + 0) * mp;
+  const double* g = pt + (slot * 2 + 1) * mp;
+  double uu[RV_ONE_E], gg[RV_ONE_E];
+#pragma unroll
+  for (int k = 0; k < RV_ONE_E; ++k) {  // (all loads in flight at once)
+    const int64_t i = static_cast<int64_t>(k) * 1024 + t;
+    const bool in = k < E && i < m;
+    uu[k] = in ? u[i] : 0.0;
+    gg[k] = in ? g[i] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < RV_ONE_E; ++k) {
+    if (k < E) {  // (uniform)
+      const int64_t i = static_cast<int64_t>(k) * 1024 + t;
+      const bool live = uu[k] > 0.0 || gg[k] > 0.0;
+      if (i < mp) flags[i] = live ? 1 : 0;
+      const unsigned long long mk = __ballot(live);
+      if (lane == 0) word[k * 16 + wave] = mk;
+    }
+  }
+  __syncthreads();
+  // counts of the words -> exclusive scan (the first 256 threads: one word each)
+  const int nwords = E * 16;
+  uint32_t n = 0, inc = 0;
+  if (t < 256) {
+    n = t < nwords ? static_cast<uint32_t>(__popcll(word[t])) : 0u;
+    inc = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t x = __shfl_up(inc, o);
+      if (lane >= o) inc += x;
+    }
+    if (lane == 63) wsum[wave] = inc;
+  }
+  __syncthreads();
+  if (t < 256) {
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    pre[t] = off + inc - n;
+  }
+  __syncthreads();
+  // thread t: rows [16 t, 16 t + 16) = quarter t & 3 of word t >> 2
+  if ((t >> 2) < nwords) {
+    const unsigned long long wd = word[t >> 2];
+    const int q = t & 3;
+    uint32_t at = pre[t >> 2] + static_cast<uint32_t>(__popcll(wd & ((1ull << (16 * q)) - 1ull)));
+    const uint32_t bits = static_cast<uint32_t>(wd >> (16 * q)) & 0xffffu;
+    const int64_t r0 = static_cast<int64_t>(t) * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int64_t i = r0 + k;
+      const bool f = (bits >> k) & 1u;
+      if (i < mp) viewpos[i] = f ? static_cast<int32_t>(at) : -1;
+      if (f) {
+        if (static_cast<int64_t>(at) < cap) rowmap[at] = static_cast<int32_t>(i);
+        ++at;
+      }
+    }
+  }
+  if (t == 0)
+    __hip_atomic_store(count_out, static_cast<int32_t>(wsum[0] + wsum[1] + wsum[2] + wsum[3]), __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void k_rv_scatter(const uint8_t* __restrict__ flags, int64_t m,
                                                      const uint32_t* __restrict__ blk,
                                                      int32_t* __restrict__ rowmap, int64_t cap,

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 
 namespace clipper_hip {
@@ -446,7 +447,26 @@ __device__ __forceinline__ void head_loads(const SolveArgs& A, HeadLoads& L) {
 #pragma unroll
       for (int k = 0; k < U; ++k) acc += x[k];
     }
-    for (; w < A.nwg_in; w += NCH) acc += p[static_cast<int64_t>(w) * Q];
+    // the rest of the chain (fewer than U rows): again every load in flight at once, then the additions in chain
+    // order — a loop of load-and-add here was a chain of 7 dependent round trips at m = 100k (13 rows after the fold)
+    // and of 19 at m = 300k: 4 and 10 us of every workgroup's head (round 4)
+    if (w < A.nwg_in) {
+      auto rest = [&](auto un) __attribute__((always_inline)) {
+        constexpr int R = decltype(un)::value;
+        double x[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const int ww = w + NCH * k;
+          x[k] = p[static_cast<int64_t>(ww < A.nwg_in ? ww : w) * Q];
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (w + NCH * k < A.nwg_in) acc += x[k];
+      };
+      if (w + NCH * 4 >= A.nwg_in) rest(std::integral_constant<int, 4>{});
+      else if (w + NCH * 10 >= A.nwg_in) rest(std::integral_constant<int, 10>{});
+      else rest(std::integral_constant<int, U>{});
+    }
   }
   L.chain = acc;
 }
@@ -969,8 +989,18 @@ __global__ __launch_bounds__(128) void k_scal_fold(const double* __restrict__ sc
   const int w0 = blockIdx.x * SCAL_FOLD;
   const int w1 = (w0 + SCAL_FOLD < nwg) ? w0 + SCAL_FOLD : nwg;
   for (int q = threadIdx.x; q < Q; q += 128) {
+    // all SCAL_FOLD loads in flight at once, then the additions in row order (a loop of load-and-add is a chain of
+    // 32 round trips: the launch took 9.5 us for 43 KB — round 4)
+    double x[SCAL_FOLD];
+#pragma unroll
+    for (int k = 0; k < SCAL_FOLD; ++k) {
+      const int w = (w0 + k < w1) ? w0 + k : w1 - 1;
+      x[k] = scal[static_cast<int64_t>(w) * Q + q];
+    }
     double acc = 0.0;
-    for (int w = w0; w < w1; ++w) acc += scal[static_cast<int64_t>(w) * Q + q];
+#pragma unroll
+    for (int k = 0; k < SCAL_FOLD; ++k)
+      if (w0 + k < w1) acc += x[k];
     out[static_cast<int64_t>(blockIdx.x) * Q + q] = acc;
   }
 }
