@@ -881,6 +881,10 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         // whatever was queued behind it does nothing. Drain, build the view from exactly the state
         // that asked, lift the hold, go on.
         mark_t("hold seen");
+        if (host_timing)
+          std::fprintf(stderr, "[solve] hold: iters %lld passes %lld trials %lld view passes %lld live %d of which outside the view %d\n",
+                       static_cast<long long>(hm->iters), static_cast<long long>(hm->n_passes), static_cast<long long>(hm->n_trials),
+                       static_cast<long long>(hm->n_view_passes), static_cast<int>(hm->hold_nlive), static_cast<int>(hm->nout));
         // (No drain: the iterations queued behind the hold do nothing but move the state between its two
         // copies, in stream order — the build's launches queue behind them and read copy h->par, where the last
         // of them leaves it; the build itself waits for the stream once. An in-process GROUP holds on every

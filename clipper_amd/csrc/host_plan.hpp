@@ -372,7 +372,7 @@ inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esiz
   }
   out.entries = total;
   target_units = std::max(1, std::min(target_units, max_units));
-  const double Te = std::max(256.0, static_cast<double>(total) / target_units);
+  const double Te0 = std::max(256.0, static_cast<double>(total) / target_units);
   const int max_cgs = std::min(K.nwv, K.tmax / nchunks);  // one wave per group in the tail; slices per unit
   if (max_cgs < 1) return;
   // A pass's time in a unit goes with its lock-step STEPS (the CU's LDS pipe issues per wave-step, however few
@@ -391,7 +391,13 @@ inline void plan_view_resident(const uint32_t* L, int ncg, int nchunks, int esiz
   std::nth_element(sorted_stp.begin(), sorted_stp.begin() + ncg / 2, sorted_stp.end());
   const double Tmed = std::max(1, sorted_stp[static_cast<size_t>(ncg / 2)]);
   std::vector<ViewUnit>& units = out.units;
-  for (int heavy_split = (nchunks >= 2 ? 1 : 0); heavy_split >= 0; --heavy_split) {
+  // Attempts: with the heavy groups split, without, then with more entries per unit — a view of 600 rows over
+  // 12 000 columns has more column groups than the chip has places for units of one group each (round 4: such views
+  // stayed with the streaming launches for no better reason)
+  const double scales[] = {1.0, 1.0, 1.35, 1.8, 2.4, 3.2};
+  for (int attempt = (nchunks >= 2 ? 0 : 1); attempt < 6; ++attempt) {
+  const int heavy_split = attempt == 0 ? 1 : 0;
+  const double Te = Te0 * scales[attempt];
   units.clear();
   int cg = 0;
   while (cg < ncg) {

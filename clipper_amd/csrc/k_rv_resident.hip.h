@@ -457,8 +457,12 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     // ---- leave? (only ever in front of a pass: what goes out is a PREPARED pass) ----------------------
     const bool out_now = kind != K_BUILD && (exchanges >= A.max_exchanges || (kind == K_TRIAL ? want_out : nout != 0));
     if (out_now) {
-      const int resume = (kind == K_TRIAL) ? 1 : 2;
-      if (resume == 1) {  // the pending window's norms (:235-237) go out with the state
+      // (a window whose point has a live row OUTSIDE the view — that is why it leaves — goes out with the RAW sums of
+      // its norms over the view's rows, resume = 3: that row's candidates are not zero, the launch that runs the pass
+      // adds the rows outside the view: k_solver.hip.h, iteration_head)
+      const int resume = (kind == K_TRIAL) ? (nout != 0 ? 3 : 1) : 2;
+      const bool window = kind == K_TRIAL;
+      if (window) {  // the pending window's norms (:235-237) go out with the state
         double r2[2 * V];
 #pragma unroll
         for (int q = 0; q < 2 * V; ++q) r2[q] = 0.0;
@@ -485,14 +489,14 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
         o->s = s;
 #pragma unroll
         for (int l = 0; l < V; ++l) {
-          const double nl = (resume == 1 && tot[2 * l] > 0.0) ? sqrt(tot[2 * l]) : 1.0;
-          o->nrm[l] = nl;
-          o->sx[l] = (resume == 1) ? tot[2 * l + 1] / nl : 0.0;
+          const double nl = (window && tot[2 * l] > 0.0) ? sqrt(tot[2 * l]) : 1.0;
+          o->nrm[l] = (resume == 3) ? tot[2 * l] : nl;
+          o->sx[l] = (resume == 3) ? tot[2 * l + 1] : (window ? tot[2 * l + 1] / nl : 0.0);
         }
         o->sel = 0;
         o->ubp = e_ubp ^ 1;
         o->ubv = 0;
-        o->phase = (resume == 1) ? static_cast<int>(PH_TRIAL) : static_cast<int>(PH_PENALTY);
+        o->phase = window ? static_cast<int>(PH_TRIAL) : static_cast<int>(PH_PENALTY);
         o->stage = ST_PASS;
         o->i = i_;
         o->j = j_;

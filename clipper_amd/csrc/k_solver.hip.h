@@ -145,7 +145,10 @@ struct SolverState {
                        // table `sel`); 1 = a WINDOW pass prepared from point slot (ubp, ubv) with step
                        // `alpha`, norms nrm / sx (phase PH_TRIAL); 2 = a pair-mode pass on the u array of
                        // that slot (phase PH_PENALTY) — what a decide-only launch and the resident solver
-                       // on a row view (k_rv_resident.hip.h) leave behind
+                       // on a row view (k_rv_resident.hip.h) leave behind; 3 = as 1, but nrm / sx hold the RAW
+                       // sums (z_l, s_l) over the view's rows only: the resident solver left because a row
+                       // outside its view became live (nout != 0), and that row's candidates are not zero —
+                       // the launch that runs the pass adds the rows outside the view (iteration_head)
 };
 
 // What outlives the alternating state: the end of the solve. Kernels launched after
@@ -920,6 +923,39 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
   if (is_writer_block()) {  // (word by word by the whole workgroup: one thread's struct copy is 70 registers)
     copy_state(stash, st, threadIdx.x, NT);
     __syncthreads();
+    if (resume == 3 && A.in_view != nullptr) {  // (uniform, rare) the window's norms: the rows outside the view are missing
+      double r[2 * V];
+#pragma unroll
+      for (int q = 0; q < 2 * V; ++q) r[q] = 0.0;
+      const double* u = pt_arr(A, V, L.ubp, L.ubv, 0);
+      const double* g = pt_arr(A, V, L.ubp, L.ubv, 1);
+      const double beta = A.prm.beta;
+      for (int64_t i = threadIdx.x; i < A.m; i += NT) {
+        if (A.in_view[i] == 0) {
+          const double ui = u[i], gi = g[i];
+          double al = L.alpha;
+#pragma unroll
+          for (int l = 0; l < V; ++l) {
+            double t = ui + al * gi;  // clipper.cpp:235-236
+            t = (t > 0.0) ? t : 0.0;
+            r[2 * l] += t * t;
+            r[2 * l + 1] += t;
+            al = al * beta;
+          }
+        }
+      }
+      block_reduce<2 * V, NT / 64>(r, lds);
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int l = 0; l < V; ++l) {
+          const double z = stash->nrm[l] + r[2 * l], sm = stash->sx[l] + r[2 * l + 1];
+          const double nl = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0 (:237)
+          stash->nrm[l] = nl;
+          stash->sx[l] = sm / nl;
+        }
+      }
+      __syncthreads();
+    }
     if (threadIdx.x == 0) {
       stash->stage = ST_RESULTS;
       stash->n_passes = L.n_passes + 1;

@@ -290,6 +290,20 @@ int main() {
             ++nview;
             nview_ok += check_view_resident(L, ncg, nchunks, esize, target, 248, fixed) ? 1 : 0;
           }
+  // a view with more column groups than the chip has places for units of one group each (600 rows x 12 500 columns:
+  // 196 groups, ten of them dense): the planner packs more entries per unit until the units fit
+  for (int ncg : {196, 223})
+    for (int esize : {4, 8}) {
+      std::snprintf(g_case, sizeof(g_case), "wide view ncg=%d esize=%d", ncg, esize);
+      auto L = directory(rng, ncg, 6, 0.16, 0.0);
+      for (int cg = ncg - 10; cg < ncg; ++cg)
+        for (int k = 0; k < 6; ++k) L[static_cast<size_t>(cg) * 6 + k] = 32u | (uint32_t(128 * 64) << 8);
+      const uint32_t fixed = 6 * 128 * 6 * 8 + (2 * 8 * 16 * 8 + 64 * 8) + (64 * 8 + 64);
+      ++nview;
+      const bool ok = check_view_resident(L, ncg, 6, esize, 170, 248, fixed);
+      nview_ok += ok ? 1 : 0;
+      REQUIRE(ok || esize == 8);
+    }
   REQUIRE(nview_ok > nview / 2);
   REQUIRE(nres_ok > nres / 4);  // (the small and the sparse ones fit)
   std::printf("view-resident plans: %d (%d fit the chip)\n", nview, nview_ok);
