@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomized A/B of the resident solver on a row view against the streamed views (clipper_hip_set_row_view 0 vs 2):
 N seeded random (m, outlier ratio, seed, value type) — node list, ifinal, score, trial and pass counts must agree.
-  python tools/rvr_random_ab.py [N=60] [seed=1] [m_lo=2500] [m_hi=24000]
+  python tools/rvr_random_ab.py [N=60] [seed=1] [m_lo=2500] [m_hi=24000] [modes=0,2]
 What found the norms of a window left with a live row outside the view (round 4). A "BAD" line with equal results and
 trial counts about 98 apart is a line search that runs into maxlsiters on rounding noise in one order of summation
 and not in the other (profiles/r04_rvr_random_ab.txt): not a defect."""
@@ -14,6 +14,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lo = int(sys.argv[3]) if len(sys.argv) > 3 else 2500
 hi = int(sys.argv[4]) if len(sys.argv) > 4 else 24000
+modes = tuple(int(x) for x in sys.argv[5].split(',')) if len(sys.argv) > 5 else (0, 2)   # e.g. 2,1: streamed views against no views
 bad = 0
 nres = 0
 for k in range(N):
@@ -23,7 +24,7 @@ for k in range(N):
     storage = abi.STORE_F64_CSC if rng.integers(0, 2) else abi.STORE_F32_CSC
     p = synth.make_euclidean_problem(m, rho, seed=seed)
     out = []
-    for mode in (0, 2):
+    for mode in modes:
         g = abi.HipClipper(storage=storage)
         g.set_row_view(mode)
         g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
