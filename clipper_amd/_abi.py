@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_affinity_pointnormal_staged", "clipper_hip_stage_u0",
     "clipper_hip_solve_staged", "clipper_hip_debug_stamps", "clipper_hip_comm_init_callback",
     "clipper_hip_read_ply_xyz", "clipper_hip_generate_synthetic_correspondences",
-    "clipper_hip_precision_recall", "clipper_hip_estimate_rigid_transform",
+    "clipper_hip_precision_recall", "clipper_hip_estimate_rigid_transform", "clipper_hip_debug_occupy",
 ]
 
 
@@ -99,7 +99,7 @@ class ViewStats(C.Structure):
         ("builds", C.c_int64), ("rows", C.c_int64), ("bytes", C.c_int64),
         ("view_passes", C.c_int64), ("passes", C.c_int64), ("build_ms", C.c_double),
         ("view_pass_avg_us", C.c_double), ("view_pass_samples", C.c_int64),
-        ("resident_launches", C.c_int64),
+        ("resident_launches", C.c_int64), ("resident_giveups", C.c_int64),
     ]
 
 
@@ -189,6 +189,7 @@ def load_library(path: str = LIB_PATH):
                                                                  ip, ip, C.POINTER(i64)]
     L.clipper_hip_precision_recall.argtypes = [ip, i64, ip, i64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.clipper_hip_estimate_rigid_transform.argtypes = [dp, i64, dp, i64, ip, i64, dp]
+    L.clipper_hip_debug_occupy.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double]
     _lib = L
     return L
 
@@ -553,6 +554,14 @@ def estimate_rigid_transform(D1, D2, A) -> np.ndarray:
 
 def device_count() -> int:
     return int(load_library().clipper_hip_device_count())
+
+
+def debug_occupy(device: int, workgroups: int, lds_bytes: int, milliseconds: float) -> None:
+    """Test infrastructure: `workgroups` wave slots with `lds_bytes` of LDS each are held for `milliseconds`
+    (blocks until the kernel is over): another tenant on the device."""
+    rc = load_library().clipper_hip_debug_occupy(device, workgroups, lds_bytes, float(milliseconds))
+    if rc < 0:
+        raise ClipperError(f"clipper_hip_debug_occupy: {rc} ({_last_error()})")
 
 
 def _last_error() -> str:

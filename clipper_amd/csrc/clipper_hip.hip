@@ -832,6 +832,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   init.nlive = init.nout = static_cast<int32_t>(std::min<int64_t>(m, 0x7fffffff));  // unknown until a tail counts
   init.rv_last = -100;
   rowview_drop(h);  // a solve starts without a view: what it builds is a function of this solve alone
+  rvr_begin_solve(h);
   h->rvp = rowview_policy(h);
   // with rescaling the first iteration runs the pair pass on u0; without, it only normalises
   init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
@@ -984,6 +985,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     h->rv_stats.view_passes = h->mirror->n_view_passes;
   }
 
+  rvr_end_solve(h);  // (launches of the resident solver on a view that gave up: counted, the context backs off)
   }  // !resident
 
   // final u
@@ -1465,6 +1467,22 @@ int clipper_hip_debug_stamps(clipper_hip_t* h, int64_t* out, int capacity) try {
   HIPCHK(hipStreamSynchronize(h->sh[0].stream));
   HIPCHK(hipMemcpy(out, h->stamps_dev, static_cast<size_t>(n) * sizeof(long long), hipMemcpyDeviceToHost));
   return n;
+} CLIPPER_HIP_GUARD_INT
+
+int clipper_hip_debug_occupy(int device, int workgroups, int lds_bytes, double milliseconds) try {
+  if (workgroups < 1 || lds_bytes < 0 || lds_bytes > static_cast<int>(RS_LDS_MAX) || !(milliseconds >= 0.0) || milliseconds > 2000.0)
+    return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  HIPCHK(hipSetDevice(device));
+  if (!raise_dynamic_lds(reinterpret_cast<const void*>(k_debug_occupy), device, static_cast<int>(RS_LDS_MAX)))
+    return fail(CLIPPER_HIP_E_HIP, "the device refuses %u bytes of dynamic LDS", RS_LDS_MAX);
+  hipStream_t st = nullptr;
+  HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  hipLaunchKernelGGL(k_debug_occupy, dim3(static_cast<unsigned>(workgroups)), dim3(64), static_cast<size_t>(lds_bytes), st,
+                     static_cast<long long>(milliseconds * 1e5));
+  const hipError_t e = hipStreamSynchronize(st);
+  hipStreamDestroy(st);
+  HIPCHK(e);
+  return 0;
 } CLIPPER_HIP_GUARD_INT
 
 int clipper_hip_device_info(const clipper_hip_t* h, char* name64, int* cus, int64_t* hbm_bytes) try {

@@ -205,9 +205,12 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
   volatile HostMirror* hm = h->mirror;
   for (int attempt = 0;; ++attempt) {
     a.xcd_mode = (!r.xcd_off && !xcd_env_off && r.nunits >= 2 && r.nunits <= 28) ? 1 : 0;
-    // longest wait for another unit's sums on the 100 MHz wall clock: 0.5 s; in the one-XCD mode 5 ms
-    // (its units compete for one XCD's CUs with whatever else runs there: rather launch again)
-    a.timeout_ticks = timeout_override ? timeout_override : (a.xcd_mode ? 500000ll : 50000000ll);
+    // longest wait for another unit's sums of ONE pass on the 100 MHz wall clock: 5 ms — five hundred passes' worth
+    // (a pass is 3-11 us); in the one-XCD mode 2 ms (its units compete for one XCD's CUs with whatever else runs
+    // there: rather launch again). A unit that is not resident by then is behind another tenant's work: the
+    // streaming launches take over, and this matrix is not tried again (r.failed). Round 4 waited 0.5 s — a thousand
+    // solves' worth — before a 0.3 ms solve went on.
+    a.timeout_ticks = timeout_override ? timeout_override : (a.xcd_mode ? 200000ll : 500000ll);
     a.epoch0 = r.epoch;
     std::memset(h->mirror, 0, sizeof(HostMirror));
     std::atomic_thread_fence(std::memory_order_seq_cst);

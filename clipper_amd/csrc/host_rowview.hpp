@@ -232,9 +232,12 @@ int rv_grow(T*& p, size_t& cap, size_t need) {
   return 0;
 }
 
-// Builds the view from the state the NEXT iteration decides from (state copy h->par). The stream is
-// idle (the caller drained it). built = false: the live rows were too many to be worth it — the view
-// in use, if any, stays as it is.
+// Builds the view from the state the NEXT iteration decides from (state copy h->par). The stream need not be
+// idle: whatever is queued behind the hold only moves the state between its two copies, and the build's launches
+// queue behind that. built = false: the live rows were too many to be worth it — the view in use, if any, stays
+// as it is, unless its store was already overwritten by a speculative fill whose count turned out wrong (never
+// seen; forced by CLIPPER_HIP_RV_TEST_MISCOUNT): then the build goes through with the real count whatever the
+// cost model says, and only an EMPTY list leaves the shard without a view (the passes stream M: always correct).
 template <int V>
 int rowview_build_shard(Ctx* h, Shard& s, bool& built);
 
@@ -311,7 +314,10 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   // is repeated with the real length.
   const int64_t asked = h->mirror->hold_nlive;
   int64_t nrows = asked;
+  static const bool test_miscount = std::getenv("CLIPPER_HIP_RV_TEST_MISCOUNT") != nullptr;  // (test knob: the first fill
+  if (test_miscount && asked > 1) nrows = asked - 1;                                          // is sized one row short)
   bool counted = false;
+  bool store_gone = false;  // the store of the view in use was overwritten by this build
   if (asked <= 0 || asked > m) {
     HIPCHK(hipStreamSynchronize(s.stream));
     nrows = *h->rv_count;
@@ -326,9 +332,10 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
       if (nrows < 0) return fail(CLIPPER_HIP_E_HIP, "row view: the row count did not arrive");
       const bool as_asked = nrows > 0 && nrows == asked;
       if (!as_asked &&
-          (nrows == 0 || static_cast<double>(nrows) > RV_ROWS_RATIO * rows_now ||
-           RV_GAIN_MARGIN * (pol.build_fixed + pol.build_per_row * static_cast<double>(nrows)) >=
-               horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row)) {
+          (nrows == 0 ||
+           (!store_gone && (static_cast<double>(nrows) > RV_ROWS_RATIO * rows_now ||
+                            RV_GAIN_MARGIN * (pol.build_fixed + pol.build_per_row * static_cast<double>(nrows)) >=
+                                horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row)))) {
         hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows));
         h->rv_stats.build_ms +=
             std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -336,6 +343,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
       }
     }
     v.valid = false;  // its store is about to be overwritten
+    store_gone = true;
     SliceOut O{};
     if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
     if (rowview_fill_by_filter(h)) rc = launch_filter(h, s, v.rowmap[next], v.viewpos, nrows, O);

@@ -9,11 +9,46 @@ void rvr_free(Ctx* h) {
   if (r.host_plan) hipHostFree(r.host_plan);
   if (r.xb) hipFree(r.xb);
   if (r.ctl) hipFree(r.ctl);
+  if (r.giveup_host) hipHostFree(r.giveup_host);
   const unsigned long long ep = r.epoch;
-  const int tu = r.target_units;
+  const int tu = r.target_units, cd = r.cooldown, cn = r.cooldown_next, mu = r.max_units_device;
   r = ViewResident{};
   r.epoch = ep;
   r.target_units = tu;
+  r.cooldown = cd;
+  r.cooldown_next = cn;
+  r.max_units_device = mu;
+}
+
+// Start of a solve: the give-up words of the previous one are gone, a back-off counts down.
+void rvr_begin_solve(Ctx* h) {
+  ViewResident& r = h->vres;
+  r.launches_this_solve = 0;
+  if (r.giveup_host) std::memset(r.giveup_host, 0, RVR_GIVEUP_SLOTS * sizeof(uint32_t));
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+
+// End of a solve (every launch of it has retired: the solve's end was seen behind them in stream order): launches
+// that gave up are taken out of `resident_launches`, counted, and the context backs off.
+void rvr_end_solve(Ctx* h) {
+  ViewResident& r = h->vres;
+  if (r.cooldown > 0 && r.launches_this_solve == 0) --r.cooldown;  // (a solve that streamed its views)
+  if (r.launches_this_solve == 0 || !r.giveup_host) return;
+  std::atomic_thread_fence(std::memory_order_acquire);
+  int gave_up = 0;
+  volatile const uint32_t* w = r.giveup_host;
+  for (int k = 0; k < std::min(r.launches_this_solve, RVR_GIVEUP_SLOTS); ++k) gave_up += (w[k] != 0u) ? 1 : 0;
+  if (gave_up > 0) {
+    h->rv_stats.resident_launches -= gave_up;
+    h->rv_stats.resident_giveups += gave_up;
+    r.cooldown = r.cooldown_next;
+    r.cooldown_next = std::min(64, 2 * r.cooldown_next);
+    if (rs_debug())
+      std::fprintf(stderr, "[view-resident] %d launch(es) gave up (error %u): the next %d solve(s) stream their views\n", gave_up,
+                   static_cast<unsigned>(w[0]), r.cooldown);
+  } else {
+    r.cooldown_next = 1;
+  }
 }
 
 bool rvr_enabled(const Ctx* h) {
@@ -22,7 +57,8 @@ bool rvr_enabled(const Ctx* h) {
     return e && std::atoi(e) == 0;
   }();
   // one device, one shard, a window the kernel is instantiated for, an inner loop that runs at all
-  return !env_off && h->rv_mode == 0 && csc_single(h) && h->sh.size() == 1 && (h->V == 6 || h->V == 4);
+  return !env_off && h->rv_mode == 0 && csc_single(h) && h->sh.size() == 1 && (h->V == 6 || h->V == 4) &&
+         h->vres.cooldown == 0;  // (backing off after a launch that gave up: rvr_end_solve)
 }
 
 // could a view of this many rows go to the resident solver? (what rvr_plan checks before it looks at the directory)
@@ -44,7 +80,24 @@ int rvr_plan(Ctx* h, Shard& s) {
     const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT_WGS");
     r.target_units = e ? std::max(1, std::atoi(e)) : -1;
   }
-  const int max_units = std::min(RVR_MAXUNITS, h->cus - 8);
+  // Co-residency is what the exchange relies on: ask the runtime once how many workgroups of the kernel (512 threads,
+  // 159 KB of LDS) the device holds at a time — a device that gives a workgroup less LDS, or a partition with
+  // fewer CUs than the properties say, gets fewer units (or none) instead of a launch that can only time out.
+  if (r.max_units_device < 0) {
+    int per_cu = 0;
+    hipError_t e = hipErrorUnknown;
+    dispatch_vt(h, [&](auto tag) {
+      using VT = decltype(tag);
+      auto kern = (h->V == 6) ? k_solve_view_resident<VT, 6> : k_solve_view_resident<VT, 4>;
+      if (raise_dynamic_lds(reinterpret_cast<const void*>(kern), s.device, static_cast<int>(RS_LDS_MAX)))
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), RVR_NT, RS_LDS_MAX);
+    });
+    if (e != hipSuccess) (void)hipGetLastError();
+    r.max_units_device = (e == hipSuccess) ? per_cu * h->cus : 0;
+    if (rs_debug()) std::fprintf(stderr, "[view-resident] the device holds %d workgroups of the kernel at a time\n", r.max_units_device);
+  }
+  if (r.max_units_device < 16) return 0;
+  const int max_units = std::min({RVR_MAXUNITS, h->cus - 8, r.max_units_device - 8});
   // one workgroup per CU (its LDS is the unit's): about two thirds of the chip by default — more units
   // shorten the pass (the LDS gathers spread over more CUs), every unit adds a granule to everybody's sweep
   const int target = r.target_units > 0 ? r.target_units : std::max(8, (2 * h->cus) / 3);
@@ -89,6 +142,11 @@ int rvr_plan(Ctx* h, Shard& s) {
     r.xb_bytes = xb_bytes;
   }
   if (!r.ctl) HIPCHK(hipMalloc(&r.ctl, 64));
+  if (!r.giveup_host) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r.giveup_host), RVR_GIVEUP_SLOTS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.giveup_host_dev), r.giveup_host, 0));
+    std::memset(r.giveup_host, 0, RVR_GIVEUP_SLOTS * sizeof(uint32_t));
+  }
   r.nunits = static_cast<int>(plan.units.size());
   r.lds_slices = plan.lds_slices;
   r.ready = true;
@@ -147,11 +205,19 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   a.epoch0 = r.epoch;
   r.epoch += 1ull << 20;  // whatever this launch publishes (even if it gives up half-way) lies below the next one's
   a.ctl = r.ctl;
+  a.giveup_host = (r.giveup_host_dev && r.launches_this_solve < RVR_GIVEUP_SLOTS) ? r.giveup_host_dev + r.launches_this_solve : nullptr;
   a.lds_slices = r.lds_slices;
-  a.timeout_ticks = 20000000ll;  // 0.2 s on the 100 MHz wall clock
+  // The longest a unit waits for the others' granules of ONE exchange, on the 100 MHz wall clock: 2 ms — a hundred
+  // iterations' worth (an iteration is 14 us, the first exchange comes 25 us into the launch). A unit that is not
+  // resident by then is behind another tenant's work; the streaming launches, which need no co-residency, take over
+  // (round 4: 0.2 s — two hundred solves' worth of waiting before a 1.2 ms solve went on).
+  a.timeout_ticks = 200000ll;
   if (const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT_TIMEOUT_TICKS")) a.timeout_ticks = std::atoll(e);  // (test knob)
+  // (a launch owns 2^20 epochs, one per exchange: the budget stays below, so that nothing it publishes can carry a
+  // tag of the next launch's range)
   a.max_exchanges = 1 << 18;
-  if (const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT_MAX_EXCHANGES")) a.max_exchanges = std::max(0, std::atoi(e));  // (test knob)
+  if (const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT_MAX_EXCHANGES"))
+    a.max_exchanges = std::min((1 << 20) - 1, std::max(0, std::atoi(e)));  // (test knob)
   a.rvp = h->rvp;
   a.rv_rows = static_cast<int>(s.rv.nrows);
   a.stamps = h->stamps_dev;
@@ -166,7 +232,8 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
     return 0;
   }
   launched = true;
-  h->rv_stats.resident_launches += 1;
+  r.launches_this_solve += 1;
+  h->rv_stats.resident_launches += 1;  // (rvr_end_solve takes the ones that gave up out again)
   return 0;
 }
 

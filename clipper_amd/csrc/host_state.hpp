@@ -223,7 +223,18 @@ struct ViewResident {
   uint32_t* ctl = nullptr;           // [0] error word, [1] arrivals at the exit
   unsigned long long epoch = 0;      // every launch takes 2^20 epochs
   int target_units = 0;              // CLIPPER_HIP_VIEW_RESIDENT_WGS (0: automatic)
+  // Launches that gave up (an exchange that timed out: a unit that did not become resident in time — another tenant
+  // on the device —, an LDS plan the device refused). The kernel leaves its error word in pinned memory, one word per
+  // launch of the solve; the host reads them when the solve is over, counts, and BACKS OFF: the next `cooldown` solves
+  // of this context stream their views, twice as many after every solve with a give-up (at most 64), one again
+  // after a solve whose launches all ran.
+  uint32_t* giveup_host = nullptr;   // pinned + mapped [RVR_GIVEUP_SLOTS]
+  uint32_t* giveup_host_dev = nullptr;
+  int launches_this_solve = 0;
+  int cooldown = 0, cooldown_next = 1;
+  int max_units_device = -1;         // workgroups of the kernel the device holds at once (occupancy query; -1: not asked yet)
 };
+constexpr int RVR_GIVEUP_SLOTS = 16;
 
 }  // namespace
 

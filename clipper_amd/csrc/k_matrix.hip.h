@@ -86,4 +86,14 @@ __global__ __launch_bounds__(256) void k_copy_words(const uint4* __restrict__ sr
     dst[i] = src[i];
 }
 
+// k_debug_occupy — test infrastructure (clipper_hip_debug_occupy): every workgroup holds its dynamic LDS and one wave
+// slot for `ticks` of the 100 MHz wall clock and does nothing else — "another tenant on the device" for the tests of
+// the resident solvers' time-outs (their units need a CU's whole LDS each and wait for each other).
+__global__ __launch_bounds__(64) void k_debug_occupy(long long ticks) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t occ_lds[];
+  if (threadIdx.x == 0) occ_lds[0] = 1;  // (the allocation is what counts)
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 }  // namespace clipper_hip

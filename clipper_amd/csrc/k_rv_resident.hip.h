@@ -80,6 +80,8 @@ struct RvrArgs {
   unsigned long long* xb;       // [2][(V + 2) * RVR_MAXROWS + RVR_MAXUNITS][2] granules, zero at allocation
   unsigned long long epoch0;
   uint32_t* ctl;                // [0] error word, [1] arrivals at the exit (zero at launch)
+  uint32_t* giveup_host;        // pinned (may be null): the error word of a launch that gave up, for the host to read
+                                // after the solve (it counts them and backs off: host_rv_resident.hpp)
   uint32_t lds_slices;          // bytes of LDS the slices of a unit may take
   long long timeout_ticks;      // longest wait for the other units' granules, 100 MHz wall clock
   int max_exchanges;            // leave to the streaming launches after this many
@@ -279,7 +281,10 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   const uint32_t total = words[0];
   const bool bad_plan = total + RS_SLICE_PAD > A.lds_slices || nslices > RVR_TMAX || U.ncgs > RVR_NWV;
   if (__syncthreads_or(bad_plan ? 1 : 0)) {
-    if (tid == 0) __hip_atomic_store(A.ctl, static_cast<uint32_t>(RVR_ERR_LDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      __hip_atomic_store(A.ctl, static_cast<uint32_t>(RVR_ERR_LDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (A.giveup_host) __hip_atomic_store(A.giveup_host, static_cast<uint32_t>(RVR_ERR_LDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;  // (the other units time out on this one's granules — or see the error word — and leave: nothing is committed)
   }
   for (int t = wave; t < nslices; t += RVR_NWV) {
@@ -722,8 +727,11 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       if (__syncthreads_or(fail)) {  // nothing is committed: the streaming launches carry on from the entry state
         if (tid == 0) {
           uint32_t expect = 0;
-          __hip_atomic_compare_exchange_strong(A.ctl, &expect, static_cast<uint32_t>(RVR_ERR_TIMEOUT), __ATOMIC_RELAXED,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (the one unit whose exchange ran out first reports; the others leave on its error word)
+          if (__hip_atomic_compare_exchange_strong(A.ctl, &expect, static_cast<uint32_t>(RVR_ERR_TIMEOUT), __ATOMIC_RELAXED,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
+              A.giveup_host)
+            __hip_atomic_store(A.giveup_host, static_cast<uint32_t>(RVR_ERR_TIMEOUT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
       }

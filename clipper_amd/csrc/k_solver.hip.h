@@ -923,7 +923,10 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
   if (is_writer_block()) {  // (word by word by the whole workgroup: one thread's struct copy is 70 registers)
     copy_state(stash, st, threadIdx.x, NT);
     __syncthreads();
-    if (resume == 3 && A.in_view != nullptr) {  // (uniform, rare) the window's norms: the rows outside the view are missing
+    if (resume == 3) {  // (uniform, rare) the window's norms: the rows outside the view are missing
+      // (no view at hand any more — nothing queues a launch like that today —: the raw sums over ALL rows, which is
+      // what the two parts add up to; the view's part that came with the state is then left out below)
+      const bool all_rows = A.in_view == nullptr;
       double r[2 * V];
 #pragma unroll
       for (int q = 0; q < 2 * V; ++q) r[q] = 0.0;
@@ -931,7 +934,7 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
       const double* g = pt_arr(A, V, L.ubp, L.ubv, 1);
       const double beta = A.prm.beta;
       for (int64_t i = threadIdx.x; i < A.m; i += NT) {
-        if (A.in_view[i] == 0) {
+        if (all_rows || A.in_view[i] == 0) {
           const double ui = u[i], gi = g[i];
           double al = L.alpha;
 #pragma unroll
@@ -948,7 +951,7 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
       if (threadIdx.x == 0) {
 #pragma unroll
         for (int l = 0; l < V; ++l) {
-          const double z = stash->nrm[l] + r[2 * l], sm = stash->sx[l] + r[2 * l + 1];
+          const double z = (all_rows ? 0.0 : stash->nrm[l]) + r[2 * l], sm = (all_rows ? 0.0 : stash->sx[l]) + r[2 * l + 1];
           const double nl = (z > 0.0) ? sqrt(z) : 1.0;  // Eigen normalize(): only if squaredNorm > 0 (:237)
           stash->nrm[l] = nl;
           stash->sx[l] = sm / nl;

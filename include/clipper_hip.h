@@ -102,8 +102,12 @@ typedef struct clipper_hip_view_stats_t {
   double view_pass_avg_us; /* mean duration of the sampled pass launches that streamed a view
                               (profiling on; 0 = none sampled)                               */
   int64_t view_pass_samples;
-  int64_t resident_launches; /* launches of the resident solver on a view (k_rv_resident.hip.h): the passes
+  int64_t resident_launches; /* launches of the resident solver on a view (k_rv_resident.hip.h) that RAN: the passes
                                 on a view that ran inside one are counted in view_passes, not sampled   */
+  int64_t resident_giveups;  /* launches of it that gave up and changed nothing (a unit that did not become resident
+                                within the exchange's time-out — e.g. another tenant on the device —, a refused LDS
+                                plan): the streaming launches did their work; the context then streams the views of
+                                its next solves (1, 2, 4, ... 64 of them) before it tries again              */
 } clipper_hip_view_stats_t;
 
 /* ---- life cycle --------------------------------------------------------------------- */
@@ -339,6 +343,11 @@ int clipper_hip_estimate_rigid_transform(const double* D1, int64_t n1, const dou
 /* Measurement only (context created with CLIPPER_HIP_STAMPS=1 in the environment): per workgroup of
  * the last pass launch {start, decision done, end, info} on the 100 MHz device wall clock. */
 int clipper_hip_debug_stamps(clipper_hip_t* h, int64_t* out, int capacity);
+
+/* Test infrastructure: occupies `workgroups` wave slots with `lds_bytes` of LDS each on `device` for `milliseconds`
+ * (a kernel that sleeps) and returns when it is over — "another tenant on the device" for the tests of the resident
+ * solvers' time-outs (tests/test_gpu_rv_resident.py runs it in a second process). */
+int clipper_hip_debug_occupy(int device, int workgroups, int lds_bytes, double milliseconds);
 
 int clipper_hip_device_info(const clipper_hip_t* h, char* name64, int* cus, int64_t* hbm_bytes);
 

@@ -268,3 +268,15 @@ def test_views_for_a_matrix_that_was_handed_over():
     assert on["nodes"] == off["nodes"] == orc["nodes"]
     assert abs(on["score"] - orc["score"]) <= 1e-6 * abs(orc["score"])
     assert abs(on["score"] - off["score"]) <= 1e-10 * abs(off["score"])
+
+
+def test_a_speculative_fill_sized_from_a_wrong_count_is_repeated():
+    """A view's fill is sized from the live count the device asked with and queued before the row list's own count
+    has come back (one wait per build). Should the two ever differ — never seen; CLIPPER_HIP_RV_TEST_MISCOUNT sizes
+    the first fill one row short — the build notices, repeats itself with the list's real length and goes through
+    (the previous view's store is gone by then: host_rowview.hpp). Same builds, same bytes, same solve bit for bit."""
+    a = _child(_BUILD_PROBE)
+    b = _child(_BUILD_PROBE, CLIPPER_HIP_RV_TEST_MISCOUNT="1")
+    for x, y in zip(a, b):
+        assert x["builds"] >= 1 and x["view_passes"] > 0, x
+        assert x == y, (x, y)
