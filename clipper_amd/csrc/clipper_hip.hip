@@ -975,6 +975,10 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
           bool built = false;
           if (int r2 = rowview_build(h, built)) return r2;
           h->rv_fresh = built;
+          // a view small enough for the resident solver: every rank runs it on a replica of the view (no exchange
+          // for the iterations inside the launch; host_rv_resident.hpp)
+          if (built)
+            if (int r2 = rvr_replica_handover(h, prm)) return r2;
           return 0;
         },
         nullptr);

@@ -37,6 +37,21 @@ SliceView row_view(const Ctx* h, const Shard& s) {
   return R;
 }
 
+// the replica of the view over ALL columns (column shards; data == null: none)
+SliceView row_view_full(const Ctx* h, const Shard& s) {
+  SliceView R{};
+  if (!s.rv.valid || !s.rv.full_valid || !h->csc_valid) return R;
+  R.data = s.rv.full.sdata;
+  R.Pre = s.rv.full.sPre;
+  R.work = nullptr;
+  R.nchunks = s.rv.full.s_nchunks;
+  R.ncg = s.rv.full.s_ncg;
+  R.nwork = 0;
+  R.rowmap = s.rv.rowmap[s.rv.cur];
+  R.nrows = s.rv.nrows;
+  return R;
+}
+
 // calls f(value type tag) for the storage's element type
 template <typename F>
 void dispatch_vt(const Ctx* h, F&& f) {
@@ -92,10 +107,12 @@ int grow_dev(T*& p, size_t& cap, size_t need, size_t elem = sizeof(T)) {
 
 // the per-slice arrays (directory, sizes, costs) of the store `st` (this shard's columns x `nrows`
 // rows) and the pinned staging of this build
-int slices_arrays(Ctx* h, Shard& sh, SliceStore& s, int64_t nrows) {
+// (wcols: the store's columns, a multiple of 64 — the shard's pitch W unless the store is a REPLICA of a row view
+// over all columns, host_rowview.hpp)
+int slices_arrays(Ctx* h, Shard& sh, SliceStore& s, int64_t nrows, int64_t wcols = -1) {
   HIPCHK(hipSetDevice(sh.device));
   if (!sh.cctl) HIPCHK(hipMalloc(&sh.cctl, CSC_ARENAS * sizeof(CscBuildCtl)));
-  s.s_ncg = static_cast<int>(h->W / SL_W);
+  s.s_ncg = static_cast<int>((wcols > 0 ? wcols : h->W) / SL_W);
   s.s_nchunks = static_cast<int>(ceil_div(nrows, SL_SUB * SL_H));
   const size_t nsl = static_cast<size_t>(s.s_ncg) * s.s_nchunks;
   if (nsl > s.scap_slices) {
@@ -129,10 +146,10 @@ int slices_arrays(Ctx* h, Shard& s) { return slices_arrays(h, s, s, h->m); }
 
 // Before a fill that writes the slices itself (k_affinity_sym): the arenas of the slice store
 // reset. out.Pre == null: compressed storage not in use.
-int emit_prepare(Ctx* h, Shard& sh, SliceStore& s, int64_t nrows, SliceOut& out) {
+int emit_prepare(Ctx* h, Shard& sh, SliceStore& s, int64_t nrows, SliceOut& out, int64_t wcols = -1) {
   out = SliceOut{};
   if (!csc_applies(h)) return 0;
-  if (int rc = slices_arrays(h, sh, s, nrows)) return rc;
+  if (int rc = slices_arrays(h, sh, s, nrows, wcols)) return rc;
   const size_t units = s.scap_bytes >= SL_TAILPAD ? (s.scap_bytes - SL_TAILPAD) / 16 : 0;
   CscBuildCtl* init = h->csc_hctl + CSC_ARENAS;  // second half: what the device starts from
   for (int k = 0; k < CSC_ARENAS; ++k) {
@@ -462,7 +479,7 @@ int csc_rebuild(Ctx* h) {
 
 bool rect_fill_possible(const Ctx* h);
 int gather_slice_bytes(Ctx* h);
-int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O);
+int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O, int64_t col0 = -1, int64_t wcols = -1);
 
 // Every compressed build the symmetric kernel cannot serve (fp64 values, column shards): the
 // rectangular tile kernel writes each shard's slices straight from its LDS images — no dense store, no

@@ -30,25 +30,28 @@ bool rect_fill_possible(const Ctx* h) {
 }
 
 // The slices of M[rows, this shard's columns] into the store O describes. rowmap == null: all rows.
-int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O) {
+// (col0, wcols) >= 0: other columns than the shard's own — [col0, col0 + wcols) — for the replica of a row view
+// over ALL columns that every rank of a sharded solve keeps for the resident solver (the points are replicated).
+int launch_rect(Ctx* h, Shard& s, const int32_t* rowmap, int64_t nrows, const SliceOut& O, int64_t col0, int64_t wcols) {
   if (!rect_fill_possible(h)) return fail(CLIPPER_HIP_E_STATE, "no built-in invariant is staged");
+  const int64_t W = wcols > 0 ? wcols : h->W;
   RectGeom G;
   G.m = h->m;
   G.nrows = nrows;
   G.rowmap = rowmap;
-  G.col0 = static_cast<int64_t>(s.slot) * h->W;
-  G.ncols = std::max<int64_t>(0, std::min<int64_t>(h->W, h->m - G.col0));
+  G.col0 = col0 >= 0 ? col0 : static_cast<int64_t>(s.slot) * h->W;
+  G.ncols = std::max<int64_t>(0, std::min<int64_t>(W, h->m - G.col0));
   const int64_t nTr = ceil_div(nrows, AT);
   const int32_t* A0 = s.Adev;
   const int32_t* A1 = s.Adev + h->m;
   const int64_t ps = h->staged_pstride;
   // a thin view (fewer 128-wide tiles than two per CU): 64-wide tiles — see k_affinity_rect
-  const bool thin = nTr * ceil_div(h->W, 128) <= 2 * static_cast<int64_t>(h->cus);
+  const bool thin = nTr * ceil_div(W, 128) <= 2 * static_cast<int64_t>(h->cus);
   dispatch_vt(h, [&](auto t) {
     using VT = decltype(t);
     auto run = [&](auto twc) {
       constexpr int TW = decltype(twc)::value;
-      G.nTc = static_cast<int>(ceil_div(h->W, TW));
+      G.nTc = static_cast<int>(ceil_div(W, TW));
       const int64_t ntiles = nTr * G.nTc;
       constexpr int64_t PER_LAUNCH = int64_t(1) << 22;  // x 512 threads < 2^32 work-items per dispatch
       constexpr int L = rect_lds_bytes<VT, TW>();
@@ -121,12 +124,12 @@ bool rowview_cost_of_filter(const Ctx* h) { return rowview_build_env() != 0 || !
 
 // ---- the row view -----------------------------------------------------------------------------------
 
-int rvr_plan(Ctx* h, Shard& s);  // host_rv_resident.hpp: does the view just built fit the resident solver?
+int rvr_plan(Ctx* h, Shard& s, bool replica);  // host_rv_resident.hpp: does the view just built fit the resident solver?
 bool rvr_candidate(const Ctx* h, int64_t nrows);
 int rowview_put_descriptor(Ctx* h, Shard& s);
 
 void rowview_drop(Ctx* h) {
-  for (auto& s : h->sh) s.rv.valid = false;
+  for (auto& s : h->sh) s.rv.valid = s.rv.full_valid = false;
   h->vres.ready = false;
 }
 
@@ -143,6 +146,14 @@ void rowview_free(Shard& s) {
   fr(v.st.sdata);
   fr(v.st.swork);
   v.st = SliceStore{};
+  fr(v.full.sSizes);
+  fr(v.full.sLq);
+  fr(v.full.sPre);
+  fr(v.full.sBlk);
+  fr(v.full.sdata);
+  fr(v.full.swork);
+  v.full = SliceStore{};
+  v.full_valid = false;
   fr(v.rowmap[0]);
   fr(v.rowmap[1]);
   fr(v.in_view[0]);
@@ -343,6 +354,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
       }
     }
     v.valid = false;  // its store is about to be overwritten
+    v.full_valid = false;
     store_gone = true;
     SliceOut O{};
     if ((rc = emit_prepare(h, s, v.st, nrows, O))) return rc;
@@ -376,7 +388,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   v.nrows = nrows;
   v.valid = true;
   built = true;
-  if ((rc = rvr_plan(h, s))) return rc;  // (the view's directory is still in the pinned staging)
+  if ((rc = rvr_plan(h, s, false))) return rc;  // (the view's directory is still in the pinned staging)
   lap("resident plan");
   if (v.plan_pending && !h->vres.ready) {  // the resident solver does not take it after all
     if ((rc = slices_plan(h, s, v.st, false))) return rc;

@@ -10,6 +10,7 @@ void rvr_free(Ctx* h) {
   if (r.xb) hipFree(r.xb);
   if (r.ctl) hipFree(r.ctl);
   if (r.giveup_host) hipHostFree(r.giveup_host);
+  if (r.backup) hipFree(r.backup);
   const unsigned long long ep = r.epoch;
   const int tu = r.target_units, cd = r.cooldown, cn = r.cooldown_next, mu = r.max_units_device;
   r = ViewResident{};
@@ -51,26 +52,34 @@ void rvr_end_solve(Ctx* h) {
   }
 }
 
-bool rvr_enabled(const Ctx* h) {
+bool rvr_common(const Ctx* h) {
   static const bool env_off = [] {
     const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT");
     return e && std::atoi(e) == 0;
   }();
-  // one device, one shard, a window the kernel is instantiated for, an inner loop that runs at all
-  return !env_off && h->rv_mode == 0 && csc_single(h) && h->sh.size() == 1 && (h->V == 6 || h->V == 4) &&
-         h->vres.cooldown == 0;  // (backing off after a launch that gave up: rvr_end_solve)
+  // one local shard, a window the kernel is instantiated for, not backing off after a launch that gave up (rvr_end_solve)
+  return !env_off && h->rv_mode == 0 && csc_possible(h) && h->sh.size() == 1 && (h->V == 6 || h->V == 4) &&
+         h->vres.cooldown == 0;
 }
+// one device, one shard: the shard's view is the whole view
+bool rvr_enabled(const Ctx* h) { return rvr_common(h) && csc_single(h); }
+// One process per shard (column shards over RCCL or the caller's exchange): every rank keeps a REPLICA of a small
+// view over all columns — scored from the points, which are replicated — and runs the launch redundantly: the same
+// bits on every rank, no exchange for the iterations inside it (reference loop clipper.cpp:226-280).
+bool rvr_replica_enabled(const Ctx* h) { return rvr_common(h) && h->multiproc && rect_fill_possible(h); }
 
 // could a view of this many rows go to the resident solver? (what rvr_plan checks before it looks at the directory)
 bool rvr_candidate(const Ctx* h, int64_t nrows) { return rvr_enabled(h) && nrows >= 1 && nrows <= RVR_MAXROWS; }
 
 // Called when a view has just been built and its directory (csc_hLq) is on the host: does it fit the
 // resident solver? Lays out the units (host_plan.hpp) into mapped pinned memory.
-int rvr_plan(Ctx* h, Shard& s) {
+int rvr_plan(Ctx* h, Shard& s, bool replica = false) {
   ViewResident& r = h->vres;
   r.ready = false;
-  if (!rvr_enabled(h) || !s.rv.valid) return 0;
+  r.on_replica = replica;
+  if (!(replica ? rvr_replica_enabled(h) && s.rv.full_valid : rvr_enabled(h)) || !s.rv.valid) return 0;
   const RowView& v = s.rv;
+  const SliceStore& vst = replica ? v.full : v.st;
   if (v.nrows < 1 || v.nrows > RVR_MAXROWS) return 0;
   static_assert(sizeof(clipper_plan::ViewUnit) == sizeof(RvrUnit), "the planner's unit is the kernel's");
   const clipper_plan::ResidentConsts K{RVR_NT, RVR_NWV, RVR_TMAX, RVR_PMAX, 2, RS_LDS_MAX,
@@ -102,11 +111,11 @@ int rvr_plan(Ctx* h, Shard& s) {
   // shorten the pass (the LDS gathers spread over more CUs), every unit adds a granule to everybody's sweep
   const int target = r.target_units > 0 ? r.target_units : std::max(8, (2 * h->cus) / 3);
   const uint32_t fixed = rvr_xt_bytes(h->V, static_cast<int>(v.nrows)) + RVR_RED_BYTES + RVR_TAB_BYTES;
-  clipper_plan::plan_view_resident(h->csc_hLq, v.st.s_ncg, v.st.s_nchunks, static_cast<int>(h->esize()), target,
+  clipper_plan::plan_view_resident(h->csc_hLq, vst.s_ncg, vst.s_nchunks, static_cast<int>(h->esize()), target,
                                    max_units, fixed, K, plan);
   if (rs_debug())
     std::fprintf(stderr, "[view-resident] plan rows=%lld ncg=%d nchunks=%d entries=%llu -> units=%zu ok=%d\n",
-                 static_cast<long long>(v.nrows), v.st.s_ncg, v.st.s_nchunks,
+                 static_cast<long long>(v.nrows), vst.s_ncg, vst.s_nchunks,
                  static_cast<unsigned long long>(plan.entries), plan.units.size(), plan.ok ? 1 : 0);
   if (!plan.ok) return 0;
   HIPCHK(hipSetDevice(s.device));
@@ -173,12 +182,12 @@ int rvr_launch_t(Ctx* h, Shard& s, const RvrArgs& a) {
 int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   launched = false;
   ViewResident& r = h->vres;
-  if (!r.ready || !rvr_enabled(h) || prm.maxiniters < 1) return 0;
+  if (!r.ready || !(r.on_replica ? rvr_replica_enabled(h) : rvr_enabled(h)) || prm.maxiniters < 1) return 0;
   Shard& s = h->sh[0];
-  if (!s.rv.valid) return 0;
+  if (!s.rv.valid || (r.on_replica && !s.rv.full_valid)) return 0;
   HIPCHK(hipSetDevice(s.device));
   RvrArgs a{};
-  a.R = row_view(h, s);
+  a.R = r.on_replica ? row_view_full(h, s) : row_view(h, s);
   a.units = reinterpret_cast<const RvrUnit*>(r.host_plan_dev);
   a.nunits = r.nunits;
   a.npieces = r.host_plan_dev + r.off_np;
@@ -190,7 +199,7 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   a.host = h->mirror_dev;
   a.host_u = h->u_pinned_dev;
   a.marks = h->profiling ? s.marks : nullptr;
-  a.kind = a.marks ? h->kind_dev : nullptr;
+  a.kind = (a.marks && !h->multiproc) ? h->kind_dev : nullptr;  // (as solve_args: a multi-process solve copies the marks itself)
   a.marks_n = h->launch_counter;  // (profiling: launch index = the device's iteration count)
   a.prm = prm;
   a.m = h->m;
@@ -234,6 +243,113 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   launched = true;
   r.launches_this_solve += 1;
   h->rv_stats.resident_launches += 1;  // (rvr_end_solve takes the ones that gave up out again)
+  return 0;
+}
+
+// ---- column shards: the hand-over of a freshly built view to redundant resident launches -------------------------
+// One flag per rank through the solver's own exchange (a one-slot block, the flag in its first element — as
+// gather_slice_bytes): all = every rank said yes. Every rank calls this the same number of times (what leads here
+// is a function of the solver state, which is bit-identical on all ranks).
+int rvr_agree(Ctx* h, bool mine, bool& all) {
+  Shard& s = h->sh[0];
+  HIPCHK(hipSetDevice(s.device));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  const double v = mine ? 1.0 : 0.0;
+  HIPCHK(hipMemcpy(s.ab + static_cast<int64_t>(s.slot) * h->W, &v, sizeof(double), hipMemcpyHostToDevice));
+  if (int rc = exchange(h, 1)) return rc;
+  if (int rc = sync_all(h)) return rc;
+  all = true;
+  for (int p = 0; p < h->world; ++p) {
+    double x = 0.0;
+    HIPCHK(hipMemcpy(&x, s.ab + static_cast<int64_t>(p) * h->W, sizeof(double), hipMemcpyDeviceToHost));
+    all = all && x == 1.0;
+  }
+  return 0;
+}
+
+// The slices of M[view rows, ALL columns] on this rank (RowView::full): the rectangular fill from the replicated
+// points with the column range widened to the whole matrix; the same row list as the shard's own view.
+int rvr_build_replica(Ctx* h, Shard& s) {
+  RowView& v = s.rv;
+  v.full_valid = false;
+  if (!v.valid) return 0;
+  const int64_t wfull = round_up(h->m, 64);
+  for (int attempt = 0;; ++attempt) {
+    SliceOut O{};
+    int rc;
+    if ((rc = emit_prepare(h, s, v.full, v.nrows, O, wfull))) return rc;
+    if ((rc = launch_rect(h, s, v.rowmap[v.cur], v.nrows, O, 0, wfull))) return rc;
+    if ((rc = emit_enqueue(h, s, v.full))) return rc;
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipGetLastError());
+    bool again = false;
+    if ((rc = emit_check(h, s, v.full, false, again, false))) return rc;  // (no work list: nothing streams the replica)
+    if (!again) break;
+    if (attempt >= 3) return fail(CLIPPER_HIP_E_HIP, "row view replica: the build keeps overflowing");
+  }
+  v.full_valid = true;
+  return 0;
+}
+
+// Called by every rank of a multi-process solve when a view has just been built (the streams are drained, the hold
+// is about to be lifted). If the view is small enough, every rank builds the replica and plans the SAME units (the
+// plan is a function of the replica's directory, which is a function of the matrix); the ranks agree that all of
+// them can (one flag each through the exchange); a decide-only iteration (with its exchange, like any other) turns
+// the held decision into a prepared pass; every rank runs the launch — redundantly, on the same bits: no exchange
+// for the iterations inside it —; the ranks agree that every launch ran, and where one gave up (a unit that did
+// not become resident in time on that GPU) the others put the state back as it was before theirs: all ranks go on
+// alike, streaming. The iterations queued afterwards find the solve finished or carry on from the prepared pass
+// the launch left, exactly as on one shard.
+int rvr_replica_handover(Ctx* h, const SolverParams& prm) {
+  ViewResident& r = h->vres;
+  r.ready = false;
+  if (!h->multiproc || h->sh.size() != 1) return 0;
+  Shard& s = h->sh[0];
+  // (the same on every rank: mode, storage, window and the view's rows are; the back-off is, because it follows
+  // the AGREED outcome below)
+  if (!rvr_replica_enabled(h) || !s.rv.valid || s.rv.nrows < 1 || s.rv.nrows > RVR_MAXROWS) return 0;
+  int rc;
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  bool mine = false;
+  if ((rc = rvr_build_replica(h, s))) return rc;
+  if (s.rv.full_valid) {
+    if ((rc = rvr_plan(h, s, true))) return rc;
+    mine = r.ready;
+  }
+  bool all = false;
+  if ((rc = rvr_agree(h, mine, all))) return rc;
+  if (rs_debug())
+    std::fprintf(stderr, "[view-resident] replica: rows %lld, %.1f MB, this rank %s, all ranks %s\n", static_cast<long long>(s.rv.nrows),
+                 static_cast<double>(s.rv.full.s_bytes) / 1e6, mine ? "ready" : "not ready", all ? "ready" : "not ready");
+  if (!all) {
+    r.ready = false;
+    return 0;
+  }
+  h->decide_only = true;
+  rc = enqueue_iteration(h, prm);
+  h->decide_only = false;
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(s.device));
+  if (!r.backup) HIPCHK(hipMalloc(reinterpret_cast<void**>(&r.backup), sizeof(SolverState) + sizeof(SolveShared)));
+  HIPCHK(hipMemcpyAsync(r.backup, s.st + h->par, sizeof(SolverState), hipMemcpyDeviceToDevice, s.stream));
+  HIPCHK(hipMemcpyAsync(r.backup + sizeof(SolverState), s.shared, sizeof(SolveShared), hipMemcpyDeviceToDevice, s.stream));
+  bool launched = false;
+  const int slot = r.launches_this_solve;
+  if ((rc = rvr_enqueue(h, prm, launched))) return rc;
+  HIPCHK(hipStreamSynchronize(s.stream));
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const bool ran = launched && !(r.giveup_host && slot < RVR_GIVEUP_SLOTS && static_cast<volatile uint32_t*>(r.giveup_host)[slot] != 0u);
+  bool all_ran = false;
+  if ((rc = rvr_agree(h, ran, all_ran))) return rc;
+  if (!all_ran) {
+    if (ran) {  // another rank's launch gave up: this rank's never happened
+      HIPCHK(hipMemcpyAsync(s.st + h->par, r.backup, sizeof(SolverState), hipMemcpyDeviceToDevice, s.stream));
+      HIPCHK(hipMemcpyAsync(s.shared, r.backup + sizeof(SolverState), sizeof(SolveShared), hipMemcpyDeviceToDevice, s.stream));
+      if (r.giveup_host && slot < RVR_GIVEUP_SLOTS) r.giveup_host[slot] = RVR_ERR_PEER;  // (counted as a give-up on every rank: they back off together)
+    }
+    r.ready = false;
+  }
+  h->rv_stats.build_ms += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
   return 0;
 }
 

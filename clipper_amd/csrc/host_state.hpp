@@ -148,6 +148,11 @@ struct RowView {
   int64_t nrows = 0;
   bool valid = false;
   bool plan_pending = false;    // the work list of the streamed pass is not planned yet (the resident solver took the view)
+  // Column shards: the REPLICA of a small view — the slices of M[rows, ALL columns], on every rank (a few MB, scored
+  // from the replicated points) — which the resident solver on a view runs on, redundantly and identically on every
+  // rank, while `st` (this shard's columns) serves the streamed passes around it (host_rv_resident.hpp)
+  SliceStore full;
+  bool full_valid = false;
 };
 
 // ---- one column slice of M on one device ------------------------------------------------
@@ -233,6 +238,9 @@ struct ViewResident {
   int launches_this_solve = 0;
   int cooldown = 0, cooldown_next = 1;
   int max_units_device = -1;         // workgroups of the kernel the device holds at once (occupancy query; -1: not asked yet)
+  bool on_replica = false;           // the plan is of RowView::full (column shards), not of the shard's own view
+  uint8_t* backup = nullptr;         // column shards: SolverState + SolveShared as they were before a launch, restored on
+                                     // the ranks whose launch ran when another rank's gave up (all ranks go on alike)
 };
 constexpr int RVR_GIVEUP_SLOTS = 16;
 

@@ -92,7 +92,7 @@ struct RvrArgs {
   uint8_t* kind;                // their pinned copy — a launch that ENDS the solve hands them over, as decide() does
   int64_t marks_n;              // the iterations queued before this launch
 };
-enum : uint32_t { RVR_ERR_LDS = 1, RVR_ERR_TIMEOUT = 2, RVR_ERR_STATE = 3 };
+enum : uint32_t { RVR_ERR_LDS = 1, RVR_ERR_TIMEOUT = 2, RVR_ERR_STATE = 3, RVR_ERR_PEER = 4 /* host: another rank's launch gave up */ };
 
 __host__ __device__ constexpr uint32_t rvr_xt_bytes(int V, int nrows) {
   const uint32_t xt = static_cast<uint32_t>((nrows + 127) / 128 * 128) * V * 8u;

@@ -143,6 +143,7 @@ def table():
     print("|---|---|---|---|---|---|---|" + "---|" * len(cols))
     n_or = n_dis = 0
     agree_cnt = {c: [0, 0] for c in cols}
+    both_cnt = {c: [0, 0] for c in cols}   # on the problems where the two oracles agree: equal to them / cases
     for c in load_cases():
         k = (c["m"], c["seed"])
         if k not in cpu:
@@ -163,6 +164,9 @@ def table():
             sa, sb = same(g, a), same(g, b)
             agree_cnt[col][0] += 1 if (sa or sb) else 0
             agree_cnt[col][1] += 1
+            if ok:
+                both_cnt[col][0] += 1 if (sa and sb) else 0
+                both_cnt[col][1] += 1
             cells.append(f"{g['ifinal']}, {g['score']:.6f}, {g['trials']} " + ("= both" if sa and sb else "= C++" if sa else "= numpy" if sb else "**neither**"))
         print(f"| {c['m']} | {c['rho']} | {c['seed']} | {ptxt} | {a['ifinal']}, {a['score']:.6f}, {a['trials']} | "
               f"{b['ifinal']}, {b['score']:.6f}, {b['trials']} | {'yes' if ok else '**NO**'} | " + " | ".join(cells) + " |")
@@ -170,7 +174,8 @@ def table():
     print(f"{n_or} problems; the two oracles disagree with each other on {n_dis}.")
     for col in cols:
         if agree_cnt[col][1]:
-            print(f"{col}: equal to at least one oracle on {agree_cnt[col][0]} of {agree_cnt[col][1]}")
+            print(f"{col}: equal to at least one oracle on {agree_cnt[col][0]} of {agree_cnt[col][1]}; "
+                  f"on the {both_cnt[col][1]} problems where the oracles agree with each other: equal to them on {both_cnt[col][0]}")
 
 
 if __name__ == "__main__":

@@ -128,11 +128,12 @@ def main():
     # 6 row views: every rank built its columns of the same views and ran the same passes on them
     st = g.view_stats()
     vs = [None] * world
-    tdist.all_gather_object(vs, (int(st.builds), int(st.rows), int(st.view_passes)))
+    tdist.all_gather_object(vs, (int(st.builds), int(st.rows), int(st.view_passes), int(st.resident_launches), int(st.resident_giveups)))
     want_views = a.m >= 3000 and a.storage != "f32"
     report(6, (len(set(vs)) == 1) and (not want_views or (st.builds >= 1 and st.view_passes >= 1)),
            f"views built {st.builds} (last: {st.rows} rows, {st.bytes / 1e6:.1f} MB on this rank), passes on a view {st.view_passes} of "
-           f"{st.passes}, view pass on this rank's shard {st.view_pass_avg_us:.1f} us; per rank (builds, rows, view passes): {vs}")
+           f"{st.passes}, view pass on this rank's shard {st.view_pass_avg_us:.1f} us; resident launches on the view's replica "
+           f"{st.resident_launches} (gave up: {st.resident_giveups}); per rank (builds, rows, view passes, resident launches, give-ups): {vs}")
     g.close()
     tdist.barrier()
     tdist.destroy_process_group()
