@@ -30,10 +30,14 @@ Prints ONE JSON line on rank 0 (see the contract in the task statement), extende
                  roofline figure. `regime` says whether those bytes fit the 256 MiB Infinity
                  Cache (then every pass after the first is served on-die and "hbm" names the
                  peak it is normalised by, not the wire it crossed). `traffic` = HBM-side bytes
-                 per launch from the PMC run recorded in profiles/pmc_r04.json
+                 per launch from the PMC run recorded in profiles/pmc_r05.json
                  (`traffic_source` names the entry and the commit it was measured at).
                  --storage f32: k_gemv on the dense store, bytes per launch = 4*m*W
   "roofline_affinity"  the fill kernel: bytes of M written per build / its duration.
+  "roofline_resident"  k_solve_view_resident, the launch that runs the iterations on the row view inside the chip's LDS
+                 (25 of the headline's 36 passes): its duration (device wall clock in every timed step; HIP events
+                 around it in one extra, untimed solve), its iterations, the LDS bytes an iteration reads against
+                 the LDS peak, and what its waves do meanwhile (PMC record: LDS-busy and waiting shares).
   "cpu_baseline" the oracle (oracle/libclipper_ref.so, a port of the reference) timed on
                  this box's host cores on the same problem, median of 3 (rank 0, N = 1 only).
 """
@@ -50,11 +54,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PMC_RECORD = "profiles/pmc_r04.json"
+PMC_RECORD = "profiles/pmc_r05.json"
+LDS_PEAK_TBPS = 150.0   # 256 CUs x 256 B/clk x ~2.4 GHz for ds_read_b64 / b128 (MI355X_MICROARCH.md, LDS)
 # the sources of the kernels the PMC record is about (the pass, its decision, the planner that cuts its work, the
 # fill): a record is quoted only if it was measured on exactly these bytes
 PMC_SOURCES = ("clipper_amd/csrc/k_slices.hip.h", "clipper_amd/csrc/k_solver.hip.h", "clipper_amd/csrc/host_plan.hpp",
-               "clipper_amd/csrc/k_affinity.hip.h", "clipper_amd/csrc/k_csc.hip.h")
+               "clipper_amd/csrc/k_affinity.hip.h", "clipper_amd/csrc/k_csc.hip.h", "clipper_amd/csrc/k_rv_resident.hip.h",
+               "clipper_amd/csrc/k_resident.hip.h")
 
 
 def kernel_sources_sha256():
@@ -180,7 +186,8 @@ def main():
             g.affinity_euclidean_staged(**inv)
             g.solve_staged()
         g.set_profiling(profile)
-        r = dict(aff_ms=[], solve_ms=[], gemv_us=0.0, gemv_n=0, view_us=0.0, view_n=0, xchg_us=0.0, xchg_n=0)
+        r = dict(aff_ms=[], solve_ms=[], gemv_us=0.0, gemv_n=0, view_us=0.0, view_n=0, xchg_us=0.0, xchg_n=0,
+                 res_us=0.0, res_iters=0, res_launches=0, res_giveups=0)
         barrier_sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -199,6 +206,10 @@ def main():
             r["view_n"] += vs.view_pass_samples
             r["xchg_us"] += tm.exchange_avg_us * tm.exchange_samples
             r["xchg_n"] += tm.exchange_samples
+            r["res_us"] += vs.resident_us
+            r["res_iters"] += vs.resident_iterations
+            r["res_launches"] += vs.resident_launches
+            r["res_giveups"] += vs.resident_giveups
         barrier_sync()
         elapsed = time.perf_counter() - t0
         g.set_profiling(False)
@@ -229,6 +240,17 @@ def main():
     host_ms = (time.perf_counter() - th0) * 1e3 / args.steps
     if N > 1:
         host_ms = cdist.max_over_ranks(host_ms)
+
+    # One more solve, untimed, with a HIP event pair around every launch of the resident solver on a view
+    # (profiling level 2: the pair costs stream time, which is why it is not in the timed region)
+    res_event = None
+    if N == 1 and not args.no_profile:
+        g.set_profiling(2)
+        g.affinity_euclidean_staged(**inv)
+        g.stage_u0(problem.u0)
+        g.solve_staged()
+        res_event = g.view_stats()
+        g.set_profiling(False)
 
     # The same step at the size whose pass is HBM-bound and whose column shards scale:
     # recorded beside the headline for every N, so that a scaling run shows a curve that CAN scale
@@ -272,7 +294,7 @@ def main():
         # from profiles/pmc_r04.json, written by tools/pmc_summary.py from a rocprofv3 --pmc run of this
         # same command, with the commit, the kernel's byte count and the sha256 of the kernel sources at that
         # time. A record taken on other sources or other bytes than today's is NOT quoted.
-        traffic, traffic_source, issue = None, None, None
+        traffic, traffic_source, issue, resident_pmc = None, None, None, None
         pmc = os.path.join(ROOT, PMC_RECORD)
         if os.path.exists(pmc):
             try:
@@ -286,7 +308,7 @@ def main():
                 if stale_bytes or sha_then != sha_now:
                     print(f"bench.py: {PMC_RECORD} was measured on other kernel sources or bytes ({then} bytes per pass then, "
                           f"{tm.gemv_bytes} today; sources {str(sha_then)[:12]} then, {sha_now[:12]} today): STALE, not quoted — "
-                          f"re-run tools/gpu_prof_r04.sh", file=sys.stderr, flush=True)
+                          f"re-run tools/gpu_prof.sh", file=sys.stderr, flush=True)
                     traffic_source = {"file": PMC_RECORD, "stale": True, "kernel_bytes_then": then,
                                       "kernel_sources_sha256_then": sha_then, "kernel_sources_sha256_now": sha_now}
                 else:
@@ -297,6 +319,7 @@ def main():
                                       "read_bytes": rec.get("pass_read_bytes"), "written_bytes": rec.get("pass_written_bytes"),
                                       "how": rec.get("how")}
                     issue = rec.get("affinity_issue")
+                    resident_pmc = rec.get("resident")
         useful = tm.gemv_useful_bytes
         achieved_useful = useful / (gemv_avg_us * 1e-6) / 1e9 if gemv_avg_us > 0 else 0.0
         regime = ("Infinity-Cache-resident: %.0f MB per pass < 256 MiB, re-read every pass — served "
@@ -304,6 +327,38 @@ def main():
                   if gemv_bytes < 256 * 2 ** 20 else "HBM-streaming: %.2f GB per pass" % (gemv_bytes / 1e9))
         aff_kernel_ms = tm.affinity_kernel_ms
         aff_achieved = tm.affinity_bytes / (aff_kernel_ms * 1e-3) / 1e9 if aff_kernel_ms > 0 else 0.0
+        roofline_resident = None
+        if R["res_launches"] > 0 and R["res_iters"] > 0:
+            V = g.window
+            ent = int(vstats.resident_entries)
+            esz = 8 if in_use == "csc64" else 4
+            # per stored entry and iteration: its value and row byte out of the unit's slices (quads of 4 values + 4 row
+            # bytes) + ceil(V / 2) ds_read_b128 gathers of the candidates' rows of the X table (16 bytes each)
+            lds_bytes = ent * (esz + 1.0 + 16.0 * ((V + 1) // 2))
+            it_us = R["res_us"] / R["res_iters"]
+            ach = lds_bytes / (it_us * 1e-6) / 1e12 if it_us > 0 else 0.0
+            units = int(vstats.resident_units)
+            peak_units = LDS_PEAK_TBPS * units / max(1, cus)
+            roofline_resident = {
+                "kernel": "k_solve_view_resident", "launches_per_solve": R["res_launches"] / args.steps,
+                "gave_up": R["res_giveups"],
+                "launch_us": round(R["res_us"] / R["res_launches"], 2),
+                "launch_us_hip_events": (round(res_event.resident_event_us / max(1, res_event.resident_launches), 2)
+                                         if res_event is not None and res_event.resident_launches > 0 else None),
+                "iterations_per_launch": R["res_iters"] / R["res_launches"],
+                "us_per_iteration": round(it_us, 3),
+                "units": units, "view_rows": int(vstats.rows), "view_bytes": int(vstats.bytes), "view_entries": ent,
+                "bound": "latency (a dependent chain per iteration: X table -> pass over the unit's slices in LDS -> "
+                         "tail -> publish -> poll -> sums -> decision), not a pipe: see `waves`",
+                "lds": {"bytes_per_iteration": lds_bytes, "achieved": round(ach, 2), "peak": round(peak_units, 1),
+                        "unit": "TB/s", "frac": round(ach / peak_units, 4) if peak_units > 0 else None,
+                        "peak_note": f"{LDS_PEAK_TBPS} TB/s chip-wide for ds_read_b64/b128 (256 B/clk/CU at 2.4 GHz) x {units}/{cus} CUs in use",
+                        "bytes_note": "stored entries x (value + row byte + ceil(V/2) x 16-byte gathers of X rows)"},
+                "waves": resident_pmc,   # PMC record: LDS-busy share of the launch's cycles, share of wave cycles spent waiting
+                "how": "launch_us: the device's 100 MHz wall clock, unit 0's first instruction to the last unit's commit, "
+                       "every timed step (free); launch_us_hip_events: hipEvent pair around the launch on its stream, one "
+                       "extra untimed solve",
+            }
         out = {
             "metric": "affinity+solve ms and GEMV HBM GB/s, n=10k assoc, 95% outliers, 1/8 GPU",
             "value": round(ms_per_step, 4),
@@ -365,10 +420,11 @@ def main():
                         "view of <= 1024 rows that fits the chip's LDS, run inside ONE resident launch (DESIGN.md 3d)",
                 "passes_on_view": int(vstats.view_passes), "passes": int(sol.n_passes), "views_built": int(vstats.builds),
                 "rows": int(vstats.rows), "bytes": int(vstats.bytes), "build_ms": round(vstats.build_ms, 4),
-                "resident_launches": int(vstats.resident_launches),
+                "resident_launches": int(vstats.resident_launches), "resident_giveups": int(vstats.resident_giveups),
                 # HIP events around streamed view passes; none when the view's iterations ran inside the resident launch
                 "pass_on_view_us": round(R["view_us"] / R["view_n"], 2) if R["view_n"] > 0 else None,
             },
+            "roofline_resident": roofline_resident,
             "scaling_probe": probe,
             "scaling_probe_cfg5": probe_cfg5,
         }

@@ -100,6 +100,8 @@ class ViewStats(C.Structure):
         ("view_passes", C.c_int64), ("passes", C.c_int64), ("build_ms", C.c_double),
         ("view_pass_avg_us", C.c_double), ("view_pass_samples", C.c_int64),
         ("resident_launches", C.c_int64), ("resident_giveups", C.c_int64),
+        ("resident_iterations", C.c_int64), ("resident_us", C.c_double), ("resident_event_us", C.c_double),
+        ("resident_entries", C.c_int64), ("resident_units", C.c_int64),
     ]
 
 
@@ -451,7 +453,8 @@ class HipClipper:
     def storage_in_use(self) -> int:
         return int(self.L.clipper_hip_storage_in_use(self.h))
 
-    def set_profiling(self, on: bool):
+    def set_profiling(self, on):
+        """False / True, or 2: also HIP events around the launches of the resident solver on a view."""
         self._check(self.L.clipper_hip_set_profiling(self.h, int(on)))
 
     def timings(self) -> Timings:

@@ -1421,6 +1421,7 @@ int clipper_hip_view_matvec(clipper_hip_t* h, const int32_t* rows, int64_t nrows
 int clipper_hip_set_profiling(clipper_hip_t* h, int on) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
   h->profiling = (on != 0);
+  h->profiling_level = on;  // 2: also an event pair around every launch of the resident solver on a view
   if (h->profiling && h->ev_pairs.empty()) {  // here, not inside the first profiled solve (~1 ms)
     HIPCHK(hipSetDevice(h->sh[0].device));
     h->ev_pairs.resize(2 * MAX_EVENT_PAIRS);

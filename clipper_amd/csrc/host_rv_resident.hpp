@@ -11,6 +11,8 @@ void rvr_free(Ctx* h) {
   if (r.ctl) hipFree(r.ctl);
   if (r.giveup_host) hipHostFree(r.giveup_host);
   if (r.backup) hipFree(r.backup);
+  for (hipEvent_t e : r.ev)
+    if (e) hipEventDestroy(e);
   const unsigned long long ep = r.epoch;
   const int tu = r.target_units, cd = r.cooldown, cn = r.cooldown_next, mu = r.max_units_device;
   r = ViewResident{};
@@ -25,7 +27,8 @@ void rvr_free(Ctx* h) {
 void rvr_begin_solve(Ctx* h) {
   ViewResident& r = h->vres;
   r.launches_this_solve = 0;
-  if (r.giveup_host) std::memset(r.giveup_host, 0, RVR_GIVEUP_SLOTS * sizeof(uint32_t));
+  r.ev_n = 0;
+  if (r.giveup_host) std::memset(r.giveup_host, 0, RVR_GIVEUP_SLOTS * 4 * sizeof(uint32_t));
   std::atomic_thread_fence(std::memory_order_seq_cst);
 }
 
@@ -38,7 +41,21 @@ void rvr_end_solve(Ctx* h) {
   std::atomic_thread_fence(std::memory_order_acquire);
   int gave_up = 0;
   volatile const uint32_t* w = r.giveup_host;
-  for (int k = 0; k < std::min(r.launches_this_solve, RVR_GIVEUP_SLOTS); ++k) gave_up += (w[k] != 0u) ? 1 : 0;
+  for (int k = 0; k < std::min(r.launches_this_solve, RVR_GIVEUP_SLOTS); ++k) {
+    if (w[4 * k] != 0u) {
+      ++gave_up;
+    } else {  // a launch that ran: its iterations and its duration by the device's wall clock (100 MHz)
+      h->rv_stats.resident_iterations += static_cast<int64_t>(w[4 * k + 1]);
+      h->rv_stats.resident_us += static_cast<double>(static_cast<uint64_t>(w[4 * k + 2]) | (static_cast<uint64_t>(w[4 * k + 3]) << 32)) * 1e-2;
+    }
+  }
+  for (int k = 0; k < r.ev_n; ++k) {  // (profiling level 2; a launch that gave up is in the sum: it took the time)
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.ev[2 * k], r.ev[2 * k + 1]) == hipSuccess) h->rv_stats.resident_event_us += static_cast<double>(ms) * 1e3;
+    else (void)hipGetLastError();
+  }
+  h->rv_stats.resident_entries = static_cast<int64_t>(r.plan_entries);
+  h->rv_stats.resident_units = r.nunits;
   if (gave_up > 0) {
     h->rv_stats.resident_launches -= gave_up;
     h->rv_stats.resident_giveups += gave_up;
@@ -152,11 +169,12 @@ int rvr_plan(Ctx* h, Shard& s, bool replica = false) {
   }
   if (!r.ctl) HIPCHK(hipMalloc(&r.ctl, 64));
   if (!r.giveup_host) {
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r.giveup_host), RVR_GIVEUP_SLOTS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r.giveup_host), RVR_GIVEUP_SLOTS * 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.giveup_host_dev), r.giveup_host, 0));
-    std::memset(r.giveup_host, 0, RVR_GIVEUP_SLOTS * sizeof(uint32_t));
+    std::memset(r.giveup_host, 0, RVR_GIVEUP_SLOTS * 4 * sizeof(uint32_t));
   }
   r.nunits = static_cast<int>(plan.units.size());
+  r.plan_entries = plan.entries;
   r.lds_slices = plan.lds_slices;
   r.ready = true;
   return 0;
@@ -214,7 +232,7 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   a.epoch0 = r.epoch;
   r.epoch += 1ull << 20;  // whatever this launch publishes (even if it gives up half-way) lies below the next one's
   a.ctl = r.ctl;
-  a.giveup_host = (r.giveup_host_dev && r.launches_this_solve < RVR_GIVEUP_SLOTS) ? r.giveup_host_dev + r.launches_this_solve : nullptr;
+  a.giveup_host = (r.giveup_host_dev && r.launches_this_solve < RVR_GIVEUP_SLOTS) ? r.giveup_host_dev + 4 * r.launches_this_solve : nullptr;
   a.lds_slices = r.lds_slices;
   // The longest a unit waits for the others' granules of ONE exchange, on the 100 MHz wall clock: 2 ms — a hundred
   // iterations' worth (an iteration is 14 us, the first exchange comes 25 us into the launch). A unit that is not
@@ -231,6 +249,12 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   a.rv_rows = static_cast<int>(s.rv.nrows);
   a.stamps = h->stamps_dev;
   HIPCHK(hipMemsetAsync(r.ctl, 0, 64, s.stream));
+  const bool timed = h->profiling_level >= 2 && r.ev_n < 16;
+  if (timed) {
+    for (int k = 0; k < 2; ++k)
+      if (!r.ev[2 * r.ev_n + k]) HIPCHK(hipEventCreate(&r.ev[2 * r.ev_n + k]));
+    HIPCHK(hipEventRecord(r.ev[2 * r.ev_n], s.stream));
+  }
   int lr = 1;
   dispatch_vt(h, [&](auto tag) {
     using VT = decltype(tag);
@@ -239,6 +263,10 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   if (lr != 0) {
     r.ready = false;  // this device does not take the launch: the streaming launches keep the view
     return 0;
+  }
+  if (timed) {
+    HIPCHK(hipEventRecord(r.ev[2 * r.ev_n + 1], s.stream));
+    ++r.ev_n;
   }
   launched = true;
   r.launches_this_solve += 1;
@@ -338,14 +366,14 @@ int rvr_replica_handover(Ctx* h, const SolverParams& prm) {
   if ((rc = rvr_enqueue(h, prm, launched))) return rc;
   HIPCHK(hipStreamSynchronize(s.stream));
   std::atomic_thread_fence(std::memory_order_acquire);
-  const bool ran = launched && !(r.giveup_host && slot < RVR_GIVEUP_SLOTS && static_cast<volatile uint32_t*>(r.giveup_host)[slot] != 0u);
+  const bool ran = launched && !(r.giveup_host && slot < RVR_GIVEUP_SLOTS && static_cast<volatile uint32_t*>(r.giveup_host)[4 * slot] != 0u);
   bool all_ran = false;
   if ((rc = rvr_agree(h, ran, all_ran))) return rc;
   if (!all_ran) {
     if (ran) {  // another rank's launch gave up: this rank's never happened
       HIPCHK(hipMemcpyAsync(s.st + h->par, r.backup, sizeof(SolverState), hipMemcpyDeviceToDevice, s.stream));
       HIPCHK(hipMemcpyAsync(s.shared, r.backup + sizeof(SolverState), sizeof(SolveShared), hipMemcpyDeviceToDevice, s.stream));
-      if (r.giveup_host && slot < RVR_GIVEUP_SLOTS) r.giveup_host[slot] = RVR_ERR_PEER;  // (counted as a give-up on every rank: they back off together)
+      if (r.giveup_host && slot < RVR_GIVEUP_SLOTS) r.giveup_host[4 * slot] = RVR_ERR_PEER;  // (counted as a give-up on every rank: they back off together)
     }
     r.ready = false;
   }

@@ -233,7 +233,11 @@ struct ViewResident {
   // launch of the solve; the host reads them when the solve is over, counts, and BACKS OFF: the next `cooldown` solves
   // of this context stream their views, twice as many after every solve with a give-up (at most 64), one again
   // after a solve whose launches all ran.
-  uint32_t* giveup_host = nullptr;   // pinned + mapped [RVR_GIVEUP_SLOTS]
+  uint32_t* giveup_host = nullptr;   // pinned + mapped [RVR_GIVEUP_SLOTS][4]: per launch of the solve {error word, iterations,
+                                     // duration in wall-clock ticks (lo, hi)} — RvrArgs::giveup_host
+  hipEvent_t ev[2 * 16] = {};        // profiling level 2: event pairs around the launches of a solve
+  int ev_n = 0;
+  uint64_t plan_entries = 0;         // stored entries of the view the plan is of
   uint32_t* giveup_host_dev = nullptr;
   int launches_this_solve = 0;
   int cooldown = 0, cooldown_next = 1;
@@ -330,6 +334,7 @@ struct clipper_hip_ctx {
   long long* stamps_dev = nullptr;  // CLIPPER_HIP_STAMPS=1: [4096][4], see SolveArgs::stamps; =2: [16384][4]
   int stamps_rows = 4096;
   bool profiling = false;
+  int profiling_level = 0;
   std::vector<hipEvent_t> ev_pairs;  // 2*MAX_EVENT_PAIRS, created by clipper_hip_set_profiling
   std::vector<int64_t> ev_launch_index;  // which mat-vec launch of the solve each pair timed
   std::vector<hipEvent_t> ev_xchg;       // 2*MAX_EVENT_PAIRS: around the exchange of the same iterations

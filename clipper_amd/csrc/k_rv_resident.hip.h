@@ -79,9 +79,11 @@ struct RvrArgs {
   double* pt;                   // point slots [2][V][2][mp]
   unsigned long long* xb;       // [2][(V + 2) * RVR_MAXROWS + RVR_MAXUNITS][2] granules, zero at allocation
   unsigned long long epoch0;
-  uint32_t* ctl;                // [0] error word, [1] arrivals at the exit (zero at launch)
-  uint32_t* giveup_host;        // pinned (may be null): the error word of a launch that gave up, for the host to read
-                                // after the solve (it counts them and backs off: host_rv_resident.hpp)
+  uint32_t* ctl;                // [0] error word, [1] arrivals at the exit (zero at launch), [4..5] unit 0's start (wall clock)
+  uint32_t* giveup_host;        // pinned (may be null), 4 words of this launch for the host to read after the solve:
+                                // [0] the error word of a launch that gave up (the host counts them and backs off:
+                                // host_rv_resident.hpp); a launch that ran: [1] its iterations (exchanges), [2..3] its
+                                // duration — unit 0's first instruction to the last unit's commit, 100 MHz wall-clock ticks
   uint32_t lds_slices;          // bytes of LDS the slices of a unit may take
   long long timeout_ticks;      // longest wait for the other units' granules, 100 MHz wall clock
   int max_exchanges;            // leave to the streaming launches after this many
@@ -208,7 +210,9 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   off += RVR_TAB_BYTES;
   uint8_t* sl = rvr_lds + off;
 
-  const long long ts0 = A.stamps ? wall_clock64() : 0;
+  const long long ts0 = wall_clock64();
+  if (unit == 0 && tid == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(A.ctl + 4), static_cast<unsigned long long>(ts0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- the state this launch starts from: a prepared pass, or nothing to do here --------------------
   const SolverState* st = A.st;
   const int e_done = A.shared->done, e_hold = st->hold, e_stage = st->stage, e_resume = st->resume;
@@ -440,6 +444,15 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
     __syncthreads();
     return words[1] != 0u;
   };
+  auto report_run = [&]() __attribute__((always_inline)) {  // (the committing thread) iterations and duration of the launch, to the host
+    if (A.giveup_host) {
+      const unsigned long long t_begin = __hip_atomic_load(reinterpret_cast<unsigned long long*>(A.ctl + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long dt = static_cast<unsigned long long>(wall_clock64()) - t_begin;
+      __hip_atomic_store(A.giveup_host + 1, static_cast<uint32_t>(exchanges), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(A.giveup_host + 2, static_cast<uint32_t>(dt & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(A.giveup_host + 3, static_cast<uint32_t>(dt >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  };
   auto write_point = [&](bool to_host) __attribute__((always_inline)) {
     double* Ux = A.pt + ((static_cast<int64_t>(e_ubp ^ 1) * V + 0) * 2 + 0) * mp;
     double* Gx = A.pt + ((static_cast<int64_t>(e_ubp ^ 1) * V + 0) * 2 + 1) * mp;
@@ -520,6 +533,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
         o->hold_slot = 0;
         o->hold_nlive = 0;
         o->resume = resume;
+        report_run();
         if (A.host) {
           HostMirror* hm = A.host;
           __hip_atomic_store(&hm->nlive, nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -959,6 +973,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
         sh->ubp = e_ubp ^ 1;
         sh->ubv = 0;
         sh->done = 1;
+        report_run();
         if (A.host) {
           HostMirror* hm = A.host;
           __hip_atomic_store(&hm->F, F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

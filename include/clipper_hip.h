@@ -108,6 +108,13 @@ typedef struct clipper_hip_view_stats_t {
                                 within the exchange's time-out — e.g. another tenant on the device —, a refused LDS
                                 plan): the streaming launches did their work; the context then streams the views of
                                 its next solves (1, 2, 4, ... 64 of them) before it tries again              */
+  int64_t resident_iterations; /* solver iterations (one exchange each) that ran inside the launches that ran  */
+  double resident_us;          /* their duration on the device's own wall clock: unit 0's first instruction to
+                                  the last unit's commit (100 MHz ticks; free, always on)                      */
+  double resident_event_us;    /* the same by HIP events around the launches (clipper_hip_set_profiling(h, 2):
+                                  an event pair costs stream time, so not in a timed region); 0 = not timed   */
+  int64_t resident_entries;    /* stored entries (quads x 4, padding included) of the view the last launch ran on */
+  int64_t resident_units;      /* workgroups (one per CU: each holds its columns of the view in LDS) of that launch */
 } clipper_hip_view_stats_t;
 
 /* ---- life cycle --------------------------------------------------------------------- */
@@ -305,8 +312,9 @@ int clipper_hip_matvec(clipper_hip_t* h, const double* x, double* yM, double* yC
 
 /* ---- measurement ---------------------------------------------------------------------- */
 
-/* When on, every mat-vec launch of a solve is bracketed by HIP events on the stream it
- * runs on; clipper_hip_get_timings then reports their mean / min duration. */
+/* When on (1), sampled mat-vec launches of a solve are bracketed by HIP events on the stream they
+ * run on; clipper_hip_get_timings then reports their mean / min duration. 2: also an event pair around
+ * every launch of the resident solver on a row view (clipper_hip_view_stats_t::resident_event_us). */
 int clipper_hip_set_profiling(clipper_hip_t* h, int on);
 int clipper_hip_get_timings(const clipper_hip_t* h, clipper_hip_timings_t* out);
 /* Launches the mat-vec kernel `reps` times back to back on resident data and returns the

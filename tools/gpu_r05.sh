@@ -15,7 +15,7 @@ for step in "$@"; do
     adj) timeout 900 python tools/maxiniters_adjudicate.py gpu > $OUT/adj_gpu.log 2>&1; echo "adj rc=$?" >> $OUT/summary.txt; tail -2 $OUT/adj_gpu.log | cut -c1-300 ;;
     hosttiming) CLIPPER_HIP_HOST_TIMING=1 timeout 120 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --probe-m 0 --no-profile > /dev/null 2> $OUT/host_timing.txt; grep "^\[solve\] init" $OUT/host_timing.txt | tail -3 ;;
     rvrtimeline) CLIPPER_HIP_STAMPS=1 timeout 120 python tools/rvr_timeline.py > $OUT/rvr_timeline.txt 2>&1; tail -20 $OUT/rvr_timeline.txt ;;
-    prof:*) bash tools/gpu_prof_r04.sh $S local "${step#prof:}" > $OUT/prof_session.txt 2>&1; tail -5 $OUT/prof_session.txt ;;
+    prof:*) bash tools/gpu_prof.sh $S $(cat .commit_for_prof 2>/dev/null || echo unknown) "${step#prof:}" > $OUT/prof_session.txt 2>&1; tail -5 $OUT/prof_session.txt ;;
     cmd:*) bash -c "${step#cmd:}" > $OUT/cmd_$(date +%s).txt 2>&1; tail -30 $OUT/cmd_*.txt | tail -40 ;;
   esac
   echo "[$step] $(( $(date +%s) - t0 )) s" | tee -a $OUT/summary.txt

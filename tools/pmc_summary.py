@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """PMC counters of a rocprofv3 --pmc run of bench.py, per kernel, and the record bench.py quotes
-(profiles/pmc_r04.json). The pass kernel is launched for passes on M, for passes on a row view
+(profiles/pmc_r05.json). The pass kernel is launched for passes on M, for passes on a row view
 (far fewer bytes) and for iterations that do nothing: a launch counts as a PASS ON M when it runs at
 least 0.6 x the longest launch of that kernel in the run.
-  tools/pmc_summary.py --key m10000_csc --bytes <bytes per pass> --commit <sha> --json profiles/pmc_r04.json <db> [...]"""
+  tools/pmc_summary.py --key m10000_csc --bytes <bytes per pass> --commit <sha> --json profiles/pmc_r05.json <db> [...]"""
 import argparse
 import json
 import os
@@ -72,6 +72,27 @@ def main():
             e["pass_instruction_mix"] = {c: s[c]["median"] for c in sorted(mixc)}
         if "SQ_LDS_BANK_CONFLICT" in s and "SQ_LDS_IDX_ACTIVE" in s and s["SQ_LDS_IDX_ACTIVE"]["median"] > 0:
             e["pass_lds_conflict_share"] = s["SQ_LDS_BANK_CONFLICT"]["median"] / s["SQ_LDS_IDX_ACTIVE"]["median"]
+    rk = next((k for k in summary if k.startswith("k_solve_view_resident")), None)
+    if rk:   # the resident solver on a row view: what its waves do (one launch per solve: the median over the run's solves)
+        s = summary[rk]
+        r = {"kernel": rk}
+        for c in ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                  "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "GRBM_GUI_ACTIVE"):
+            if c in s:
+                r[c] = s[c]["median"]
+                r.setdefault("kernel_us_under_the_profiler", s[c]["median_duration_us"])
+        if "SQ_WAIT_ANY" in r and r.get("SQ_WAVE_CYCLES", 0) > 0:
+            r["waiting_share_of_wave_cycles"] = r["SQ_WAIT_ANY"] / r["SQ_WAVE_CYCLES"]
+        if "SQ_LDS_IDX_ACTIVE" in r and "kernel_us_under_the_profiler" in r:
+            # SQ_LDS_IDX_ACTIVE sums the LDS-array cycles of every CU that ran a unit; the launch lasts us x clock cycles on
+            # each of them (the clock from GRBM_GUI_ACTIVE / wall time where recorded, else 2.4 GHz)
+            us = r["kernel_us_under_the_profiler"]
+            clk = (r["GRBM_GUI_ACTIVE"] / (us * 1e-6)) if r.get("GRBM_GUI_ACTIVE", 0) > 0 else 2.4e9
+            r["clock_GHz"] = clk / 1e9
+            r["lds_busy_share_per_cu_cycle_at_246_units"] = r["SQ_LDS_IDX_ACTIVE"] / (246.0 * us * 1e-6 * clk)
+        if "SQ_LDS_BANK_CONFLICT" in r and r.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
+            r["lds_conflict_share"] = r["SQ_LDS_BANK_CONFLICT"] / r["SQ_LDS_IDX_ACTIVE"]
+        e["resident"] = r
     ak = next((k for k in summary if k.startswith("k_affinity_sym")), None) or next((k for k in summary if k.startswith("k_affinity")), None)
     if ak and "SQ_INSTS_VALU" in summary[ak]:
         s = summary[ak]
