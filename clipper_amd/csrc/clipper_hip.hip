@@ -876,6 +876,11 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     uint64_t spins = 0;
     h->rv_fresh = false;
     constexpr int run_ahead = RUN_AHEAD;
+    h->enqueue_one = [h, &prm]() { return enqueue_iteration(h, prm); };
+    struct ClearEnqueue {
+      Ctx* c;
+      ~ClearEnqueue() { c->enqueue_one = nullptr; }
+    } clear_enqueue{h};
     while (!hm->done) {
       if (hm->hold) {
         // The decision asked for a row view (k_solver.hip.h, LIVE ROWS) and put the solve on hold:
@@ -900,16 +905,21 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         bool built = false;
         if ((rc = rowview_build(h, built))) return rc;
         mark_t("view built");
-        h->rv_fresh = built;
+        const bool early = h->early_decide_done;  // the decide-only iteration went out behind the fill (host_rowview.hpp):
+        h->early_decide_done = false;             // the hold is lifted, rv_fresh was used by it
+        if (early) ++queued;
+        else h->rv_fresh = built;
         if (built && h->vres.ready) {
           // The view fits the LDS of the chip: the iterations on it run as ONE launch (k_rv_resident.hip.h).
           // A decide-only iteration turns the held decision into a prepared pass; the resident launch starts
           // from it and leaves a prepared pass (or the end of the solve) for whatever is queued behind it.
-          h->decide_only = true;
-          rc = enqueue_iteration(h, prm);
-          h->decide_only = false;
-          if (rc) return rc;
-          ++queued;
+          if (!early) {
+            h->decide_only = true;
+            rc = enqueue_iteration(h, prm);
+            h->decide_only = false;
+            if (rc) return rc;
+            ++queued;
+          }
           bool launched = false;
           if ((rc = rvr_enqueue(h, prm, launched))) return rc;
           mark_t("resident queued");

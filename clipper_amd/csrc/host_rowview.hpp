@@ -329,6 +329,9 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
   if (test_miscount && asked > 1) nrows = asked - 1;                                          // is sized one row short)
   bool counted = false;
   bool store_gone = false;  // the store of the view in use was overwritten by this build
+  bool early_done = false;  // the hold was lifted and the decide-only iteration queued behind the first fill (below)
+  const bool early_ok = h->enqueue_one != nullptr && h->sh.size() == 1 && !h->multiproc;
+  h->early_decide_done = false;
   if (asked <= 0 || asked > m) {
     HIPCHK(hipStreamSynchronize(s.stream));
     nrows = *h->rv_count;
@@ -362,6 +365,34 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
     else rc = launch_rect(h, s, v.rowmap[next], nrows, O);
     if (rc) return rc;
     if ((rc = emit_enqueue(h, s, v.st))) return rc;
+    // EARLY HAND-OVER (round 5). A view the resident solver may take, sized from the count the device asked with:
+    // everything the decide-only iteration needs of the view is known before the fill has run — the row flags and
+    // the list (queued above), the rows' number, the store's arrays — so the descriptor, the lift of the hold and
+    // the decide-only iteration itself are queued HERE, behind the fill, and run on the device while the host
+    // sleeps in its one wait and plans the units: the resident launch is the only thing left to queue afterwards
+    // (round 4: all of it after the wait — 25 us of launches and small kernels with the device idle). Should the
+    // fill turn out unusable (an arena that overflowed: the first view of a size; a count that differed: never
+    // seen) the view is built again below as before — the state has moved on to a prepared pass by then, which is
+    // what the launches after ANY build start from (iteration_head), on the view if there is one, on M if not.
+    if (early_ok && attempt == 0 && !counted && rvr_candidate(h, nrows)) {
+      const int cur0 = v.cur;
+      const int64_t nrows0 = v.nrows;
+      v.cur = next;
+      v.nrows = nrows;
+      v.valid = true;  // (provisional: the launches queued right here read the flags, the list and the rows' number)
+      v.st.s_nwork = 0;
+      if ((rc = rowview_put_descriptor(h, s))) return rc;
+      hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0);
+      h->rv_fresh = true;
+      h->decide_only = true;
+      rc = h->enqueue_one ? h->enqueue_one() : CLIPPER_HIP_E_INTERNAL;
+      h->decide_only = false;
+      if (rc) return rc;
+      early_done = true;
+      v.valid = false;
+      v.cur = cur0;
+      v.nrows = nrows0;
+    }
     HIPCHK(hipStreamSynchronize(s.stream));
     HIPCHK(hipGetLastError());
     lap("filled");
@@ -395,7 +426,8 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
     v.plan_pending = false;
   }
   if ((rc = rowview_put_descriptor(h, s))) return rc;  // (no work list yet while its plan is pending: no item for anybody)
-  hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0);
+  if (!early_done) hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0);
+  h->early_decide_done = early_done;
   h->rv_stats.build_ms +=
       std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
   return 0;

@@ -28,6 +28,13 @@ void rvr_begin_solve(Ctx* h) {
   ViewResident& r = h->vres;
   r.launches_this_solve = 0;
   r.ev_n = 0;
+  // the launches' control words (error word, arrivals, unit 0's start): one block per launch of a solve, all of them
+  // zeroed HERE, at the start of the solve, instead of by a memset in front of every launch (on the critical path)
+  if (r.ctl && r.ctl_dirty) {
+    Shard& s = h->sh[0];
+    if (hipSetDevice(s.device) == hipSuccess && hipMemsetAsync(r.ctl, 0, RVR_GIVEUP_SLOTS * 64, s.stream) == hipSuccess) r.ctl_dirty = false;
+    else (void)hipGetLastError();
+  }
   if (r.giveup_host) std::memset(r.giveup_host, 0, RVR_GIVEUP_SLOTS * 4 * sizeof(uint32_t));
   std::atomic_thread_fence(std::memory_order_seq_cst);
 }
@@ -167,7 +174,11 @@ int rvr_plan(Ctx* h, Shard& s, bool replica = false) {
     HIPCHK(hipMemsetAsync(r.xb, 0, xb_bytes, s.stream));  // no granule may carry a future epoch
     r.xb_bytes = xb_bytes;
   }
-  if (!r.ctl) HIPCHK(hipMalloc(&r.ctl, 64));
+  if (!r.ctl) {
+    HIPCHK(hipMalloc(&r.ctl, RVR_GIVEUP_SLOTS * 64));
+    HIPCHK(hipMemsetAsync(r.ctl, 0, RVR_GIVEUP_SLOTS * 64, s.stream));
+    r.ctl_dirty = false;
+  }
   if (!r.giveup_host) {
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r.giveup_host), RVR_GIVEUP_SLOTS * 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.giveup_host_dev), r.giveup_host, 0));
@@ -231,7 +242,8 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   }
   a.epoch0 = r.epoch;
   r.epoch += 1ull << 20;  // whatever this launch publishes (even if it gives up half-way) lies below the next one's
-  a.ctl = r.ctl;
+  const bool own_ctl = r.launches_this_solve < RVR_GIVEUP_SLOTS;  // (its block was zeroed when the solve began)
+  a.ctl = r.ctl + (own_ctl ? 16 * r.launches_this_solve : 0);
   a.giveup_host = (r.giveup_host_dev && r.launches_this_solve < RVR_GIVEUP_SLOTS) ? r.giveup_host_dev + 4 * r.launches_this_solve : nullptr;
   a.lds_slices = r.lds_slices;
   // The longest a unit waits for the others' granules of ONE exchange, on the 100 MHz wall clock: 2 ms — a hundred
@@ -248,7 +260,8 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   a.rvp = h->rvp;
   a.rv_rows = static_cast<int>(s.rv.nrows);
   a.stamps = h->stamps_dev;
-  HIPCHK(hipMemsetAsync(r.ctl, 0, 64, s.stream));
+  if (!own_ctl) HIPCHK(hipMemsetAsync(r.ctl, 0, 64, s.stream));  // (more launches in one solve than blocks: block 0, cleared each time)
+  r.ctl_dirty = true;
   const bool timed = h->profiling_level >= 2 && r.ev_n < 16;
   if (timed) {
     for (int k = 0; k < 2; ++k)

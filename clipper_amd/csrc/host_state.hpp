@@ -225,7 +225,8 @@ struct ViewResident {
   size_t off_np = 0, off_wc = 0, off_pc = 0;
   unsigned long long* xb = nullptr;  // exchange buffer (granules), zero at allocation
   size_t xb_bytes = 0;
-  uint32_t* ctl = nullptr;           // [0] error word, [1] arrivals at the exit
+  uint32_t* ctl = nullptr;           // [RVR_GIVEUP_SLOTS][16]: per launch of a solve [0] error word, [1] arrivals at the exit, [4..5] unit 0's start
+  bool ctl_dirty = false;            // a launch used a block since the blocks were last zeroed (rvr_begin_solve zeroes them)
   unsigned long long epoch = 0;      // every launch takes 2^20 epochs
   int target_units = 0;              // CLIPPER_HIP_VIEW_RESIDENT_WGS (0: automatic)
   // Launches that gave up (an exchange that timed out: a unit that did not become resident in time — another tenant
@@ -309,6 +310,9 @@ struct clipper_hip_ctx {
   Resident res;
   ViewResident vres;
   bool decide_only = false;  // the next iteration's G launch only decides (hand-over to the resident solver on a view)
+  std::function<int()> enqueue_one;  // set by a one-process solve while it runs: queues one solver iteration (the view
+                                     // build uses it to queue the decide-only iteration behind its fill, host_rowview.hpp)
+  bool early_decide_done = false;    // ... and did: the hold is lifted, the decide-only iteration is in the stream
   int resident_mode = 0;   // 0 = use the resident solver where the slices fit, 1 = never
   int last_solver = 0;     // what the last solve ran on: 0 = streaming launches, 1 = resident
 
