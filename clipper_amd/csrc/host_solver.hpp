@@ -681,6 +681,9 @@ int stage_inputs(Ctx* h, const double* D1, int d, int64_t n1, const double* D2, 
   int rc = ensure_problem(h, m);
   if (rc) return rc;
   const int64_t pstride = round_up(m, 64);
+  // (the fill kernels address the gathered point tables with 32-bit byte offsets: k_affinity.hip.h, pt_at)
+  if (static_cast<int64_t>(d) * pstride * static_cast<int64_t>(sizeof(double)) >= (int64_t(1) << 32))
+    return fail(CLIPPER_HIP_E_SCOPE, "point tables of %d x %lld doubles exceed 4 GiB", d, static_cast<long long>(pstride));
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     rc = upload_points(h, s, D1, D2, d, n1, n2, pstride);

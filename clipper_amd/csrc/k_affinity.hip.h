@@ -233,16 +233,26 @@ __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+// A coordinate of the gathered point tables [d][pstride] at a 32-bit BYTE offset from the (wave-uniform) table
+// pointer: one v_lshl_add per load and the load's own base + offset addressing, instead of a 64-bit multiply-add
+// per address — the exact scores' twelve gathers per surviving pair were 5.9 M of the fill kernel's 61.9 M
+// wave-instructions at m = 10k, at the 64-bit rate (profiles/pmc_r04.json). The tables are d * pstride * 8 bytes:
+// 14 MB at m = 300 000 with normals; the host refuses point tables beyond 2^32 bytes (stage_inputs).
+__device__ __forceinline__ double pt_at(const double* __restrict__ P, uint32_t byte_off) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P) + byte_off);
+}
+
 template <typename T, int D>
 __device__ __forceinline__ double exact_euclid_score(const double* __restrict__ P1,
                                                      const double* __restrict__ P2,
                                                      int64_t pstride, int64_t r, int64_t g,
                                                      const EuclidParams& prm) {
+  const uint32_t pb = static_cast<uint32_t>(pstride) << 3, rb = static_cast<uint32_t>(r) << 3, gb = static_cast<uint32_t>(g) << 3;
   double s1 = 0.0, s2 = 0.0;  // euclidean_distance.cpp:18-19, sequential fma chain
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    const double t1 = P1[k * pstride + r] - P1[k * pstride + g];
-    const double t2 = P2[k * pstride + r] - P2[k * pstride + g];
+    const double t1 = pt_at(P1, k * pb + rb) - pt_at(P1, k * pb + gb);
+    const double t2 = pt_at(P2, k * pb + rb) - pt_at(P2, k * pb + gb);
     s1 = fma(t1, t1, s1);
     s2 = fma(t2, t2, s2);
   }
@@ -361,13 +371,14 @@ __device__ __forceinline__ double exact_pointnormal_score(const double* __restri
                                                           const double* __restrict__ P2,
                                                           int64_t pstride, int64_t r, int64_t g,
                                                           const PointNormalParams& prm) {
+  const uint32_t pb = static_cast<uint32_t>(pstride) << 3, rb = static_cast<uint32_t>(r) << 3, gb = static_cast<uint32_t>(g) << 3;
   double p1r[6], p1g[6], p2r[6], p2g[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    p1r[k] = P1[k * pstride + r];
-    p1g[k] = P1[k * pstride + g];
-    p2r[k] = P2[k * pstride + r];
-    p2g[k] = P2[k * pstride + g];
+    p1r[k] = pt_at(P1, k * pb + rb);
+    p1g[k] = pt_at(P1, k * pb + gb);
+    p2r[k] = pt_at(P2, k * pb + rb);
+    p2g[k] = pt_at(P2, k * pb + gb);
   }
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
