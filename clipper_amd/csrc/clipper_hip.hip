@@ -491,6 +491,7 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
     std::vector<int32_t> ri;
     std::vector<double> va;
   } Mn, Cn;
+  int64_t dropped_below = 0;  // entries below the diagonal, which the reference never reads: dropped, and reported
   auto upper_only = [&](const char* what, const int64_t*& cp, const int32_t*& ri, const double*& va, Csc& out) -> int {
     bool strict = true;
     for (int64_t j = 0; j < m && strict; ++j)
@@ -504,7 +505,10 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
     for (int64_t j = 0; j < m; ++j) {
       for (int64_t p = cp[j]; p < cp[j + 1]; ++p) {
         const int64_t i = ri[p];
-        if (i > j) continue;
+        if (i > j) {
+          ++dropped_below;
+          continue;
+        }
         if (i == j) {
           if (va[p] != 0.0)
             return fail(CLIPPER_HIP_E_INVALID, "%s: a stored diagonal entry (%lld,%lld) — the matrices must not have diagonal values set",
@@ -523,6 +527,11 @@ int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
   };
   if ((rc = upper_only("M", Mcolptr, Mrow, Mval, Mn))) return rc;
   if ((rc = upper_only("C", Ccolptr, Crow, Cval, Cn))) return rc;
+  // (a warning, not an error — the call goes on and returns 0 unless something else fails: clipper_hip_last_error()
+  // tells a caller who handed over both triangles, or only the lower one, what became of them)
+  if (dropped_below > 0)
+    (void)fail(0, "warning: %lld stored entries below the diagonal were ignored (the matrices are read through their upper "
+                  "triangle, as the reference's selfadjointView<Upper> does: clipper.cpp:194-271)", static_cast<long long>(dropped_below));
   const int64_t nnzM = Mcolptr[m], nnzC = Ccolptr[m];
   if (h->A.size() != static_cast<size_t>(2 * m)) h->A.clear();
   h->nodes.clear();

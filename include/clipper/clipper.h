@@ -109,7 +109,13 @@ class CLIPPER {
   Constraint getConstraintMatrix();  ///< dense symmetric + identity (clipper.cpp:140-145)
 
   void setMatrixData(const Affinity& M, const Constraint& C);              ///< clipper.cpp:149-158
-  void setSparseMatrixData(const SpAffinity& M, const SpConstraint& C);    ///< clipper.cpp:162-166
+  /// clipper.cpp:162-166. Read the way the reference's solver reads what it keeps — through the UPPER triangle
+  /// (selfadjointView<Upper>, clipper.cpp:194-271): entries below the diagonal are ignored (reported as a warning
+  /// through the C ABI's clipper_hip_last_error()); a lower-triangular matrix is an empty one. One divergence, by design: a stored NON-ZERO
+  /// diagonal entry — which the reference would count once on top of the identity it adds, and which its own
+  /// contract excludes (clipper.h:137-138) — is refused here (the diagonal is implicit in every storage of this
+  /// build); explicit zeros on the diagonal are dropped.
+  void setSparseMatrixData(const SpAffinity& M, const SpConstraint& C);
 
   Association getInitialAssociations();   ///< clipper.cpp:117-120
   Association getSelectedAssociations();  ///< clipper.cpp:124-127

@@ -199,7 +199,9 @@ int clipper_hip_set_matrix(clipper_hip_t* h, const double* M, const double* C, i
  * lower-triangular one is an empty matrix, as in the reference). The same (row, column) stored twice
  * is an error with the compressed storage. The diagonal is implicit in this library: a stored
  * non-zero diagonal entry (outside the reference's contract, clipper.h:137-138; it would count once
- * on top of the identity there) is refused with CLIPPER_HIP_E_INVALID; explicit zeros are dropped. */
+ * on top of the identity there) is refused with CLIPPER_HIP_E_INVALID; explicit zeros are dropped.
+ * When entries below the diagonal were ignored the call still returns 0 and clipper_hip_last_error() holds a
+ * warning that says how many (a caller that stored both triangles, or only the lower one, can tell). */
 int clipper_hip_set_sparse(clipper_hip_t* h, int64_t m, const int64_t* Mcolptr,
                            const int32_t* Mrow, const double* Mval, const int64_t* Ccolptr,
                            const int32_t* Crow, const double* Cval);

@@ -311,6 +311,7 @@ def test_set_sparse_equals_set_matrix(m, storage):
     PL = sp.csc_matrix((np.ones_like(L.data), L.indices, L.indptr), shape=L.shape)
     c = abi.HipClipper(storage=storage)
     c.set_sparse_matrix_data(m, L.indptr, L.indices, L.data, PL.indptr, PL.indices, PL.data)
+    assert "below the diagonal" in c.last_error() and str(2 * L.nnz) in c.last_error()   # (M's and C's: accepted, with a warning — ADVICE r04)
     assert np.array_equal(c.get_affinity_matrix(), np.eye(m))
     assert np.array_equal(c.get_constraint_matrix(), np.eye(m))
     r = ref.RefClipper()
@@ -349,6 +350,7 @@ def test_set_sparse_full_symmetric_input_counts_every_pair_once(storage):
     PF = sp.csc_matrix((np.ones_like(F.data), F.indices, F.indptr), shape=F.shape)
     b = abi.HipClipper(storage=storage)
     b.set_sparse_matrix_data(m, F.indptr, F.indices, F.data, PF.indptr, PF.indices, PF.data)
+    assert "below the diagonal" in b.last_error()     # the lower copies were ignored, and the caller is told
     assert b.storage_in_use == storage
     assert np.array_equal(b.get_affinity_matrix(), Ma)
     assert np.array_equal(b.get_constraint_matrix(), Ca)
