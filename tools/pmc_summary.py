@@ -87,7 +87,8 @@ def main():
             # SQ_LDS_IDX_ACTIVE sums the LDS-array cycles of every CU that ran a unit; the launch lasts us x clock cycles on
             # each of them (the clock from GRBM_GUI_ACTIVE / wall time where recorded, else 2.4 GHz)
             us = r["kernel_us_under_the_profiler"]
-            clk = (r["GRBM_GUI_ACTIVE"] / (us * 1e-6)) if r.get("GRBM_GUI_ACTIVE", 0) > 0 else 2.4e9
+            # (GRBM_GUI_ACTIVE comes back summed over the chip's 8 XCDs)
+            clk = (r["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e-6)) if r.get("GRBM_GUI_ACTIVE", 0) > 0 else 2.4e9
             r["clock_GHz"] = clk / 1e9
             r["lds_busy_share_per_cu_cycle_at_246_units"] = r["SQ_LDS_IDX_ACTIVE"] / (246.0 * us * 1e-6 * clk)
         if "SQ_LDS_BANK_CONFLICT" in r and r.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
