@@ -27,7 +27,6 @@ int free_shard_buffers(Shard& s) {
   fr(s.scal);
   fr(s.st);
   fr(s.shared);
-  fr(s.claim);
   fr(s.marks);
   fr(s.gOff);
   fr(s.gPre);
@@ -149,8 +148,6 @@ int ensure_problem(Ctx* h, int64_t m) {
     HIPCHK(hipMalloc(&s.st, 2 * sizeof(SolverState)));
     HIPCHK(hipMemsetAsync(s.st, 0, 2 * sizeof(SolverState), s.stream));
     HIPCHK(hipMalloc(&s.shared, sizeof(SolveShared)));
-    HIPCHK(hipMalloc(&s.claim, 64));
-    HIPCHK(hipMemsetAsync(s.claim, 0, 64, s.stream));
     HIPCHK(hipMalloc(&s.marks, KIND_CAP));
     HIPCHK(hipMemsetAsync(s.marks, 0, KIND_CAP, s.stream));
     HIPCHK(hipMemsetAsync(s.shared, 0, sizeof(SolveShared), s.stream));
@@ -230,26 +227,8 @@ template <int V>
 void launch_pass_csc(Ctx* h, Shard& s, const SolveArgs& a) {
   const SliceView M = slice_view(h, s), R = row_view(h, s);
   // (the LAST workgroup records the decided state: on M it is the one with the least to stream)
-  const int nmax = std::max(M.nwork, R.nwork);
-  dim3 grid(static_cast<unsigned>(nmax)), block(SL_NW * 64);
+  dim3 grid(static_cast<unsigned>(std::max(M.nwork, R.nwork))), block(SL_NW * 64);
   const SliceView* rdev = s.rv.desc;  // (read only while a.in_view says there is a view)
-  // A list longer than the workgroups the chip holds: one persistent workgroup per place, one decision each, the
-  // items claimed with their chains requested ahead (k_gemv_slices_multi; CLIPPER_HIP_PASS_PERSIST=0: the plain grid)
-  static const bool persist_env = [] {
-    const char* e = std::getenv("CLIPPER_HIP_PASS_PERSIST");
-    return !(e && std::atoi(e) == 0);
-  }();
-  const int places = h->cus * SL_OCC;
-  if constexpr (V > 1) {
-    if (persist_env && nmax > places) {
-      grid = dim3(static_cast<unsigned>(places));
-      if (h->storage == CLIPPER_HIP_STORE_F64)
-        hipLaunchKernelGGL((k_gemv_slices_multi<double, 1, V>), grid, block, 0, s.stream, M, rdev, a);
-      else
-        hipLaunchKernelGGL((k_gemv_slices_multi<float, 1, V>), grid, block, 0, s.stream, M, rdev, a);
-      return;
-    }
-  }
   if (h->storage == CLIPPER_HIP_STORE_F64)
     hipLaunchKernelGGL((k_gemv_slices<double, 1, V>), grid, block, 0, s.stream, M, rdev, a);
   else
@@ -391,7 +370,6 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.rv_rows = view ? static_cast<int>(s.rv.nrows) : 0;
   a.rvp = h->rvp;
   a.decide_only = h->decide_only ? 1 : 0;
-  a.claim = s.claim;
   return a;
 }
 

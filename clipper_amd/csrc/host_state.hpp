@@ -172,7 +172,6 @@ struct Shard : SliceStore {
   SolverState* st = nullptr;      // ST[2], see SolverState
   uint8_t* marks = nullptr;       // [KIND_CAP] per-iteration pass marks (profiling), see SolveArgs
   SolveShared* shared = nullptr;
-  unsigned* claim = nullptr;      // item counter of the persistent pass (SolveArgs::claim)
   // affinity inputs (staged once, reused while the sizes fit)
   double *P1 = nullptr, *P2 = nullptr;  // gathered point tables [d][pstride]
   float *P1f = nullptr, *P2f = nullptr; // the same, rounded to fp32 (prefilter input)

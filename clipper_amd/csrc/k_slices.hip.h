@@ -516,356 +516,6 @@ __global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices(SliceView M,
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// The PERSISTENT, SOFTWARE-PIPELINED pass (round 5): for work lists longer than the
-// workgroups the chip holds (m >= 30k). One workgroup per PLACE; it decides once, streams its first item
-// (blockIdx.x, as k_gemv_slices does) and then CLAIMS further items from a counter — and every chain that made a
-// new workgroup's head 9-12 us under a streaming chip (claim -> work item -> directory -> header -> row list ->
-// x rows) is requested one or two chunk visits ahead of its use, across the item boundary exactly as
-// slice_core requests it from chunk to chunk inside an item:
-//     visit c (a chunk of the current item) ... at its start: the x values of visit c + 1 (their row-list entries
-//     arrived during visit c - 1), the row-list entries of visit c + 2, the header of the slice of visit c + 1 (its
-//     directory word arrived during c - 1), the directory word of visit c + 2 — whether c + 1 / c + 2 belong to this
-//     item or to the NEXT one, whose work item has been in registers since the previous item.
-//   claims: the index of the item after next is claimed (one atomic by thread 0, handed to the workgroup through
-//     LDS at the visit's barrier) while the current item streams; its work item is loaded (one dword per lane)
-//     during the next item. Nothing a workgroup needs at an item switch is requested at the switch.
-// Who computes which item is decided at run time; WHAT an item computes and WHERE it goes (its own partial-sum
-// slot) is not: the sums, and with them the solve, are bit for bit those of k_gemv_slices on the same work list.
-// The counter is zeroed by the tail of every iteration (k_tail) and by k_init.
-// ------------------------------------------------------------------------------------------
-struct SliceItem {
-  int strip, slot, t0, t1, q0, q1;
-  int valid;  // the index was inside the list
-};
-
-// a work item, one dword per lane (lanes 0 .. 7), requested now and read later
-__device__ __forceinline__ int slice_item_request(const SliceViewG& M, int idx) {
-  const int lane = threadIdx.x & 63;
-  const CLIPPER_GLOBAL int* w = reinterpret_cast<const CLIPPER_GLOBAL int*>(M.work + ((idx >= 0 && idx < M.nwork) ? idx : 0));
-  return w[lane & 7];
-}
-__device__ __forceinline__ SliceItem slice_item_take(const SliceViewG& M, int idx, int wv) {
-  SliceItem it;
-  it.strip = __builtin_amdgcn_readlane(wv, 0);
-  it.slot = __builtin_amdgcn_readlane(wv, 1);
-  it.t0 = __builtin_amdgcn_readlane(wv, 2);
-  it.t1 = __builtin_amdgcn_readlane(wv, 3);
-  it.q0 = __builtin_amdgcn_readlane(wv, 4);
-  it.q1 = __builtin_amdgcn_readlane(wv, 5);
-  it.valid = (idx >= 0 && idx < M.nwork) ? 1 : 0;
-  return it;
-}
-
-template <typename VT, int H, bool WINDOW, int V, int NSLOT, int NW, int D>
-__device__ __forceinline__ void slice_core_multi(const SliceViewG& M, const SliceJob<H, NW>& J, int wv_second, int64_t ld,
-                                                 int64_t m, double d, const WindowSource& WS,
-                                                 const double* __restrict__ X, int xstride,
-                                                 double* __restrict__ part, double* lds, unsigned* claim,
-                                                 int* mail /* LDS [2]: a claimed index, by the parity of the claim */) {
-  constexpr int NS = WINDOW ? V + 1 : 2;
-  constexpr int XP = WINDOW ? sl_xpitch(V) : 1;
-  constexpr int XL = WINDOW ? sl_xload(V) : 1;
-  constexpr int R = SL_SUB * H;
-  constexpr int NT = NW * 64;
-  constexpr int QB = 4 * static_cast<int>(sizeof(VT));
-  static_assert(H == 1, "one sub-block per chunk");
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grid = static_cast<int>(gridDim.x);
-
-  // ---- the items: W0 streams; W1 is next (index i1, work item in wv1 / W1); the one after (i2) is being claimed
-  // and fetched. The first THREE items of a workgroup are static (blockIdx.x + 0, 1, 2 x grid), the rest claimed:
-  // the first claim of a workgroup then falls into its second item — spread over the launch by the spread of the
-  // first items — instead of into every workgroup's first visit at once (same-address atomics serialise at tens of
-  // nanoseconds each: 1 536 of them in one burst was +10 % on every pass, the first version of this kernel).
-  // A list of at most three rounds is never claimed from at all.
-  SliceItem W0;
-  W0.strip = J.strip; W0.slot = J.slot; W0.t0 = J.t0; W0.t1 = J.t1; W0.q0 = J.q0; W0.q1 = J.q1; W0.valid = J.live;
-  int i1 = static_cast<int>(blockIdx.x) + grid;
-  int wv1 = wv_second;       // (requested ahead of the decision)
-  SliceItem W1;
-  W1.valid = 0; W1.strip = W1.slot = W1.t0 = W1.t1 = W1.q0 = W1.q1 = 0;
-  bool w1_known = false;     // W1 has been taken out of wv1
-  const bool claims = M.nwork > 3 * grid;
-  int i2 = static_cast<int>(blockIdx.x) + 2 * grid;   // (-1: not claimed yet)
-  if (i2 > M.nwork) i2 = M.nwork;
-  int wv2 = 0;
-  bool w2_requested = false;
-  unsigned claimed = 0;      // (thread 0) the atomic's result
-  int nclaims = 0;           // claims this workgroup has made (parity of the mail slot)
-
-  double acc[NS];
-#pragma unroll
-  for (int v = 0; v < NS; ++v) acc[v] = 0.0;
-  auto write_out = [&](const SliceItem& W) {  // the item's partial sums into ITS slot (write-through, as slice_core)
-    const int cg = W.strip * NW + wave;
-    const int64_t c = static_cast<int64_t>(cg) * SL_W + lane;
-    if (cg < M.ncg && c < ld && W.valid != 0) {
-#pragma unroll
-      for (int v = 0; v < NS; ++v) {
-        const int slot = (v == NS - 1) ? NSLOT - 1 : v;
-        __hip_atomic_store(&part[(static_cast<int64_t>(W.slot) * NSLOT + slot) * ld + c], acc[v], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-#pragma unroll
-    for (int v = 0; v < NS; ++v) acc[v] = 0.0;
-  };
-  // the operands of an item's FIRST visit requested where nothing ran ahead of it (a workgroup's first item, an
-  // item behind a filler): exposed, as in k_gemv_slices
-  SliceXStage<WINDOW, XL, XP, R, NT> xst;
-  SliceHead<H> cur = J.first;
-  uint64_t pre_next = 0;
-  bool have_ridx = false, have_pre = false;
-  int buf = 0;
-  auto prologue = [&](const SliceItem& W, bool head_too) {
-    const int kk = W.t0;
-    xst.index(static_cast<int64_t>(kk) * R, M.nrows, M.rowmap);
-    xst.load(WS, X, xstride, static_cast<int64_t>(kk) * R, M.nrows);
-    const int cg = W.strip * NW + wave;
-    if (head_too && cg < M.ncg) cur.load(M.data + 16 * M.Pre[static_cast<int64_t>(cg) * M.nchunks + kk], lane);
-    __syncthreads();  // (whoever still reads this buffer is through)
-    xst.store(WS, lds + buf * (R * XP));
-    have_ridx = false;
-    have_pre = false;
-    if (kk + 1 < W.t1) {  // the second visit is this item's: its row-list entries and directory word now
-      xst.index(static_cast<int64_t>(kk + 1) * R, M.nrows, M.rowmap);
-      have_ridx = true;
-      if (cg < M.ncg) {
-        pre_next = M.Pre[static_cast<int64_t>(cg) * M.nchunks + kk + 1];
-        have_pre = true;
-      }
-    }
-    __syncthreads();
-  };
-  if (W0.valid != 0 && W0.t0 < W0.t1) {
-    // (the header and, where the item has a second chunk, its directory word came with the job: slice_begin)
-    xst.index(static_cast<int64_t>(W0.t0) * R, M.nrows, M.rowmap);
-    xst.load(WS, X, xstride, static_cast<int64_t>(W0.t0) * R, M.nrows);
-    __syncthreads();  // the decision at the head of the launch used the same LDS
-    xst.store(WS, lds);
-    if (W0.t0 + 1 < W0.t1) {
-      xst.index(static_cast<int64_t>(W0.t0 + 1) * R, M.nrows, M.rowmap);
-      have_ridx = true;
-      pre_next = J.pre1;
-      have_pre = (W0.strip * NW + wave) < M.ncg;
-    }
-    __syncthreads();
-  } else {
-    __syncthreads();
-  }
-
-  while (W0.valid != 0) {
-    const bool w0_visits = W0.t0 < W0.t1;
-    if (w0_visits) {
-      int k = W0.t0;
-      for (;;) {
-        // -- the next item's work item (requested a visit or more ago) -----------------------------------------
-        if (!w1_known) {
-          W1 = slice_item_take(M, i1, wv1);
-          w1_known = true;
-        }
-        // -- visits c + 1 and c + 2: inside W0, or the first chunks of W1; -1: none / not known yet ------------
-        int in1 = -1, s1 = 0, k1 = 0, in2 = -1, s2 = 0, k2 = 0;
-        const bool w1_visits = W1.valid != 0 && W1.t0 < W1.t1;
-        if (k + 1 < W0.t1) { in1 = 0; s1 = W0.strip; k1 = k + 1; }
-        else if (w1_visits) { in1 = 1; s1 = W1.strip; k1 = W1.t0; }
-        if (in1 == 0) {
-          if (k1 + 1 < W0.t1) { in2 = 0; s2 = W0.strip; k2 = k1 + 1; }
-          else if (w1_visits) { in2 = 1; s2 = W1.strip; k2 = W1.t0; }
-        } else if (in1 == 1) {
-          if (k1 + 1 < W1.t1) { in2 = 1; s2 = W1.strip; k2 = k1 + 1; }
-        }
-        const int cg0 = W0.strip * NW + wave, cg1 = s1 * NW + wave, cg2 = s2 * NW + wave;
-        const bool mine = cg0 < M.ncg;
-        const bool more = in1 >= 0;
-        // -- the claim of the item after next: thread 0 asks now, the workgroup learns it at this visit's barrier
-        const bool claiming = i2 < 0;  // (uniform)
-        if (claiming && threadIdx.x == 0) claimed = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (i2 >= 0 && !w2_requested) {  // ... and its work item a visit later
-          wv2 = slice_item_request(M, i2);
-          w2_requested = true;
-        }
-        // -- requests for the next two visits ---------------------------------------------------------------
-        bool late_x = false, late_head = false;
-        SliceHead<H> nxt = cur;
-        uint64_t pre_next2 = 0;
-        bool have_pre2 = false;
-        if (more) {
-          if (have_ridx) xst.load(WS, X, xstride, static_cast<int64_t>(k1) * R, M.nrows);
-          else {
-            xst.index(static_cast<int64_t>(k1) * R, M.nrows, M.rowmap);
-            late_x = true;
-          }
-          if (cg1 < M.ncg) {
-            if (have_pre) nxt.load(M.data + 16 * pre_next, lane);
-            else {
-              pre_next = M.Pre[static_cast<int64_t>(cg1) * M.nchunks + k1];
-              late_head = true;
-            }
-          }
-        }
-        if (in2 >= 0 && !late_x) xst.index(static_cast<int64_t>(k2) * R, M.nrows, M.rowmap);
-        if (in2 >= 0 && cg2 < M.ncg) {
-          pre_next2 = M.Pre[static_cast<int64_t>(cg2) * M.nchunks + k2];
-          have_pre2 = true;
-        }
-        // -- this visit's steps (slice_core's loop) ---------------------------------------------------------
-        const double* xs = lds + buf * (R * XP);
-        double* xnext = lds + (buf ^ 1) * (R * XP);
-        if (mine) {
-          const int maxq = __builtin_amdgcn_readfirstlane(cur.maxq);
-          const int qend = maxq < W0.q1 ? maxq : W0.q1;
-          const int tot = cur.nq[0];
-          gbytes_t fbase = cur.sp + 16 + H * 64 + sl_so_bytes(maxq);
-          if (W0.q0 > 0 && W0.q0 < maxq)
-            fbase = cur.sp + reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(cur.sp + 16 + H * 64)[W0.q0 / SL_SO];
-          SliceQuad<VT> mv[D];
-          uint32_t rw[D];
-          auto issue = [&](int q, SliceQuad<VT>& vq, uint32_t& rq) {
-            const bool active = q < tot && q < qend;
-            const uint64_t mask = __ballot(active);
-            const int cnt = __builtin_amdgcn_readfirstlane(__popcll(mask));
-            const uint32_t rank = active ? sl_lane_rank(mask) : 0u;
-            vq.load(fbase + rank * QB);
-            rq = *reinterpret_cast<const CLIPPER_GLOBAL uint32_t*>(fbase + cnt * QB + rank * 4);
-            fbase += cnt * QB + ((cnt * 4 + 15) & ~15);
-          };
-#pragma unroll
-          for (int j = 0; j < D; ++j) issue(W0.q0 + j, mv[j], rw[j]);
-          for (int qb = W0.q0; qb < qend; qb += D) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-              const int q = qb + j;
-              if (q < tot && q < qend) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const VT mf = mv[j].v[e];
-                  const double mm = static_cast<double>(mf);
-                  const double ii = mf != VT(0) ? 1.0 : 0.0;
-                  const uint32_t row = (rw[j] >> (8 * e)) & 255u;
-                  if constexpr (WINDOW) {
-                    const double* xr = xs + row * XP;
-                    double xv[XP];
-#pragma unroll
-                    for (int v = 0; v < XP; v += 2) {
-                      const double2 t2 = *reinterpret_cast<const double2*>(xr + v);
-                      xv[v] = t2.x;
-                      xv[v + 1] = t2.y;
-                    }
-                    acc[0] = fma(mm, xv[0], acc[0]);
-                    acc[V] = fma(ii, xv[0], acc[V]);
-                    if (V > 1) {
-                      const double w = fma(d, ii, mm);
-#pragma unroll
-                      for (int v = 1; v < V; ++v) acc[v] = fma(w, xv[v], acc[v]);
-                    }
-                  } else {
-                    const double xv = xs[row];
-                    acc[0] = fma(mm, xv, acc[0]);
-                    acc[1] = fma(ii, xv, acc[1]);
-                  }
-                }
-              }
-              issue(q + D, mv[j], rw[j]);
-            }
-          }
-        }
-        // -- what could not be requested ahead (a workgroup's first visits, one-chunk items) --------------------
-        if (late_x) {
-          xst.load(WS, X, xstride, static_cast<int64_t>(k1) * R, M.nrows);
-          if (in2 >= 0) xst.index(static_cast<int64_t>(k2) * R, M.nrows, M.rowmap);
-        }
-        if (late_head && cg1 < M.ncg) nxt.load(M.data + 16 * pre_next, lane);
-        if (more) xst.store(WS, xnext);
-        if (claiming && threadIdx.x == 0) mail[nclaims & 1] = static_cast<int>(claimed);
-        __syncthreads();
-        if (claiming) {
-          const long long idx = 3ll * grid + static_cast<unsigned>(mail[nclaims & 1]);
-          i2 = idx < M.nwork ? static_cast<int>(idx) : M.nwork;  // (past the list: no item, no further claims)
-          ++nclaims;
-        }
-        // -- on to the next visit -----------------------------------------------------------------------------
-        have_ridx = in2 >= 0;
-        cur = nxt;
-        pre_next = pre_next2;
-        have_pre = have_pre2;
-        if (more) buf ^= 1;
-        if (in1 != 0) break;  // W0 is through
-        k = k1;
-      }
-    }
-    write_out(W0);
-    // ---- the next item becomes the current one ----------------------------------------------------------------
-    if (!w1_known) {
-      W1 = slice_item_take(M, i1, wv1);
-      w1_known = true;
-    }
-    const bool prepared = w0_visits && W1.valid != 0 && W1.t0 < W1.t1;  // its first visit was requested during W0's last
-    W0 = W1;
-    if (i2 < 0) {  // (W0 had no visit to claim during: a filler — ask now, in the open)
-      if (threadIdx.x == 0) mail[nclaims & 1] = static_cast<int>(__hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      __syncthreads();
-      const long long idx = 3ll * grid + static_cast<unsigned>(mail[nclaims & 1]);
-      i2 = idx < M.nwork ? static_cast<int>(idx) : M.nwork;
-      ++nclaims;
-    }
-    i1 = i2;
-    wv1 = w2_requested ? wv2 : slice_item_request(M, i1);
-    w1_known = false;
-    i2 = (i1 >= M.nwork || !claims) ? M.nwork : -1;  // (behind the end of the list nothing is claimed any more)
-    w2_requested = false;
-    if (W0.valid != 0 && W0.t0 < W0.t1 && !prepared) prologue(W0, true);
-  }
-}
-
-// window or pair mode by the plan of this iteration (the persistent pass)
-template <typename VT, int H, int V, int NW, int D>
-__device__ __forceinline__ void slices_by_plan_multi(const SliceViewG& M, const SliceJob<H, NW>& J, int wv_second,
-                                                     const SolveArgs& A, const PassPlan& plan, double* lds, int* mail) {
-  if (plan.phase == PH_TRIAL) {
-    const WindowSource WS{A.pt + static_cast<int64_t>(plan.src) * 2 * A.mp,
-                          A.pt + (static_cast<int64_t>(plan.src) * 2 + 1) * A.mp, plan.alpha0, A.prm.beta};
-    slice_core_multi<VT, H, true, V, nslot(V), NW, D>(M, J, wv_second, A.W, A.m, plan.d, WS, nullptr, 0, A.part, lds, A.claim, mail);
-  } else {
-    const bool fu = plan.from_u >= 0;
-    const double* X = fu ? A.pt + static_cast<int64_t>(plan.from_u) * 2 * A.mp
-                         : A.Xin + static_cast<int64_t>(plan.sel) * A.mp * VS;
-    slice_core_multi<VT, H, false, V, nslot(V), NW, D>(M, J, wv_second, A.W, A.m, 0.0, WindowSource{}, X, fu ? 1 : VS,
-                                                       A.part, lds, A.claim, mail);
-  }
-}
-
-// G of a solver iteration on the slices where the work list is longer than the workgroups the chip holds: one
-// workgroup per place, one decision each, the items behind the first two claimed from A.claim (slice_core_multi)
-template <typename VT, int H, int V>
-__global__ __launch_bounds__(SL_NW * 64, SL_OCC) void k_gemv_slices_multi(SliceView M, const SliceView* __restrict__ RV, SolveArgs A) {
-  __shared__ __attribute__((aligned(16))) double lds[sl_lds_doubles(V, H, SL_NW)];
-  __shared__ __attribute__((aligned(16))) SolverState stash;
-  __shared__ int mail[2];
-  SliceViewG G = to_global(M);
-  SliceJob<H, SL_NW> J, JV;
-  slice_begin<H, SL_NW>(G, J, blockIdx.x);
-  int wv = slice_item_request(G, static_cast<int>(blockIdx.x + gridDim.x));  // the workgroup's second item
-  SliceViewG GV = G;
-  int wvv = 0;
-  if (A.in_view != nullptr) {
-    GV = to_global(*RV);
-    slice_begin<H, SL_NW>(GV, JV, blockIdx.x);
-    wvv = slice_item_request(GV, static_cast<int>(blockIdx.x + gridDim.x));
-  }
-  PassPlan plan;
-  if (!iteration_head<V, SL_NW * 64>(A, lds, &stash, plan)) return;
-  if (plan.view) {
-    G = GV;
-    J = JV;
-    wv = wvv;
-  }
-  slices_by_plan_multi<VT, H, V, SL_NW, SL_D>(G, J, wv, A, plan, lds, mail);
-  flush_state(A, &stash);
-}
-
 // the pair-mode product alone on table X (matvec API, micro-benchmark): a -> slot 0, b -> slot 1
 template <typename VT, int H>
 __global__ __launch_bounds__(SL_NW * 64, 2) void k_gemv_slices_plain(SliceView M, int64_t ld,

@@ -233,8 +233,6 @@ struct SolveArgs {
                            // it covers the live rows of every outcome, whatever the tail counted
   int rv_rows;             // rows of the view
   ViewPolicy rvp;
-  unsigned* claim;         // the persistent pass's item counter (k_gemv_slices_multi, k_slices.hip.h): zeroed by k_init and by
-                           // the tail of every iteration
   int decide_only;         // this G launch only DECIDES: a decision that ends in a pass records that pass as
                            // prepared (SolverState::resume) instead of running it — the hand-over to the
                            // resident solver on a row view (k_rv_resident.hip.h), which starts from a
@@ -1007,7 +1005,6 @@ __global__ __launch_bounds__(256) void k_init(SolveArgs A, SolverState init, Sol
       *st0 = init;
       A.shared->done = 0;
       A.shared->hold = 0;
-      if (A.claim != nullptr) *A.claim = 0u;
     }
   }
 }
@@ -1061,8 +1058,6 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   __shared__ double red[NTW * NRED > 2 * TAIL_SPLIT * TAIL_THREADS ? NTW * NRED : 2 * TAIL_SPLIT * TAIL_THREADS];
   const int v = blockIdx.y;
   const long long c0 = A.stamps ? wall_clock64() : 0;
-  // (the next pass's item counter, whatever this tail does: the pass before it is over, the next one not begun)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && A.claim != nullptr) *A.claim = 0u;
   const SolverState* st = A.st_next;
   const int te = threadIdx.x & (TAIL_THREADS - 1);  // element of the workgroup
   const int grp = threadIdx.x / TAIL_THREADS;        // slot quarter (FUSED_REDUCE), else 0
