@@ -58,7 +58,9 @@ void rvr_end_solve(Ctx* h) {
   }
   for (int k = 0; k < r.ev_n; ++k) {  // (profiling level 2; a launch that gave up is in the sum: it took the time)
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.ev[2 * k], r.ev[2 * k + 1]) == hipSuccess) h->rv_stats.resident_event_us += static_cast<double>(ms) * 1e3;
+    // (the solve's end was SEEN from inside the launch: its end event may still be a few microseconds out)
+    if (hipEventSynchronize(r.ev[2 * k + 1]) == hipSuccess && hipEventElapsedTime(&ms, r.ev[2 * k], r.ev[2 * k + 1]) == hipSuccess)
+      h->rv_stats.resident_event_us += static_cast<double>(ms) * 1e3;
     else (void)hipGetLastError();
   }
   h->rv_stats.resident_entries = static_cast<int64_t>(r.plan_entries);
@@ -76,21 +78,27 @@ void rvr_end_solve(Ctx* h) {
   }
 }
 
-bool rvr_common(const Ctx* h) {
+// What every rank of a sharded solve knows alike: the mode set through the API, the storage, the window — the
+// GATE of a hand-over. What only this process knows — an environment switch, a back-off after a launch that gave up,
+// a device that refuses the LDS — is `rvr_local_ok`: on one shard the two are simply and-ed; with column shards the
+// local part is what a rank SAYS in the agreement round, never what decides whether it enters it
+// (a rank that skipped a round its peers entered would leave them waiting in the exchange).
+bool rvr_gate(const Ctx* h) { return h->rv_mode == 0 && csc_possible(h) && h->sh.size() == 1 && (h->V == 6 || h->V == 4); }
+bool rvr_local_ok(const Ctx* h) {
   static const bool env_off = [] {
     const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT");
     return e && std::atoi(e) == 0;
   }();
-  // one local shard, a window the kernel is instantiated for, not backing off after a launch that gave up (rvr_end_solve)
-  return !env_off && h->rv_mode == 0 && csc_possible(h) && h->sh.size() == 1 && (h->V == 6 || h->V == 4) &&
-         h->vres.cooldown == 0;
+  return !env_off && h->vres.cooldown == 0;  // (backing off after a launch that gave up: rvr_end_solve)
 }
+bool rvr_common(const Ctx* h) { return rvr_gate(h) && rvr_local_ok(h); }
 // one device, one shard: the shard's view is the whole view
 bool rvr_enabled(const Ctx* h) { return rvr_common(h) && csc_single(h); }
 // One process per shard (column shards over RCCL or the caller's exchange): every rank keeps a REPLICA of a small
 // view over all columns — scored from the points, which are replicated — and runs the launch redundantly: the same
 // bits on every rank, no exchange for the iterations inside it (reference loop clipper.cpp:226-280).
-bool rvr_replica_enabled(const Ctx* h) { return rvr_common(h) && h->multiproc && rect_fill_possible(h); }
+bool rvr_replica_gate(const Ctx* h) { return rvr_gate(h) && h->multiproc && rect_fill_possible(h); }
+bool rvr_replica_enabled(const Ctx* h) { return rvr_replica_gate(h) && rvr_local_ok(h); }
 
 // could a view of this many rows go to the resident solver? (what rvr_plan checks before it looks at the directory)
 bool rvr_candidate(const Ctx* h, int64_t nrows) { return rvr_enabled(h) && nrows >= 1 && nrows <= RVR_MAXROWS; }
@@ -346,16 +354,19 @@ int rvr_replica_handover(Ctx* h, const SolverParams& prm) {
   r.ready = false;
   if (!h->multiproc || h->sh.size() != 1) return 0;
   Shard& s = h->sh[0];
-  // (the same on every rank: mode, storage, window and the view's rows are; the back-off is, because it follows
-  // the AGREED outcome below)
-  if (!rvr_replica_enabled(h) || !s.rv.valid || s.rv.nrows < 1 || s.rv.nrows > RVR_MAXROWS) return 0;
+  // The GATE: only what is the same on every rank — mode, storage, window, the view's rows. Everything a single
+  // rank may see differently (an environment switch, its back-off, a device that refuses the plan) goes into the
+  // flag it brings to the agreement, not into whether it comes.
+  if (!rvr_replica_gate(h) || !s.rv.valid || s.rv.nrows < 1 || s.rv.nrows > RVR_MAXROWS || prm.maxiniters < 1) return 0;
   int rc;
   const auto t0 = std::chrono::high_resolution_clock::now();
   bool mine = false;
-  if ((rc = rvr_build_replica(h, s))) return rc;
-  if (s.rv.full_valid) {
-    if ((rc = rvr_plan(h, s, true))) return rc;
-    mine = r.ready;
+  if (rvr_local_ok(h)) {
+    if ((rc = rvr_build_replica(h, s))) return rc;
+    if (s.rv.full_valid) {
+      if ((rc = rvr_plan(h, s, true))) return rc;
+      mine = r.ready;
+    }
   }
   bool all = false;
   if ((rc = rvr_agree(h, mine, all))) return rc;
@@ -377,6 +388,11 @@ int rvr_replica_handover(Ctx* h, const SolverParams& prm) {
   bool launched = false;
   const int slot = r.launches_this_solve;
   if ((rc = rvr_enqueue(h, prm, launched))) return rc;
+  if (!launched) {  // (the device refused the launch: an attempt that gave up, for the books and the back-off)
+    r.launches_this_solve += 1;
+    h->rv_stats.resident_launches += 1;
+    if (r.giveup_host && slot < RVR_GIVEUP_SLOTS) r.giveup_host[4 * slot] = RVR_ERR_STATE;
+  }
   HIPCHK(hipStreamSynchronize(s.stream));
   std::atomic_thread_fence(std::memory_order_acquire);
   const bool ran = launched && !(r.giveup_host && slot < RVR_GIVEUP_SLOTS && static_cast<volatile uint32_t*>(r.giveup_host)[4 * slot] != 0u);
