@@ -150,6 +150,26 @@ int rvr_plan(Ctx* h, Shard& s, bool replica = false) {
                  static_cast<long long>(v.nrows), vst.s_ncg, vst.s_nchunks,
                  static_cast<unsigned long long>(plan.entries), plan.units.size(), plan.ok ? 1 : 0);
   if (!plan.ok) return 0;
+  if (rs_debug() && std::atoi(std::getenv("CLIPPER_HIP_RESIDENT_DEBUG")) >= 2) {  // the units, one line each (tools/rvr_timeline.py --units)
+    for (size_t ui = 0; ui < plan.units.size(); ++ui) {
+      const clipper_plan::ViewUnit& U = plan.units[ui];
+      uint64_t ent = 0;
+      for (int c = 0; c < U.ncgs; ++c) ent += plan.ent[static_cast<size_t>(U.cg0 + c)];
+      if (U.l1 - U.l0 < 64) ent = ent * static_cast<uint64_t>(U.l1 - U.l0) / 64;
+      int wmax = 0, wsum = 0;
+      for (int w = 0; w < RVR_NWV; ++w) {
+        int st = 0;
+        for (int j = 0; j < plan.npieces[ui * RVR_NWV + w]; ++j) {
+          const uint32_t pc = plan.pieces[(ui * RVR_NWV + w) * RVR_PMAX + j];
+          st += static_cast<int>((pc >> 16) & 255u) - static_cast<int>((pc >> 8) & 255u);
+        }
+        wmax = std::max(wmax, st);
+        wsum += st;
+      }
+      std::fprintf(stderr, "[view-resident-unit] %zu cg0 %d ncgs %d lanes %d-%d pack %d entries %llu steps_max_wave %d steps_sum %d\n", ui, U.cg0, U.ncgs,
+                   U.l0, U.l1, U.pack, static_cast<unsigned long long>(ent), wmax, wsum);
+    }
+  }
   HIPCHK(hipSetDevice(s.device));
   const size_t off_np = plan.units.size() * sizeof(RvrUnit);
   const size_t off_wc = off_np + static_cast<size_t>(round_up(static_cast<int64_t>(plan.npieces.size()), 16));

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--m", type=int, default=10000)
     ap.add_argument("--rho", type=float, default=0.95)
     ap.add_argument("--storage", default="csc")
+    ap.add_argument("--units", action="store_true", help="print every unit's pass duration of turn 6")
     a = ap.parse_args()
     p = synth.make_euclidean_problem(a.m, a.rho, seed=12345)
     g = abi.HipClipper(storage=abi.STORE_F32_CSC if a.storage == "csc" else abi.STORE_F64_CSC)
@@ -62,6 +63,9 @@ def main():
             print(f"   turn 6, all {len(per)} units, {name:11s}: min {v.min():6.2f}  p50 {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us"
                   + (f"   (slowest units: {np.argsort(-v)[:6].tolist()})" if c == 1 else ""))
         pd = rel[:, 1] - rel[:, 0]
+        if a.units:   # every unit's pass of turn 6 (beside CLIPPER_HIP_RESIDENT_DEBUG=2's plan lines on stderr)
+            for i, v in enumerate(pd):
+                print(f"unit {i} pass_us {v:.2f}")
         print(f"   turn 6, pass duration per unit: min {pd.min():.2f} p50 {np.median(pd):.2f} p90 {np.percentile(pd, 90):.2f} max {pd.max():.2f} us")
     print(f"   launch: slices -> LDS {(end[1] - end[0]) / 100:.2f} us, loop {(end[2] - end[1]) / 100:.2f} us, total {(end[2] - end[0]) / 100:.2f} us")
     g.close()
