@@ -328,11 +328,11 @@ int rvr_agree(Ctx* h, bool mine, bool& all) {
   if (int rc = exchange(h, 1)) return rc;
   if (int rc = sync_all(h)) return rc;
   all = true;
-  for (int p = 0; p < h->world; ++p) {
-    double x = 0.0;
-    HIPCHK(hipMemcpy(&x, s.ab + static_cast<int64_t>(p) * h->W, sizeof(double), hipMemcpyDeviceToHost));
-    all = all && x == 1.0;
-  }
+  // (the first element of every rank's block, in one strided copy)
+  std::vector<double> flags(static_cast<size_t>(h->world), 0.0);
+  HIPCHK(hipMemcpy2D(flags.data(), sizeof(double), s.ab, static_cast<size_t>(h->W) * sizeof(double), sizeof(double),
+                     static_cast<size_t>(h->world), hipMemcpyDeviceToHost));
+  for (double x : flags) all = all && x == 1.0;
   return 0;
 }
 
