@@ -91,6 +91,10 @@ def parse():
                     help="size of the `scaling_probe` object: the same step at the size whose pass is "
                          "HBM-bound and whose shards scale (0 = no probe)")
     ap.add_argument("--probe-steps", type=int, default=3)
+    ap.add_argument("--rank-path", action="store_true",
+                    help="(testing) with one GPU: the multi-process construction of --gpus N > 1 in a 1-rank world — "
+                         "clipper_hip_create_rank, ncclCommInitRank, every exchange through ncclAllGather — so that the "
+                         "code path the driver's multi-GPU runs take can be exercised on a one-GPU box")
     ap.add_argument("--sources-sha", action="store_true", help="print the sha256 of the kernel sources a PMC record is tied to, and exit")
     return ap.parse_args()
 
@@ -168,7 +172,10 @@ def main():
     storage = {"f32": abi.STORE_F32, "f64": abi.STORE_F64, "csc": abi.STORE_F32_CSC,
                "csc64": abi.STORE_F64_CSC}[args.storage]
     problem = synth.make_euclidean_problem(args.m, rho, seed=args.seed)  # identical on every rank
-    if N > 1:
+    if N == 1 and args.rank_path:
+        os.environ["CLIPPER_HIP_FORCE_RCCL"] = "1"   # a 1-rank world still goes through ncclAllGather
+        cdist.init_process_group("gloo")
+    if N > 1 or args.rank_path:
         g = abi.HipClipper(device=local_rank, storage=storage, rank=rank, world=N)
         uid = cdist.broadcast_bytes(g.unique_id() if rank == 0 else None, 128, src=0)
         g.comm_init(uid)   # ncclCommInitRank inside libclipper_hip.so (RCCL over xGMI)
@@ -378,7 +385,8 @@ def main():
                              f"{{sigma=0.015,epsilon=0.05}}, clipper::Params defaults, "
                              f"explicit u0 (seed {args.seed}+1)"),
                 "m": args.m, "rho": rho, "storage": in_use,
-                "parallelism": "single GPU" if N == 1 else f"column-sharded M over {N} GPUs, RCCL all-gather per pass",
+                "parallelism": ("single GPU" if N == 1 and not args.rank_path else
+                                f"column-sharded M over {N} GPU(s), one process each, RCCL all-gather per pass"),
                 "device": name, "cus": cus,
             },
             "affinity_ms": round(sum(aff_ms) / len(aff_ms), 4),
@@ -436,7 +444,7 @@ def main():
                 "rel_dscore": abs(sref.score - sol.score) / abs(sref.score),
             }
         print(json.dumps(out), flush=True)
-    if N > 1:
+    if N > 1 or args.rank_path:
         dist.destroy_process_group()
     g.close()
 
