@@ -46,10 +46,15 @@ def _worker(rank, world, port, m, storage, out_dir, rho=0.9, seed=77, env=None):
         tdist.all_gather(out, t)
         return np.concatenate([o.numpy() for o in out])
 
-    p = synth.make_euclidean_problem(m, rho, seed=seed)     # identical on every rank
+    pointnormal = bool((env or {}).get("TEST_POINTNORMAL"))
+    p = (synth.make_pointnormal_problem(m, rho, seed=seed) if pointnormal
+         else synth.make_euclidean_problem(m, rho, seed=seed))     # identical on every rank
     g = abi.HipClipper(device=0, storage=storage, rank=rank, world=world)
     g.comm_init_callback(allgather)
-    g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    if pointnormal:
+        g.score_pairwise_consistency_pointnormal(p.D1, p.D2, p.A)
+    else:
+        g.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
     used = g.storage_in_use
     s = g.solve(p.u0)
     vs1 = g.view_stats()
@@ -202,4 +207,31 @@ def test_a_rank_whose_launch_gives_up_takes_the_other_rank_with_it(tmp_path):
     one.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
     s = one.solve(p.u0)
     assert r0["nodes"].tolist() == s.nodes.tolist() and int(r0["trials"]) == s.n_trials
+    one.close()
+
+
+def test_two_ranks_pointnormal_with_views(tmp_path):
+    """PointNormalDistance (6-DoF surfels) through the multi-process driver with row views: the per-rank fills and —
+    where the view is small enough — the replica are scored by the PointNormal variant of the rectangular kernel.
+    Both ranks equal, and equal to one GPU's node list."""
+    from clipper_amd import _abi as abi
+    from clipper_amd import synth
+
+    m, rho, seed = 9000, 0.93, 31
+    # (these solves are short — ten trials: the build side of the view policy's cost model is scaled down so that a view
+    # is asked for at all)
+    env = {"CLIPPER_HIP_VIEW_RESIDENT_WGS": "120", "TEST_POINTNORMAL": "1", "CLIPPER_HIP_RV_BUILD_SCALE": "0.02"}
+    r0, r1 = _run_ranks(tmp_path, 2, m, abi.STORE_F32_CSC, rho, seed, env)
+    assert np.array_equal(r0["u"], r1["u"]) and np.array_equal(r0["nodes"], r1["nodes"]) and int(r0["calls"]) == int(r1["calls"])
+    assert int(r0["resident"]) == int(r1["resident"]) >= 1 and int(r0["giveups"]) == int(r1["giveups"]) == 0
+    assert int(r0["views"]) == int(r1["views"]) >= 1
+    p = synth.make_pointnormal_problem(m, rho, seed=seed)
+    one = abi.HipClipper(device=0, storage=abi.STORE_F32_CSC)
+    one.score_pairwise_consistency_pointnormal(p.D1, p.D2, p.A)
+    s = one.solve(p.u0)
+    st = one.view_stats()
+    print(f"PointNormal m={m}: views {int(r0['views'])} (one GPU: {st.builds}, {st.rows} rows), resident launches per rank "
+          f"{int(r0['resident'])}, trials {int(r0['trials'])} / one GPU {s.n_trials}")
+    assert sorted(r0["nodes"].tolist()) == sorted(s.nodes.tolist()) and int(r0["ifinal"]) == s.ifinal
+    assert abs(float(r0["score"]) - s.score) <= 1e-9 * abs(s.score)
     one.close()
