@@ -125,6 +125,12 @@ bool rowview_cost_of_filter(const Ctx* h) { return rowview_build_env() != 0 || !
 // ---- the row view -----------------------------------------------------------------------------------
 
 int rvr_plan(Ctx* h, Shard& s, bool replica);  // host_rv_resident.hpp: does the view just built fit the resident solver?
+// the control block of the resident launch that may follow the build in progress (null: none allocated yet, or the
+// solve has used up its blocks — the launch then clears block 0 itself)
+uint32_t* rvr_ctl_block(Ctx* h) {
+  ViewResident& r = h->vres;
+  return (r.ctl != nullptr && r.launches_this_solve < RVR_GIVEUP_SLOTS) ? r.ctl + 16 * r.launches_this_solve : nullptr;
+}
 bool rvr_candidate(const Ctx* h, int64_t nrows);
 int rowview_put_descriptor(Ctx* h, Shard& s);
 
@@ -350,7 +356,8 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
            (!store_gone && (static_cast<double>(nrows) > RV_ROWS_RATIO * rows_now ||
                             RV_GAIN_MARGIN * (pol.build_fixed + pol.build_per_row * static_cast<double>(nrows)) >=
                                 horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row)))) {
-        hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows));
+        hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows),
+                           static_cast<uint32_t*>(nullptr));
         h->rv_stats.build_ms +=
             std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
         return 0;
@@ -382,7 +389,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
       v.valid = true;  // (provisional: the launches queued right here read the flags, the list and the rows' number)
       v.st.s_nwork = 0;
       if ((rc = rowview_put_descriptor(h, s))) return rc;
-      hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0);
+      hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0, rvr_ctl_block(h));
       h->rv_fresh = true;
       h->decide_only = true;
       rc = h->enqueue_one ? h->enqueue_one() : CLIPPER_HIP_E_INTERNAL;
@@ -426,7 +433,7 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
     v.plan_pending = false;
   }
   if ((rc = rowview_put_descriptor(h, s))) return rc;  // (no work list yet while its plan is pending: no item for anybody)
-  if (!early_done) hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0);
+  if (!early_done) hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, 0, rvr_ctl_block(h));
   h->early_decide_done = early_done;
   h->rv_stats.build_ms +=
       std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();

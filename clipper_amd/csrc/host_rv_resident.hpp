@@ -28,13 +28,8 @@ void rvr_begin_solve(Ctx* h) {
   ViewResident& r = h->vres;
   r.launches_this_solve = 0;
   r.ev_n = 0;
-  // the launches' control words (error word, arrivals, unit 0's start): one block per launch of a solve, all of them
-  // zeroed HERE, at the start of the solve, instead of by a memset in front of every launch (on the critical path)
-  if (r.ctl && r.ctl_dirty) {
-    Shard& s = h->sh[0];
-    if (hipSetDevice(s.device) == hipSuccess && hipMemsetAsync(r.ctl, 0, RVR_GIVEUP_SLOTS * 64, s.stream) == hipSuccess) r.ctl_dirty = false;
-    else (void)hipGetLastError();
-  }
+  // (the launches' control words — error word, arrivals, unit 0's start — are one block per launch of a solve, zeroed by
+  // the k_rv_resume of the view build that precedes every launch: no memset on any critical path)
   if (r.giveup_host) std::memset(r.giveup_host, 0, RVR_GIVEUP_SLOTS * 4 * sizeof(uint32_t));
   std::atomic_thread_fence(std::memory_order_seq_cst);
 }
@@ -205,7 +200,6 @@ int rvr_plan(Ctx* h, Shard& s, bool replica = false) {
   if (!r.ctl) {
     HIPCHK(hipMalloc(&r.ctl, RVR_GIVEUP_SLOTS * 64));
     HIPCHK(hipMemsetAsync(r.ctl, 0, RVR_GIVEUP_SLOTS * 64, s.stream));
-    r.ctl_dirty = false;
   }
   if (!r.giveup_host) {
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&r.giveup_host), RVR_GIVEUP_SLOTS * 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
@@ -270,7 +264,7 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   }
   a.epoch0 = r.epoch;
   r.epoch += 1ull << 20;  // whatever this launch publishes (even if it gives up half-way) lies below the next one's
-  const bool own_ctl = r.launches_this_solve < RVR_GIVEUP_SLOTS;  // (its block was zeroed when the solve began)
+  const bool own_ctl = r.launches_this_solve < RVR_GIVEUP_SLOTS;  // (its block was zeroed by the build's k_rv_resume)
   a.ctl = r.ctl + (own_ctl ? 16 * r.launches_this_solve : 0);
   a.giveup_host = (r.giveup_host_dev && r.launches_this_solve < RVR_GIVEUP_SLOTS) ? r.giveup_host_dev + 4 * r.launches_this_solve : nullptr;
   a.lds_slices = r.lds_slices;
@@ -289,7 +283,6 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   a.rv_rows = static_cast<int>(s.rv.nrows);
   a.stamps = h->stamps_dev;
   if (!own_ctl) HIPCHK(hipMemsetAsync(r.ctl, 0, 64, s.stream));  // (more launches in one solve than blocks: block 0, cleared each time)
-  r.ctl_dirty = true;
   const bool timed = h->profiling_level >= 2 && r.ev_n < 16;
   if (timed) {
     for (int k = 0; k < 2; ++k)

@@ -226,7 +226,6 @@ struct ViewResident {
   unsigned long long* xb = nullptr;  // exchange buffer (granules), zero at allocation
   size_t xb_bytes = 0;
   uint32_t* ctl = nullptr;           // [RVR_GIVEUP_SLOTS][16]: per launch of a solve [0] error word, [1] arrivals at the exit, [4..5] unit 0's start
-  bool ctl_dirty = false;            // a launch used a block since the blocks were last zeroed (rvr_begin_solve zeroes them)
   unsigned long long epoch = 0;      // every launch takes 2^20 epochs
   int target_units = 0;              // CLIPPER_HIP_VIEW_RESIDENT_WGS (0: automatic)
   // Launches that gave up (an exchange that timed out: a unit that did not become resident in time — another tenant

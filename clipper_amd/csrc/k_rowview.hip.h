@@ -308,7 +308,10 @@ __global__ __launch_bounds__(AT_WAVES * 64, AT_WAVES / 2) void k_slice_filter_ro
 
 // the host has built the view the state asked for (or refused: too many rows once the pending
 // candidates were counted in): the hold is lifted, the policy's counters move on
-__global__ void k_rv_resume(SolverState* st, SolveShared* shared, int refused_rows) {
+__global__ void k_rv_resume(SolverState* st, SolveShared* shared, int refused_rows, uint32_t* ctl16 = nullptr) {
+  // (the control words of the resident launch that may follow this build — error word, arrivals, unit 0's start —
+  // zeroed here, on the way: no memset in front of the launch, none at the start of a solve)
+  if (ctl16 != nullptr && blockIdx.x == 0 && threadIdx.x < 16) ctl16[threadIdx.x] = 0u;
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     shared->hold = 0;
     st->hold = 0;
