@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "clipper_hip_get_selected_associations", "clipper_hip_matvec", "clipper_hip_set_profiling",
     "clipper_hip_set_window", "clipper_hip_window", "clipper_hip_densest_subgraph",
     "clipper_hip_set_resident", "clipper_hip_last_solver",
-    "clipper_hip_set_row_view", "clipper_hip_get_view_stats", "clipper_hip_view_matvec",
+    "clipper_hip_set_row_view", "clipper_hip_get_view_stats", "clipper_hip_view_matvec", "clipper_hip_set_subproblem",
     "clipper_hip_storage_in_use", "clipper_hip_knn", "clipper_hip_distance_based_correspondences",
     "clipper_hip_get_timings", "clipper_hip_bench_matvec", "clipper_hip_device_info",
     "clipper_hip_stage_inputs", "clipper_hip_affinity_euclidean_staged",
@@ -102,6 +102,9 @@ class ViewStats(C.Structure):
         ("resident_launches", C.c_int64), ("resident_giveups", C.c_int64),
         ("resident_iterations", C.c_int64), ("resident_us", C.c_double), ("resident_event_us", C.c_double),
         ("resident_entries", C.c_int64), ("resident_units", C.c_int64),
+        ("sub_entries", C.c_int64), ("sub_leaves", C.c_int64), ("sub_passes", C.c_int64),
+        ("sub_rows", C.c_int64), ("sub_bytes", C.c_int64), ("sub_build_ms", C.c_double),
+        ("sub_pass_avg_us", C.c_double), ("sub_pass_samples", C.c_int64),
     ]
 
 
@@ -173,6 +176,7 @@ def load_library(path: str = LIB_PATH):
     L.clipper_hip_last_solver.argtypes = [vp]
     L.clipper_hip_storage_in_use.argtypes = [vp]
     L.clipper_hip_set_row_view.argtypes = [vp, C.c_int]
+    L.clipper_hip_set_subproblem.argtypes = [vp, C.c_int]
     L.clipper_hip_get_view_stats.argtypes = [vp, C.POINTER(ViewStats)]
     L.clipper_hip_view_matvec.argtypes = [vp, ip, i64, dp, dp, dp]
     L.clipper_hip_knn.argtypes = [C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_int, C.c_int, ip, dp]
@@ -435,6 +439,11 @@ class HipClipper:
     def set_row_view(self, mode: int):
         """0 = build row views of M[live rows, :] during a solve where that pays, 1 = never."""
         self._check(self.L.clipper_hip_set_row_view(self.h, int(mode)))
+
+    def set_subproblem(self, mode: int):
+        """0 = hand a solve over to the live sub-problem (the associations that can still be selected) where that is
+        provably exact and pays, 1 = never."""
+        self._check(self.L.clipper_hip_set_subproblem(self.h, int(mode)))
 
     def view_matvec(self, rows, x):
         """(M_off[:, rows] x[rows], C_off[:, rows] x[rows]) through a row view built for `rows`."""

@@ -42,8 +42,8 @@ def build_hip(force: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, "clipper_hip.hip"), os.path.join(CSRC, "kernels.hip.h"),
             *[os.path.join(CSRC, f) for f in ("k_solver.hip.h", "k_gemv.hip.h", "k_csc.hip.h", "k_slices.hip.h", "k_resident.hip.h", "host_resident.hpp", "k_rv_resident.hip.h", "host_rv_resident.hpp",
-                                              "k_affinity.hip.h", "k_matrix.hip.h", "k_rowview.hip.h", "k_knn.hip.h")],
-            *[os.path.join(CSRC, f) for f in ("host_state.hpp", "host_solver.hpp", "host_matrix.hpp", "host_plan.hpp", "host_batch.hpp", "host_rowview.hpp", "host_registration.hpp")],
+                                              "k_affinity.hip.h", "k_matrix.hip.h", "k_rowview.hip.h", "k_subproblem.hip.h", "k_knn.hip.h")],
+            *[os.path.join(CSRC, f) for f in ("host_state.hpp", "host_solver.hpp", "host_matrix.hpp", "host_plan.hpp", "host_batch.hpp", "host_rowview.hpp", "host_subproblem.hpp", "host_registration.hpp")],
             os.path.join(CSRC, "dsd_host.h"),
             os.path.join(ROOT, "include", "clipper_hip.h"),
             os.path.join(ROOT, "include", "clipper_abi.h")]

@@ -52,6 +52,7 @@ using namespace clipper_hip;
 #include "host_rowview.hpp"
 #include "host_resident.hpp"
 #include "host_rv_resident.hpp"
+#include "host_subproblem.hpp"
 #include "host_registration.hpp"
 
 // ============================================================================================
@@ -151,6 +152,7 @@ void clipper_hip_destroy(clipper_hip_t* h) try {
     if (s.stream) hipStreamSynchronize(s.stream);
   }
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  sub_free(h);  // (the live sub-problem's context borrows this one's stream: before the stream goes)
   for (auto& s : h->sh) {
     free_shard_buffers(s);
     if (s.ev_reduced) hipEventDestroy(s.ev_reduced);
@@ -842,6 +844,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   init.rv_last = -100;
   rowview_drop(h);  // a solve starts without a view: what it builds is a function of this solve alone
   rvr_begin_solve(h);
+  sub_begin_solve(h);
   h->rvp = rowview_policy(h);
   // with rescaling the first iteration runs the pair pass on u0; without, it only normalises
   init.phase = P->rescale_u0 ? PH_RESCALE : PH_NORMALIZE;
@@ -886,6 +889,11 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     h->rv_fresh = false;
     constexpr int run_ahead = RUN_AHEAD;
     h->enqueue_one = [h, &prm]() { return enqueue_iteration(h, prm); };
+    // (while the solve runs on the live sub-problem the same launches go out with the child context's arguments)
+    auto enqueue_next = [&]() { return enqueue_iteration(h->sub.active ? h->sub.ctx : h, prm); };
+    auto sub_account = [&]() {  // the passes since the hand-over ran on the sub-problem
+      h->sub.sub_passes += std::max<int64_t>(0, hm->n_passes - h->sub.passes_at_entry);
+    };
     struct ClearEnqueue {
       Ctx* c;
       ~ClearEnqueue() { c->enqueue_one = nullptr; }
@@ -906,11 +914,24 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         // shard: its streams are drained, the shards' builds are not ordered with each other otherwise.)
         if (h->sh.size() > 1 && (rc = sync_all(h))) return rc;
         std::atomic_thread_fence(std::memory_order_acquire);
+        const int hold_reason = hm->hold;
         hm->hold = 0;
         queued = hm->iters;              // the iterations that did nothing never counted
         h->launch_counter = hm->iters;   // (profiling: launch index = the device's iteration count)
         while (h->ev_used > 0 && h->ev_launch_index[static_cast<size_t>(h->ev_used - 1)] >= hm->iters)
           --h->ev_used;                  // event pairs around launches that did nothing
+        if (hold_reason == 2) {  // the hand-over to the live sub-problem (host_subproblem.hpp)
+          if ((rc = sub_enter(h, prm))) return rc;
+          ++queued;  // (its decide-only iteration)
+          mark_t("sub-problem entered");
+          continue;
+        }
+        if (hold_reason == 3) {  // ... and the way back
+          sub_account();
+          if ((rc = sub_leave(h))) return rc;
+          mark_t("sub-problem left");
+          continue;
+        }
         bool built = false;
         if ((rc = rowview_build(h, built))) return rc;
         mark_t("view built");
@@ -934,11 +955,17 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
           mark_t("resident queued");
         }
         if ((rc = rowview_finish_plan(h))) return rc;  // (a work list put off while the resident launch was prepared)
+        // a view the resident solver does not take: the live sub-problem of its rows is prepared now, and entered
+        // when the decision finds that nothing outside it can come back to life
+        if (built && !h->vres.ready && !early) {
+          if ((rc = sub_prepare(h))) return rc;
+          mark_t("sub-problem prepared");
+        }
         continue;
       }
       if (hm->iters > queued) queued = hm->iters;  // (a resident launch retired many iterations at once)
       if (queued - hm->iters < run_ahead) {
-        if ((rc = enqueue_iteration(h, prm))) return rc;
+        if ((rc = enqueue_next())) return rc;
         ++queued;
         spins = 0;
       } else if ((++spins & 0xfffff) == 0) {
@@ -953,6 +980,10 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     }
     mark_t("done seen");
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (h->sub.active) {  // the solve ended on the live sub-problem (its deciding workgroup wrote u through the list of S)
+      sub_account();
+      h->sub.active = false;
+    }
     fin.F = hm->F;
     fin.d = hm->d;
     fin.n_passes = hm->n_passes;
@@ -1068,6 +1099,13 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     info->n_trials = fin.n_trials;
   }
   h->rv_stats.passes = fin.n_passes;
+  h->rv_stats.sub_leaves = h->sub.leaves;
+  h->rv_stats.sub_passes = h->sub.sub_passes;
+  h->rv_stats.sub_build_ms = h->sub.build_ms;
+  if (h->rv_stats.sub_entries > 0 && h->sub.ctx) {
+    h->rv_stats.sub_rows = h->sub.nS;
+    h->rv_stats.sub_bytes = static_cast<int64_t>(h->sub.ctx->sh[0].s_bytes);
+  }
 
   // mat-vec timings from the event pairs
   h->tm.gemv_avg_us = h->tm.gemv_min_us = 0.0;
@@ -1079,8 +1117,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     // transition (0); launches queued past convergence have no mark
     const uint8_t* kind = h->kind;
     const int64_t iters_run = std::min<int64_t>(h->launch_counter, KIND_CAP);
-    double sum = 0.0, mn = 1e30, vsum = 0.0;
-    int64_t nreal = 0, nview = 0;
+    double sum = 0.0, mn = 1e30, vsum = 0.0, ssum = 0.0;
+    int64_t nreal = 0, nview = 0, nsub = 0;
     for (int k = 0; k < h->ev_used; ++k) {
       const int64_t li = h->ev_launch_index[static_cast<size_t>(k)];
       if (li >= iters_run || !kind[static_cast<size_t>(li)]) continue;
@@ -1091,7 +1129,12 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         ++nview;
         continue;
       }
-      if (kind[static_cast<size_t>(li)] == 3) continue;  // a pair-mode pass (one vector): not the window pass the roofline is about
+      if (kind[static_cast<size_t>(li)] == 4) {  // a window pass on the live sub-problem
+        ssum += ms;
+        ++nsub;
+        continue;
+      }
+      if (kind[static_cast<size_t>(li)] == 3 || kind[static_cast<size_t>(li)] == 5) continue;  // a pair-mode pass (one vector): not the window pass the roofline is about
       sum += ms;
       mn = std::min<double>(mn, ms);
       ++nreal;
@@ -1119,6 +1162,10 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     if (nview > 0) {
       h->rv_stats.view_pass_avg_us = vsum / static_cast<double>(nview) * 1e3;
       h->rv_stats.view_pass_samples = nview;
+    }
+    if (nsub > 0) {
+      h->rv_stats.sub_pass_avg_us = ssum / static_cast<double>(nsub) * 1e3;
+      h->rv_stats.sub_pass_samples = nsub;
     }
     if (nreal > 0) {
       h->tm.gemv_avg_us = sum / static_cast<double>(nreal) * 1e3;
@@ -1320,6 +1367,14 @@ int clipper_hip_set_row_view(clipper_hip_t* h, int mode) try {
   h->rv_mode = mode;
   if (mode == 1) rowview_drop(h);
   if (mode != 0) h->vres.ready = false;
+  return 0;
+} CLIPPER_HIP_GUARD_INT
+
+int clipper_hip_set_subproblem(clipper_hip_t* h, int mode) try {
+  if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
+  if (mode != 0 && mode != 1) return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic) or 1 (never)");
+  h->sub_mode = mode;
+  if (mode == 1) h->sub.ready = false;
   return 0;
 } CLIPPER_HIP_GUARD_INT
 

@@ -370,6 +370,29 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.rv_rows = view ? static_cast<int>(s.rv.nrows) : 0;
   a.rvp = h->rvp;
   a.decide_only = h->decide_only ? 1 : 0;
+  // the live sub-problem (host_subproblem.hpp)
+  a.sub_state = 0;
+  a.sub_ncol = 0.0;
+  a.colmap = nullptr;
+  if (h->parent != nullptr) {  // these launches run ON a sub-problem: they report where the parent's would
+    Ctx* p = h->parent;
+    a.host = p->mirror_dev;
+    a.host_u = p->u_pinned_dev;
+    a.marks = p->profiling ? p->sh[0].marks : nullptr;
+    a.kind = a.marks ? p->kind_dev : nullptr;
+    a.stamps = p->stamps_dev;
+    a.stamps_wide = p->stamps_rows > 4096 ? 1 : 0;
+    a.sub_state = 2;
+    a.sub_ncol = p->sub.ncol;
+    a.colmap = p->sub.colmap;
+    // (test knob, CLIPPER_HIP_SUB_TEST_LEAVE = k: the k-th launch after every hand-over is told that a column outside
+    // holds 1e300 entries — its decision, if it plans a window, hands the solve back)
+    static const int test_leave = std::getenv("CLIPPER_HIP_SUB_TEST_LEAVE") ? std::atoi(std::getenv("CLIPPER_HIP_SUB_TEST_LEAVE")) : 0;
+    if (test_leave > 0 && p->sub.launches_since_entry >= test_leave) a.sub_ncol = 1e300;
+  } else if (h->sub.ready && !h->sub.active && !h->decide_only) {
+    a.sub_state = 1;
+    a.sub_ncol = h->sub.ncol;
+  }
   return a;
 }
 
@@ -384,23 +407,26 @@ int enqueue_iteration_v(Ctx* h, const SolverParams& prm) {
   // timing events cost ~5-10 us of stream time each: sample every 8th launch only
   Shard& s0 = h->sh[0];
   constexpr int every = PROFILE_EVERY;
+  // (the launches of a live sub-problem are sampled into the PARENT's record: one series of launch indices per solve)
+  Ctx* hp = h->parent != nullptr ? h->parent : h;
   // iterations 4, 11, then every `every`-th: short solves (20 iterations) still get samples, and
   // one of them is a pass (3 and 9 both hit transitions at cfg4)
-  const bool prof = h->profiling && (h->launch_counter % every == 4 || h->launch_counter == 11) &&
-                    h->ev_used < MAX_EVENT_PAIRS;
+  const bool prof = hp->profiling && (hp->launch_counter % every == 4 || hp->launch_counter == 11) &&
+                    hp->ev_used < MAX_EVENT_PAIRS;
   for (auto& s : h->sh) {
     HIPCHK(hipSetDevice(s.device));
     const SolveArgs a = solve_args(h, s, prm, par);
-    if (prof && &s == &s0) HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used], s.stream));
+    if (prof && &s == &s0) HIPCHK(hipEventRecord(hp->ev_pairs[2 * hp->ev_used], s.stream));
     if (h->csc_valid) launch_pass_csc<V>(h, s, a);
     else launch_pass<V>(h, s, a);
     if (prof && &s == &s0) {
-      HIPCHK(hipEventRecord(h->ev_pairs[2 * h->ev_used + 1], s.stream));
-      h->ev_launch_index[h->ev_used] = h->launch_counter;
-      ++h->ev_used;
+      HIPCHK(hipEventRecord(hp->ev_pairs[2 * hp->ev_used + 1], s.stream));
+      hp->ev_launch_index[hp->ev_used] = hp->launch_counter;
+      ++hp->ev_used;
     }
   }
-  ++h->launch_counter;
+  ++hp->launch_counter;
+  if (h->parent != nullptr) ++hp->sub.launches_since_entry;
   const bool fresh_used = h->rv_fresh;
   const int xk = (prof && sharded) ? h->ev_used - 1 : -1;  // this iteration's exchange is timed too
   if (xk >= 0) HIPCHK(hipEventRecord(h->ev_xchg[2 * xk], s0.stream));

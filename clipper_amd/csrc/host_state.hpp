@@ -248,6 +248,32 @@ struct ViewResident {
 };
 constexpr int RVR_GIVEUP_SLOTS = 16;
 
+// the live sub-problem (k_subproblem.hip.h, host_subproblem.hpp): the associations that can still be selected, as a
+// CLIPPER problem of their own — a child context on the parent's device and stream, kept from solve to solve
+constexpr int SUB_MAX_ENTRIES = 4;   // hand-overs per solve (each leave costs a host round trip)
+constexpr int64_t SUB_MIN_M = 12000; // full problems below this keep their views (the resident solver on a view takes them)
+struct SubProblem {
+  struct clipper_hip_ctx* ctx = nullptr;
+  int32_t* cnt = nullptr;     // [mp] entries of every column among the view's rows (an upper bound: quads x 4)
+  uint8_t* flags = nullptr;   // [mp] 1 = the association is in the sub-problem
+  int32_t* colmap = nullptr;  // [mp] sub-problem index -> association
+  int32_t* pos = nullptr;     // [mp] association -> sub-problem index, or -1
+  uint32_t* blk = nullptr;    // block counts / offsets of the list build
+  int32_t* nout_acc = nullptr;  // device counter of k_sub_leave
+  size_t cap = 0, cap_blk = 0;
+  SubRecord* rec = nullptr;   // pinned + mapped: what the selection found
+  SubRecord* rec_dev = nullptr;
+  bool ready = false;    // a sub-problem of the view in use stands ready: the decision may ask for the hand-over
+  bool active = false;   // the solve's launches run on it
+  int entries = 0;       // hand-overs of this solve
+  int launches_since_entry = 0;  // launches on it since the last hand-over (test knob CLIPPER_HIP_SUB_TEST_LEAVE)
+  int64_t nS = 0;        // its associations
+  double ncol = 0.0;     // the largest entry count among the view's rows of a column outside it
+  // reporting (clipper_hip_view_stats_t)
+  int64_t passes_at_entry = 0, sub_passes = 0, leaves = 0;
+  double build_ms = 0.0;
+};
+
 }  // namespace
 
 struct clipper_hip_ctx {
@@ -333,6 +359,11 @@ struct clipper_hip_ctx {
   int32_t* rv_count = nullptr;      // pinned + mapped: rows of the view being built
   int32_t* rv_count_dev = nullptr;
   clipper_hip_view_stats_t rv_stats{};
+  // the live sub-problem: this context's (`sub`), or the context this one IS the sub-problem of (`parent`: its
+  // launches report into the parent's progress record and borrow the parent's stream)
+  SubProblem sub;
+  struct clipper_hip_ctx* parent = nullptr;
+  int sub_mode = 0;           // 0 = automatic, 1 = never (clipper_hip_set_subproblem / CLIPPER_HIP_SUBPROBLEM=0)
 
   long long* stamps_dev = nullptr;  // CLIPPER_HIP_STAMPS=1: [4096][4], see SolveArgs::stamps; =2: [16384][4]
   int stamps_rows = 4096;

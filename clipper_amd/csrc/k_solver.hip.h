@@ -237,6 +237,12 @@ struct SolveArgs {
                            // prepared (SolverState::resume) instead of running it — the hand-over to the
                            // resident solver on a row view (k_rv_resident.hip.h), which starts from a
                            // prepared pass and leaves one behind
+  // the live sub-problem (k_subproblem.hip.h)
+  int sub_state;           // 0: none. 1: a sub-problem stands ready — the decision puts the solve on hold (hold = 2)
+                           // for the hand-over once no column outside it can come back to life. 2: these launches
+                           // RUN on the sub-problem — the decision hands the solve back (hold = 3) when one could
+  double sub_ncol;         // stored entries among the live rows of any column outside the sub-problem, at most
+  const int32_t* colmap;   // sub_state == 2: element i of the vectors is association colmap[i] of the full problem
 };
 constexpr int KIND_CAP = 1 << 16;
 
@@ -519,6 +525,20 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   int action = ACT_SLOW;
   int next_phase = PH_TRIAL;
   bool need_pair = false;  // the pass of this iteration is a pair-mode pass on the accepted x
+  // The live sub-problem (k_subproblem.hip.h): no column outside it can come back to life under ANY candidate of the
+  // window this decision leaves pending — d^2 s_l^2 >= kappa (1 + d)^2 N z_l for its raw sums (z_l, s_l) =
+  // (||x_l||^2, sum x_l), which the tail left at sums[nb + 2 l], sums[nb + 2 l + 1]. Every workgroup evaluates it.
+  bool sub_ok = true;
+  auto sub_bound = [&](const double* sums, int nb) {
+    if (A.sub_state == 0) return;
+    const double kap = (A.sub_state == 1 ? 1.10 : 1.01) * A.sub_ncol;  // SUB_ENTER_MARGIN / SUB_STAY_MARGIN
+    const double lhs = d * d, rhs = (1.0 + d) * (1.0 + d) * kap;
+#pragma unroll
+    for (int l = 0; l < V; ++l) {
+      const double z = sums[nb + 2 * l], sl = sums[nb + 2 * l + 1];
+      sub_ok = sub_ok && (lhs * sl * sl >= rhs * z);
+    }
+  };
 
   if (phase == PH_TRIAL || phase == PH_BUILD) {
     // sums[q] = the chains of head_loads(), added in chain order
@@ -560,6 +580,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
         sel = V;
         action = ACT_PASS;
+        sub_bound(sums, V * NR);
         if (writer && tid == 0) {  // the norms are only recorded (for the tail): no other workgroup needs them
 #pragma unroll
           for (int l = 0; l < V; ++l) {
@@ -600,6 +621,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
           k_ = 0;
           sel = jstar;  // the tail already built max(x + beta^l gradFnew, 0) in table jstar
           action = ACT_PASS;
+          sub_bound(sums, jstar * NR + 2);
           if (writer && tid == 0) {
 #pragma unroll
             for (int l = 0; l < V; ++l) {
@@ -622,6 +644,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         k_ = 0;
         sel = 0;
         action = ACT_PASS;
+        sub_bound(sums, 2);
         if (writer && tid == 0) {
 #pragma unroll
           for (int l = 0; l < V; ++l) {
@@ -740,8 +763,10 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   // that the host needs neither a copy nor a wait on the stream once it sees `done`
   if (writer && action == ACT_DONE && A.host_u != nullptr) {
     const double* u = pt_arr(A, V, ubp, ubv, 0);
+    // (on the live sub-problem element i is association colmap[i]; the host zeroed the rest at the hand-over)
     for (int64_t i = tid; i < m; i += NT)
-      __hip_atomic_store(A.host_u + i, u[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(A.host_u + (A.colmap != nullptr ? static_cast<int64_t>(A.colmap[i]) : i), u[i], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     if (A.kind != nullptr && A.marks != nullptr) {
       const int64_t n = (n_iters < KIND_CAP) ? n_iters : KIND_CAP;
       for (int64_t i = tid; i < n; i += NT)
@@ -756,28 +781,40 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   // (a view built from exactly this state covers every outcome by construction — whatever the tail,
   // which ran before the view existed, counted)
   if (A.rv_fresh != 0 && action != ACT_SLOW) nout = 0;
-  // Is it time to build a (smaller) row view? A function of the state alone; see LIVE ROWS.
-  if (action == ACT_PASS && next_phase == PH_TRIAL && A.rvp.on != 0 && A.rv_fresh == 0 &&
-      view_wanted(A, nlive, nout, n_iters, L.rv_builds, L.rv_last, L.rv_backoff)) {
-    // HOLD: this iteration decides nothing — the state it read goes on unchanged, marked
+  // HOLD: this iteration decides nothing — the state it read goes on unchanged, marked with what the host is asked for
+  // (1: a row view of the decided point's live rows; 2: the hand-over to the live sub-problem)
+  auto put_on_hold = [&](int reason) {
     if (writer) {  // (block-uniform; word by word: a struct copy by one thread is 66 registers)
       copy_state(A.st_next, st, tid, NT);
       __syncthreads();
       if (tid == 0) {
-        A.st_next->hold = 1;
+        A.st_next->hold = reason;
         A.st_next->hold_slot = ubp * V + ubv;  // (after the decision: the accepted candidate's slot, or the unchanged point's)
         A.st_next->hold_nlive = nlive;
-        A.shared->hold = 1;
+        A.shared->hold = reason;
         if (A.host != nullptr) {
           __hip_atomic_store(&A.host->hold_nlive, nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(&A.host->hold, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&A.host->hold, reason, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
+  };
+  // Is it time to build a (smaller) row view? A function of the state alone; see LIVE ROWS.
+  if (action == ACT_PASS && next_phase == PH_TRIAL && A.rvp.on != 0 && A.rv_fresh == 0 && A.sub_state != 2 &&
+      view_wanted(A, nlive, nout, n_iters, L.rv_builds, L.rv_last, L.rv_backoff)) {
+    put_on_hold(1);
     return false;
   }
   const bool on_view = A.in_view != nullptr && nout == 0 && action == ACT_PASS &&
                        (next_phase == PH_TRIAL || need_pair);
+  // The live sub-problem stands ready and the window this decision leaves pending cannot bring a column outside it back
+  // to life (and the view covers the live rows: they all lie inside it): hold for the hand-over.
+  if (A.sub_state == 1 && A.decide_only == 0 && on_view && next_phase == PH_TRIAL && !need_pair && sub_ok) {
+    put_on_hold(2);
+    return false;
+  }
+  // ... or these launches run ON it and the pending window could: the pass is left prepared and the solve goes back
+  const bool sub_leave = A.sub_state == 2 && action == ACT_PASS && !sub_ok;
   // ---- record the decided state (workgroup (0,0), one thread) ------------------------------
   // A pass iteration parks it in LDS and writes it out AFTER the streaming loop (flush_state):
   // a global store ahead of the loop would make the compiler treat the table rows as possibly
@@ -824,7 +861,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
     };
     if (action == ACT_PASS) record(stash, true);
     else record(A.st_next, false);
-    if (A.decide_only != 0 && action == ACT_PASS) {
+    if ((A.decide_only != 0 || sub_leave) && action == ACT_PASS) {
       // the pass is left PREPARED: window from point slot (ubp, ubv) with step `alpha` and the norms just
       // parked, or (penalty update) the pair-mode pass on that slot's u
       stash->stage = ST_PASS;
@@ -832,6 +869,10 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       stash->n_passes = n_passes;
       stash->view = 0;
       stash->n_view_passes = L.n_view_passes;
+      if (sub_leave) {  // (hold = 3: the host scatters the point back and goes on with the full problem's launches)
+        stash->hold = 3;
+        A.shared->hold = 3;
+      }
     }
     if (action == ACT_DONE) {
       SolveShared* sh = A.shared;
@@ -857,14 +898,16 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         // every store above (and the vectors this workgroup wrote) before the flag
         __hip_atomic_store(&hm->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      if (action != ACT_PASS || A.decide_only != 0) {
+      if (action != ACT_PASS || A.decide_only != 0 || sub_leave) {
+        __hip_atomic_store(&hm->n_passes, n_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->nlive, nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->nout, nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hm->iters, n_iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (sub_leave) __hip_atomic_store(&hm->hold, 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
-  if (A.decide_only != 0 && action == ACT_PASS) {  // (block-uniform) nothing streams: the prepared pass goes out as the state
+  if ((A.decide_only != 0 || sub_leave) && action == ACT_PASS) {  // (block-uniform) nothing streams: the prepared pass goes out as the state
     if (writer) {
       __syncthreads();
       copy_state(A.st_next, stash, tid, NT);
@@ -979,13 +1022,15 @@ __device__ __forceinline__ void flush_state(const SolveArgs& A, const SolverStat
   if (threadIdx.x == 0) {
     const int64_t n_iters = stash->n_iters;
     // what this launch streamed: 1 = a window pass on M, 2 = a pass on the row view, 3 = a pair-mode pass
-    // on M (one vector: initialisation, penalty update) — the pass timings keep them apart
+    // on M (one vector: initialisation, penalty update), 4 / 5 = a window / pair-mode pass on the live
+    // sub-problem — the pass timings keep them apart
     if (A.marks != nullptr && n_iters <= KIND_CAP)
-      A.marks[n_iters - 1] = stash->view ? 2 : (stash->phase == PH_TRIAL ? 1 : 3);
+      A.marks[n_iters - 1] = A.sub_state == 2 ? (stash->phase == PH_TRIAL ? 4 : 5) : stash->view ? 2 : (stash->phase == PH_TRIAL ? 1 : 3);
     if (A.host != nullptr) {
       __hip_atomic_store(&A.host->nlive, stash->nlive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(&A.host->nout, stash->nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(&A.host->n_view_passes, stash->n_view_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&A.host->n_passes, stash->n_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(&A.host->iters, n_iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }

@@ -34,6 +34,7 @@
 //   k_affinity.hip.h  k_gather_points, k_affinity_* (plain, compacting strips, symmetric tiles + emission)
 //   k_matrix.hip.h    k_from_dense_upper, k_from_csc, k_gather_sub
 //   k_rowview.hip.h   the row list of a row view of M (the live rows of the solver's current points)
+//   k_subproblem.hip.h  the live sub-problem: column counts of a view, the selection, the hand-over and the way back
 //   k_knn.hip.h       brute-force k-nearest neighbours (putative associations)
 #pragma once
 
@@ -45,4 +46,5 @@
 #include "k_affinity.hip.h"
 #include "k_matrix.hip.h"
 #include "k_rowview.hip.h"
+#include "k_subproblem.hip.h"
 #include "k_knn.hip.h"

@@ -115,6 +115,15 @@ typedef struct clipper_hip_view_stats_t {
                                   an event pair costs stream time, so not in a timed region); 0 = not timed   */
   int64_t resident_entries;    /* stored entries (quads x 4, padding included) of the view the last launch ran on */
   int64_t resident_units;      /* workgroups (one per CU: each holds its columns of the view in LDS) of that launch */
+  /* the live sub-problem (csrc/k_subproblem.hip.h, clipper_hip_set_subproblem below) */
+  int64_t sub_entries;         /* hand-overs of the last solve to the sub-problem of the associations that can still be selected */
+  int64_t sub_leaves;          /* ... and hand-overs back (a column outside it could have come back to life)   */
+  int64_t sub_passes;          /* passes of the last solve that ran on the sub-problem (not counted in view_passes) */
+  int64_t sub_rows;            /* associations of the sub-problem (0: none was prepared)                       */
+  int64_t sub_bytes;           /* bytes its slices hold                                                        */
+  double sub_build_ms;         /* host wall clock spent preparing it (selection, gather, fill, plan)           */
+  double sub_pass_avg_us;      /* mean duration of the sampled window passes on it (profiling on; 0 = none)    */
+  int64_t sub_pass_samples;
 } clipper_hip_view_stats_t;
 
 /* ---- life cycle --------------------------------------------------------------------- */
@@ -297,6 +306,14 @@ int clipper_hip_last_solver(const clipper_hip_t* h);
  * live (csrc/k_rv_resident.hip.h); mode 2 (also: CLIPPER_HIP_VIEW_RESIDENT=0) keeps the views but streams them. */
 int clipper_hip_set_row_view(clipper_hip_t* h, int mode);
 int clipper_hip_get_view_stats(const clipper_hip_t* h, clipper_hip_view_stats_t* out);
+
+/* The live sub-problem: once a row view exists and the penalty d is large, no association outside a small set S (the
+ * view's rows and the few columns with many entries among them) can get a positive gradient again — by a bound on
+ * clipper.cpp:238-241 that the decision checks for every candidate it plans — and the solve continues on the
+ * associations of S as a problem of its own (csrc/k_subproblem.hip.h): the same launches on M[S,S]. Exact: what is left
+ * out is provably zero. mode 0 = automatic (one shard, built-in invariants, m >= 12 000: smaller problems' views are taken
+ * by the resident solver), 1 = never (also: CLIPPER_HIP_SUBPROBLEM=0). */
+int clipper_hip_set_subproblem(clipper_hip_t* h, int mode);
 
 /* The products of clipper_hip_matvec through a row view built for the given rows (ascending association
  * indices): yM = M_off[:, rows] x[rows], yC likewise — what a pass of the solver computes when it
