@@ -54,13 +54,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PMC_RECORD = "profiles/pmc_r05.json"
+PMC_RECORD = "profiles/pmc_r06.json"
 LDS_PEAK_TBPS = 150.0   # 256 CUs x 256 B/clk x ~2.4 GHz for ds_read_b64 / b128 (MI355X_MICROARCH.md, LDS)
 # the sources of the kernels the PMC record is about (the pass, its decision, the planner that cuts its work, the
 # fill): a record is quoted only if it was measured on exactly these bytes
 PMC_SOURCES = ("clipper_amd/csrc/k_slices.hip.h", "clipper_amd/csrc/k_solver.hip.h", "clipper_amd/csrc/host_plan.hpp",
                "clipper_amd/csrc/k_affinity.hip.h", "clipper_amd/csrc/k_csc.hip.h", "clipper_amd/csrc/k_rv_resident.hip.h",
-               "clipper_amd/csrc/k_resident.hip.h")
+               "clipper_amd/csrc/k_resident.hip.h", "clipper_amd/csrc/k_rowview.hip.h", "clipper_amd/csrc/k_gemv.hip.h",
+               "clipper_amd/csrc/k_subproblem.hip.h", "clipper_amd/csrc/k_matrix.hip.h", "clipper_amd/csrc/host_rv_resident.hpp",
+               "clipper_amd/csrc/host_resident.hpp", "clipper_amd/csrc/host_rowview.hpp", "clipper_amd/csrc/host_subproblem.hpp")
 
 
 def kernel_sources_sha256():
@@ -194,7 +196,7 @@ def main():
             g.solve_staged()
         g.set_profiling(profile)
         r = dict(aff_ms=[], solve_ms=[], gemv_us=0.0, gemv_n=0, view_us=0.0, view_n=0, xchg_us=0.0, xchg_n=0,
-                 res_us=0.0, res_iters=0, res_launches=0, res_giveups=0)
+                 res_us=0.0, res_iters=0, res_launches=0, res_giveups=0, sub_us=0.0, sub_n=0)
         barrier_sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -211,6 +213,8 @@ def main():
             r["gemv_n"] += tm.gemv_launches
             r["view_us"] += vs.view_pass_avg_us * vs.view_pass_samples
             r["view_n"] += vs.view_pass_samples
+            r["sub_us"] += vs.sub_pass_avg_us * vs.sub_pass_samples
+            r["sub_n"] += vs.sub_pass_samples
             r["xchg_us"] += tm.exchange_avg_us * tm.exchange_samples
             r["xchg_n"] += tm.exchange_samples
             r["res_us"] += vs.resident_us
@@ -266,6 +270,15 @@ def main():
         P = timed_steps(pp, psteps, 1, not args.no_profile)
         ptm, pvs = P["tm"], P["vs"]
         pass_us = P["gemv_us"] / max(1, P["gemv_n"])
+        view_us = P["view_us"] / max(1, P["view_n"])
+        sub_us = P["sub_us"] / max(1, P["sub_n"])
+
+        def roof(nbytes, us):   # a streamed pass against the HBM peak: bytes its slices hold / its launch's duration
+            if us <= 0 or nbytes <= 0:
+                return None
+            gbps = nbytes / (us * 1e-6) / 1e9
+            return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(gbps / HBM_PEAK_GBPS, 4), "bytes_per_launch": int(nbytes), "us_per_launch": round(us, 2)}
         return {
             "m": pm, "rho": 0.95, "steps": psteps, "n_gpus": N,
             "ms_per_step": round(P["ms_per_step"], 3),
@@ -276,7 +289,14 @@ def main():
             "pass_on_M_GBps": round(ptm.gemv_bytes / (pass_us * 1e-6) / 1e9, 1) if pass_us > 0 else 0.0,
             "pass_on_M_frac_of_hbm_peak": round(ptm.gemv_bytes / (pass_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if pass_us > 0 else 0.0,
             "passes_on_a_row_view": int(pvs.view_passes), "view_rows": int(pvs.rows), "view_bytes": int(pvs.bytes),
-            "pass_on_view_us": round(P["view_us"] / max(1, P["view_n"]), 1),
+            "pass_on_view_us": round(view_us, 1),
+            "roofline_view": roof(pvs.bytes, view_us),
+            # the live sub-problem: the passes behind the view run on M[S,S], S = the associations
+            # that can still be selected
+            "passes_on_the_sub_problem": int(pvs.sub_passes), "sub_rows": int(pvs.sub_rows), "sub_bytes": int(pvs.sub_bytes),
+            "sub_entries": int(pvs.sub_entries), "sub_leaves": int(pvs.sub_leaves), "sub_build_ms": round(pvs.sub_build_ms, 3),
+            "pass_on_sub_us": round(sub_us, 1),
+            "roofline_sub": roof(pvs.sub_bytes, sub_us),
             "exchange_us": round(P["xchg_us"] / max(1, P["xchg_n"]), 1) if N > 1 else None,
             "exchange_bytes_per_rank": ptm.exchange_bytes if N > 1 else None,
             "nodes": int(len(P["sol"].nodes)), "score": P["sol"].score,
@@ -431,6 +451,22 @@ def main():
                 "resident_launches": int(vstats.resident_launches), "resident_giveups": int(vstats.resident_giveups),
                 # HIP events around streamed view passes; none when the view's iterations ran inside the resident launch
                 "pass_on_view_us": round(R["view_us"] / R["view_n"], 2) if R["view_n"] > 0 else None,
+            },
+            # the pass on a streamed view against the HBM peak (none at the headline: its view's iterations run inside
+            # the resident launch — `roofline_resident`; the probe carries the figure of the size that streams)
+            "roofline_view": ({"bound": "hbm", "achieved": round(vstats.bytes / (R["view_us"] / R["view_n"] * 1e-6) / 1e9, 1),
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(vstats.bytes / (R["view_us"] / R["view_n"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "bytes_per_launch": int(vstats.bytes), "us_per_launch": round(R["view_us"] / R["view_n"], 2)}
+                              if R["view_n"] > 0 and vstats.bytes > 0 else None),
+            "live_subproblem": {
+                "what": "once a row view exists and the penalty d is large, no association outside a small set S can get a "
+                        "positive gradient again (a bound on clipper.cpp:238-241 checked by every decision): the solve "
+                        "continues on M[S,S] as a problem of its own (DESIGN.md 3e). m >= 12 000 only: below, the view's "
+                        "iterations run inside the resident launch",
+                "entries": int(vstats.sub_entries), "leaves": int(vstats.sub_leaves), "passes_on_it": int(vstats.sub_passes),
+                "associations": int(vstats.sub_rows), "bytes": int(vstats.sub_bytes), "build_ms": round(vstats.sub_build_ms, 4),
+                "pass_us": round(R["sub_us"] / R["sub_n"], 2) if R["sub_n"] > 0 else None,
             },
             "roofline_resident": roofline_resident,
             "scaling_probe": probe,
