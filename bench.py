@@ -355,6 +355,9 @@ def main():
         aff_kernel_ms = tm.affinity_kernel_ms
         aff_achieved = tm.affinity_bytes / (aff_kernel_ms * 1e-3) / 1e9 if aff_kernel_ms > 0 else 0.0
         roofline_resident = None
+        if R["res_giveups"] > 0:  # (a give-up puts the context on the streamed route — the line would describe the fall-back)
+            print(f"bench.py: {R['res_giveups']} launch(es) of the resident solver on a view GAVE UP during the timed steps: "
+                  f"`value` was measured (partly) on the streamed fall-back", file=sys.stderr, flush=True)
         if R["res_launches"] > 0 and R["res_iters"] > 0:
             V = g.window
             ent = int(vstats.resident_entries)

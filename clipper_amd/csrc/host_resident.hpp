@@ -210,7 +210,8 @@ int resident_solve(Ctx* h, const SolverParams& prm, bool rescale, SolveShared& f
     // there: rather launch again). A unit that is not resident by then is behind another tenant's work: the
     // streaming launches take over, and this matrix is not tried again (r.failed). Round 4 waited 0.5 s — a thousand
     // solves' worth — before a 0.3 ms solve went on.
-    a.timeout_ticks = timeout_override ? timeout_override : (a.xcd_mode ? 200000ll : 500000ll);
+    // (ten times as long for a context's first launch — cold code object, clock ramp-up, a serialising profiler)
+    a.timeout_ticks = timeout_override ? timeout_override : (a.xcd_mode ? 200000ll : 500000ll) * (r.epoch == 0 ? 10 : 1);
     a.epoch0 = r.epoch;
     std::memset(h->mirror, 0, sizeof(HostMirror));
     std::atomic_thread_fence(std::memory_order_seq_cst);

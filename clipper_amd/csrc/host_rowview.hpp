@@ -356,8 +356,12 @@ int rowview_build_shard(Ctx* h, Shard& s, bool& built) {
            (!store_gone && (static_cast<double>(nrows) > RV_ROWS_RATIO * rows_now ||
                             RV_GAIN_MARGIN * (pol.build_fixed + pol.build_per_row * static_cast<double>(nrows)) >=
                                 horizon * (rows_now - static_cast<double>(nrows)) * pol.pass_per_row)))) {
-        hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows),
-                           static_cast<uint32_t*>(nullptr));
+        // (a refusal AFTER the early hand-over — the hold is lifted and the decide-only iteration is in the
+        // stream already: the caller must count it, and the state has moved on: no second resume)
+        if (!early_done)
+          hipLaunchKernelGGL(k_rv_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared, static_cast<int>(nrows),
+                             static_cast<uint32_t*>(nullptr));
+        h->early_decide_done = early_done;
         h->rv_stats.build_ms +=
             std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
         return 0;

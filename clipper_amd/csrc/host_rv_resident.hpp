@@ -236,6 +236,11 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   if (!r.ready || !(r.on_replica ? rvr_replica_enabled(h) : rvr_enabled(h)) || prm.maxiniters < 1) return 0;
   Shard& s = h->sh[0];
   if (!s.rv.valid || (r.on_replica && !s.rv.full_valid)) return 0;
+  // Every launch of a solve has its own control block and give-up slot: a launch without one could time out unseen
+  // (with column shards the ranks would then disagree on what was committed). A solve builds at most
+  // RV_MAX_BUILDS views and launches at most once per build, so this never binds; it is enforced all the same.
+  static_assert(RV_MAX_BUILDS <= RVR_GIVEUP_SLOTS, "one give-up slot per view a solve can build");
+  if (r.launches_this_solve >= RVR_GIVEUP_SLOTS) return 0;
   HIPCHK(hipSetDevice(s.device));
   RvrArgs a{};
   a.R = r.on_replica ? row_view_full(h, s) : row_view(h, s);
@@ -273,6 +278,9 @@ int rvr_enqueue(Ctx* h, const SolverParams& prm, bool& launched) {
   // resident by then is behind another tenant's work; the streaming launches, which need no co-residency, take over
   // (round 4: 0.2 s — two hundred solves' worth of waiting before a 1.2 ms solve went on).
   a.timeout_ticks = 200000ll;
+  // (the first launch of a context waits ten times as long — a cold code object, a clock that ramps up or a
+  // profiler that serialises kernels must not look like another tenant and send the context into its back-off)
+  if (r.epoch == 0) a.timeout_ticks = 2000000ll;
   if (const char* e = std::getenv("CLIPPER_HIP_VIEW_RESIDENT_TIMEOUT_TICKS")) a.timeout_ticks = std::atoll(e);  // (test knob)
   // (a launch owns 2^20 epochs, one per exchange: the budget stays below, so that nothing it publishes can carry a
   // tag of the next launch's range)
@@ -374,15 +382,29 @@ int rvr_replica_handover(Ctx* h, const SolverParams& prm) {
   int rc;
   const auto t0 = std::chrono::high_resolution_clock::now();
   bool mine = false;
-  if (rvr_local_ok(h)) {
-    if ((rc = rvr_build_replica(h, s))) return rc;
-    if (s.rv.full_valid) {
-      if ((rc = rvr_plan(h, s, true))) return rc;
-      mine = r.ready;
+  //  A LOCAL failure in front of the first agreement — the replica's build, the plan, the backup's
+  // allocation — must not keep this rank out of a round its peers enter: it says "no" in the agreement and reports
+  // its error afterwards. A solve never launches more often than it has give-up slots (rvr_enqueue).
+  int local_rc = 0;
+  if (rvr_local_ok(h) && r.launches_this_solve < RVR_GIVEUP_SLOTS) {
+    local_rc = rvr_build_replica(h, s);
+    if (!local_rc && s.rv.full_valid) {
+      local_rc = rvr_plan(h, s, true);
+      mine = !local_rc && r.ready;
+    }
+    if (mine && !r.backup && hipMalloc(reinterpret_cast<void**>(&r.backup), sizeof(SolverState) + sizeof(SolveShared)) != hipSuccess) {
+      (void)hipGetLastError();
+      r.backup = nullptr;
+      local_rc = fail(CLIPPER_HIP_E_NOMEM, "resident solver on a view: no memory for the state's backup");
+      mine = false;
     }
   }
   bool all = false;
   if ((rc = rvr_agree(h, mine, all))) return rc;
+  if (local_rc) {
+    r.ready = false;
+    return local_rc;
+  }
   if (rs_debug())
     std::fprintf(stderr, "[view-resident] replica: rows %lld, %.1f MB, this rank %s, all ranks %s\n", static_cast<long long>(s.rv.nrows),
                  static_cast<double>(s.rv.full.s_bytes) / 1e6, mine ? "ready" : "not ready", all ? "ready" : "not ready");
@@ -395,7 +417,6 @@ int rvr_replica_handover(Ctx* h, const SolverParams& prm) {
   h->decide_only = false;
   if (rc) return rc;
   HIPCHK(hipSetDevice(s.device));
-  if (!r.backup) HIPCHK(hipMalloc(reinterpret_cast<void**>(&r.backup), sizeof(SolverState) + sizeof(SolveShared)));
   HIPCHK(hipMemcpyAsync(r.backup, s.st + h->par, sizeof(SolverState), hipMemcpyDeviceToDevice, s.stream));
   HIPCHK(hipMemcpyAsync(r.backup + sizeof(SolverState), s.shared, sizeof(SolveShared), hipMemcpyDeviceToDevice, s.stream));
   bool launched = false;

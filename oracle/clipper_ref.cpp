@@ -69,6 +69,9 @@ struct clipper_ref_ctx {
   std::vector<int32_t> A; /* column-major m x 2 */
   Csc M, C;
   std::vector<int32_t> nodes;
+  /* the order of the additions inside M x, C x (clipper_ref_set_sum_mode): 0 = the reference's, 1 = the same additions
+   * with the columns swept from the last to the first, 2 = every output accumulated in extended precision */
+  int sum_mode = 0;
 };
 
 namespace {
@@ -182,7 +185,10 @@ std::vector<int32_t> above_threshold(const double* x, int64_t n, double thr) {
  * 205,219,240-241,268,271). Column sweep as Eigen's sparse self-adjoint kernel does:
  * entry (i,j), i<j, contributes val*x[j] to y[i] and val*x[i] to y[j]. Single thread
  * (Eigen's product is not parallel). */
-void symv_upper(const Csc& S, const double* x, double* y) {
+void symv_upper_reordered(const Csc& S, const double* x, double* y, int mode);
+
+void symv_upper(const Csc& S, const double* x, double* y, int mode = 0) {
+  if (mode != 0) return symv_upper_reordered(S, x, y, mode);
   const int64_t n = S.n;
   for (int64_t i = 0; i < n; ++i) y[i] = 0.0;
   for (int64_t j = 0; j < n; ++j) {
@@ -196,6 +202,51 @@ void symv_upper(const Csc& S, const double* x, double* y) {
        * members the reference builds itself hold nothing else (clipper.cpp:61-64, 151-157);
        * a matrix handed to setSparseMatrixData (clipper.cpp:162-166) may: an entry below the
        * diagonal is ignored, a stored diagonal counts ONCE. */
+      if (i > j) continue;
+      if (i == j) {
+        yj += v * xj;
+        continue;
+      }
+      y[i] += v * xj;
+      yj += v * x[i];
+    }
+    y[j] += yj;
+  }
+}
+
+/* The SAME product with its additions in another order — not the reference's: what the reference's answer is worth
+ * where its decisions sit on the last bits of these sums (tests/test_oracle_golden.py).
+ *   mode 1: columns swept from the last to the first, a column's entries from the last to the first;
+ *   mode 2: every output accumulated in extended precision (x87 long double, 64-bit mantissa) and rounded once —
+ *           the product nearly as if the sums were exact. */
+void symv_upper_reordered(const Csc& S, const double* x, double* y, int mode) {
+  const int64_t n = S.n;
+  if (mode == 2) {
+    std::vector<long double> acc(static_cast<size_t>(n), 0.0L);
+    for (int64_t j = 0; j < n; ++j) {
+      const long double xj = x[j];
+      for (int64_t p = S.colptr[static_cast<size_t>(j)]; p < S.colptr[static_cast<size_t>(j) + 1]; ++p) {
+        const int32_t i = S.row[static_cast<size_t>(p)];
+        const long double v = S.val[static_cast<size_t>(p)];
+        if (i > j) continue;
+        if (i == j) {
+          acc[static_cast<size_t>(j)] += v * xj;
+          continue;
+        }
+        acc[static_cast<size_t>(i)] += v * xj;
+        acc[static_cast<size_t>(j)] += v * static_cast<long double>(x[i]);
+      }
+    }
+    for (int64_t i = 0; i < n; ++i) y[i] = static_cast<double>(acc[static_cast<size_t>(i)]);
+    return;
+  }
+  for (int64_t i = 0; i < n; ++i) y[i] = 0.0;
+  for (int64_t j = n - 1; j >= 0; --j) {
+    const double xj = x[j];
+    double yj = 0.0;
+    for (int64_t p = S.colptr[static_cast<size_t>(j) + 1] - 1; p >= S.colptr[static_cast<size_t>(j)]; --p) {
+      const int32_t i = S.row[static_cast<size_t>(p)];
+      const double v = S.val[static_cast<size_t>(p)];
       if (i > j) continue;
       if (i == j) {
         yj += v * xj;
@@ -428,14 +479,24 @@ int clipper_ref_get_matrix(const clipper_ref_t* h, double* M_out, double* C_out)
   return 0;
 }
 
+/* (test infrastructure of the test infrastructure) the order of the additions inside the products: see symv_upper_reordered */
+int clipper_ref_set_sum_mode(clipper_ref_t* h, int mode) {
+  if (!h || mode < 0 || mode > 2) {
+    g_err = "sum mode must be 0 (the reference's order), 1 (reversed) or 2 (extended precision)";
+    return -1;
+  }
+  h->sum_mode = mode;
+  return 0;
+}
+
 int64_t clipper_ref_nnz(const clipper_ref_t* h) {
   return h ? static_cast<int64_t>(h->M.row.size()) : 0;
 }
 
 int clipper_ref_matvec(const clipper_ref_t* h, const double* x, double* yM, double* yC) {
   if (!h || !x) return -1;
-  if (yM) symv_upper(h->M, x, yM);
-  if (yC) symv_upper(h->C, x, yC);
+  if (yM) symv_upper(h->M, x, yM, h->sum_mode);
+  if (yC) symv_upper(h->C, x, yC, h->sum_mode);
   return 0;
 }
 
@@ -458,10 +519,10 @@ int clipper_ref_solve(clipper_ref_t* h, const double* u0_in, const clipper_param
   /* one pass = the pair (M_off*x, C_off*x); the reference evaluates the two products
    * wherever it needs them, here they are counted as it evaluates them. */
   auto matvec_M = [&](const std::vector<double>& x, std::vector<double>& y) {
-    symv_upper(h->M, x.data(), y.data());
+    symv_upper(h->M, x.data(), y.data(), h->sum_mode);
   };
   auto matvec_C = [&](const std::vector<double>& x, std::vector<double>& y) {
-    symv_upper(h->C, x.data(), y.data());
+    symv_upper(h->C, x.data(), y.data(), h->sum_mode);
   };
 
   /* :193-198 — one power-method step, then normalise */

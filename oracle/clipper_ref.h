@@ -67,6 +67,12 @@ int clipper_ref_get_nodes(const clipper_ref_t* h, int32_t* nodes_out, int32_t ca
 /* CLIPPER::getSelectedAssociations (clipper.cpp:124-127): column-major k x 2. */
 int clipper_ref_get_selected_associations(const clipper_ref_t* h, int32_t* A_out, int32_t capacity);
 
+/* The order of the additions inside every product M_off*x, C_off*x of the solver and of clipper_ref_matvec:
+ * 0 = the reference's (Eigen's column sweep; the default and the only PARITY mode), 1 = the same additions with columns
+ * and entries swept backwards, 2 = every output accumulated in extended precision. Modes 1 and 2 exist to measure how much
+ * of the reference's answer is decided by rounding (tests/test_oracle_golden.py::test_summation_order_*). */
+int clipper_ref_set_sum_mode(clipper_ref_t* h, int mode);
+
 /* One symmetric product pair y_M = M_off*x, y_C = C_off*x (clipper.cpp:194,202,...);
  * exposed so tests can check the GPU mat-vec in isolation. */
 int clipper_ref_matvec(const clipper_ref_t* h, const double* x, double* yM, double* yC);

@@ -105,6 +105,7 @@ def lib():
         C.c_void_p, i64, C.POINTER(i64), ip, dp, C.POINTER(i64), ip, dp]
     L.clipper_ref_get_matrix.argtypes = [C.c_void_p, dp, dp]
     L.clipper_ref_nnz.argtypes = [C.c_void_p]
+    L.clipper_ref_set_sum_mode.argtypes = [C.c_void_p, C.c_int]
     L.clipper_ref_nnz.restype = i64
     L.clipper_ref_solve.argtypes = [C.c_void_p, dp, C.POINTER(Params), dp, C.POINTER(SolveInfo)]
     L.clipper_ref_get_nodes.argtypes = [C.c_void_p, ip, C.c_int32]
@@ -212,6 +213,10 @@ class RefClipper:
     @property
     def nnz(self):
         return int(self.L.clipper_ref_nnz(self.h))
+
+    def set_sum_mode(self, mode: int):
+        """order of the additions inside M x, C x: 0 = the reference's (parity), 1 = reversed, 2 = extended precision"""
+        self._check(self.L.clipper_ref_set_sum_mode(self.h, int(mode)))
 
     def get_initial_associations(self):
         A = np.zeros((self.m, 2), dtype=np.int32, order="F")

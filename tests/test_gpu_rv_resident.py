@@ -172,7 +172,8 @@ def test_another_tenant_on_the_device_costs_milliseconds_not_seconds():
     assert child.exitcode == 0
     assert st.resident_giveups == 1 and st.resident_launches == 0, (st.resident_launches, st.resident_giveups)
     assert np.array_equal(s.u, s2.u) and s.n_trials == s2.n_trials and s.nodes.tolist() == s2.nodes.tolist()
-    assert dt < 10e-3, f"{dt * 1e3:.1f} ms"
+    # (a bound that a loaded box keeps — the regression it guards against was 200 ms)
+    assert dt < 100e-3, f"{dt * 1e3:.1f} ms"
     s3 = g.solve(p.u0)                         # backing off: streamed, no attempt
     assert g.view_stats().resident_launches == 0 and g.view_stats().resident_giveups == 0
     s4 = g.solve(p.u0)                         # the tenant is gone: the launch runs again
@@ -180,6 +181,30 @@ def test_another_tenant_on_the_device_costs_milliseconds_not_seconds():
     assert s4.nodes.tolist() == s0.nodes.tolist() and s4.n_trials == s0.n_trials
     g.close()
     g2.close()
+
+
+def test_two_inner_iterations_still_give_a_sound_answer():
+    """maxiniters = 2 cuts every inner loop off after two steps: the homotopy advances from unconverged points and the
+    reference's own answer depends on the order of its sums (profiles/r05_maxiniters_adjudication.md: the two oracles
+    disagree with each other there), so nothing can be pinned — but every route must still end on a sound answer: the
+    planted inliers (precision >= 0.95 against the ground truth), as many nodes as round(score), and an objective
+    within a few percent of the oracle's."""
+    p = synth.make_euclidean_problem(9000, 0.95, seed=314)
+    prm = ref.Params(maxiniters=2)
+    rr = ref.RefClipper(prm)
+    rr.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    so = rr.solve(p.u0)
+    for storage in (abi.STORE_F32_CSC, abi.STORE_F64_CSC):
+        for mode in (0, 2, 1):   # resident on a view / streamed views / no views
+            g = _ctx(p, storage, mode)
+            g.params.maxiniters = 2
+            s = g.solve(p.u0)
+            sel = g.get_selected_associations()
+            prec, rec = synth.precision_recall(sel, p.Agt)
+            assert len(s.nodes) == int(np.floor(s.score + 0.5)), (storage, mode)
+            assert prec >= 0.95 and rec >= 0.5, (storage, mode, prec, rec)
+            assert abs(s.score - so.score) <= 0.05 * abs(so.score), (storage, mode, s.score, so.score)
+            g.close()
 
 
 def test_matrix_without_points_and_parameter_variants():
