@@ -155,6 +155,14 @@ CLIPPER::~CLIPPER() {
 void CLIPPER::setDevice(int device) {
   if (h_) throw std::logic_error("CLIPPER::setDevice must be called before the first GPU call");
   device_ = device;
+  devices_.clear();
+}
+
+void CLIPPER::setDevices(const std::vector<int>& devices) {
+  if (h_) throw std::logic_error("CLIPPER::setDevices must be called before the first GPU call");
+  if (devices.empty()) throw std::invalid_argument("CLIPPER::setDevices: an empty device list");
+  devices_ = devices;
+  device_ = devices.front();
 }
 
 void CLIPPER::setStorage(Storage storage) {
@@ -174,6 +182,17 @@ void CLIPPER::setRowViews(bool on) {
   if (h_) check(clipper_hip_set_row_view(h_, on ? 0 : 1), "set_row_view");
 }
 
+void CLIPPER::setLiveSubproblem(bool on) {
+  subproblem_ = on;
+  if (h_) check(clipper_hip_set_subproblem(h_, on ? 0 : 1), "set_subproblem");
+}
+
+long long CLIPPER::lastSolvePassesOnTheSubproblem() const {
+  clipper_hip_view_stats_t st{};
+  if (h_ == nullptr || clipper_hip_get_view_stats(h_, &st) < 0) return 0;
+  return st.sub_passes;
+}
+
 long long CLIPPER::lastSolvePassesOnAView() const {
   clipper_hip_view_stats_t st{};
   if (h_ == nullptr || clipper_hip_get_view_stats(h_, &st) < 0) return 0;
@@ -182,12 +201,15 @@ long long CLIPPER::lastSolvePassesOnAView() const {
 
 clipper_hip_ctx* CLIPPER::handle() {
   if (!h_) {
-    h_ = clipper_hip_create(device_, static_cast<int>(storage_));
+    h_ = devices_.size() > 1
+             ? clipper_hip_create_group(devices_.data(), static_cast<int>(devices_.size()), static_cast<int>(storage_))
+             : clipper_hip_create(device_, static_cast<int>(storage_));
     if (!h_)
       throw std::runtime_error(std::string("clipper: cannot create the GPU context: ") +
                                clipper_hip_last_error());
     if (!resident_) check(clipper_hip_set_resident(h_, 1), "set_resident");
     if (!row_views_) check(clipper_hip_set_row_view(h_, 1), "set_row_view");
+    if (!subproblem_) check(clipper_hip_set_subproblem(h_, 1), "set_subproblem");
   }
   return h_;
 }

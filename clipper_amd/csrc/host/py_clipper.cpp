@@ -304,6 +304,9 @@ PYBIND11_MODULE(clipperpy, m) {
       .def("set_parallelize", &clipper::CLIPPER::setParallelize)
       // additions of this build
       .def("set_device", &clipper::CLIPPER::setDevice, "device"_a)
+      .def("set_devices", &clipper::CLIPPER::setDevices, "devices"_a)
+      .def("set_live_subproblem", &clipper::CLIPPER::setLiveSubproblem, "on"_a)
+      .def("last_solve_passes_on_the_subproblem", &clipper::CLIPPER::lastSolvePassesOnTheSubproblem)
       .def("set_storage", &clipper::CLIPPER::setStorage, "storage"_a)
       .def("set_resident_solver", &clipper::CLIPPER::setResidentSolver, "on"_a)
       .def("set_row_views", &clipper::CLIPPER::setRowViews, "on"_a)

@@ -124,6 +124,10 @@ class CLIPPER {
 
   // ---- additions of this build -----------------------------------------------------------
   void setDevice(int device);        ///< HIP device ordinal (default 0); before the first call
+  /// Multi-GPU through the class, no launcher: M is column-sharded over the listed devices of this process
+  /// (one shard per entry; an ordinal may repeat — several logical shards on one GPU), each pass ends with the exchange
+  /// of the shards' partial products. Over the C ABI's clipper_hip_create_group; one entry = setDevice. Before the first call.
+  void setDevices(const std::vector<int>& devices);
   void setStorage(Storage storage);  ///< default F32_CSC (compressed; dense fp32 where it does not apply); before the first call
   /// Problems of up to 2048 associations are solved by ONE launch that keeps M on chip (the resident
   /// solver); false = always the streaming launches. Same result either way. Switching
@@ -134,6 +138,10 @@ class CLIPPER {
   /// instead of M (same sums up to the order of the partial sums). false = every pass streams M. Any time.
   void setRowViews(bool on);
   long long lastSolvePassesOnAView() const;  ///< how many passes of the last solve() streamed a view
+  /// The live sub-problem: once a row view exists and the penalty is large, the solve continues on the
+  /// associations that can still be selected — provably the same result. false = the passes keep streaming the view. Any time.
+  void setLiveSubproblem(bool on);
+  long long lastSolvePassesOnTheSubproblem() const;
   struct PathStats {
     long long n_passes = 0, n_trials = 0;
     double affinity_kernel_ms = 0, d = 0;
@@ -148,6 +156,8 @@ class CLIPPER {
   Solution soln_;
   PathStats stats_;
   int device_ = 0;
+  std::vector<int> devices_;  ///< more than one entry: column shards (setDevices)
+  bool subproblem_ = true;
   Storage storage_ = Storage::F32_CSC;
   bool resident_ = true;
   bool row_views_ = true;

@@ -108,6 +108,33 @@ int main() {
     std::printf("CLIPPER.EuclideanDistance ok (%d/20 random u0 reach the 3-clique)\n", ok);
   }
 
+  // ---- multi-GPU through the class: column shards over a device list, here two logical shards on
+  // device 0 — the same answer as one shard, no launcher ----------------------------------------------------
+  {
+    clipper::CLIPPER sharded(invariant, params);
+    sharded.setDevices({0, 0});
+    sharded.scorePairwiseConsistency(model, data);
+    clipper::CLIPPER single(invariant, params);
+    single.scorePairwiseConsistency(model, data);
+    clipper::VectorXd u0(12);
+    for (int i = 0; i < 12; ++i) u0(i) = 1.0 / std::sqrt(12.0);
+    sharded.solve(u0);
+    single.solve(u0);
+    EXPECT(sharded.getSolution().nodes == single.getSolution().nodes);
+    EXPECT(std::fabs(sharded.getSolution().score - single.getSolution().score) < 1e-9);
+    clipper::Affinity Ms = sharded.getAffinityMatrix(), M1 = single.getAffinityMatrix();
+    for (int i = 0; i < 12; ++i)
+      for (int j = 0; j < 12; ++j) EXPECT(Ms(i, j) == M1(i, j));
+    bool threw = false;
+    try {
+      sharded.setDevices({0});  // (after the first GPU call: refused, like setDevice)
+    } catch (const std::logic_error&) {
+      threw = true;
+    }
+    EXPECT(threw);
+    std::printf("CLIPPER.setDevices ok (two logical shards on one device)\n");
+  }
+
   // ---- get/set round trip (clipper_test.cpp:115-133), solved with solve() ------------------
   {
     clipper::CLIPPER clipper(invariant, params);

@@ -113,6 +113,27 @@ def test_clipperpy_row_views_switch(clipperpy):
     assert abs(res[0].score - res[1].score) <= 1e-9 * res[1].score
 
 
+def test_clipperpy_set_devices_shards_the_columns(clipperpy):
+    """multi-GPU through the class ("keeps the CLIPPER class a plain drop-in, no launcher"): set_devices with a
+    device list column-shards M inside the process — here three logical shards on device 0 — and the answer is one
+    shard's; the live sub-problem's switch rides along."""
+    p = synth.make_euclidean_problem(9000, 0.95, seed=21)
+    ip = clipperpy.invariants.EuclideanDistanceParams()
+    ip.sigma, ip.epsilon = 0.015, 0.05
+    res = []
+    for devices in (None, [0, 0, 0]):
+        c = clipperpy.CLIPPER(clipperpy.invariants.EuclideanDistance(ip), clipperpy.Params())
+        if devices:
+            c.set_devices(devices)
+        c.set_live_subproblem(devices is None)
+        c.score_pairwise_consistency(p.D1, p.D2, p.A)
+        c.solve(p.u0)
+        res.append(c.get_solution())
+        assert c.last_solve_passes_on_the_subproblem() == 0   # (m < 12 000: the resident launch takes the view)
+    assert list(res[0].nodes) == list(res[1].nodes) and res[0].ifinal == res[1].ifinal
+    assert abs(res[0].score - res[1].score) <= 1e-9 * res[1].score
+
+
 def test_python_custom_invariant_is_scored_on_host_and_solved_on_gpu(clipperpy):
     # the notebook's use case (examples/python/ex4_bunny.ipynb cell 12): a Python subclass
     class PyEuclid(clipperpy.invariants.PairwiseInvariant):

@@ -7,6 +7,7 @@ no GPU parity claim means anything.
 import numpy as np
 import pytest
 
+from clipper_amd import synth
 from oracle import clipper_ref as ref
 
 
@@ -298,3 +299,95 @@ def test_k_largest_walk_over_the_positive_entries_alone():
         x = np.round(rng.random(n), 1) * (rng.random(n) < rng.random())   # zeros and many exact ties
         for k in (1, 2, int(np.count_nonzero(x)), int(np.count_nonzero(x)) + 1, n):
             assert sparse_walk(x, k) == ref.k_largest(x, k).tolist(), (x.tolist(), k)
+
+
+# ------------------------------------------------------------------------------------------
+# What the reference's answer is worth where its decisions sit on rounding: the oracle evaluates the SAME
+# additions in other orders (clipper_ref_set_sum_mode: 1 = swept backwards, 2 = extended-precision
+# accumulation). Mode 0 stays the only parity mode; these tests make the "order spread" a tested property
+# instead of a narrative (NOTEBOOK.md "Adjudication, closed").
+# ------------------------------------------------------------------------------------------
+
+def _solve_in_mode(r, p, mode, **kw):
+    r.params = ref.Params(**kw)
+    r.set_sum_mode(mode)
+    try:
+        return r.solve(p.u0)
+    finally:
+        r.set_sum_mode(0)
+
+
+def test_summation_order_moves_no_result_at_default_parameters():
+    p = synth.make_euclidean_problem(3000, 0.9, seed=5)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    x = np.random.default_rng(0).random(3000)
+    prods = []
+    for mode in (0, 1, 2):
+        r.set_sum_mode(mode)
+        prods.append(r.matvec(x))
+    r.set_sum_mode(0)
+    for yM, yC in prods[1:]:
+        assert np.max(np.abs(yM - prods[0][0])) <= 1e-14 * np.max(prods[0][0])   # the same additions, another order
+        assert np.array_equal(yC, prods[0][1]) or np.max(np.abs(yC - prods[0][1])) <= 1e-13 * np.max(prods[0][1])
+    sols = [_solve_in_mode(r, p, mode) for mode in (0, 1, 2)]
+    for s in sols[1:]:
+        assert sorted(s.nodes.tolist()) == sorted(sols[0].nodes.tolist()) and s.ifinal == sols[0].ifinal
+        assert abs(s.score - sols[0].score) <= 1e-9 * abs(sols[0].score)
+        # the trial COUNT is the one quantity that may move (accept tests on the last bits of sums): a few percent
+        assert abs(s.n_trials - sols[0].n_trials) <= max(2, sols[0].n_trials // 10)
+
+
+def test_adjudication_m9132_the_oracle_disagrees_with_itself():
+    """One of the two problems of profiles/r05_maxiniters_adjudication.md on which the C++ and the numpy oracle had
+    agreed (ifinal 15) and five of six GPU routes had not. With `maxiniters = 2` the oracle's three orders of the same
+    additions end on THREE different `ifinal` (15 / 16 / 14): the earlier agreement was a coincidence of two orders.
+    The node set and the objective (to 2e-6: d ~ 1e8 there) are the same on all of them."""
+    p = synth.make_euclidean_problem(9132, 0.985, seed=944071)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    kw = dict(beta=0.1, maxlsiters=20, maxiniters=2, maxoliters=40, tol_u=1e-6, tol_F=1e-7, rescale_u0=0 + 1, eps=1e-9)
+    sols = [_solve_in_mode(r, p, mode, **kw) for mode in (0, 1, 2)]
+    assert len({s.ifinal for s in sols}) >= 2, [s.ifinal for s in sols]
+    for s in sols[1:]:
+        assert sorted(s.nodes.tolist()) == sorted(sols[0].nodes.tolist())
+        assert abs(s.score - sols[0].score) <= 2e-6 * abs(sols[0].score)
+
+
+def test_adjudication_m8295_one_ulp_of_d_sum_u_exceeds_the_tolerances():
+    """The other one: all three orders of the oracle end on ifinal 16 (153 - 155 trials), all GPU routes on 19 - 21
+    (tools/adjudicate_trace.py: identical trial counts through 16 outer iterations, d and F to 1e-9; in the 17th the
+    oracle's first trial ends the inner loop on |dF| < tol_F, the GPU's does not). At that state d * sum(u) = 1.1e8: ONE
+    ulp of it moves every gradF[i] by 1.5e-8 and F = u . gradF by 2.3e-7 — more than tol_F = eps = 1e-7 — so the test
+    that ends the solve is decided by how sum(u), C u and M u happened to round. Shown here on the oracle alone: F at
+    that state, evaluated with its own products in the three orders and sum(u) in two, spreads over more than tol_F, and
+    so does the dF that its stopping test looks at."""
+    import math
+    p = synth.make_euclidean_problem(8295, 0.97, seed=759923)
+    r = ref.RefClipper()
+    r.score_pairwise_consistency_euclidean(p.D1, p.D2, p.A, **synth.EUCLID_BENCH_PARAMS)
+    kw = dict(beta=0.25, maxlsiters=20, maxiniters=2, maxoliters=16, tol_u=1e-8, tol_F=1e-7, rescale_u0=0, eps=1e-7)
+    s = _solve_in_mode(r, p, 0, **kw)
+    u, d = np.asarray(s.u), s.d
+    assert s.ifinal == 16 and d > 1e6
+    assert np.spacing(d * u.sum()) * u.sum() > 1e-7            # one ulp of d sum(u), times sum(u): beyond tol_F and eps
+
+    def F_at(x, mode, ssum):                                     # clipper.cpp:219-220 at (x, d)
+        r.set_sum_mode(mode)
+        Mx, Cx = r.matvec(x)
+        r.set_sum_mode(0)
+        g = (1 + d) * x - d * ssum(x) + Mx + Cx * d
+        return float((x * g).sum()), g
+
+    sums = (lambda x: float(np.cumsum(x)[-1]), lambda x: math.fsum(x.tolist()))
+    g0 = F_at(u, 0, sums[0])[1]
+    x = np.maximum(u + g0, 0)                                    # the first trial of the 17th outer iteration (alpha = 1)
+    xn = x / np.sqrt(x @ x)
+    Fs, dFs = [], []
+    for mode in (0, 1, 2):
+        for ssum in sums:
+            F, Fn = F_at(u, mode, ssum)[0], F_at(xn, mode, ssum)[0]
+            Fs.append(F)
+            dFs.append(Fn - F)
+    assert max(Fs) - min(Fs) > 1e-7, (min(Fs), max(Fs))
+    assert max(dFs) - min(dFs) > 1e-7, (min(dFs), max(dFs))     # |dF| < tol_F (clipper.cpp:261) is a coin toss here

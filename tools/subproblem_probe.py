@@ -33,8 +33,10 @@ def main():
         out = {"m": m, "rho": a.rho, "storage": a.storage}
         for name in a.modes.split(","):
             g = abi.HipClipper(storage=storage)
-            g.set_row_view(1 if name == "noviews" else 0)
-            g.set_subproblem(0 if name == "sub" else 1)
+            # noviews | views (no sub-problem) | sub (the default route) | sub_streamed (views never resident: the
+            # sub-problem also where the resident launch would have taken the view)
+            g.set_row_view(1 if name == "noviews" else (2 if name == "sub_streamed" else 0))
+            g.set_subproblem(0 if name in ("sub", "sub_streamed") else 1)
             if a.profile:
                 g.set_profiling(True)
             g.stage_inputs(p.D1, p.D2, p.A)
@@ -53,7 +55,7 @@ def main():
                              nodes=int(len(s.nodes)),
                              nodes_sha=hashlib.sha256(np.asarray(s.nodes, np.int32).tobytes()).hexdigest()[:16],
                              u_hashes=sorted(hashes), builds=int(st.builds), rows=int(st.rows), view_passes=int(st.view_passes),
-                             view_build_ms=round(st.build_ms, 3), pass_us=round(tm.gemv_avg_us, 2),
+                             view_build_ms=round(st.build_ms, 3), resident_launches=int(st.resident_launches), pass_us=round(tm.gemv_avg_us, 2),
                              view_pass_us=round(st.view_pass_avg_us, 2), sub_entries=int(st.sub_entries),
                              sub_leaves=int(st.sub_leaves), sub_passes=int(st.sub_passes), sub_rows=int(st.sub_rows),
                              sub_bytes=int(st.sub_bytes), sub_build_ms=round(st.sub_build_ms, 3),
