@@ -958,7 +958,12 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
         // a view the resident solver does not take: the live sub-problem of its rows is prepared now, and entered
         // when the decision finds that nothing outside it can come back to life
         if (built && !h->vres.ready && !early) {
-          if ((rc = sub_prepare(h))) return rc;
+          // (an optimisation: if it cannot be prepared — no memory for the child's buffers — the solve goes on without)
+          if (int r2 = sub_prepare(h)) {
+            if (r2 != CLIPPER_HIP_E_NOMEM) return r2;
+            (void)hipGetLastError();
+            h->sub.ready = false;
+          }
           mark_t("sub-problem prepared");
         }
         continue;

@@ -8,6 +8,7 @@ using Ctx = clipper_hip_ctx;
 
 void rowview_free(Shard& s);
 void rowview_drop(Ctx* h);
+void sub_free(Ctx* h);
 
 int free_shard_buffers(Shard& s) {
   hipSetDevice(s.device);
@@ -120,6 +121,7 @@ int ensure_problem(Ctx* h, int64_t m) {
   h->V = V;
   plan_tiles(h);
   if (same) return 0;
+  sub_free(h);  // (the live sub-problem of another problem size: its context and lists go with the buffers)
   for (auto& s : h->sh) {
     free_shard_buffers(s);
     HIPCHK(hipSetDevice(s.device));

@@ -2,7 +2,7 @@
 # Profiles at a given commit (rounds 4, 5): rocprofv3 kernel stats of bench.py at m = 10k and 100k (default storage; views
 # streamed as well at 10k; the dense fp32 store at 10k — north_star's literal row-blocked M*u), then the PMC counter
 # passes (HBM traffic; LDS / VALU activity) of the same commands, tied to the sha256 of the kernel sources.
-#   usage: tools/gpu_prof.sh <tag> <commit> [sizes]      -> gpurun_out/<tag>/ (kernel_stats_*.txt, pmc_*.txt, pmc_r05.json)
+#   usage: tools/gpu_prof.sh <tag> <commit> [sizes]      -> gpurun_out/<tag>/ (kernel_stats_*.txt, pmc_*.txt, pmc_r06.json)
 TAG=${1:-r04p}; COMMIT=${2:-unknown}; SIZES=${3:-"10000 100000"}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -27,7 +27,7 @@ for m in $SIZES; do
     name=$(echo $set | tr ' ' '_')
     ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --pmc $set -d $ROOT/$OUT/pmc_m${m}_$name -o pmc -- $B2 > $ROOT/$OUT/pmc_m${m}_$name.log 2>&1 )
   done
-  python tools/pmc_summary.py --key m${m}_csc --bytes $bytes --commit $COMMIT --sources-sha $SHA --json $OUT/pmc_r05.json $(find $OUT -path "*pmc_m${m}_*" -name '*.db') > $OUT/pmc_m$m.txt 2>&1
+  python tools/pmc_summary.py --key m${m}_csc --bytes $bytes --commit $COMMIT --sources-sha $SHA --json $OUT/pmc_r06.json $(find $OUT -path "*pmc_m${m}_*" -name '*.db') > $OUT/pmc_m$m.txt 2>&1
 done
 find $OUT -name '*.db' -delete
 for m in $SIZES; do echo "== m=$m"; head -12 $OUT/kernel_stats_m$m.txt; grep -E "k_gemv_slices|k_affinity_sym|k_tail|k_solve_view" $OUT/pmc_m$m.txt | head -40; done

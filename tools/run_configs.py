@@ -92,6 +92,10 @@ def run(name, cfg, reps, storage, with_cpu):
                passes_on_view=int(vs.view_passes), views_built=int(vs.builds), view_rows=int(vs.rows),
                view_bytes=int(vs.bytes), view_build_ms=round(vs.build_ms, 4),
                view_pass_us=round(float(np.median(vgemv)), 2) if np.median(vgemv) > 0 else None,
+               # the live sub-problem (the passes behind the view that ran on M[S,S])
+               passes_on_sub=int(vs.sub_passes), sub_rows=int(vs.sub_rows), sub_bytes=int(vs.sub_bytes),
+               sub_entries=int(vs.sub_entries), sub_leaves=int(vs.sub_leaves), sub_build_ms=round(vs.sub_build_ms, 4),
+               sub_pass_us=round(vs.sub_pass_avg_us, 2) if vs.sub_pass_samples > 0 else None,
                trials=int(sol.n_trials),
                score=sol.score, nodes=int(len(sol.nodes)), ifinal=int(sol.ifinal))
     prec, rec = synth.precision_recall(g.get_selected_associations(), p.Agt)
