@@ -53,7 +53,8 @@ def main():
             out[name] = dict(solve_ms=round(float(np.median(times[1:])), 4), first_ms=round(times[0], 4),
                              passes=int(s.n_passes), trials=int(s.n_trials), ifinal=int(s.ifinal), score=float(s.score),
                              nodes=int(len(s.nodes)),
-                             nodes_sha=hashlib.sha256(np.asarray(s.nodes, np.int32).tobytes()).hexdigest()[:16],
+                             nodes_sha=hashlib.sha256(np.sort(np.asarray(s.nodes, np.int32)).tobytes()).hexdigest()[:16],
+                             order_sha=hashlib.sha256(np.asarray(s.nodes, np.int32).tobytes()).hexdigest()[:16],
                              u_hashes=sorted(hashes), builds=int(st.builds), rows=int(st.rows), view_passes=int(st.view_passes),
                              view_build_ms=round(st.build_ms, 3), resident_launches=int(st.resident_launches), pass_us=round(tm.gemv_avg_us, 2),
                              view_pass_us=round(st.view_pass_avg_us, 2), sub_entries=int(st.sub_entries),
@@ -66,7 +67,10 @@ def main():
         if len(names) > 1:
             ref = names[0]
             for n in names[1:]:
+                # (same_order: the selected LIST as produced — near-equal entries of u trade places when partial sums
+                # associate differently; the suite compares lists up to such ties)
                 out[f"{n}_vs_{ref}"] = dict(same_nodes=out[n]["nodes_sha"] == out[ref]["nodes_sha"],
+                                            same_order=out[n]["order_sha"] == out[ref]["order_sha"],
                                             same_ifinal=out[n]["ifinal"] == out[ref]["ifinal"],
                                             rel_dscore=abs(out[n]["score"] - out[ref]["score"]) / abs(out[ref]["score"]),
                                             max_du=float(np.max(np.abs(out[n + "_u"] - out[ref + "_u"]))),
