@@ -344,8 +344,15 @@ def main():
                                       "measured_at_commit": rec.get("commit"), "kernel_bytes_then": then,
                                       "kernel_sources_sha256": sha_then,
                                       "read_bytes": rec.get("pass_read_bytes"), "written_bytes": rec.get("pass_written_bytes"),
+                                      "written_note": "what a pass writes is its partial sums: one slot of (V + 1) x W doubles per work "
+                                                      "item of a strip (28 slots at the headline: 28 x 7 x 10 048 x 8 B = 15.8 MB nominal, "
+                                                      "14.1 MB counted) - written through (sc1) while the launch runs, read by k_tail",
                                       "how": rec.get("how")}
                     issue = rec.get("affinity_issue")
+                    if issue and issue.get("SQ_ACTIVE_INST_VALU") and issue.get("simd_cycles_available"):
+                        # the DIRECT busy counter (quad-cycles, summed over the SIMDs) against the launch's SIMD cycles: how much of
+                        # the time a SIMD's VALU pipe is executing — the binding resource of the fill (NOTEBOOK.md, round 6)
+                        issue["valu_pipe_active_frac"] = round(4.0 * issue["SQ_ACTIVE_INST_VALU"] / issue["simd_cycles_available"], 4)
                     resident_pmc = rec.get("resident")
         useful = tm.gemv_useful_bytes
         achieved_useful = useful / (gemv_avg_us * 1e-6) / 1e9 if gemv_avg_us > 0 else 0.0
@@ -435,7 +442,8 @@ def main():
                 if (compressed and gemv_avg_us > 0) else None,
             },
             "roofline_affinity": {
-                "bound": "valu-issue", "kernel": "k_affinity_sym (writes the slices itself)" if compressed else "affinity fill",
+                "bound": "valu-issue (VALU pipe active 0.59 of all SIMD cycles at m = 10k, 0.66 at 100k: `issue.valu_pipe_active_frac`)",
+                "kernel": "k_affinity_sym (writes the slices itself)" if compressed else "affinity fill",
                 "kernel_ms": round(aff_kernel_ms, 4),
                 # VALU instructions the launch issued (SQ_INSTS_VALU) x 4 cycles per wave64 instruction on a
                 # 16-lane fp64 / 32-lane fp32 SIMD-cycle budget = kernel time x SIMDs x clock: PMC record
