@@ -104,7 +104,7 @@ class ViewStats(C.Structure):
         ("resident_entries", C.c_int64), ("resident_units", C.c_int64),
         ("sub_entries", C.c_int64), ("sub_leaves", C.c_int64), ("sub_passes", C.c_int64),
         ("sub_rows", C.c_int64), ("sub_bytes", C.c_int64), ("sub_build_ms", C.c_double),
-        ("sub_pass_avg_us", C.c_double), ("sub_pass_samples", C.c_int64),
+        ("sub_pass_avg_us", C.c_double), ("sub_pass_samples", C.c_int64), ("sub_dense", C.c_int64),
     ]
 
 

@@ -890,7 +890,7 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
     constexpr int run_ahead = RUN_AHEAD;
     h->enqueue_one = [h, &prm]() { return enqueue_iteration(h, prm); };
     // (while the solve runs on the live sub-problem the same launches go out with the child context's arguments)
-    auto enqueue_next = [&]() { return enqueue_iteration(h->sub.active ? h->sub.ctx : h, prm); };
+    auto enqueue_next = [&]() { return enqueue_iteration(h->sub.active ? h->sub.use : h, prm); };
     auto sub_account = [&]() {  // the passes since the hand-over ran on the sub-problem
       h->sub.sub_passes += std::max<int64_t>(0, hm->n_passes - h->sub.passes_at_entry);
     };
@@ -1107,9 +1107,12 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   h->rv_stats.sub_leaves = h->sub.leaves;
   h->rv_stats.sub_passes = h->sub.sub_passes;
   h->rv_stats.sub_build_ms = h->sub.build_ms;
-  if (h->rv_stats.sub_entries > 0 && h->sub.ctx) {
+  if (h->rv_stats.sub_entries > 0 && h->sub.use) {
     h->rv_stats.sub_rows = h->sub.nS;
-    h->rv_stats.sub_bytes = static_cast<int64_t>(h->sub.ctx->sh[0].s_bytes);
+    // what a pass on it streams: the slices, or (a mostly non-zero sub-problem) the dense fp32 store
+    h->rv_stats.sub_bytes = h->sub.use->csc_valid ? static_cast<int64_t>(h->sub.use->sh[0].s_bytes)
+                                                   : static_cast<int64_t>(algorithmic_gemv_bytes(h->sub.use));
+    h->rv_stats.sub_dense = h->sub.use->csc_valid ? 0 : 1;
   }
 
   // mat-vec timings from the event pairs
@@ -1356,7 +1359,8 @@ int clipper_hip_window(const clipper_hip_t* h) try {
 
 int clipper_hip_set_resident(clipper_hip_t* h, int mode) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
-  if (mode != 0 && mode != 1) return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic) or 1 (never)");
+  if (mode != 0 && mode != 1 && mode != 2)
+    return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic), 1 (never) or 2 (the sub-problem always as slices)");
   h->resident_mode = mode;
   return 0;
 } CLIPPER_HIP_GUARD_INT
@@ -1377,7 +1381,8 @@ int clipper_hip_set_row_view(clipper_hip_t* h, int mode) try {
 
 int clipper_hip_set_subproblem(clipper_hip_t* h, int mode) try {
   if (!h) return fail(CLIPPER_HIP_E_INVALID, "invalid argument");
-  if (mode != 0 && mode != 1) return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic) or 1 (never)");
+  if (mode != 0 && mode != 1 && mode != 2)
+    return fail(CLIPPER_HIP_E_INVALID, "mode must be 0 (automatic), 1 (never) or 2 (the sub-problem always as slices)");
   h->sub_mode = mode;
   if (mode == 1) h->sub.ready = false;
   return 0;

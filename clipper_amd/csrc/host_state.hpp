@@ -253,7 +253,9 @@ constexpr int RVR_GIVEUP_SLOTS = 16;
 constexpr int SUB_MAX_ENTRIES = 4;   // hand-overs per solve (each leave costs a host round trip)
 constexpr int64_t SUB_MIN_M = 12000; // full problems below this keep their views (the resident solver on a view takes them)
 struct SubProblem {
-  struct clipper_hip_ctx* ctx = nullptr;
+  struct clipper_hip_ctx* ctx = nullptr;        // M[S,S] as slices
+  struct clipper_hip_ctx* ctx_dense = nullptr;  // M[S,S] as a dense fp32 store (where it is mostly non-zero: the inlier block)
+  struct clipper_hip_ctx* use = nullptr;        // the one the solve is handed over to
   int32_t* cnt = nullptr;     // [mp] entries of every column among the view's rows (an upper bound: quads x 4)
   uint8_t* flags = nullptr;   // [mp] 1 = the association is in the sub-problem
   int32_t* colmap = nullptr;  // [mp] sub-problem index -> association
@@ -363,7 +365,7 @@ struct clipper_hip_ctx {
   // launches report into the parent's progress record and borrow the parent's stream)
   SubProblem sub;
   struct clipper_hip_ctx* parent = nullptr;
-  int sub_mode = 0;           // 0 = automatic, 1 = never (clipper_hip_set_subproblem / CLIPPER_HIP_SUBPROBLEM=0)
+  int sub_mode = 0;           // 0 = automatic, 1 = never (clipper_hip_set_subproblem / CLIPPER_HIP_SUBPROBLEM=0), 2 = always as slices
 
   long long* stamps_dev = nullptr;  // CLIPPER_HIP_STAMPS=1: [4096][4], see SolveArgs::stamps; =2: [16384][4]
   int stamps_rows = 4096;

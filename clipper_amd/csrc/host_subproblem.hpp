@@ -16,7 +16,7 @@ bool sub_enabled(const Ctx* h) {
     return e && std::atoi(e) == 0;
   }();
   static const int64_t min_m = std::getenv("CLIPPER_HIP_SUBPROBLEM_MIN_M") ? std::atoll(std::getenv("CLIPPER_HIP_SUBPROBLEM_MIN_M")) : SUB_MIN_M;
-  return !env_off && h->sub_mode == 0 && h->parent == nullptr && h->sh.size() == 1 && h->world == 1 && !h->multiproc &&
+  return !env_off && h->sub_mode != 1 && h->parent == nullptr && h->sh.size() == 1 && h->world == 1 && !h->multiproc &&
          h->csc_valid && !h->explicitC && h->m >= min_m && rect_fill_possible(h);
 }
 
@@ -30,11 +30,14 @@ void sub_begin_solve(Ctx* h) {
 
 void sub_free(Ctx* h) {
   SubProblem& sp = h->sub;
-  if (sp.ctx) {
-    sp.ctx->sh[0].stream = nullptr;  // (the parent's: not the child's to destroy)
-    clipper_hip_destroy(sp.ctx);
-    sp.ctx = nullptr;
+  for (Ctx** pc : {&sp.ctx, &sp.ctx_dense}) {
+    if (*pc) {
+      (*pc)->sh[0].stream = nullptr;  // (the parent's: not the child's to destroy)
+      clipper_hip_destroy(*pc);
+      *pc = nullptr;
+    }
   }
+  sp.use = nullptr;
   if (!h->sh.empty()) hipSetDevice(h->sh[0].device);
   auto fr = [](auto*& p) {
     if (p) hipFree(p);
@@ -144,33 +147,51 @@ int sub_prepare_v(Ctx* h) {
                  static_cast<long long>(v.nrows), static_cast<long long>(nS), sp.rec->n0, sp.rec->ncol);
   // worth a problem of its own: not much more than the view's rows, and far fewer than the full problem's columns
   if (nS < 64 || sp.rec->ncol < 0 || nS > 2 * v.nrows + 1024 || 3 * nS > m) return 0;
-  if (!sp.ctx) {
-    const int storage = h->compressed ? (h->storage == CLIPPER_HIP_STORE_F64 ? CLIPPER_HIP_STORE_F64_CSC : CLIPPER_HIP_STORE_F32_CSC)
-                                      : h->storage;
-    sp.ctx = make_ctx(&s.device, 1, storage, 1, 0, false);
-    if (!sp.ctx) return CLIPPER_HIP_E_HIP;
-    // one stream for both: the child's fills, plans and launches are ordered with the parent's by construction
-    hipStreamDestroy(sp.ctx->sh[0].stream);
-    sp.ctx->sh[0].stream = s.stream;
-    sp.ctx->parent = h;
-  }
+  // the child context(s): on the parent's device and stream (their fills, plans and launches are ordered with the
+  // parent's by construction), filled with the invariant the parent's matrix was scored with
+  auto build_child = [&](Ctx*& c, int storage) -> int {
+    if (!c) {
+      c = make_ctx(&s.device, 1, storage, 1, 0, false);
+      if (!c) return CLIPPER_HIP_E_HIP;
+      hipStreamDestroy(c->sh[0].stream);
+      c->sh[0].stream = s.stream;
+      c->parent = h;
+    }
+    if (int r2 = sub_stage(h, c, nS)) return r2;
+    if (h->fill_kind == 1)
+      return clipper_hip_affinity_euclidean_staged(c, h->fill_e.sigma, h->fill_e.epsilon, h->fill_e.mindist, h->fill_e.affinityeps);
+    return clipper_hip_affinity_pointnormal_staged(c, h->fill_n.sigp, h->fill_n.epsp, h->fill_n.sign, h->fill_n.epsn,
+                                                   h->fill_n.affinityeps);
+  };
+  const int storage = h->compressed ? (h->storage == CLIPPER_HIP_STORE_F64 ? CLIPPER_HIP_STORE_F64_CSC : CLIPPER_HIP_STORE_F32_CSC)
+                                    : h->storage;
+  if ((rc = build_child(sp.ctx, storage))) return rc;
   Ctx* c = sp.ctx;
-  if ((rc = sub_stage(h, c, nS))) return rc;
-  if (h->fill_kind == 1)
-    rc = clipper_hip_affinity_euclidean_staged(c, h->fill_e.sigma, h->fill_e.epsilon, h->fill_e.mindist, h->fill_e.affinityeps);
-  else
-    rc = clipper_hip_affinity_pointnormal_staged(c, h->fill_n.sigp, h->fill_n.epsp, h->fill_n.sign, h->fill_n.epsn,
-                                                 h->fill_n.affinityeps);
-  if (rc) return rc;
   if (!c->csc_valid) return 0;  // (a fill route without slices: not taken)
+  sp.use = c;
+  // Mostly non-zero (the inliers of a registration problem are consistent with each other: M[S,S] IS the dense block the
+  // slices' work list cuts by step range)? Then a dense fp32 store holds it in 4 bytes per element instead of 5.3 per
+  // stored entry, its pass (k_gemv: wave-uniform multipliers, no gathers) runs at 0.7 of the HBM peak where the pass on
+  // the slices reaches 0.47, and the window comes from candidate tables (k_sub_enter writes the pending one).
+  static const bool dense_off = std::getenv("CLIPPER_HIP_SUB_DENSE") && std::atoi(std::getenv("CLIPPER_HIP_SUB_DENSE")) == 0;
+  const double density = static_cast<double>(c->sh[0].s_entries) / (static_cast<double>(nS) * static_cast<double>(nS));
+  if (!dense_off && h->sub_mode != 2 && h->storage == CLIPPER_HIP_STORE_F32 && density >= 0.5 && nS >= 1024) {
+    if ((rc = build_child(sp.ctx_dense, CLIPPER_HIP_STORE_F32))) {
+      if (rc != CLIPPER_HIP_E_NOMEM) return rc;
+      (void)hipGetLastError();
+    } else if (sp.ctx_dense->has_matrix && !sp.ctx_dense->csc_valid) {
+      sp.use = sp.ctx_dense;
+    }
+  }
   HIPCHK(hipSetDevice(s.device));
   sp.nS = nS;
   sp.ncol = static_cast<double>(std::max(1, sp.rec->ncol));
   sp.ready = true;
   sp.build_ms += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
   if (host_timing)
-    std::fprintf(stderr, "[sub] ready: %lld associations, %.1f MB of slices, %d work items, prepared in %.2f ms\n",
-                 static_cast<long long>(nS), c->sh[0].s_bytes * 1e-6, c->sh[0].s_nwork, sp.build_ms);
+    std::fprintf(stderr, "[sub] ready: %lld associations, %.1f MB of slices (%d work items), density %.2f -> %s, prepared in %.2f ms\n",
+                 static_cast<long long>(nS), c->sh[0].s_bytes * 1e-6, c->sh[0].s_nwork, density,
+                 sp.use == sp.ctx_dense ? "a dense fp32 store" : "slices", sp.build_ms);
   return 0;
 }
 
@@ -186,9 +207,9 @@ int enqueue_iteration(Ctx* h, const SolverParams& prm);
 // a decide-only iteration turns the held decision into a prepared pass, the point and the state move over.
 int sub_enter(Ctx* h, const SolverParams& prm) {
   SubProblem& sp = h->sub;
-  if (!sp.ready || sp.active || !sp.ctx) return fail(CLIPPER_HIP_E_INTERNAL, "sub-problem: a hand-over nobody prepared");
+  if (!sp.ready || sp.active || !sp.use) return fail(CLIPPER_HIP_E_INTERNAL, "sub-problem: a hand-over nobody prepared");
   Shard& s = h->sh[0];
-  Ctx* c = sp.ctx;
+  Ctx* c = sp.use;
   Shard& cs = c->sh[0];
   HIPCHK(hipSetDevice(s.device));
   hipLaunchKernelGGL(k_sub_resume, dim3(1), dim3(64), 0, s.stream, s.st + h->par, s.shared);
@@ -200,7 +221,8 @@ int sub_enter(Ctx* h, const SolverParams& prm) {
   std::memset(h->u_pinned, 0, static_cast<size_t>(h->m) * sizeof(double));
   std::atomic_thread_fence(std::memory_order_seq_cst);
   hipLaunchKernelGGL(k_sub_enter, dim3(static_cast<unsigned>(ceil_div(c->mp, 256))), dim3(256), 0, s.stream, s.st + h->par, s.pt,
-                     s.cab, h->mp, h->V, sp.colmap, sp.nS, cs.st, cs.shared, cs.pt, cs.cab, c->mp);
+                     s.cab, h->mp, h->V, sp.colmap, sp.nS, cs.st, cs.shared, cs.pt, cs.cab, c->mp,
+                     c->csc_valid ? static_cast<double*>(nullptr) : cs.X[0], prm.beta);
   c->par = 0;
   c->decide_only = false;
   c->rv_fresh = false;
@@ -216,9 +238,9 @@ int sub_enter(Ctx* h, const SolverParams& prm) {
 // one of the pending candidates. The point and the state go back; the full problem's launches run that pass.
 int sub_leave(Ctx* h) {
   SubProblem& sp = h->sub;
-  if (!sp.active || !sp.ctx) return fail(CLIPPER_HIP_E_INTERNAL, "sub-problem: nothing to leave");
+  if (!sp.active || !sp.use) return fail(CLIPPER_HIP_E_INTERNAL, "sub-problem: nothing to leave");
   Shard& s = h->sh[0];
-  Ctx* c = sp.ctx;
+  Ctx* c = sp.use;
   Shard& cs = c->sh[0];
   HIPCHK(hipSetDevice(s.device));
   hipLaunchKernelGGL(k_sub_leave, dim3(static_cast<unsigned>(ceil_div(h->mp, 256))), dim3(256), 0, s.stream, cs.st + c->par, cs.pt,

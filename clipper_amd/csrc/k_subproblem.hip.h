@@ -154,20 +154,36 @@ __global__ __launch_bounds__(256) void k_sub_gather_points(const double* __restr
 
 // The hand-over: the full problem's state (a prepared pass: SolverState::resume) and its current point (u, gradF)
 // and (a, b) at the associations of S become the sub-problem's. Grid over the sub-problem's padded length.
+// `ctab` (a sub-problem kept as a DENSE store: its pass reads the pending window from a candidate table, k_gemv.hip.h):
+// table `sel` of the set the first launch reads — row i = max(u + alpha beta^l g, 0), l < V, the tail's own expression
+// and chain of multiplications (k_tail) —, written when the prepared pass is a window.
 __global__ __launch_bounds__(256) void k_sub_enter(const SolverState* __restrict__ pst, const double* __restrict__ ppt,
                                                     const double* __restrict__ pcab, int64_t pmp, int V,
                                                     const int32_t* __restrict__ colmap, int64_t nS,
                                                     SolverState* __restrict__ cst, SolveShared* __restrict__ cshared,
-                                                    double* __restrict__ cpt, double* __restrict__ ccab, int64_t cmp) {
+                                                    double* __restrict__ cpt, double* __restrict__ ccab, int64_t cmp,
+                                                    double* __restrict__ ctab, double beta) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   const int64_t slot = static_cast<int64_t>(pst->ubp) * V + pst->ubv;
   if (i < cmp) {
     const bool in = i < nS;
     const int64_t c = in ? colmap[i] : 0;
-    cpt[(slot * 2 + 0) * cmp + i] = in ? ppt[(slot * 2 + 0) * pmp + c] : 0.0;
-    cpt[(slot * 2 + 1) * cmp + i] = in ? ppt[(slot * 2 + 1) * pmp + c] : 0.0;
+    const double ui = in ? ppt[(slot * 2 + 0) * pmp + c] : 0.0;
+    const double gi = in ? ppt[(slot * 2 + 1) * pmp + c] : 0.0;
+    cpt[(slot * 2 + 0) * cmp + i] = ui;
+    cpt[(slot * 2 + 1) * cmp + i] = gi;
     ccab[i] = in ? pcab[c] : 0.0;
     ccab[cmp + i] = in ? pcab[pmp + c] : 0.0;
+    if (ctab != nullptr && pst->resume == 1) {
+      double row[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      double al = pst->alpha;
+      for (int l = 0; l < V; ++l) {
+        const double t = ui + al * gi;  // clipper.cpp:235-236
+        row[l] = (t > 0.0) ? t : 0.0;
+        al = al * beta;
+      }
+      store_row(ctab + (static_cast<int64_t>(pst->sel) * cmp + i) * VS, row);
+    }
   }
   if (blockIdx.x == 0) {
     copy_state(cst, pst, threadIdx.x, 256);

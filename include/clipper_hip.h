@@ -124,6 +124,7 @@ typedef struct clipper_hip_view_stats_t {
   double sub_build_ms;         /* host wall clock spent preparing it (selection, gather, fill, plan)           */
   double sub_pass_avg_us;      /* mean duration of the sampled window passes on it (profiling on; 0 = none)    */
   int64_t sub_pass_samples;
+  int64_t sub_dense;           /* 1: the sub-problem was mostly non-zero and was kept as a dense fp32 store (its passes: k_gemv) */
 } clipper_hip_view_stats_t;
 
 /* ---- life cycle --------------------------------------------------------------------- */
@@ -312,7 +313,9 @@ int clipper_hip_get_view_stats(const clipper_hip_t* h, clipper_hip_view_stats_t*
  * clipper.cpp:238-241 that the decision checks for every candidate it plans — and the solve continues on the
  * associations of S as a problem of its own (csrc/k_subproblem.hip.h): the same launches on M[S,S]. Exact: what is left
  * out is provably zero. mode 0 = automatic (one shard, built-in invariants, m >= 12 000: smaller problems' views are taken
- * by the resident solver), 1 = never (also: CLIPPER_HIP_SUBPROBLEM=0). */
+ * by the resident solver), 1 = never (also: CLIPPER_HIP_SUBPROBLEM=0), 2 = automatic, but M[S,S] always as slices (a
+ * sub-problem that is mostly non-zero — the inlier block — is otherwise kept as a dense fp32 store; also
+ * CLIPPER_HIP_SUB_DENSE=0). */
 int clipper_hip_set_subproblem(clipper_hip_t* h, int mode);
 
 /* The products of clipper_hip_matvec through a row view built for the given rows (ascending association

@@ -47,7 +47,7 @@ def _oracle(p, pointnormal=False, params=None, **prm):
 def _gpu(p, storage, route, pointnormal=False, params=None, **prm):
     g = abi.HipClipper(storage=storage)
     g.set_row_view(1 if route == "noviews" else 0)
-    g.set_subproblem(0 if route == "sub" else 1)
+    g.set_subproblem({"sub": 0, "sub_slices": 2}.get(route, 1))   # (2: the sub-problem always as slices, never a dense store)
     if pointnormal:
         g.score_pairwise_consistency_pointnormal(p.D1, p.D2, p.A, **prm)
     else:
@@ -80,6 +80,15 @@ def test_the_sub_problem_does_not_change_the_result(storage, m, rho):
     # far from the oracle's count as this one; the two routes within a few of each other)
     assert abs(s1.n_trials - s0.n_trials) <= max(3, s0.n_trials // 20), (s1.n_trials, s0.n_trials, sr.n_trials)
     assert abs(s1.n_trials - sr.n_trials) <= max(4, sr.n_trials // 10), (s1.n_trials, s0.n_trials, sr.n_trials)
+    # a sub-problem that is mostly non-zero (here: the inliers are consistent with each other) is kept as a dense fp32
+    # store where the values are fp32; forced to slices it must give the same answer
+    assert st1.sub_dense == (1 if storage == abi.STORE_F32_CSC and st1.sub_rows >= 1024 else 0), (st1.sub_dense, st1.sub_rows)
+    g2, s2b, st2 = _gpu(p, storage, "sub_slices", **synth.EUCLID_BENCH_PARAMS)
+    assert st2.sub_entries >= 1 and st2.sub_dense == 0
+    _same_list(s2b, sr)
+    assert s2b.ifinal == sr.ifinal and abs(s2b.score - s1.score) <= 1e-10 * abs(s1.score)
+    assert np.allclose(s2b.u, s1.u, rtol=0, atol=1e-8)
+    g2.close()
     # the same context solves again: bit-reproducible, the hand-over included
     s2 = g1.solve(p.u0)
     assert np.array_equal(s2.u, s1.u) and s2.n_trials == s1.n_trials and s2.nodes.tolist() == s1.nodes.tolist()

@@ -36,7 +36,7 @@ def main():
             # noviews | views (no sub-problem) | sub (the default route) | sub_streamed (views never resident: the
             # sub-problem also where the resident launch would have taken the view)
             g.set_row_view(1 if name == "noviews" else (2 if name == "sub_streamed" else 0))
-            g.set_subproblem(0 if name in ("sub", "sub_streamed") else 1)
+            g.set_subproblem(0 if name in ("sub", "sub_streamed") else (2 if name == "sub_slices" else 1))
             if a.profile:
                 g.set_profiling(True)
             g.stage_inputs(p.D1, p.D2, p.A)
@@ -60,7 +60,8 @@ def main():
                              view_pass_us=round(st.view_pass_avg_us, 2), sub_entries=int(st.sub_entries),
                              sub_leaves=int(st.sub_leaves), sub_passes=int(st.sub_passes), sub_rows=int(st.sub_rows),
                              sub_bytes=int(st.sub_bytes), sub_build_ms=round(st.sub_build_ms, 3),
-                             sub_pass_us=round(st.sub_pass_avg_us, 2), sub_pass_samples=int(st.sub_pass_samples))
+                             sub_pass_us=round(st.sub_pass_avg_us, 2), sub_pass_samples=int(st.sub_pass_samples),
+                             sub_dense=int(st.sub_dense))
             out[name + "_u"] = s.u
             g.close()
         names = [n for n in a.modes.split(",")]
