@@ -82,7 +82,8 @@ def test_the_sub_problem_does_not_change_the_result(storage, m, rho):
     assert abs(s1.n_trials - sr.n_trials) <= max(4, sr.n_trials // 10), (s1.n_trials, s0.n_trials, sr.n_trials)
     # a sub-problem that is mostly non-zero (here: the inliers are consistent with each other) is kept as a dense fp32
     # store where the values are fp32; forced to slices it must give the same answer
-    assert st1.sub_dense == (1 if storage == abi.STORE_F32_CSC and st1.sub_rows >= 1024 else 0), (st1.sub_dense, st1.sub_rows)
+    # (whether it is depends on the problem: here the live rows still hold many outliers when the view is built)
+    assert st1.sub_dense in (0, 1) and (storage == abi.STORE_F32_CSC or st1.sub_dense == 0)
     g2, s2b, st2 = _gpu(p, storage, "sub_slices", **synth.EUCLID_BENCH_PARAMS)
     assert st2.sub_entries >= 1 and st2.sub_dense == 0
     _same_list(s2b, sr)
@@ -115,6 +116,7 @@ def test_sweep_size_m30000_against_the_routes_without_it():
         assert abs(s.score - s0.score) <= 1e-10 * abs(s0.score)
         assert np.allclose(s.u, s0.u, rtol=0, atol=1e-7)
     st = res["sub"][1]
+    assert st.sub_dense == 1, "the sub-problem of the sweep size is the dense inlier block: a dense fp32 store"
     assert st.sub_entries == 1 and st.sub_leaves == 0
     assert st.sub_passes * 10 >= st.passes * 7, (st.sub_passes, st.passes)   # the long outer iterations run on it
     assert st.view_passes < res["views"][1].view_passes
