@@ -185,7 +185,9 @@ int sub_prepare_v(Ctx* h) {
   }
   HIPCHK(hipSetDevice(s.device));
   sp.nS = nS;
-  sp.ncol = static_cast<double>(std::max(1, sp.rec->ncol));
+  // N of the bound: the counts are over the VIEW's rows; on the sub-problem a row of S outside the view may come back
+  // to life (it is inside S: fine) and then adds at most one entry to any column — |S \ R| on top, once and for all
+  sp.ncol = static_cast<double>(std::max(1, sp.rec->ncol)) + static_cast<double>(std::max<int64_t>(0, nS - v.nrows));
   sp.ready = true;
   sp.build_ms += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
   if (host_timing)

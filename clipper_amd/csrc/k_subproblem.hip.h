@@ -9,6 +9,9 @@
 //             <= -d sum(u) + (1 + d) sqrt(N_c) ||u||        (0 <= M <= 1 for the built-in invariants, Cauchy-Schwarz)
 // with N_c = stored entries of column c among the rows where u is not zero. So with s = sum(x), z = ||x||^2 of an
 // un-normalised candidate x:   d^2 s^2 > (1 + d)^2 N_c z   ==>   gradF[c] < 0 at x / ||x||,
+// (N_c is counted over the rows of the view, where every live row lies when the solve is handed over; the rows of S
+// outside the view may come back to life later — they are inside S — and add at most |S \ view| entries to a column:
+// the host adds that to N.) Then
 // column c stays at zero whatever the line search accepts, and NOTHING the reference computes from here on reads
 // gradF[c] other than through that sign (Fnew = unew . gradFnew, the norms, the penalty sums :268-274 all carry
 // unew[c] = 0). The penalty d grows by orders of magnitude from the second outer iteration on (m = 10k: 0.73 ->
