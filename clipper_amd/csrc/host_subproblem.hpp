@@ -119,7 +119,7 @@ int sub_prepare_v(Ctx* h) {
     sp.cap = static_cast<size_t>(mp);
   }
   if ((rc = rv_grow(sp.blk, sp.cap_blk, static_cast<size_t>(nblk) + 2))) return rc;
-  if (!sp.nout_acc) HIPCHK(hipMalloc(&sp.nout_acc, 4 * sizeof(int32_t)));
+  if (!sp.nout_acc) HIPCHK(hipMalloc(&sp.nout_acc, 8 * sizeof(int32_t)));
   if (!sp.rec) {
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sp.rec), 64, hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&sp.rec_dev), sp.rec, 0));
@@ -165,24 +165,28 @@ int sub_prepare_v(Ctx* h) {
   };
   const int storage = h->compressed ? (h->storage == CLIPPER_HIP_STORE_F64 ? CLIPPER_HIP_STORE_F64_CSC : CLIPPER_HIP_STORE_F32_CSC)
                                     : h->storage;
-  if ((rc = build_child(sp.ctx, storage))) return rc;
-  Ctx* c = sp.ctx;
-  if (!c->csc_valid) return 0;  // (a fill route without slices: not taken)
-  sp.use = c;
   // Mostly non-zero (the inliers of a registration problem are consistent with each other: M[S,S] IS the dense block the
   // slices' work list cuts by step range)? Then a dense fp32 store holds it in 4 bytes per element instead of 5.3 per
-  // stored entry, its pass (k_gemv: wave-uniform multipliers, no gathers) runs at 0.7 of the HBM peak where the pass on
-  // the slices reaches 0.47, and the window comes from candidate tables (k_sub_enter writes the pending one).
+  // stored entry and its pass is k_gemv (wave-uniform multipliers, no gathers; the window from candidate tables:
+  // k_sub_enter writes the pending one): 37 -> 30 us per pass at m = 100k, 236 -> 182 us at 300k (0.71 of the HBM peak).
+  // How dense it will be is known before it is built: the selection summed the counts of the columns it took.
   static const bool dense_off = std::getenv("CLIPPER_HIP_SUB_DENSE") && std::atoi(std::getenv("CLIPPER_HIP_SUB_DENSE")) == 0;
-  const double density = static_cast<double>(c->sh[0].s_entries) / (static_cast<double>(nS) * static_cast<double>(nS));
-  if (!dense_off && h->sub_mode != 2 && h->storage == CLIPPER_HIP_STORE_F32 && density >= 0.5 && nS >= 1024) {
-    if ((rc = build_child(sp.ctx_dense, CLIPPER_HIP_STORE_F32))) {
-      if (rc != CLIPPER_HIP_E_NOMEM) return rc;
-      (void)hipGetLastError();
-    } else if (sp.ctx_dense->has_matrix && !sp.ctx_dense->csc_valid) {
-      sp.use = sp.ctx_dense;
-    }
+  const double in_entries = static_cast<double>((static_cast<unsigned long long>(sp.rec->entries_hi) << 32) | sp.rec->entries_lo);
+  const double density = in_entries / (static_cast<double>(nS) * static_cast<double>(std::max<int64_t>(1, v.nrows)));
+  const bool dense = !dense_off && h->sub_mode != 2 && h->storage == CLIPPER_HIP_STORE_F32 && density >= 0.5 && nS >= 1024;
+  Ctx* c = nullptr;
+  if (dense) {
+    rc = build_child(sp.ctx_dense, CLIPPER_HIP_STORE_F32);
+    if (rc == 0 && sp.ctx_dense->has_matrix && !sp.ctx_dense->csc_valid) c = sp.ctx_dense;
+    else if (rc != 0 && rc != CLIPPER_HIP_E_NOMEM) return rc;
+    else (void)hipGetLastError();
   }
+  if (c == nullptr) {
+    if ((rc = build_child(sp.ctx, storage))) return rc;
+    if (!sp.ctx->csc_valid) return 0;  // (a fill route without slices: not taken)
+    c = sp.ctx;
+  }
+  sp.use = c;
   HIPCHK(hipSetDevice(s.device));
   sp.nS = nS;
   // N of the bound: the counts are over the VIEW's rows; on the sub-problem a row of S outside the view may come back
@@ -191,9 +195,9 @@ int sub_prepare_v(Ctx* h) {
   sp.ready = true;
   sp.build_ms += std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
   if (host_timing)
-    std::fprintf(stderr, "[sub] ready: %lld associations, %.1f MB of slices (%d work items), density %.2f -> %s, prepared in %.2f ms\n",
-                 static_cast<long long>(nS), c->sh[0].s_bytes * 1e-6, c->sh[0].s_nwork, density,
-                 sp.use == sp.ctx_dense ? "a dense fp32 store" : "slices", sp.build_ms);
+    std::fprintf(stderr, "[sub] ready: %lld associations, density %.2f -> %s (%.1f MB), prepared in %.2f ms\n",
+                 static_cast<long long>(nS), density, c->csc_valid ? "slices" : "a dense fp32 store",
+                 (c->csc_valid ? static_cast<double>(c->sh[0].s_bytes) : algorithmic_gemv_bytes(c)) * 1e-6, sp.build_ms);
   return 0;
 }
 

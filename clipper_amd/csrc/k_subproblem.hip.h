@@ -77,6 +77,7 @@ struct SubRecord {
   int32_t ncol;    // the largest count of a column outside S (k_sub_publish)
   int32_t n0;      // the threshold the selection used
   int32_t pad;
+  uint32_t entries_lo, entries_hi;  // the counts of the columns in S, summed: how dense M[S,S] will be (k_sub_publish)
 };
 
 // flags[c] = c is in S: a row of the view, or a column with more than N0 entries among the view's rows;
@@ -85,9 +86,12 @@ template <int V>
 __global__ __launch_bounds__(256) void k_sub_flags(const SolverState* __restrict__ st, const int32_t* __restrict__ cnt,
                                                     const uint8_t* __restrict__ in_view, int64_t m, int64_t mp,
                                                     uint8_t* __restrict__ flags, uint32_t* __restrict__ blk,
-                                                    int32_t* __restrict__ acc /* device: [1] = max count outside S, [2] = N0 */) {
+                                                    int32_t* __restrict__ acc /* device: [1] = max count outside S, [2] = N0,
+                                                                                 [4..5] = the counts of the columns IN S, summed (u64) */) {
   __shared__ uint32_t wsum[4];
   __shared__ int wmax[4];
+  __shared__ unsigned long long wcnt[4];
+  unsigned long long insum = 0;
   const double s = st->s;  // sum(u) of the current (normalised) point
   const double n0d = floor(SUB_THETA * s * s);
   const int n0 = n0d < 2.0e9 ? static_cast<int>(n0d) : 2000000000;
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(256) void k_sub_flags(const SolverState* __restrict
       const int c = cnt[i];
       in = in_view[i] != 0 || c > n0;
       if (!in) mx = c > mx ? c : mx;
+      else insum += static_cast<unsigned long long>(c);
     }
     if (i < mp) flags[i] = in ? 1 : 0;
     n += in ? 1u : 0u;
@@ -111,10 +116,12 @@ __global__ __launch_bounds__(256) void k_sub_flags(const SolverState* __restrict
     n += __shfl_xor(n, o);
     const int t = __shfl_xor(mx, o);
     mx = t > mx ? t : mx;
+    insum += __shfl_xor(insum, o);
   }
   if ((threadIdx.x & 63) == 0) {
     wsum[threadIdx.x >> 6] = n;
     wmax[threadIdx.x >> 6] = mx;
+    wcnt[threadIdx.x >> 6] = insum;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -122,16 +129,19 @@ __global__ __launch_bounds__(256) void k_sub_flags(const SolverState* __restrict
     int b = wmax[0];
     for (int w = 1; w < 4; ++w) b = wmax[w] > b ? wmax[w] : b;
     atomicMax(&acc[1], b);  // (zeroed by k_sub_begin)
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc + 4), wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
     if (blockIdx.x == 0) acc[2] = n0;
   }
 }
 // the counters of a selection, zeroed in front of it / handed to the host (mapped memory) behind it
 __global__ void k_sub_begin(int32_t* acc) {
-  if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+  if (threadIdx.x < 8) acc[threadIdx.x] = 0;
 }
 __global__ void k_sub_publish(const int32_t* __restrict__ acc, SubRecord* __restrict__ rec) {
   if (threadIdx.x == 0) {
     __hip_atomic_store(&rec->ncol, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&rec->entries_lo, static_cast<uint32_t>(acc[4]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&rec->entries_hi, static_cast<uint32_t>(acc[5]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&rec->n0, acc[2], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
