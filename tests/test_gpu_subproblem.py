@@ -73,8 +73,9 @@ def test_the_sub_problem_does_not_change_the_result(storage, m, rho):
         assert abs(s.score - sr.score) <= 1e-6 * abs(sr.score)
         assert s.ifinal == sr.ifinal
     # outside S the solution is zero on every route; inside it the same point to rounding
+    # (u itself: the iteration stops at |du| < 1e-8, and at d ~ 1e4 two orders of the same sums end 1e-8 apart)
     assert abs(s1.score - s0.score) <= 1e-10 * abs(s0.score)
-    assert np.allclose(s1.u, s0.u, rtol=0, atol=1e-8)
+    assert np.allclose(s1.u, s0.u, rtol=0, atol=1e-7)
     assert np.allclose(s1.u, sr.u, rtol=0, atol=1e-7)
     # (trial counts: accept tests that sit on rounding errors — DESIGN.md section 5 —: the route with views alone is as
     # far from the oracle's count as this one; the two routes within a few of each other)
@@ -88,7 +89,7 @@ def test_the_sub_problem_does_not_change_the_result(storage, m, rho):
     assert st2.sub_entries >= 1 and st2.sub_dense == 0
     _same_list(s2b, sr)
     assert s2b.ifinal == sr.ifinal and abs(s2b.score - s1.score) <= 1e-10 * abs(s1.score)
-    assert np.allclose(s2b.u, s1.u, rtol=0, atol=1e-8)
+    assert np.allclose(s2b.u, s1.u, rtol=0, atol=1e-7)
     g2.close()
     # the same context solves again: bit-reproducible, the hand-over included
     s2 = g1.solve(p.u0)
