@@ -295,6 +295,7 @@ def main():
             # that can still be selected
             "passes_on_the_sub_problem": int(pvs.sub_passes), "sub_rows": int(pvs.sub_rows), "sub_bytes": int(pvs.sub_bytes),
             "sub_entries": int(pvs.sub_entries), "sub_leaves": int(pvs.sub_leaves), "sub_build_ms": round(pvs.sub_build_ms, 3),
+            "sub_storage": "dense fp32 (k_gemv)" if pvs.sub_dense else "slices",
             "pass_on_sub_us": round(sub_us, 1),
             "roofline_sub": roof(pvs.sub_bytes, sub_us),
             "exchange_us": round(P["xchg_us"] / max(1, P["xchg_n"]), 1) if N > 1 else None,
