@@ -842,6 +842,8 @@ int clipper_hip_solve_staged(clipper_hip_t* h, const clipper_params_t* P, double
   for (int l = 0; l < VS; ++l) init.nrm[l] = 1.0;
   init.nlive = init.nout = static_cast<int32_t>(std::min<int64_t>(m, 0x7fffffff));  // unknown until a tail counts
   init.rv_last = -100;
+  init.weff = 0;
+  init.zero_run = 2;  // (no line search has rejected anything yet: the first windows multiply candidate 0 alone)
   rowview_drop(h);  // a solve starts without a view: what it builds is a function of this solve alone
   rvr_begin_solve(h);
   sub_begin_solve(h);

@@ -372,6 +372,8 @@ SolveArgs solve_args(Ctx* h, Shard& s, const SolverParams& prm, int par) {
   a.rv_rows = view ? static_cast<int>(s.rv.nrows) : 0;
   a.rvp = h->rvp;
   a.decide_only = h->decide_only ? 1 : 0;
+  // the window in use (SolverState::weff): the pass on the slices of one shard may multiply candidate 0 alone
+  a.adaptive_window = (h->csc_valid && h->world == 1 && !h->multiproc && h->sh.size() == 1 && h->adaptive_window) ? 1 : 0;
   // the live sub-problem (host_subproblem.hpp)
   a.sub_state = 0;
   a.sub_ncol = 0.0;
@@ -630,6 +632,8 @@ Ctx* make_ctx(const int* devices, int nlocal, int storage, int world, int first_
     const int v = std::atoi(w);
     if (v == 1 || v == 4 || v == 6 || v == 8) h->V_forced = v;
   }
+  if (const char* e = std::getenv("CLIPPER_HIP_ADAPTIVE_WINDOW"))
+    if (std::atoi(e) == 0) h->adaptive_window = false;
   // CLIPPER_HIP_RESIDENT = 0: never the resident solver
   if (const char* e = std::getenv("CLIPPER_HIP_RESIDENT"))
     if (std::atoi(e) == 0) h->resident_mode = 1;

@@ -365,6 +365,7 @@ struct clipper_hip_ctx {
   // launches report into the parent's progress record and borrow the parent's stream)
   SubProblem sub;
   struct clipper_hip_ctx* parent = nullptr;
+  bool adaptive_window = true;   // CLIPPER_HIP_ADAPTIVE_WINDOW=0: every window pass multiplies all V candidates
   int sub_mode = 0;           // 0 = automatic, 1 = never (clipper_hip_set_subproblem / CLIPPER_HIP_SUBPROBLEM=0), 2 = always as slices
 
   long long* stamps_dev = nullptr;  // CLIPPER_HIP_STAMPS=1: [4096][4], see SolveArgs::stamps; =2: [16384][4]

@@ -533,6 +533,8 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
         o->hold_slot = 0;
         o->hold_nlive = 0;
         o->resume = resume;
+        o->weff = V;       // (the prepared pass multiplies the whole window; the streaming launches' policy starts over)
+        o->zero_run = 0;
         report_run();
         if (A.host) {
           HostMirror* hm = A.host;

@@ -447,7 +447,10 @@ __device__ __forceinline__ void slices_by_plan(const SliceViewG& M, const SliceJ
   if (plan.phase == PH_TRIAL) {
     const WindowSource WS{A.pt + static_cast<int64_t>(plan.src) * 2 * A.mp,
                           A.pt + (static_cast<int64_t>(plan.src) * 2 + 1) * A.mp, plan.alpha0, A.prm.beta};
-    slice_core<VT, H, true, V, nslot(V), NW, D>(M, J, A.W, A.m, plan.d, WS, nullptr, 0, A.part, lds);
+    // (SolverState::weff) candidate 0 alone — a and b apart, the same two fmas per entry in the same order as in the
+    // full window: the same bits — or the whole window
+    if (V > 1 && plan.weff == 1) slice_core<VT, H, true, 1, nslot(V), NW, D>(M, J, A.W, A.m, plan.d, WS, nullptr, 0, A.part, lds);
+    else slice_core<VT, H, true, V, nslot(V), NW, D>(M, J, A.W, A.m, plan.d, WS, nullptr, 0, A.part, lds);
   } else {  // pair mode: straight on the u array of a point slot, or on candidate 0 of a table
     const bool fu = plan.from_u >= 0;
     const double* X = fu ? A.pt + static_cast<int64_t>(plan.from_u) * 2 * A.mp

@@ -149,6 +149,15 @@ struct SolverState {
                        // sums (z_l, s_l) over the view's rows only: the resident solver left because a row
                        // outside its view became live (nout != 0), and that row's candidates are not zero —
                        // the launch that runs the pass adds the rows outside the view (iteration_head)
+  // THE WINDOW IN USE (round 6). A window of V candidates pays when line searches reject; while they do not — the whole
+  // first two outer iterations of every problem looked at: the penalty is small, alpha = 1 is accepted every time —
+  // candidates 1 .. V-1 are never looked at, and a pass that multiplies candidate 0 alone (the pair-mode loop: one LDS
+  // gather per entry instead of three, two fmas instead of seven) is 30 % shorter at m = 10k. `weff` = how many
+  // candidates of the pending window the pass of this iteration multiplies and its tail evaluates (1 or V; 0 = V): the
+  // decision walks exactly those, "all rejected" means weff more factors of beta. WHICH candidates exist, their order
+  // and every sum formed for one of them are the same for any weff: only the grouping of trials into passes changes.
+  int32_t weff;
+  int32_t zero_run;    // line searches in a row that accepted their first trial (the policy: weff = 1 from two on)
 };
 
 // What outlives the alternating state: the end of the solve. Kernels launched after
@@ -237,6 +246,8 @@ struct SolveArgs {
                            // prepared (SolverState::resume) instead of running it — the hand-over to the
                            // resident solver on a row view (k_rv_resident.hip.h), which starts from a
                            // prepared pass and leaves one behind
+  int adaptive_window;     // 1: the decision may plan a pass on candidate 0 alone (SolverState::weff; the pass on the slices of
+                           // one shard); 0: every window pass multiplies all V candidates
   // the live sub-problem (k_subproblem.hip.h)
   int sub_state;           // 0: none. 1: a sub-problem stands ready — the decision puts the solve on hold (hold = 2)
                            // for the hand-over once no column outside it can come back to life. 2: these launches
@@ -391,6 +402,7 @@ struct PassPlan {
   // the arrays of point slot `src` (p*V + v) — what the pass on the slices stages (k_slices.hip.h)
   int src;
   double alpha0;
+  int weff;    // candidates of the window this pass multiplies (1 or V)
 };
 
 constexpr int VU = 4;  // elements per thread per sweep step (all NT threads of the workgroup sweep)
@@ -407,7 +419,7 @@ struct HeadLoads {
   double d, F, alpha, s;
   int i, j, k, ubp, ubv, sel;
   int64_t n_passes, n_trials, n_iters, n_view_passes;
-  int nlive, nout, hold, rv_builds, rv_last, rv_backoff;
+  int nlive, nout, hold, rv_builds, rv_last, rv_backoff, weff, zero_run;
   double chain;  // this thread's share of sum_w scal[w][q]
 };
 
@@ -440,6 +452,8 @@ __device__ __forceinline__ void head_loads(const SolveArgs& A, HeadLoads& L) {
   L.rv_builds = st->rv_builds;
   L.rv_last = st->rv_last;
   L.rv_backoff = st->rv_backoff;
+  L.weff = st->weff;
+  L.zero_run = st->zero_run;
   // sums[q] = sum over the tail workgroups w of scal[w][q]: NCH interleaved chains per
   // quantity (w = c, c + NCH, ...), added in chain order
   const int tid = threadIdx.x;
@@ -500,6 +514,8 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   const int phase = L.phase;
   double d = L.d, F = L.F, alpha = L.alpha, s = L.s;
   int i_ = L.i, j_ = L.j, k_ = L.k, ubp = L.ubp, ubv = L.ubv, sel = L.sel;
+  const int wprev = (L.weff >= 1 && L.weff <= V) ? L.weff : V;  // candidates the pass just evaluated
+  int zero_run = L.zero_run;
   int64_t n_passes = L.n_passes, n_trials = L.n_trials;
   const int64_t n_iters = L.n_iters + 1;
   // live rows of the current point / of them outside the row view: unchanged while the point is
@@ -562,7 +578,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       double Fnew = 0.0, deltaF = 0.0;
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        if (jstar < 0) {
+        if (jstar < 0 && v < wprev) {
           ++n_trials;
           Fnew = sums[v * NR + 0];
           deltaF = Fnew - F;  // :244
@@ -576,8 +592,8 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         }
       }
       if (jstar < 0) {
-        // all V candidates rejected: the v = 0 tail already built the next V step sizes from
-        // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
+        // all `wprev` candidates rejected: the v = 0 tail already built the next V step sizes from
+        // the unchanged (u, g) in table V; alpha was multiplied by beta `wprev` times above
         sel = V;
         action = ACT_PASS;
         sub_bound(sums, V * NR);
@@ -591,6 +607,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
           }
         }
       } else {
+        zero_run = (k_ == 0) ? (zero_run < 1000000 ? zero_run + 1 : zero_run) : 0;  // this line search is over
         const double deltau = sqrt(sums[jstar * NR + 1]);
         live_code(sums[jstar * NR + NR - 1]);  // the point becomes candidate jstar
         s = st->sx[jstar];
@@ -815,6 +832,9 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   }
   // ... or these launches run ON it and the pending window could: the pass is left prepared and the solve goes back
   const bool sub_leave = A.sub_state == 2 && action == ACT_PASS && !sub_ok;
+  // How many candidates of the window the pass multiplies (SolverState::weff): one while line searches have been
+  // accepting their first trial (two in a row, or none has run yet) and this one has not rejected anything either.
+  const int wnext = (A.adaptive_window != 0 && k_ == 0 && zero_run >= 2) ? 1 : V;
   // ---- record the decided state (workgroup (0,0), one thread) ------------------------------
   // A pass iteration parks it in LDS and writes it out AFTER the streaming loop (flush_state):
   // a global store ahead of the loop would make the compiler treat the table rows as possibly
@@ -858,6 +878,8 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       o->hold_slot = 0;
       o->hold_nlive = 0;
       o->resume = 0;
+      o->weff = wnext;
+      o->zero_run = zero_run;
     };
     if (action == ACT_PASS) record(stash, true);
     else record(A.st_next, false);
@@ -927,6 +949,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   plan.src = __builtin_amdgcn_readfirstlane(ubp * V + ubv);
   plan.alpha0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(alpha)),
                                  __builtin_amdgcn_readfirstlane(__double2loint(alpha)));
+  plan.weff = __builtin_amdgcn_readfirstlane(wnext);
   return action == ACT_PASS;
 }
 #undef VEC_CHUNKS
@@ -963,6 +986,7 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
   plan.d = st->d;
   plan.src = __builtin_amdgcn_readfirstlane(slot);  // (read by window passes only)
   plan.alpha0 = L.alpha;
+  plan.weff = __builtin_amdgcn_readfirstlane((A.adaptive_window != 0 && L.weff == 1) ? 1 : V);
   if (is_writer_block()) {  // (word by word by the whole workgroup: one thread's struct copy is 70 registers)
     copy_state(stash, st, threadIdx.x, NT);
     __syncthreads();
@@ -1009,6 +1033,7 @@ __device__ __forceinline__ bool iteration_head(const SolveArgs& A, double* lds,
       stash->view = on_view;
       stash->n_view_passes = L.n_view_passes + on_view;
       stash->resume = 0;
+      stash->weff = plan.weff;  // (what the pass multiplies is what its tail evaluates and the next decision walks)
     }
   }
   return true;
@@ -1115,6 +1140,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   const int ubp = st->ubp, ubv = st->ubv, sel = st->sel;
   const double d = st->d, alpha = st->alpha, s_cur = st->s;
   const double nrmv = st->nrm[v], sxv = st->sx[v];
+  const int weff = (st->weff >= 1 && st->weff <= V) ? st->weff : V;  // candidates the pass multiplied (SolverState::weff)
   // the pass streamed the row view: its own (fewer) partial-sum slots
   const int nslots_pass = st->view ? A.rv_nslots : A.ntiles;
   // "live and outside the view" weighs 1 + 2^26 in the live code
@@ -1173,6 +1199,7 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
   if (done) return;
   if (st->hold) return;             // the solve waits for a row view: nothing was decided, nothing ran
   if (stage != ST_RESULTS) return;  // a pass was only prepared: nothing to evaluate
+  if (phase == PH_TRIAL && v >= weff) return;  // a candidate the pass did not multiply: the decision will not look at it
   const long long c1 = A.stamps ? wall_clock64() + (p0 > 1e300 ? 1 : 0) : 0;
 
   if (phase != PH_TRIAL && phase != PH_BUILD) {
@@ -1261,12 +1288,12 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
       }
       if constexpr (TABLES) store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
       if (v == 0) {
-        // next window if all V candidates are rejected: V more factors of beta (:248)
+        // next window if all `weff` candidates are rejected: as many more factors of beta (:248)
         const double gi = pt_arr(A, V, ubp, ubv, 1)[i];
         double row2[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         al = alpha;
 #pragma unroll
-        for (int l = 0; l < V; ++l) al = al * beta;
+        for (int l = 0; l < V; ++l) al = (l < weff) ? al * beta : al;
 #pragma unroll
         for (int l = 0; l < V; ++l) {
           double t = ui + al * gi;

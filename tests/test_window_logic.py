@@ -72,3 +72,25 @@ def test_window_saves_passes_when_the_line_search_backtracks():
     if rejected > 0:
         assert r6.n_passes < r1.n_passes
     assert r6.accepted and sum(j + 1 for j in r6.accepted) <= r6.n_trials
+
+
+@pytest.mark.parametrize("V", [4, 6])
+@pytest.mark.parametrize("m,density,seed,clique", [(40, 0.3, 1, 8), (120, 0.15, 2, 15), (200, 0.1, 3, 25), (300, 0.08, 11, 40)])
+def test_the_window_in_use_changes_passes_not_trials(V, m, density, seed, clique):
+    """SolverState::weff (round 6): while line searches accept their first trial a pass multiplies candidate 0 alone and
+    the decision walks that one candidate; after a rejection the whole window again. Whatever the policy predicts, the
+    trials, the decisions and the result are the oracle's — a wrong guess costs a pass, nothing else."""
+    Mup, Cup, u0 = _random_problem(m, density, seed, clique)
+    s_ref = ref.numpy_solve(Mup, Cup, u0, ref.Params())
+    r = wm.solve(Mup + Mup.T, Cup + Cup.T, u0, wm.Params(), V, adaptive=True)
+    rf = wm.solve(Mup + Mup.T, Cup + Cup.T, u0, wm.Params(), V, adaptive=False)
+    assert r.n_trials == rf.n_trials == s_ref.n_trials and r.ifinal == s_ref.ifinal
+    assert abs(r.F - s_ref.score) <= 1e-10 * max(1.0, abs(s_ref.score))
+    assert np.allclose(r.u, s_ref.u, rtol=0, atol=1e-10)
+    assert r.n_passes <= r.n_trials + 3 + r.ifinal
+    for kw in (dict(beta=0.5), dict(maxiniters=3, maxoliters=40), dict(rescale_u0=False)):   # (a line search capped at two trials runs the loops to their limits: minutes)
+        p = ref.Params(**{k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()})
+        s2 = ref.numpy_solve(Mup, Cup, u0, p)
+        r2 = wm.solve(Mup + Mup.T, Cup + Cup.T, u0, wm.Params(**kw), V, adaptive=True)
+        assert r2.n_trials == s2.n_trials and r2.ifinal == s2.ifinal, kw
+        assert np.allclose(r2.u, s2.u, rtol=0, atol=1e-10), kw

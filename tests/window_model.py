@@ -44,8 +44,10 @@ class Result:
     accepted: list = field(default_factory=list)   # window index of every accepted trial
 
 
-def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int) -> Result:
-    """Moff, Coff: dense symmetric, zero diagonal."""
+def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int, adaptive: bool = False) -> Result:
+    """Moff, Coff: dense symmetric, zero diagonal. adaptive: the window IN USE (SolverState::weff, k_solver.hip.h) —
+    a pass multiplies candidate 0 alone while line searches have been accepting their first trial (two in a row, or
+    none has run yet), the decision walks exactly the candidates the pass multiplied."""
     m = len(u0)
     tables = np.zeros((V + 1, m, V))          # candidate tables of the pending set
     nrm, sx = np.ones(V), np.zeros(V)
@@ -63,6 +65,7 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
     results = not P.rescale_u0                # PH_NORMALIZE consumes no pass: decide at once
     sums = None
     from_u = False
+    weff, zero_run = V, 2
 
     def build_window(base_u, base_g, alpha0):
         tab = np.zeros((m, V))
@@ -94,7 +97,7 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
             action = "slow"
             if phase == PH_TRIAL:
                 jstar = -1
-                for v in range(V):
+                for v in range(weff):
                     n_trials += 1
                     Fnew = sums["F"][v]
                     deltaF = Fnew - F
@@ -111,6 +114,7 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
                     sel, nrm, sx = V, sums["none_nrm"], sums["none_sx"]
                     action = "pass"
                 else:
+                    zero_run = zero_run + 1 if k_ == 0 else 0
                     accepted.append(jstar)
                     deltau = np.sqrt(sums["du2"][jstar])
                     s = sx_pass[jstar]
@@ -180,6 +184,7 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
             phase, results = PH_BUILD, True
             continue
         # ---- pass iteration: G streams M, T = tail ------------------------------------------
+        weff = 1 if (adaptive and k_ == 0 and zero_run >= 2) else V
         n_passes += 1
         X = tables[sel]
         if phase != PH_TRIAL:                       # pair mode (nrm = 1)
@@ -191,7 +196,7 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
         sx_pass = sx.copy()
         out_tables = {}
         W = Moff + d * Coff
-        for v in range(V):
+        for v in range(weff):
             xi = X[:, v] / nrm[v]
             if v == 0:                              # a and b apart, the reference's expression
                 an, bn = (Moff @ X[:, 0]) / nrm[0], (Coff @ X[:, 0]) / nrm[0]
@@ -206,7 +211,7 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int)
             sums["du2"][v] = float(du @ du)
             out_tables[v], sums["nrm"][v], sums["sx"][v] = build_window(xi, gn, 1.0)
         al = alpha
-        for _ in range(V):
+        for _ in range(weff):
             al = al * P.beta
         out_tables[V], sums["none_nrm"], sums["none_sx"] = build_window(u, g, al)
         for k, t in out_tables.items():
