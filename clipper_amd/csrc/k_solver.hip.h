@@ -154,8 +154,10 @@ struct SolverState {
   // candidates 1 .. V-1 are never looked at, and a pass that multiplies candidate 0 alone (the pair-mode loop: one LDS
   // gather per entry instead of three, two fmas instead of seven) is 30 % shorter at m = 10k. `weff` = how many
   // candidates of the pending window the pass of this iteration multiplies and its tail evaluates (1 or V; 0 = V): the
-  // decision walks exactly those, "all rejected" means weff more factors of beta. WHICH candidates exist, their order
-  // and every sum formed for one of them are the same for any weff: only the grouping of trials into passes changes.
+  // decision walks exactly those. A pass on candidate 0 alone whose candidate is REJECTED was a wrong guess: the decision
+  // discards it and the same window is multiplied again, whole — so every candidate that is ever walked sits at the
+  // window index, and is formed by the expressions, it has without any of this: the solve is bit for bit the one with
+  // full windows, a wrong guess costs one pass (one or two per solve: the policy below).
   int32_t weff;
   int32_t zero_run;    // line searches in a row that accepted their first trial (the policy: weff = 1 from two on)
 };
@@ -541,6 +543,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   int action = ACT_SLOW;
   int next_phase = PH_TRIAL;
   bool need_pair = false;  // the pass of this iteration is a pair-mode pass on the accepted x
+  bool redo = false;       // the pass on candidate 0 alone guessed wrong: the same window again, whole
   // The live sub-problem (k_subproblem.hip.h): no column outside it can come back to life under ANY candidate of the
   // window this decision leaves pending — d^2 s_l^2 >= kappa (1 + d)^2 N z_l for its raw sums (z_l, s_l) =
   // (||x_l||^2, sum x_l), which the tail left at sums[nb + 2 l], sums[nb + 2 l + 1]. Every workgroup evaluates it.
@@ -591,9 +594,27 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
           if (accept) jstar = v;
         }
       }
-      if (jstar < 0) {
-        // all `wprev` candidates rejected: the v = 0 tail already built the next V step sizes from
-        // the unchanged (u, g) in table V; alpha was multiplied by beta `wprev` times above
+      if (jstar < 0 && wprev < V) {
+        // A pass on candidate 0 ALONE (SolverState::weff) whose candidate was rejected: the guess was wrong. Nothing of
+        // it is used: the SAME window is multiplied again, whole — every candidate then sits at the index and is formed
+        // by the expressions it would have had without the guess, and the solve is bit for bit the one with full windows
+        // (the trial is counted when that pass is walked). The pending window's norms go on unchanged.
+        alpha = L.alpha;
+        k_ = L.k;
+        n_trials = L.n_trials;
+        zero_run = 0;
+        redo = true;
+        action = ACT_PASS;
+        if (writer && tid == 0) {
+#pragma unroll
+          for (int l = 0; l < V; ++l) {
+            stash->nrm[l] = st->nrm[l];
+            stash->sx[l] = st->sx[l];
+          }
+        }
+      } else if (jstar < 0) {
+        // all V candidates rejected: the v = 0 tail already built the next V step sizes from
+        // the unchanged (u, g) in table V; alpha was multiplied by beta V times above
         sel = V;
         action = ACT_PASS;
         sub_bound(sums, V * NR);
@@ -834,7 +855,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   const bool sub_leave = A.sub_state == 2 && action == ACT_PASS && !sub_ok;
   // How many candidates of the window the pass multiplies (SolverState::weff): one while line searches have been
   // accepting their first trial (two in a row, or none has run yet) and this one has not rejected anything either.
-  const int wnext = (A.adaptive_window != 0 && k_ == 0 && zero_run >= 2) ? 1 : V;
+  const int wnext = (A.adaptive_window != 0 && !redo && k_ == 0 && zero_run >= 2) ? 1 : V;
   // ---- record the decided state (workgroup (0,0), one thread) ------------------------------
   // A pass iteration parks it in LDS and writes it out AFTER the streaming loop (flush_state):
   // a global store ahead of the loop would make the compiler treat the table rows as possibly
@@ -1288,12 +1309,13 @@ __global__ __launch_bounds__(TAIL_THREADS * (FUSED_REDUCE ? TAIL_SPLIT : 1)) voi
       }
       if constexpr (TABLES) store_row(A.Xout + (static_cast<int64_t>(v) * A.mp + i) * VS, row);
       if (v == 0) {
-        // next window if all `weff` candidates are rejected: as many more factors of beta (:248)
+        // next window if all V candidates are rejected: V more factors of beta (:248)
+        // (after a pass on candidate 0 alone — weff = 1 — this outcome is not used: a rejection repeats the window)
         const double gi = pt_arr(A, V, ubp, ubv, 1)[i];
         double row2[VS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         al = alpha;
 #pragma unroll
-        for (int l = 0; l < V; ++l) al = (l < weff) ? al * beta : al;
+        for (int l = 0; l < V; ++l) al = al * beta;
 #pragma unroll
         for (int l = 0; l < V; ++l) {
           double t = ui + al * gi;

@@ -65,7 +65,7 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int,
     results = not P.rescale_u0                # PH_NORMALIZE consumes no pass: decide at once
     sums = None
     from_u = False
-    weff, zero_run = V, 2
+    weff, zero_run, redo = V, 2, False
 
     def build_window(base_u, base_g, alpha0):
         tab = np.zeros((m, V))
@@ -97,6 +97,7 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int,
             action = "slow"
             if phase == PH_TRIAL:
                 jstar = -1
+                before = (alpha, k_, n_trials)
                 for v in range(weff):
                     n_trials += 1
                     Fnew = sums["F"][v]
@@ -110,7 +111,13 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int,
                     if accept:
                         jstar = v
                         break
-                if jstar < 0:
+                if jstar < 0 and weff < V:
+                    # the pass on candidate 0 alone guessed wrong: the same window again, whole (nothing of it is used)
+                    alpha, k_, n_trials = before
+                    zero_run, redo = 0, True
+                    tables = tables_before      # (the device builds a pending window from its point slot, which no tail
+                    action = "pass"             # overwrites: the slices path has no tables; this model keeps them)
+                elif jstar < 0:
                     sel, nrm, sx = V, sums["none_nrm"], sums["none_sx"]
                     action = "pass"
                 else:
@@ -184,7 +191,8 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int,
             phase, results = PH_BUILD, True
             continue
         # ---- pass iteration: G streams M, T = tail ------------------------------------------
-        weff = 1 if (adaptive and k_ == 0 and zero_run >= 2) else V
+        weff = 1 if (adaptive and not redo and k_ == 0 and zero_run >= 2 and phase == PH_TRIAL) else V
+        redo = False
         n_passes += 1
         X = tables[sel]
         if phase != PH_TRIAL:                       # pair mode (nrm = 1)
@@ -211,9 +219,10 @@ def solve(Moff: np.ndarray, Coff: np.ndarray, u0: np.ndarray, P: Params, V: int,
             sums["du2"][v] = float(du @ du)
             out_tables[v], sums["nrm"][v], sums["sx"][v] = build_window(xi, gn, 1.0)
         al = alpha
-        for _ in range(weff):
+        for _ in range(V):
             al = al * P.beta
         out_tables[V], sums["none_nrm"], sums["none_sx"] = build_window(u, g, al)
+        tables_before = tables.copy() if weff < V else None
         for k, t in out_tables.items():
             tables[k] = t
         results = True
