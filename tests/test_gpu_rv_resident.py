@@ -285,7 +285,7 @@ def test_a_row_outside_the_view_becomes_live_inside_the_launch():
     assert s2.n_trials == 95 and abs(s1.n_trials - 95) <= 2
     assert s1.nodes.tolist() == s2.nodes.tolist() and s1.ifinal == s2.ifinal
     assert abs(s1.score - s2.score) <= 1e-10 * abs(s2.score)
-    assert abs(s1.n_passes - s2.n_passes) <= 2
+    assert abs(s1.n_passes - s2.n_passes) <= 5   # (the streamed route repeats a window whose single-candidate pass guessed wrong: SolverState::weff)
     g1.close()
     g2.close()
 
