@@ -20,9 +20,11 @@ D1, D2, A, u0 and D2H of u inside: SURVEY 8d's wording of the metric) is timed o
 of warmed steps and reported beside it as `ms_per_step_host_buffers`.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement), extended with
-  "roofline"     achieved GB/s of the dominant kernel (the pass: one sweep over M for a whole
-                 line-search window), from HIP events recorded on the solver stream around every
-                 20th launch in the timed region (an event pair costs ~30 us of stream time).
+  "roofline"     achieved GB/s of the dominant kernel (the pass: one sweep over M for the candidates of the
+                 line-search window in use - DESIGN.md 3a: candidate 0 alone while line searches accept their
+                 first trial, which covers every pass on M of the headline; all six otherwise), from HIP
+                 events recorded on the solver stream around every 20th launch in the timed region (an event
+                 pair costs ~30 us of stream time).
                  Default storage "csc" (one GPU): k_gemv_slices streams the slices of M — bytes per
                  launch = what the slices hold (headers, lengths, value and row quads), NOT
                  s*m^2; `useful_bytes_per_launch` / `frac_useful` count stored entries only
