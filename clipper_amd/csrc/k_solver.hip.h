@@ -605,6 +605,17 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
         zero_run = 0;
         redo = true;
         action = ACT_PASS;
+        // (the live sub-problem's bound for that window, from the norms the state carries: z = nrm^2, s = sx nrm — this
+        // decision may be the first one that is asked, e.g. right after a view and its sub-problem were built)
+        if (A.sub_state != 0) {
+          const double kap = (A.sub_state == 1 ? 1.10 : 1.01) * A.sub_ncol;
+          const double rhs = (1.0 + d) * (1.0 + d) * kap;
+#pragma unroll
+          for (int l = 0; l < V; ++l) {
+            const double dsx = d * st->sx[l];
+            sub_ok = sub_ok && (dsx * dsx >= rhs);
+          }
+        }
         if (writer && tid == 0) {
 #pragma unroll
           for (int l = 0; l < V; ++l) {
