@@ -316,7 +316,7 @@ __global__ void k_rv_resume(SolverState* st, SolveShared* shared, int refused_ro
     shared->hold = 0;
     st->hold = 0;
     if (refused_rows == 0) st->rv_builds += 1;  // a refusal does not use up one of the solve's views
-    st->rv_last = static_cast<int32_t>(st->n_iters);
+    st->rv_last = static_cast<int32_t>(st->n_iters) - st->n_redo;  // (the policy's clock: SolverState::n_redo)
     st->rv_backoff = refused_rows;
   }
 }

@@ -387,6 +387,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
   int64_t n_passes = st->n_passes, n_trials = st->n_trials, n_iters = st->n_iters, n_view_passes = st->n_view_passes;
   int nlive = st->nlive, nout = 0;
   const int rv_builds = st->rv_builds, rv_last = st->rv_last, rv_backoff = st->rv_backoff;
+  const int n_redo = st->n_redo;  // (the view policy's clock runs in iterations that were not repeats: k_solver.hip.h)
 
   // ---- row role: rows t and t + 512 of the view; column role: this thread's own column --------------
   const double* Ue = A.pt + ((static_cast<int64_t>(e_ubp) * V + e_ubv) * 2 + 0) * mp;
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       } else {
         alpha = 1.0;  // :227
         k_ = 0;
-        want_out = nout != 0 || view_wanted_v(A.rvp, m, true, A.rv_rows, nlive, nout, n_iters + 1, rv_builds, rv_last, rv_backoff);
+        want_out = nout != 0 || view_wanted_v(A.rvp, m, true, A.rv_rows, nlive, nout, n_iters + 1 - n_redo, rv_builds, rv_last, rv_backoff);
         continue;
       }
     } else if (kind == K_PAIR) {
@@ -941,7 +942,7 @@ __global__ __launch_bounds__(RVR_NT) void k_solve_view_resident(RvrArgs A) {
       alpha = 1.0;
       k_ = 0;
       kind = K_TRIAL;
-      want_out = nout != 0 || view_wanted_v(A.rvp, m, true, A.rv_rows, nlive, nout, n_iters + 1, rv_builds, rv_last, rv_backoff);
+      want_out = nout != 0 || view_wanted_v(A.rvp, m, true, A.rv_rows, nlive, nout, n_iters + 1 - n_redo, rv_builds, rv_last, rv_backoff);
       continue;
     }
     if (penalty) {  // :276-280

@@ -160,6 +160,10 @@ struct SolverState {
   // full windows, a wrong guess costs one pass (one or two per solve: the policy below).
   int32_t weff;
   int32_t zero_run;    // line searches in a row that accepted their first trial (the policy: weff = 1 from two on)
+  int32_t n_redo;      // windows multiplied a second time so far. The view policy counts time in iterations; it is given
+                       // n_iters - n_redo, so that a solve asks for its views (and is handed over to its sub-problem) at
+                       // the same points with and without the guesses — which keeps the two bit-identical
+  int32_t pad_;
 };
 
 // What outlives the alternating state: the end of the solve. Kernels launched after
@@ -421,7 +425,7 @@ struct HeadLoads {
   double d, F, alpha, s;
   int i, j, k, ubp, ubv, sel;
   int64_t n_passes, n_trials, n_iters, n_view_passes;
-  int nlive, nout, hold, rv_builds, rv_last, rv_backoff, weff, zero_run;
+  int nlive, nout, hold, rv_builds, rv_last, rv_backoff, weff, zero_run, n_redo;
   double chain;  // this thread's share of sum_w scal[w][q]
 };
 
@@ -456,6 +460,7 @@ __device__ __forceinline__ void head_loads(const SolveArgs& A, HeadLoads& L) {
   L.rv_backoff = st->rv_backoff;
   L.weff = st->weff;
   L.zero_run = st->zero_run;
+  L.n_redo = st->n_redo;
   // sums[q] = sum over the tail workgroups w of scal[w][q]: NCH interleaved chains per
   // quantity (w = c, c + NCH, ...), added in chain order
   const int tid = threadIdx.x;
@@ -850,7 +855,7 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
   };
   // Is it time to build a (smaller) row view? A function of the state alone; see LIVE ROWS.
   if (action == ACT_PASS && next_phase == PH_TRIAL && A.rvp.on != 0 && A.rv_fresh == 0 && A.sub_state != 2 &&
-      view_wanted(A, nlive, nout, n_iters, L.rv_builds, L.rv_last, L.rv_backoff)) {
+      view_wanted(A, nlive, nout, n_iters - (L.n_redo + (redo ? 1 : 0)), L.rv_builds, L.rv_last, L.rv_backoff)) {
     put_on_hold(1);
     return false;
   }
@@ -912,6 +917,8 @@ __device__ __forceinline__ bool decide(const SolveArgs& A, const HeadLoads& L, d
       o->resume = 0;
       o->weff = wnext;
       o->zero_run = zero_run;
+      o->n_redo = L.n_redo + (redo ? 1 : 0);
+      o->pad_ = 0;
     };
     if (action == ACT_PASS) record(stash, true);
     else record(A.st_next, false);
