@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """PMC counters of a rocprofv3 --pmc run of bench.py, per kernel, and the record bench.py quotes
 (profiles/pmc_r05.json). The pass kernel is launched for passes on M, for passes on a row view
-(far fewer bytes) and for iterations that do nothing: a launch counts as a PASS ON M when it runs at
-least 0.6 x the longest launch of that kernel in the run.
+(far fewer bytes) and for iterations that do nothing: a launch counts as a PASS ON M when its counter reads at
+least 0.6 x the largest value any launch of that kernel shows in the run.
   tools/pmc_summary.py --key m10000_csc --bytes <bytes per pass> --commit <sha> --json profiles/pmc_r05.json <db> [...]"""
 import argparse
 import json
@@ -33,8 +33,11 @@ def main():
     for k in sorted(per):
         for c in sorted(per[k]):
             rows = per[k][c]
-            dmax = max(d for _, d in rows)
-            keep = [(v, d) for v, d in rows if d >= 0.6 * dmax] if k.startswith(("k_gemv", "k_tail")) else rows
+            # The passes ON M among the launches of the pass kernel (and their tails): the launches that do the most work — by
+            # the counter's own value, not by duration: since round 6 a pass on M multiplies candidate 0 alone and is SHORTER
+            # at m = 10k than the transition iterations whose sweeps run in one workgroup (37 us, next to no traffic).
+            vmax = max(v for v, _ in rows)
+            keep = [(v, d) for v, d in rows if v >= 0.6 * vmax] if (k.startswith(("k_gemv", "k_tail")) and vmax > 0) else rows
             sel = sorted(v for v, _ in keep)
             durs = sorted(d for _, d in keep)
             med = sel[len(sel) // 2]
