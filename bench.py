@@ -347,9 +347,11 @@ def main():
                                       "measured_at_commit": rec.get("commit"), "kernel_bytes_then": then,
                                       "kernel_sources_sha256": sha_then,
                                       "read_bytes": rec.get("pass_read_bytes"), "written_bytes": rec.get("pass_written_bytes"),
-                                      "written_note": "what a pass writes is its partial sums: one slot of (V + 1) x W doubles per work "
-                                                      "item of a strip (28 slots at the headline: 28 x 7 x 10 048 x 8 B = 15.8 MB nominal, "
-                                                      "14.1 MB counted) - written through (sc1) while the launch runs, read by k_tail",
+                                      "written_note": "what a pass writes is its partial sums, one slot per work item of a strip (28 at the "
+                                                      "headline), written through (sc1) while the launch runs and read by k_tail: a pass on "
+                                                      "candidate 0 alone writes 2 of the V + 1 rows of a slot (28 x 2 x 10 048 x 8 B = 4.5 MB "
+                                                      "nominal, 4.0 MB counted), a pass on all six candidates 7 (15.8 MB nominal, 14.1 MB "
+                                                      "counted in round 5 - not the < 5 MB the review estimated)",
                                       "how": rec.get("how")}
                     issue = rec.get("affinity_issue")
                     if issue and issue.get("SQ_ACTIVE_INST_VALU") and issue.get("simd_cycles_available"):
