@@ -6,9 +6,9 @@ agree; trial and pass counts are compared at 2 %. ONE context per problem (the m
 `leave`: with CLIPPER_HIP_SUB_TEST_LEAVE set by the caller the hand-backs are exercised as well. maxiniters < 5 is left
 out of the random parameters: there the reference's own answer depends on the order of its sums (NOTEBOOK.md).
 With random parameters the COUNTS may part at the end of a solve without any route being wrong: a line search at the
-converged point is decided by the rounding of F (4 or 99 trials, same u), and an inner loop that is cut off by maxiniters
-stops on |dF| < tol_F where dF is smaller than the rounding of F itself (tools/sub_case_dump.py shows both, NOTEBOOK.md
-round 6). Two node lists that differ only in associations whose u lies within 2 max|du| of the selection boundary in both
+converged point is decided by the rounding of F (4 or 99 trials, same u), and where every inner loop is cut off by
+maxiniters far from converged a trial accepted on one route and rejected on another moves u by 1e-7 — between ANY two
+routes, which one being a matter of tol_F (tools/sub_case_dump.py shows both, NOTEBOOK.md round 6). Two node lists that differ only in associations whose u lies within 2 max|du| of the selection boundary in both
 solves are reported as a TIE, not as a different result."""
 import sys
 sys.path.insert(0, '.')
