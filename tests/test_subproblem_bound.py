@@ -61,10 +61,15 @@ def _iterate(Ms, Cs, u0, p, hook):
     return u
 
 
-@pytest.mark.parametrize("m,rho,seed", [(1200, 0.9, 11), (1500, 0.95, 12), (900, 0.8, 13)])
-def test_gradient_is_negative_outside_the_subproblem_while_the_bound_holds(m, rho, seed):
-    prob = synth.make_euclidean_problem(m, rho, seed=seed)
-    Mup, _ = ref.numpy_affinity_euclidean(prob.D1, prob.D2, prob.A, **synth.EUCLID_BENCH_PARAMS)
+@pytest.mark.parametrize("m,rho,seed,pointnormal", [(1200, 0.9, 11, False), (1500, 0.95, 12, False), (900, 0.8, 13, False),
+                                                    (1000, 0.9, 14, True)])
+def test_gradient_is_negative_outside_the_subproblem_while_the_bound_holds(m, rho, seed, pointnormal):
+    if pointnormal:
+        prob = synth.make_pointnormal_problem(m, rho, seed=seed)
+        Mup = ref.numpy_affinity_pointnormal(prob.D1, prob.D2, prob.A)
+    else:
+        prob = synth.make_euclidean_problem(m, rho, seed=seed)
+        Mup, _ = ref.numpy_affinity_euclidean(prob.D1, prob.D2, prob.A, **synth.EUCLID_BENCH_PARAMS)
     Ms = Mup + Mup.T
     Cs = (Ms != 0).astype(float)
     assert Ms.max() <= 1.0   # the premise: no stored entry exceeds 1
